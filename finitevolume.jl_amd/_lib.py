@@ -1,0 +1,189 @@
+"""ctypes binding of libfvhip.so (include/fvhip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is visible
+the import / context creation fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(_HERE, "libfvhip.so")
+
+FV_OK = 0
+FV_ERR_ARG = 1
+FV_ERR_SOURCE_AT_DIRICHLET = 2
+FV_ERR_INDEX = 3
+FV_ERR_NOMEM = 4
+FV_ERR_HIP = 5
+FV_ERR_STATE = 6
+FV_ERR_DT = 7
+FV_ERR_TOO_LARGE = 8
+FV_ERR_COMM = 9
+
+FV_STEP_FORWARD = 0
+FV_STEP_ADJOINT = 1
+FV_COMM_ID_BYTES = 128
+
+
+class FVError(RuntimeError):
+    """Julia's `error(msg)` / BoundsError at the reference's call sites."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [
+        ("converged", C.c_int32),
+        ("iters", C.c_int32),
+        ("relres", C.c_double),
+        ("bnorm", C.c_double),
+        ("solve_ms", C.c_double),
+        ("resnorm_len", C.c_int64),
+    ]
+
+
+c_ctx = C.c_void_p
+c_prob = C.c_void_p
+P = C.POINTER
+_i64p = C.c_void_p  # arrays are passed as raw addresses (host or device)
+_f64p = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/fvhip.h declares
+SIGNATURES = {
+    "fv_abi_version": (C.c_int, []),
+    "fv_ctx_create": (C.c_int, [C.c_int, P(c_ctx)]),
+    "fv_ctx_destroy": (None, [c_ctx]),
+    "fv_ctx_synchronize": (C.c_int, [c_ctx]),
+    "fv_last_error": (C.c_char_p, [c_ctx]),
+    "fv_device_info": (C.c_int, [c_ctx, C.c_char_p, C.c_int, P(C.c_int), P(C.c_int64)]),
+    "fv_regulargrid_sizes": (C.c_int, [_i64p, P(C.c_int64), P(C.c_int64)]),
+    "fv_regulargrid": (C.c_int, [c_ctx, _f64p, _f64p, _i64p, _f64p, _i64p, _i64p, _f64p, _f64p]),
+    "fv_nodehycos2neighborhycos": (C.c_int, [c_ctx, C.c_int64, _i64p, _i64p, C.c_int64, _f64p, C.c_int, _f64p]),
+    "fv_getfreenodes": (C.c_int, [c_ctx, C.c_int64, C.c_int64, _i64p, C.c_void_p, _i64p, P(C.c_int64)]),
+    "fv_getnodei2dirichleti": (C.c_int, [c_ctx, C.c_int64, _f64p, C.c_int64, _i64p, _i64p, P(C.c_int64)]),
+    "fv_problem_create": (C.c_int, [c_ctx, C.c_int64, C.c_int64, _i64p, _i64p, _f64p, C.c_int64, _i64p, P(c_prob)]),
+    "fv_problem_create_regulargrid": (C.c_int, [c_ctx, _f64p, _f64p, _i64p, C.c_int64, _i64p, P(c_prob)]),
+    "fv_problem_create_from_csc": (C.c_int, [c_ctx, C.c_int64, _i64p, _i64p, _f64p, P(c_prob)]),
+    "fv_problem_destroy": (None, [c_prob]),
+    "fv_problem_sizes": (C.c_int, [c_prob, P(C.c_int64), P(C.c_int64), P(C.c_int64), P(C.c_int64)]),
+    "fv_problem_get_free_maps": (C.c_int, [c_prob, C.c_void_p, _i64p]),
+    "fv_problem_get_grid": (C.c_int, [c_prob, _i64p, _i64p, _f64p, _f64p]),
+    "fv_assemble": (C.c_int, [c_prob, C.c_int64, _f64p, _i64p, C.c_int, _f64p, _f64p, P(C.c_int64)]),
+    "fv_get_csc": (C.c_int, [c_prob, _i64p, _i64p, _f64p]),
+    "fv_get_b": (C.c_int, [c_prob, _f64p]),
+    "fv_freenodes2nodes": (C.c_int, [c_prob, _f64p, _f64p]),
+    "fv_solve_steady": (C.c_int, [c_prob, _f64p, C.c_double, C.c_int64, _f64p, _f64p, _f64p, C.c_int64, P(SolveInfo)]),
+    "fv_transient_begin": (C.c_int, [c_prob, C.c_double, _f64p, _f64p]),
+    "fv_state_alloc": (C.c_int, [c_prob, P(C.c_int32)]),
+    "fv_state_free": (C.c_int, [c_prob, C.c_int32]),
+    "fv_state_set_nodes": (C.c_int, [c_prob, C.c_int32, _f64p]),
+    "fv_state_set_free": (C.c_int, [c_prob, C.c_int32, _f64p]),
+    "fv_state_get_nodes": (C.c_int, [c_prob, C.c_int32, _f64p]),
+    "fv_state_get_free": (C.c_int, [c_prob, C.c_int32, _f64p]),
+    "fv_state_copy": (C.c_int, [c_prob, C.c_int32, C.c_int32]),
+    "fv_state_norm2_diff": (C.c_int, [c_prob, C.c_int32, C.c_int32, P(C.c_double)]),
+    "fv_transient_step": (C.c_int, [c_prob, C.c_int32, C.c_int32, C.c_double, _f64p, C.c_int, C.c_double, C.c_int64, P(SolveInfo)]),
+    "fv_transient_run_fixed": (C.c_int, [c_prob, C.c_int32, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_void_p, P(SolveInfo), P(C.c_double)]),
+    "fv_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
+    "fv_bench_spmv": (C.c_int, [c_prob, C.c_double, C.c_int32, P(C.c_double)]),
+    "fv_dot": (C.c_int, [c_prob, _f64p, _f64p, P(C.c_double)]),
+    "fv_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "fv_comm_init": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p]),
+    "fv_comm_destroy": (C.c_int, [c_ctx]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfvhip.so (no GPU is touched until a context is created)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        raise ImportError(
+            "libfvhip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C finitevolume.jl_amd/csrc`. There is no CPU fallback." % LIBPATH
+        )
+    lib = C.CDLL(LIBPATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    """Address of a numpy array (or None)."""
+    if a is None:
+        return None
+    return a.ctypes.data
+
+
+def ai64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def af64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def check(rc, ctx=None):
+    if rc == FV_OK:
+        return
+    lib = load()
+    msg = lib.fv_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    raise FVError(rc, msg or ("libfvhip error %d" % rc))
+
+
+class Context:
+    """One GPU (fv_ctx)."""
+
+    def __init__(self, device=0):
+        lib = load()
+        h = c_ctx()
+        rc = lib.fv_ctx_create(int(device), C.byref(h))
+        if rc != FV_OK:
+            check(rc, None)
+        self.handle = h
+        self.device = int(device)
+
+    def check(self, rc):
+        check(rc, self.handle)
+
+    def synchronize(self):
+        self.check(load().fv_ctx_synchronize(self.handle))
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int()
+        mem = C.c_int64()
+        self.check(load().fv_device_info(self.handle, name, 256, C.byref(cus), C.byref(mem)))
+        return name.value.decode(), cus.value, mem.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            load().fv_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return _default_ctx

@@ -1,0 +1,376 @@
+"""Host-side mirror of FiniteVolume.jl's functions for the accelerated path.
+
+Same names, positional orders, return tuples and error behaviour as the Julia
+package (/root/reference/src/{FiniteVolume,grid,transient}.jl); all arithmetic is
+done by libfvhip.so on the MI355X.  Julia conventions are kept at this surface:
+indices are 1-based int64, `neighbors` is an (F, 2) int64 array standing for
+Vector{Pair{Int,Int}} (a list of pairs or a (node1, node2) tuple is accepted),
+`coords` is 3 x N.
+
+Closures cannot cross the C ABI, so `metaindex` (a callable i -> index, or an
+index array) is pre-evaluated over 1:F here, `getb(t)` is evaluated on the host
+each step and uploaded, and `callback(t, dt)` is invoked from this side's loop.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import FVError, SolveInfo, af64, ai64, default_context, load, ptr
+
+SQRT_EPS = math.sqrt(np.finfo(np.float64).eps)  # IterativeSolvers' default tol
+
+
+# ------------------------------------------------------------------ helpers
+def _split_neighbors(neighbors):
+    if isinstance(neighbors, tuple) and len(neighbors) == 2 and np.ndim(neighbors[0]) == 1:
+        return ai64(neighbors[0]), ai64(neighbors[1])
+    nb = np.asarray(neighbors, dtype=np.int64)
+    if nb.size == 0:
+        return np.empty(0, np.int64), np.empty(0, np.int64)
+    if nb.ndim != 2 or nb.shape[1] != 2:
+        raise TypeError("neighbors must be (F, 2) pairs")
+    return np.ascontiguousarray(nb[:, 0]), np.ascontiguousarray(nb[:, 1])
+
+
+def _metaindex_array(metaindex, F):
+    if metaindex is None:
+        return None
+    if callable(metaindex):
+        return ai64([metaindex(i) for i in range(1, F + 1)])
+    return ai64(metaindex)
+
+
+class ConvergenceHistory:
+    """What callers read from IterativeSolvers' history: isconverged, data[:resnorm]."""
+
+    def __init__(self, info, resnorm=None):
+        self.isconverged = bool(info.converged)
+        self.iters = int(info.iters)
+        self.mvps = int(info.iters) + 1
+        self.relres = float(info.relres)
+        self.solve_ms = float(info.solve_ms)
+        self.data = {"resnorm": resnorm if resnorm is not None else np.empty(0)}
+
+    def __repr__(self):
+        return "ConvergenceHistory(%s after %d iterations, relres=%.3e)" % (
+            "converged" if self.isconverged else "not converged", self.iters, self.relres)
+
+
+class SparseMatrixCSC:
+    """Julia's SparseMatrixCSC{Float64,Int64}: 1-based colptr/rowval + nzval."""
+
+    def __init__(self, m, n, colptr, rowval, nzval):
+        self.m, self.n = int(m), int(n)
+        self.colptr, self.rowval, self.nzval = colptr, rowval, nzval
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    def copy(self):
+        return SparseMatrixCSC(self.m, self.n, self.colptr.copy(), self.rowval.copy(), self.nzval.copy())
+
+    def toscipy(self):
+        import scipy.sparse as sp
+
+        return sp.csc_matrix((self.nzval, self.rowval - 1, self.colptr - 1), shape=(self.m, self.n))
+
+    @staticmethod
+    def fromscipy(M):
+        M = M.tocsc()
+        M.sort_indices()
+        return SparseMatrixCSC(M.shape[0], M.shape[1], M.indptr.astype(np.int64) + 1, M.indices.astype(np.int64) + 1, M.data.astype(np.float64))
+
+    @staticmethod
+    def fromdense(A):
+        import scipy.sparse as sp
+
+        return SparseMatrixCSC.fromscipy(sp.csc_matrix(np.asarray(A, dtype=np.float64)))
+
+
+# ------------------------------------------------------------------ grid (src/grid.jl)
+def regulargrid(mins, maxs, ns, ctx=None):
+    """grid.jl:56-110 -> coords (3,N), neighbors (F,2), areasoverlengths, volumes."""
+    assert len(mins) == len(maxs)
+    assert len(mins) == len(ns)
+    if len(mins) != 3:
+        raise FVError(_lib.FV_ERR_ARG, "only 3 dimensions supported")
+    ctx = ctx or default_context()
+    lib = load()
+    mins_, maxs_, ns_ = af64(mins), af64(maxs), ai64(ns)
+    N, F = C.c_int64(), C.c_int64()
+    ctx.check(lib.fv_regulargrid_sizes(ptr(ns_), C.byref(N), C.byref(F)))
+    N, F = N.value, F.value
+    coords = np.empty((N, 3), np.float64)
+    n1 = np.empty(F, np.int64)
+    n2 = np.empty(F, np.int64)
+    aol = np.empty(F, np.float64)
+    vol = np.empty(N, np.float64)
+    ctx.check(lib.fv_regulargrid(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), ptr(coords), ptr(n1), ptr(n2), ptr(aol), ptr(vol)))
+    return coords.T, np.stack([n1, n2], axis=1), aol, vol
+
+
+def nodehycos2neighborhycos(neighbors, nodehycos, logtransformhyco=False, ctx=None):
+    """grid.jl:14-33; nodehycos is the (n3, n2, n1) array (column-major order == node order)."""
+    ctx = ctx or default_context()
+    n1, n2 = _split_neighbors(neighbors)
+    nh = af64(np.asarray(nodehycos).ravel(order="F"))
+    out = np.empty(len(n1), np.float64)
+    ctx.check(load().fv_nodehycos2neighborhycos(ctx.handle, len(n1), ptr(n1), ptr(n2), len(nh), ptr(nh), int(bool(logtransformhyco)), ptr(out)))
+    return out
+
+
+# ------------------------------------------------------------------ maps (FiniteVolume.jl:20-44)
+def getfreenodes(n, dirichletnodes, ctx=None):
+    ctx = ctx or default_context()
+    d = ai64(dirichletnodes)
+    freenode = np.empty(n, np.uint8)
+    n2f = np.empty(n, np.int64)
+    nfree = C.c_int64()
+    ctx.check(load().fv_getfreenodes(ctx.handle, int(n), len(d), ptr(d), ptr(freenode), ptr(n2f), C.byref(nfree)))
+    return freenode.astype(bool), n2f
+
+
+def getnodei2dirichleti(sources, dirichletnodes, ctx=None):
+    ctx = ctx or default_context()
+    s, d = af64(sources), ai64(dirichletnodes)
+    out = np.empty(len(s), np.int64)
+    bad = C.c_int64()
+    ctx.check(load().fv_getnodei2dirichleti(ctx.handle, len(s), ptr(s), len(d), ptr(d), ptr(out), C.byref(bad)))
+    return out
+
+
+# ------------------------------------------------------------------ device problem
+class Problem:
+    """fv_problem: the mesh + Dirichlet set resident on the GPU (symbolic CSR built once)."""
+
+    def __init__(self, handle, ctx):
+        self.handle, self.ctx = handle, ctx
+        N, F, n, nnz = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        ctx.check(load().fv_problem_sizes(handle, C.byref(N), C.byref(F), C.byref(n), C.byref(nnz)))
+        self.N, self.F, self.n, self.nnz = N.value, F.value, n.value, nnz.value
+        self._sources = None
+        self._dheads = None
+
+    @classmethod
+    def create(cls, neighbors, areasoverlengths, N, dirichletnodes, ctx=None):
+        ctx = ctx or default_context()
+        n1, n2 = _split_neighbors(neighbors)
+        aol, d = af64(areasoverlengths), ai64(dirichletnodes)
+        if len(aol) < len(n1):
+            raise FVError(_lib.FV_ERR_INDEX, "BoundsError: %d areasoverlengths for %d neighbors" % (len(aol), len(n1)))
+        h = _lib.c_prob()
+        ctx.check(load().fv_problem_create(ctx.handle, int(N), len(n1), ptr(n1), ptr(n2), ptr(aol), len(d), ptr(d), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def regulargrid(cls, mins, maxs, ns, dirichletnodes, ctx=None):
+        ctx = ctx or default_context()
+        mins_, maxs_, ns_, d = af64(mins), af64(maxs), ai64(ns), ai64(dirichletnodes)
+        h = _lib.c_prob()
+        ctx.check(load().fv_problem_create_regulargrid(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), len(d), ptr(d), C.byref(h)))
+        return cls(h, ctx)
+
+    @classmethod
+    def from_csc(cls, A, ctx=None):
+        ctx = ctx or default_context()
+        colptr, rowval, nzval = ai64(A.colptr), ai64(A.rowval), af64(A.nzval)
+        h = _lib.c_prob()
+        ctx.check(load().fv_problem_create_from_csc(ctx.handle, A.n, ptr(colptr), ptr(rowval), ptr(nzval), C.byref(h)))
+        return cls(h, ctx)
+
+    def check(self, rc):
+        self.ctx.check(rc)
+
+    def free_maps(self):
+        freenode = np.empty(self.N, np.uint8)
+        n2f = np.empty(self.N, np.int64)
+        self.check(load().fv_problem_get_free_maps(self.handle, ptr(freenode), ptr(n2f)))
+        return freenode.astype(bool), n2f
+
+    def assemble(self, conductivities, sources, dirichletheads, metaindex=None, logtransformconductivity=False):
+        K, s, dh = af64(conductivities), af64(sources), af64(dirichletheads)
+        if len(s) != self.N:
+            raise FVError(_lib.FV_ERR_ARG, "sources must have one entry per node")
+        mi = _metaindex_array(metaindex, self.F)
+        bad = C.c_int64()
+        self.check(load().fv_assemble(self.handle, len(K), ptr(K), ptr(mi), int(bool(logtransformconductivity)), ptr(s), ptr(dh), C.byref(bad)))
+        return self
+
+    def csc(self):
+        colptr = np.empty(self.n + 1, np.int64)
+        rowval = np.empty(self.nnz, np.int64)
+        nzval = np.empty(self.nnz, np.float64)
+        self.check(load().fv_get_csc(self.handle, ptr(colptr), ptr(rowval), ptr(nzval)))
+        return SparseMatrixCSC(self.n, self.n, colptr, rowval, nzval)
+
+    def b(self):
+        b = np.empty(self.n, np.float64)
+        self.check(load().fv_get_b(self.handle, ptr(b)))
+        return b
+
+    def freenodes2nodes(self, result):
+        r = af64(result)
+        head = np.empty(self.N, np.float64)
+        self.check(load().fv_freenodes2nodes(self.handle, ptr(r), ptr(head)))
+        return head
+
+    def solve_steady(self, x0=None, rtol=SQRT_EPS, maxiter=400, want_head=True, want_resnorm=True):
+        x0_ = af64(x0) if x0 is not None else None
+        head = np.empty(self.N, np.float64) if want_head else None
+        res = np.empty(self.n, np.float64)
+        hist = np.empty(max(int(maxiter), 1), np.float64) if want_resnorm else None
+        info = SolveInfo()
+        self.check(load().fv_solve_steady(self.handle, ptr(x0_), float(rtol), int(maxiter), ptr(head), ptr(res), ptr(hist), len(hist) if hist is not None else 0, C.byref(info)))
+        ch = ConvergenceHistory(info, hist[: info.resnorm_len].copy() if hist is not None else None)
+        return head, res, ch
+
+    def spmv(self, x, sigma=0.0):
+        x_ = af64(x)
+        y = np.empty(self.n, np.float64)
+        self.check(load().fv_spmv(self.handle, ptr(x_), float(sigma), ptr(y)))
+        return y
+
+    def dot(self, a, b):
+        a_, b_ = af64(a), af64(b)
+        out = C.c_double()
+        self.check(load().fv_dot(self.handle, ptr(a_), ptr(b_), C.byref(out)))
+        return out.value
+
+    def bench_spmv(self, sigma=0.0, reps=20):
+        ms = C.c_double()
+        self.check(load().fv_bench_spmv(self.handle, float(sigma), int(reps), C.byref(ms)))
+        return ms.value
+
+    # ---- transient
+    def transient_begin(self, Ss, volumes, u0_nodes):
+        v = af64(volumes) if volumes is not None else None
+        u = af64(u0_nodes) if u0_nodes is not None else None
+        self.check(load().fv_transient_begin(self.handle, float(Ss), ptr(v), ptr(u)))
+        return DeviceVector(self, 0, owned=False)
+
+    def new_state(self):
+        s = C.c_int32()
+        self.check(load().fv_state_alloc(self.handle, C.byref(s)))
+        return DeviceVector(self, s.value, owned=True)
+
+    def step(self, src, dst, dt, bhat=None, mode=_lib.FV_STEP_FORWARD, rtol=SQRT_EPS, maxiter=1000):
+        bh = af64(bhat) if bhat is not None else None
+        info = SolveInfo()
+        self.check(load().fv_transient_step(self.handle, src.slot, dst.slot, float(dt), ptr(bh), int(mode), float(rtol), int(maxiter), C.byref(info)))
+        return info
+
+    def run_fixed(self, state, dt, nsteps, rtol=SQRT_EPS, maxiter=1000):
+        iters = np.zeros(max(int(nsteps), 1), np.int32)
+        info = SolveInfo()
+        ms = C.c_double()
+        self.check(load().fv_transient_run_fixed(self.handle, state.slot, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
+        return iters[: int(nsteps)], info, ms.value
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            load().fv_problem_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceVector:
+    """A state vector over the free cells, resident on the GPU (a slot of its Problem)."""
+
+    def __init__(self, problem, slot, owned=True):
+        self.problem, self.slot, self.owned = problem, int(slot), owned
+
+    def free_values(self):
+        out = np.empty(self.problem.n, np.float64)
+        self.problem.check(load().fv_state_get_free(self.problem.handle, self.slot, ptr(out)))
+        return out
+
+    def node_values(self):
+        out = np.empty(self.problem.N, np.float64)
+        self.problem.check(load().fv_state_get_nodes(self.problem.handle, self.slot, ptr(out)))
+        return out
+
+    def set_free(self, u):
+        u_ = af64(u)
+        self.problem.check(load().fv_state_set_free(self.problem.handle, self.slot, ptr(u_)))
+        return self
+
+    def norm2_diff(self, other):
+        out = C.c_double()
+        self.problem.check(load().fv_state_norm2_diff(self.problem.handle, self.slot, other.slot, C.byref(out)))
+        return out.value
+
+    def __array__(self, dtype=None, copy=None):
+        return self.free_values()
+
+    def __len__(self):
+        return self.problem.n
+
+    def __del__(self):
+        try:
+            if self.owned and self.problem.handle:
+                load().fv_state_free(self.problem.handle, self.slot)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ assembly (FiniteVolume.jl:75-155)
+class DeviceMatrix(SparseMatrixCSC):
+    """The matrix assembleA returns: a genuine SparseMatrixCSC (host copies of the
+    index/value arrays) that also remembers the device problem it was assembled on."""
+
+    def __init__(self, problem, csc):
+        super().__init__(csc.m, csc.n, csc.colptr, csc.rowval, csc.nzval)
+        self.problem = problem
+
+
+def _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity, ctx=None):
+    p = Problem.create(neighbors, areasoverlengths, len(sources), dirichletnodes, ctx)
+    p.assemble(conductivities, sources, dirichletheads, metaindex, logtransformconductivity)
+    return p
+
+
+def assembleA(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, ctx=None):
+    """FiniteVolume.jl:75-108"""
+    src = af64(sources)
+    # assembleA itself never validates the sources (only assembleb does, :111)
+    p = _assembled_problem(neighbors, areasoverlengths, conductivities, np.zeros_like(src), dirichletnodes, dirichletheads, metaindex, logtransformconductivity, ctx)
+    return DeviceMatrix(p, p.csc())
+
+
+def assembleb(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, ctx=None):
+    """FiniteVolume.jl:110-139"""
+    p = _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity, ctx)
+    return p.b()
+
+
+def freenodes2nodes(result, sources, dirichletnodes, dirichletheads, ctx=None):
+    """FiniteVolume.jl:141-155 -> head, freenode, nodei2freenodei"""
+    ctx = ctx or default_context()
+    getnodei2dirichleti(sources, dirichletnodes, ctx)  # the reference validates here too (:142)
+    N = len(sources)
+    p = Problem.create(np.empty((0, 2), np.int64), np.empty(0), N, dirichletnodes, ctx)
+    p.assemble(np.empty(0), sources, dirichletheads)
+    head = p.freenodes2nodes(result)
+    freenode, n2f = p.free_maps()
+    return head, freenode, n2f
+
+
+def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None):
+    """FiniteVolume.jl:157-165 -> head, ch, A, b, freenode.
+
+    The reference preconditions CG with Ruge-Stuben AMG; this build runs
+    Jacobi-PCG on the GPU (BASELINE.json north_star), so `maxiter` counts Jacobi-PCG
+    iterations.  As in the reference, non-convergence is reported through
+    ch.isconverged, not raised."""
+    p = _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, None, False, ctx)
+    head, _, ch = p.solve_steady(None, rtol, maxiter)
+    freenode, _ = p.free_maps()
+    return head, ch, DeviceMatrix(p, p.csc()), p.b(), freenode

@@ -1,0 +1,212 @@
+// Context, error reporting and the device exclusive scan used by the map and
+// CSR-pointer builders.
+#include "fv_internal.h"
+
+static thread_local std::string g_err;
+
+void fv_set_error(fv_ctx *ctx, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->err = buf;
+    g_err = buf;
+}
+
+extern "C" int fv_abi_version(void) { return FVHIP_ABI_VERSION; }
+
+extern "C" const char *fv_last_error(fv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int fv_ctx_create(int device, fv_ctx **out)
+{
+    if (!out)
+        return FV_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        fv_set_error(nullptr, "no HIP device visible (hipGetDeviceCount: %s); libfvhip has no CPU fallback",
+                     hipGetErrorString(e));
+        return FV_ERR_HIP;
+    }
+    if (device < 0 || device >= count) {
+        fv_set_error(nullptr, "device %d out of range (have %d)", device, count);
+        return FV_ERR_ARG;
+    }
+    fv_ctx *ctx = new fv_ctx();
+    ctx->device = device;
+    FV_HIP(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    FV_HIP(ctx, hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->total_mem = (int64_t)prop.totalGlobalMem;
+    ctx->name = prop.name;
+    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    FV_HIP(ctx, hipEventCreate(&ctx->ev0));
+    FV_HIP(ctx, hipEventCreate(&ctx->ev1));
+    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comp, hipEventDisableTiming));
+    ctx->pinned_bytes = 4096;
+    FV_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    *out = ctx;
+    return FV_OK;
+}
+
+extern "C" void fv_ctx_destroy(fv_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    fv_comm_destroy(ctx);
+    if (ctx->pinned)
+        (void)hipHostFree(ctx->pinned);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_halo) (void)hipEventDestroy(ctx->ev_halo);
+    if (ctx->ev_comp) (void)hipEventDestroy(ctx->ev_comp);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    delete ctx;
+}
+
+extern "C" int fv_ctx_synchronize(fv_ctx *ctx)
+{
+    if (!ctx)
+        return FV_ERR_ARG;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_HIP(ctx, hipDeviceSynchronize());
+    return FV_OK;
+}
+
+extern "C" int fv_device_info(fv_ctx *ctx, char *name, int name_cap, int *compute_units, int64_t *total_mem_bytes)
+{
+    if (!ctx)
+        return FV_ERR_ARG;
+    if (name && name_cap > 0)
+        snprintf(name, (size_t)name_cap, "%s", ctx->name.c_str());
+    if (compute_units)
+        *compute_units = ctx->num_cus;
+    if (total_mem_bytes)
+        *total_mem_bytes = ctx->total_mem;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ exclusive scan
+// Three-phase hierarchical scan: tiles of 2048 int32 (256 threads x 8), tile
+// totals scanned recursively in int64, then added back.  Deterministic.
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = FV_BLOCK * SCAN_ITEMS;
+
+template <class Tin>
+__global__ __launch_bounds__(FV_BLOCK) void scan_tile_kernel(const Tin *__restrict__ in, int64_t n,
+                                                              int64_t *__restrict__ local, int64_t *__restrict__ tile_sums)
+{
+    __shared__ int64_t wave_tot[FV_BLOCK / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int64_t v[SCAN_ITEMS];
+    int64_t tsum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int64_t i = base + k;
+        v[k] = (i < n) ? (int64_t)in[i] : 0;
+        tsum += v[k];
+    }
+    // inclusive scan of tsum across the wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t inc = tsum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int64_t o = __shfl_up(inc, off, 64);
+        if (lane >= off)
+            inc += o;
+    }
+    if (lane == 63)
+        wave_tot[wave] = inc;
+    __syncthreads();
+    int64_t woff = 0;
+    for (int w = 0; w < wave; w++)
+        woff += wave_tot[w];
+    int64_t run = woff + inc - tsum; // exclusive prefix of this thread within the tile
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const int64_t i = base + k;
+        if (i < n)
+            local[i] = run;
+        run += v[k];
+    }
+    if (threadIdx.x == FV_BLOCK - 1)
+        tile_sums[blockIdx.x] = run;
+}
+
+template <class Tout>
+__global__ __launch_bounds__(FV_BLOCK) void scan_add_kernel(const int64_t *__restrict__ local,
+                                                             const int64_t *__restrict__ tile_off, int64_t n,
+                                                             Tout *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        out[i] = (Tout)(local[i] + tile_off[i / SCAN_TILE]);
+}
+
+// in-place-capable recursive scan on int64 data: data[i] <- exclusive prefix, returns total (host)
+static int scan_i64_inplace(fv_ctx *ctx, int64_t *data, int64_t n, int64_t *total)
+{
+    if (n <= 0) {
+        *total = 0;
+        return FV_OK;
+    }
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    DevBuf<int64_t> local, sums;
+    FV_TRY(local.alloc(ctx, (size_t)n));
+    FV_TRY(sums.alloc(ctx, (size_t)ntiles));
+    hipLaunchKernelGGL(scan_tile_kernel<int64_t>, dim3((unsigned)ntiles), dim3(FV_BLOCK), 0, ctx->stream, data, n, local.p,
+                       sums.p);
+    FV_LAUNCH_CHECK(ctx);
+    if (ntiles > 1) {
+        FV_TRY(scan_i64_inplace(ctx, sums.p, ntiles, total));
+    } else {
+        FV_HIP(ctx, hipMemcpyAsync(total, sums.p, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        FV_HIP(ctx, hipMemsetAsync(sums.p, 0, sizeof(int64_t), ctx->stream));
+    }
+    hipLaunchKernelGGL(scan_add_kernel<int64_t>, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, local.p, sums.p, n,
+                       data);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+int fv_exclusive_scan_i32(fv_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total)
+{
+    if (n <= 0) {
+        *total = 0;
+        int32_t z = 0;
+        FV_HIP(ctx, hipMemcpyAsync(out, &z, sizeof z, hipMemcpyHostToDevice, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FV_OK;
+    }
+    const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    DevBuf<int64_t> local, sums;
+    FV_TRY(local.alloc(ctx, (size_t)n));
+    FV_TRY(sums.alloc(ctx, (size_t)ntiles));
+    hipLaunchKernelGGL(scan_tile_kernel<int32_t>, dim3((unsigned)ntiles), dim3(FV_BLOCK), 0, ctx->stream, in, n, local.p,
+                       sums.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(scan_i64_inplace(ctx, sums.p, ntiles, total));
+    if (*total > 0x7fffffffLL) {
+        fv_set_error(ctx, "scan total %lld exceeds the int32 device index range", (long long)*total);
+        return FV_ERR_TOO_LARGE;
+    }
+    hipLaunchKernelGGL(scan_add_kernel<int32_t>, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, local.p, sums.p, n,
+                       out);
+    FV_LAUNCH_CHECK(ctx);
+    const int32_t t32 = (int32_t)*total;
+    FV_HIP(ctx, hipMemcpyAsync(out + n, &t32, sizeof t32, hipMemcpyHostToDevice, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}

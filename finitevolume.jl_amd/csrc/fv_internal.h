@@ -1,0 +1,181 @@
+// Internal declarations shared by the HIP translation units of libfvhip.so.
+// gfx950 (MI355X, wave64) only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "fvhip.h"
+
+constexpr int FV_BLOCK = 256;        // 4 waves of 64
+constexpr int FV_MAX_PARTIALS = 2048; // 8 blocks/CU x 256 CUs: one partial per block
+
+struct fv_ctx {
+    int device = 0;
+    int num_cus = 256;
+    int64_t total_mem = 0;
+    std::string name;
+    hipStream_t stream = nullptr;  // compute
+    hipStream_t stream2 = nullptr; // halo / collectives
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_halo = nullptr, ev_comp = nullptr;
+    void *pinned = nullptr; // small pinned scratch for scalar read-back
+    size_t pinned_bytes = 0;
+    std::string err;
+    // RCCL
+    void *comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
+
+#define FV_HIP(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t e__ = (call);                                                                                \
+        if (e__ != hipSuccess) {                                                                                \
+            fv_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__);      \
+            return FV_ERR_HIP;                                                                                  \
+        }                                                                                                       \
+    } while (0)
+
+#define FV_TRY(expr)                                                                                            \
+    do {                                                                                                        \
+        int rc__ = (expr);                                                                                      \
+        if (rc__ != FV_OK)                                                                                      \
+            return rc__;                                                                                        \
+    } while (0)
+
+#define FV_LAUNCH_CHECK(ctx) FV_HIP(ctx, hipGetLastError())
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(fv_ctx *ctx, size_t count)
+    {
+        release();
+        if (count == 0)
+            count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            fv_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+            return FV_ERR_NOMEM;
+        }
+        n = count;
+        return FV_OK;
+    }
+    int zero(fv_ctx *ctx) { FV_HIP(ctx, hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream)); return FV_OK; }
+};
+
+// never 0: every kernel bounds-checks, and a zero-sized grid is a launch error
+inline unsigned fv_blocks(int64_t n, int per_block = FV_BLOCK)
+{
+    const int64_t b = (n + per_block - 1) / per_block;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+
+// Device-side PCG scalars (one instance per problem).
+struct PcgScalars {
+    double rz[2];  // r.M^-1.r, indexed by iteration parity
+    double rr;     // ||r||^2 (recurrence)
+    double tol2;   // (rtol*||b||)^2
+    double bnorm2; // ||b||^2
+    double pq;     // last p.Ap (diagnostic)
+    int32_t iters;
+    int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN)
+};
+
+struct fv_problem {
+    fv_ctx *ctx = nullptr;
+    int64_t N = 0, F = 0, n = 0, nnz = 0, ndir = 0, E = 0;
+    bool from_grid = false, from_csc = false, assembled = false, transient_ready = false;
+    int64_t ns[3] = {0, 0, 0};
+
+    // mesh (0-based int32 on device)
+    DevBuf<int32_t> node1, node2;
+    DevBuf<double> aol, gridvol;
+    DevBuf<int32_t> nodemap; // N: >= 0 free index, < 0: -(dirichlet position + 1), last occurrence wins
+    DevBuf<int32_t> f2n;     // n: free index -> node
+    DevBuf<int32_t> dnodes0; // ndir: Dirichlet nodes, 0-based, caller order
+
+    // symbolic structure of assembleA
+    DevBuf<int32_t> incptr;    // n+1: incident (face,end) entries per free row
+    DevBuf<uint32_t> inc_face; // E: face<<1 | end, ascending per row == face order
+    DevBuf<uint32_t> inc_slot; // E: bit31 = first contribution to its slot; low bits = slot - rowptr[row]; 0x7fffffff = other end is Dirichlet
+    DevBuf<int32_t> rowptr, colind, diagpos;
+
+    // numeric
+    DevBuf<double> cond, vals, b, diagA, dheads;
+
+    // transient
+    double Ss = 1.0;
+    DevBuf<double> D; // Ss * volumes[free]
+    std::vector<double *> slots;
+    std::vector<char> slot_used;
+
+    // PCG workspace
+    DevBuf<double> r, pvec, q, minv, rhs, tmp;
+    DevBuf<double> part_pq, part_rz, part_rr, part_bb;
+    DevBuf<double> hist;
+    DevBuf<PcgScalars> scal;
+    int64_t hist_cap = 0;
+
+    ~fv_problem()
+    {
+        for (double *s : slots)
+            if (s)
+                (void)hipFree(s);
+    }
+};
+
+// ---- fv_scan.hip
+// out[i] = sum(in[0..i-1]) for i in [0, n]; out has n+1 entries. total returned on host.
+int fv_exclusive_scan_i32(fv_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
+
+// ---- fv_grid.hip
+int fv_grid_axes(const double mins[3], const double maxs[3], const int64_t ns[3], std::vector<double> ax[3]);
+int fv_grid_generate_device(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3], int32_t *node1,
+                            int32_t *node2, double *aol, double *volumes, double *coords);
+
+// ---- fv_assembly.hip
+int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes_host_or_dev);
+int fv_build_symbolic(fv_problem *p);
+int fv_widen_indices(fv_ctx *ctx, const int32_t *src, int64_t *dst, int64_t n, int64_t add);
+int fv_narrow_indices(fv_ctx *ctx, const int64_t *src, int32_t *dst, int64_t n, int64_t lo, int64_t hi, int *bad);
+int fv_scatter_nodes(fv_problem *p, const double *ufree_dev, double *head_dev); // freenodes2nodes on device buffers
+int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev);  // u[freenodes]
+
+// ---- fv_pcg.hip
+int fv_pcg_prepare(fv_problem *p);
+// Solve (A + sigma*D) x = rhs, x holds the initial guess (x0_zero: treat as zeros).
+int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool x0_zero, double rtol, int64_t maxiter,
+                 fv_solve_info *info, bool time_it);
+int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null);
+int fv_spmv_grid(fv_problem *p);
+int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);
+int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double *out_host);
+
+// copy helper: dst/src may be host or device
+inline int fv_copy(fv_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    if (bytes == 0)
+        return FV_OK;
+    FV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}

@@ -1,0 +1,425 @@
+// Steady solve, implicit time stepping and device-resident state vectors.
+// Reference: /root/reference/src/FiniteVolume.jl:157-165 (solvediffusion),
+// src/transient.jl:7-22 (scalebyvolume!), :60-76 (backwardeuleronestep!),
+// :130-154 (fixed stepper + outer loop), :188-205 (adjointintegrate).
+//
+// The reference row-scales A by 1/(Ss*V) and shifts the stored diagonal by
+// +-1/dt around every solve.  Here A is never touched: each step solves the
+// equivalent symmetric positive definite system
+//        (D/dt + A) u+ = D u/dt + b ,     D = diag(Ss*V_free)
+// with the shift applied inside the SpMV and the Jacobi diagonal.
+#include "fv_internal.h"
+
+static int need_assembled(fv_problem *p, const char *who)
+{
+    if (!p->assembled) {
+        fv_set_error(p->ctx, "%s: call fv_assemble first", who);
+        return FV_ERR_STATE;
+    }
+    return FV_OK;
+}
+
+static int slot_ptr(fv_problem *p, int32_t slot, double **out)
+{
+    if (slot < 0 || slot >= (int32_t)p->slots.size() || !p->slot_used[(size_t)slot]) {
+        fv_set_error(p->ctx, "invalid state slot %d", (int)slot);
+        return FV_ERR_ARG;
+    }
+    *out = p->slots[(size_t)slot];
+    return FV_OK;
+}
+
+static int slot_new(fv_problem *p, int32_t *slot)
+{
+    for (size_t i = 0; i < p->slots.size(); i++)
+        if (!p->slot_used[i]) {
+            p->slot_used[i] = 1;
+            *slot = (int32_t)i;
+            return FV_OK;
+        }
+    double *d = nullptr;
+    hipError_t e = hipMalloc((void **)&d, ((size_t)p->n + 2) * sizeof(double));
+    if (e != hipSuccess) {
+        fv_set_error(p->ctx, "hipMalloc of a state vector failed: %s", hipGetErrorString(e));
+        return FV_ERR_NOMEM;
+    }
+    p->slots.push_back(d);
+    p->slot_used.push_back(1);
+    *slot = (int32_t)p->slots.size() - 1;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ steady (a8)
+extern "C" int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol, int64_t maxiter, double *head_nodes,
+                               double *result_free, double *resnorm, int64_t resnorm_cap, fv_solve_info *info)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_assembled(p, "fv_solve_steady"));
+    FV_TRY(fv_pcg_prepare(p));
+    if (resnorm && resnorm_cap > 0) {
+        const int64_t want = resnorm_cap < maxiter ? resnorm_cap : maxiter;
+        if (want > p->hist_cap) {
+            FV_TRY(p->hist.alloc(ctx, (size_t)want));
+            p->hist_cap = want;
+        }
+    }
+    double *x = p->tmp.p;
+    if (x0_free)
+        FV_HIP(ctx, hipMemcpyAsync(x, x0_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    fv_solve_info local;
+    double *saved_hist = p->hist.p;
+    const int64_t saved_cap = p->hist_cap;
+    if (!resnorm) { // no history wanted: do not write it
+        p->hist.p = nullptr;
+        p->hist_cap = 0;
+    }
+    const int rc = fv_pcg_solve(p, x, p->b.p, 0.0, x0_free == nullptr, rtol, maxiter, &local, true);
+    p->hist.p = saved_hist;
+    p->hist_cap = saved_cap;
+    FV_TRY(rc);
+    if (resnorm && resnorm_cap > 0) {
+        int64_t len = local.iters < resnorm_cap ? local.iters : resnorm_cap;
+        if (len > p->hist_cap)
+            len = p->hist_cap;
+        FV_TRY(fv_copy(ctx, resnorm, p->hist.p, (size_t)len * sizeof(double)));
+        local.resnorm_len = len;
+    }
+    if (result_free)
+        FV_TRY(fv_copy(ctx, result_free, x, (size_t)p->n * sizeof(double)));
+    if (head_nodes) {
+        DevBuf<double> hd;
+        FV_TRY(hd.alloc(ctx, (size_t)p->N));
+        FV_TRY(fv_scatter_nodes(p, x, hd.p));
+        FV_TRY(fv_copy(ctx, head_nodes, hd.p, (size_t)p->N * sizeof(double)));
+    }
+    if (info)
+        *info = local;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ transient set-up (a9)
+__global__ __launch_bounds__(FV_BLOCK) void storage_kernel(int64_t n, const int32_t *__restrict__ f2n, const double *__restrict__ vol,
+                                                            double Ss, double *__restrict__ D)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        D[i] = vol ? Ss * vol[f2n[i]] : Ss; // `Ss * volumes`, transient.jl:160,169
+}
+
+extern "C" int fv_transient_begin(fv_problem *p, double Ss, const double *volumes, const double *u0_nodes)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_assembled(p, "fv_transient_begin"));
+    FV_TRY(fv_pcg_prepare(p));
+    FV_TRY(p->D.alloc(ctx, (size_t)p->n + 2));
+    p->Ss = Ss;
+    DevBuf<double> dvol;
+    const double *vol = nullptr;
+    if (volumes) {
+        FV_TRY(dvol.alloc(ctx, (size_t)p->N));
+        FV_HIP(ctx, hipMemcpyAsync(dvol.p, volumes, (size_t)p->N * sizeof(double), hipMemcpyDefault, ctx->stream));
+        vol = dvol.p;
+    } else if (p->from_grid)
+        vol = p->gridvol.p;
+    if (p->n > 0) {
+        hipLaunchKernelGGL(storage_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->f2n.p, vol, Ss, p->D.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    if (p->slots.empty()) {
+        int32_t s0;
+        FV_TRY(slot_new(p, &s0));
+    }
+    p->slot_used[0] = 1;
+    if (u0_nodes) {
+        DevBuf<double> du;
+        FV_TRY(du.alloc(ctx, (size_t)p->N));
+        FV_HIP(ctx, hipMemcpyAsync(du.p, u0_nodes, (size_t)p->N * sizeof(double), hipMemcpyDefault, ctx->stream));
+        FV_TRY(fv_gather_free(p, du.p, p->slots[0])); // u0[freenodes], transient.jl:170
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else
+        FV_HIP(ctx, hipMemsetAsync(p->slots[0], 0, (size_t)p->n * sizeof(double), ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->transient_ready = true;
+    return FV_OK;
+}
+
+static int need_transient(fv_problem *p, const char *who)
+{
+    if (!p->transient_ready) {
+        fv_set_error(p->ctx, "%s: call fv_transient_begin first", who);
+        return FV_ERR_STATE;
+    }
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ state vectors
+extern "C" int fv_state_alloc(fv_problem *p, int32_t *slot)
+{
+    if (!p || !slot)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    FV_TRY(need_transient(p, "fv_state_alloc"));
+    return slot_new(p, slot);
+}
+
+extern "C" int fv_state_free(fv_problem *p, int32_t slot)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    double *d;
+    FV_TRY(slot_ptr(p, slot, &d));
+    if (slot == 0) {
+        fv_set_error(p->ctx, "slot 0 is owned by the problem");
+        return FV_ERR_ARG;
+    }
+    p->slot_used[(size_t)slot] = 0;
+    return FV_OK;
+}
+
+extern "C" int fv_state_set_nodes(fv_problem *p, int32_t slot, const double *u_nodes)
+{
+    if (!p || !u_nodes)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    double *d;
+    FV_TRY(slot_ptr(p, slot, &d));
+    DevBuf<double> du;
+    FV_TRY(du.alloc(ctx, (size_t)p->N));
+    FV_HIP(ctx, hipMemcpyAsync(du.p, u_nodes, (size_t)p->N * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_gather_free(p, du.p, d));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+extern "C" int fv_state_set_free(fv_problem *p, int32_t slot, const double *u_free)
+{
+    if (!p || !u_free)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    double *d;
+    FV_TRY(slot_ptr(p, slot, &d));
+    return fv_copy(p->ctx, d, u_free, (size_t)p->n * sizeof(double));
+}
+
+extern "C" int fv_state_get_nodes(fv_problem *p, int32_t slot, double *u_nodes)
+{
+    if (!p || !u_nodes)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    double *d;
+    FV_TRY(slot_ptr(p, slot, &d));
+    DevBuf<double> hd;
+    FV_TRY(hd.alloc(ctx, (size_t)p->N));
+    FV_TRY(fv_scatter_nodes(p, d, hd.p));
+    return fv_copy(ctx, u_nodes, hd.p, (size_t)p->N * sizeof(double));
+}
+
+extern "C" int fv_state_get_free(fv_problem *p, int32_t slot, double *u_free)
+{
+    if (!p || !u_free)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    double *d;
+    FV_TRY(slot_ptr(p, slot, &d));
+    return fv_copy(p->ctx, u_free, d, (size_t)p->n * sizeof(double));
+}
+
+extern "C" int fv_state_copy(fv_problem *p, int32_t src, int32_t dst)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    double *a, *b;
+    FV_TRY(slot_ptr(p, src, &a));
+    FV_TRY(slot_ptr(p, dst, &b));
+    if (a != b)
+        FV_TRY(fv_copy(p->ctx, b, a, (size_t)p->n * sizeof(double)));
+    return FV_OK;
+}
+
+extern "C" int fv_state_norm2_diff(fv_problem *p, int32_t a, int32_t b, double *out)
+{
+    if (!p || !out)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    double *pa, *pb;
+    FV_TRY(slot_ptr(p, a, &pa));
+    FV_TRY(slot_ptr(p, b, &pb));
+    return fv_norm2_diff_device(p, pa, pb, out);
+}
+
+// ------------------------------------------------------------------ one implicit step (a11)
+// forward:  rhs = D*(bhat + u/dt)         (bhat = volume-scaled b of the reference, transient.jl:71)
+//           rhs = b + D*(u/dt)            (bhat absent: the assembled, unscaled b)
+// adjoint:  the state is g = D w;  rhs = bhat + g/dt, initial guess w = g/D, afterwards g+ = D w+
+__global__ __launch_bounds__(FV_BLOCK) void step_rhs_kernel(int64_t n, int mode, double dt, const double *__restrict__ u,
+                                                             const double *__restrict__ D, const double *__restrict__ bhat,
+                                                             const double *__restrict__ b, double *__restrict__ rhs,
+                                                             double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const double ui = u[i], di = D[i];
+    if (mode == FV_STEP_FORWARD) {
+        rhs[i] = bhat ? di * (bhat[i] + ui / dt) : b[i] + di * (ui / dt);
+        x[i] = ui;
+    } else {
+        rhs[i] = (bhat ? bhat[i] : 0.0) + ui / dt;
+        x[i] = ui / di;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double *__restrict__ D, double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        x[i] *= D[i];
+}
+
+static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
+                     int64_t maxiter, fv_solve_info *info, bool time_it)
+{
+    fv_ctx *ctx = p->ctx;
+    if (!(dt > 0)) {
+        fv_set_error(ctx, "time step must be positive"); // transient.jl:68-70
+        return FV_ERR_DT;
+    }
+    // the solve runs in tmp so that src == dst is allowed
+    if (p->n > 0) {
+        hipLaunchKernelGGL(step_rhs_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, mode, dt, usrc, p->D.p,
+                           bhat_dev, p->b.p, p->rhs.p, p->tmp.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_TRY(fv_pcg_solve(p, p->tmp.p, p->rhs.p, 1.0 / dt, false, rtol, maxiter, info, time_it));
+    if (mode == FV_STEP_ADJOINT && p->n > 0) {
+        hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, p->tmp.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_HIP(ctx, hipMemcpyAsync(udst, p->tmp.p, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return FV_OK;
+}
+
+extern "C" int fv_transient_step(fv_problem *p, int32_t src, int32_t dst, double dt, const double *bhat_free, int mode, double rtol,
+                                 int64_t maxiter, fv_solve_info *info)
+{
+    if (!p || (mode != FV_STEP_FORWARD && mode != FV_STEP_ADJOINT))
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_transient(p, "fv_transient_step"));
+    double *a, *b;
+    FV_TRY(slot_ptr(p, src, &a));
+    FV_TRY(slot_ptr(p, dst, &b));
+    DevBuf<double> dbh;
+    const double *bh = nullptr;
+    if (bhat_free) {
+        FV_TRY(dbh.alloc(ctx, (size_t)p->n));
+        FV_HIP(ctx, hipMemcpyAsync(dbh.p, bhat_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+        bh = dbh.p;
+    }
+    FV_TRY(step_impl(p, a, b, dt, bh, mode, rtol, maxiter, info, true));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, int64_t nsteps, double rtol, int64_t maxiter,
+                                      int32_t *iters_per_step, fv_solve_info *last_info, double *total_ms)
+{
+    if (!p || nsteps < 0)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_transient(p, "fv_transient_run_fixed"));
+    double *u;
+    FV_TRY(slot_ptr(p, slot, &u));
+    hipEvent_t e0, e1;
+    FV_HIP(ctx, hipEventCreate(&e0));
+    FV_HIP(ctx, hipEventCreate(&e1));
+    FV_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    fv_solve_info inf = {};
+    int rc = FV_OK;
+    for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
+        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false);
+        if (iters_per_step)
+            iters_per_step[s] = inf.iters;
+    }
+    if (rc == FV_OK) {
+        hipError_t e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess)
+            e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) {
+            fv_set_error(ctx, "event timing failed: %s", hipGetErrorString(e));
+            rc = FV_ERR_HIP;
+        }
+        if (total_ms)
+            *total_ms = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (last_info)
+        *last_info = inf;
+    return rc;
+}
+
+// ------------------------------------------------------------------ kernel-level entry points
+extern "C" int fv_spmv(fv_problem *p, const double *x_free, double sigma, double *y_free)
+{
+    if (!p || !x_free || !y_free)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_assembled(p, "fv_spmv"));
+    if (sigma != 0.0)
+        FV_TRY(need_transient(p, "fv_spmv with sigma != 0"));
+    FV_TRY(fv_pcg_prepare(p));
+    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, x_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_spmv_launch(p, p->tmp.p, p->rhs.p, sigma, nullptr));
+    return fv_copy(ctx, y_free, p->rhs.p, (size_t)p->n * sizeof(double));
+}
+
+extern "C" int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms)
+{
+    if (!p || reps <= 0 || !avg_ms)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_assembled(p, "fv_bench_spmv"));
+    if (sigma != 0.0)
+        FV_TRY(need_transient(p, "fv_bench_spmv with sigma != 0"));
+    FV_TRY(fv_pcg_prepare(p));
+    // the PCG's own kernel: SpMV with the p.q epilogue, on the resident search direction
+    FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p)); // warm
+    FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int32_t i = 0; i < reps; i++)
+        FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p));
+    FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    FV_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    FV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / reps;
+    return FV_OK;
+}
+
+extern "C" int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *out)
+{
+    if (!p || !a_free || !b_free || !out)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(fv_pcg_prepare(p));
+    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, a_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_HIP(ctx, hipMemcpyAsync(p->rhs.p, b_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    return fv_dot_device(p, p->tmp.p, p->rhs.p, out);
+}

@@ -1,0 +1,190 @@
+/*
+ * fvhip.h — C ABI of libfvhip.so, the MI355X (gfx950) implementation of
+ * FiniteVolume.jl's hot path: grid/connectivity generation, Dirichlet
+ * elimination + sparse assembly into CSR, the steady solve and the implicit
+ * (backward-Euler) transient step, solved by Jacobi-preconditioned CG built
+ * from hand-written HIP kernels.
+ *
+ * The reference (madsjulia/FiniteVolume.jl) is pure Julia and exposes no FFI:
+ * its "interface" is a set of Julia functions.  Each entry point below names
+ * the reference function(s) it replaces (file:line under /root/reference) —
+ * the Julia shim (finitevolume.jl_amd/julia/FiniteVolumeHIP.jl) and the Python
+ * mirror (finitevolume.jl_amd/) `ccall`/ctypes exactly these symbols.
+ *
+ * Conventions
+ *   - Index arrays crossing the boundary are int64 and 1-BASED, as Julia's
+ *     `Int` arrays are (neighbors' Pair halves, dirichletnodes, metaindex,
+ *     colptr/rowval).  On the device they are int32 0-based.
+ *   - Reals are double (Float64).
+ *   - Every pointer argument may address host memory or device memory of the
+ *     context's GPU; the library copies with hipMemcpyDefault during the call
+ *     and never retains caller pointers.  Outputs go to caller-allocated
+ *     buffers whose lengths come from the *_sizes queries.
+ *   - Every function returns an int status (FV_OK == 0).  On failure
+ *     fv_last_error() returns a message; for the reference's own validation
+ *     errors the message text is the reference's (e.g. FiniteVolume.jl:26).
+ *     No C++ exception or abort crosses the boundary.
+ *   - One host thread per context; calls are synchronous at return.
+ *     Not re-entrant on the same handle.
+ */
+#ifndef FVHIP_H
+#define FVHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVHIP_ABI_VERSION 1
+
+enum {
+    FV_OK = 0,
+    FV_ERR_ARG = 1,
+    FV_ERR_SOURCE_AT_DIRICHLET = 2, /* FiniteVolume.jl:25-27 */
+    FV_ERR_INDEX = 3,               /* Julia BoundsError analogue */
+    FV_ERR_NOMEM = 4,
+    FV_ERR_HIP = 5,
+    FV_ERR_STATE = 6,     /* call order (e.g. solve before assemble) */
+    FV_ERR_DT = 7,        /* "time step must be positive", transient.jl:68-70 */
+    FV_ERR_TOO_LARGE = 8, /* exceeds int32 device indexing */
+    FV_ERR_COMM = 9       /* RCCL failure */
+};
+
+typedef struct fv_ctx fv_ctx;         /* one GPU + its streams (+ RCCL communicator) */
+typedef struct fv_problem fv_problem; /* device-resident mesh, CSR operator, vectors */
+
+/* What IterativeSolvers' ConvergenceHistory carries for the callers of
+ * solvediffusion (FiniteVolume.jl:161,164: ch.isconverged, ch.data[:resnorm]). */
+typedef struct fv_solve_info {
+    int32_t converged;   /* ||r||_2 <= rtol*||b||_2 reached */
+    int32_t iters;       /* PCG iterations performed */
+    double relres;       /* final ||r||_2 / ||b||_2 (recurrence residual) */
+    double bnorm;        /* ||b||_2 of the system solved */
+    double solve_ms;     /* device time of the solve, HIP events */
+    int64_t resnorm_len; /* entries written to the caller's resnorm buffer */
+} fv_solve_info;
+
+/* ---------------------------------------------------------------- lifecycle */
+int fv_abi_version(void);
+int fv_ctx_create(int device, fv_ctx **out);
+void fv_ctx_destroy(fv_ctx *ctx);
+int fv_ctx_synchronize(fv_ctx *ctx);
+/* ctx may be NULL: last error of the calling thread outside any context. */
+const char *fv_last_error(fv_ctx *ctx);
+int fv_device_info(fv_ctx *ctx, char *name, int name_cap, int *compute_units, int64_t *total_mem_bytes);
+
+/* ---------------------------------------------------------------- a1/a2: src/grid.jl */
+/* regulargrid(mins, maxs, ns) sizes — grid.jl:61,69 */
+int fv_regulargrid_sizes(const int64_t ns[3], int64_t *N, int64_t *F);
+/* regulargrid — grid.jl:56-110.  coords is 3 x N column-major (may be NULL);
+ * node1/node2 are the halves of neighbors::Vector{Pair{Int,Int}}. */
+int fv_regulargrid(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3], double *coords,
+                   int64_t *node1, int64_t *node2, double *areasoverlengths, double *volumes);
+/* nodehycos2neighborhycos — grid.jl:14-33 (nodehycos in (n3,n2,n1) column-major order == node order) */
+int fv_nodehycos2neighborhycos(fv_ctx *ctx, int64_t F, const int64_t *node1, const int64_t *node2, int64_t N,
+                               const double *nodehycos, int logtransformhyco, double *neighborhycos);
+
+/* ---------------------------------------------------------------- a3/a4: src/FiniteVolume.jl:20-44 */
+/* getfreenodes(n, dirichletnodes) -> freenode::Vector{Bool} (as u8), nodei2freenodei */
+int fv_getfreenodes(fv_ctx *ctx, int64_t N, int64_t ndir, const int64_t *dirichletnodes, uint8_t *freenode,
+                    int64_t *nodei2freenodei, int64_t *nfree);
+/* getnodei2dirichleti(sources, dirichletnodes); *badnode receives the offending
+ * node when FV_ERR_SOURCE_AT_DIRICHLET is returned. */
+int fv_getnodei2dirichleti(fv_ctx *ctx, int64_t N, const double *sources, int64_t ndir, const int64_t *dirichletnodes,
+                           int64_t *nodei2dirichleti, int64_t *badnode);
+
+/* ---------------------------------------------------------------- problem = mesh + Dirichlet set */
+/* Uploads the connectivity and builds, on the device, the free-node maps and
+ * the symbolic CSR of assembleA (FiniteVolume.jl:75-108: rows sorted, repeats
+ * merged) once; fv_assemble then only refills values. */
+int fv_problem_create(fv_ctx *ctx, int64_t N, int64_t F, const int64_t *node1, const int64_t *node2,
+                      const double *areasoverlengths, int64_t ndir, const int64_t *dirichletnodes, fv_problem **out);
+/* Same, with regulargrid's connectivity generated directly on the device
+ * (no F-sized host arrays: the 464^3 configuration has 3e8 faces). */
+int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3],
+                                  int64_t ndir, const int64_t *dirichletnodes, fv_problem **out);
+/* A general symmetric operator given as SparseMatrixCSC (1-based), for the
+ * generic integrator entry backwardeulerintegrate(u0, A, b, dt0, t0, tfinal)
+ * (transient.jl:123-154) and for the adjoint's transpose(A) (transient.jl:193):
+ * all n unknowns are free, D = I. */
+int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t *colptr, const int64_t *rowval,
+                               const double *nzval, fv_problem **out);
+void fv_problem_destroy(fv_problem *p);
+/* N cells, F faces, n free cells, nnz stored entries of A */
+int fv_problem_sizes(fv_problem *p, int64_t *N, int64_t *F, int64_t *n, int64_t *nnz);
+int fv_problem_get_free_maps(fv_problem *p, uint8_t *freenode, int64_t *nodei2freenodei);
+/* grid arrays of a regulargrid-created problem (any pointer may be NULL) */
+int fv_problem_get_grid(fv_problem *p, int64_t *node1, int64_t *node2, double *areasoverlengths, double *volumes);
+
+/* ---------------------------------------------------------------- a5/a6/a7: assembly */
+/* assembleA + assembleb (FiniteVolume.jl:75-139) in one pass over the faces.
+ * K has nK entries; metaindex is NULL (the default i->i; nK == F, or nK == 1
+ * meaning one conductivity for every face) or F 1-based indices into K
+ * (`metaindex.(1:F)` pre-evaluated by the caller: closures cannot cross a C ABI).
+ * Values are combined in face order, as sparse(I,J,V,n,n,+) does. */
+int fv_assemble(fv_problem *p, int64_t nK, const double *conductivities, const int64_t *metaindex,
+                int logtransformconductivity, const double *sources, const double *dirichletheads, int64_t *badnode);
+/* The assembled A as SparseMatrixCSC{Float64,Int64} arrays (colptr n+1, rowval nnz,
+ * nzval nnz; 1-based).  A is symmetric, so these are also its CSR arrays. */
+int fv_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval);
+int fv_get_b(fv_problem *p, double *b);
+/* freenodes2nodes (FiniteVolume.jl:141-155): scatter n free values to N cells, fill Dirichlet heads */
+int fv_freenodes2nodes(fv_problem *p, const double *result_free, double *head_nodes);
+
+/* ---------------------------------------------------------------- a8: steady solve */
+/* solvediffusion (FiniteVolume.jl:157-165): A x = b from x0 (NULL = zeros) by
+ * Jacobi-PCG (replaces the reference's RS-AMG-PCG).  head_nodes
+ * (N) and/or result_free (n) may be NULL.  resnorm (capacity resnorm_cap, may be
+ * NULL) receives ||r||_2 after every iteration, like ch.data[:resnorm]. */
+int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol, int64_t maxiter, double *head_nodes,
+                    double *result_free, double *resnorm, int64_t resnorm_cap, fv_solve_info *info);
+
+/* ---------------------------------------------------------------- a9-a14: transient */
+/* scalebyvolume! (transient.jl:7-22) folded into the operator: D = Ss*volumes[free].
+ * volumes == NULL uses the grid's own volumes (regulargrid-created problems) or 1.
+ * State slot 0 := u0[free] (transient.jl:170).  u0 may be NULL (zeros). */
+int fv_transient_begin(fv_problem *p, double Ss, const double *volumes, const double *u0_nodes);
+/* device-resident state vectors over the free cells */
+int fv_state_alloc(fv_problem *p, int32_t *slot);
+int fv_state_free(fv_problem *p, int32_t slot);
+int fv_state_set_nodes(fv_problem *p, int32_t slot, const double *u_nodes);
+int fv_state_set_free(fv_problem *p, int32_t slot, const double *u_free);
+int fv_state_get_nodes(fv_problem *p, int32_t slot, double *u_nodes); /* freenodes2nodes, transient.jl:172 */
+int fv_state_get_free(fv_problem *p, int32_t slot, double *u_free);
+int fv_state_copy(fv_problem *p, int32_t src, int32_t dst);
+/* ||u_a - u_b||_2 — the step-doubling error, transient.jl:81 */
+int fv_state_norm2_diff(fv_problem *p, int32_t a, int32_t b, double *out);
+
+#define FV_STEP_FORWARD 0 /* (I/dt + D^-1 A) u+ = u/dt + bhat          transient.jl:65-76 */
+#define FV_STEP_ADJOINT 1 /* (I/dt + A D^-1) g+ = g/dt + bhat          transient.jl:188-205 (transpose(A)) */
+/* backwardeuleronestep! (transient.jl:60-76): one implicit step of size dt from
+ * slot src into slot dst (src == dst allowed), initial guess u_src.  Solved in
+ * the equivalent SPD form (D/dt + A) u+ = D u/dt + b.  bhat_free is the
+ * volume-scaled right-hand side getb(t) of the reference (n values) or NULL to
+ * use the assembled b.  dt <= 0 -> FV_ERR_DT. */
+int fv_transient_step(fv_problem *p, int32_t src, int32_t dst, double dt, const double *bhat_free, int mode,
+                      double rtol, int64_t maxiter, fv_solve_info *info);
+/* fixedbackwardeulerstep! x nsteps (transient.jl:130-154) without leaving the
+ * device: slot is advanced in place; iters_per_step (nsteps, may be NULL). */
+int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, int64_t nsteps, double rtol, int64_t maxiter,
+                           int32_t *iters_per_step, fv_solve_info *last_info, double *total_ms);
+
+/* ---------------------------------------------------------------- kernel-level entry points (parity tests, roofline) */
+/* y = (A + sigma*D) x on n free unknowns */
+int fv_spmv(fv_problem *p, const double *x_free, double sigma, double *y_free);
+/* reps back-to-back launches of the PCG SpMV kernel on resident vectors;
+ * average launch duration from HIP events on the launch stream. */
+int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms);
+int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *out);
+
+/* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
+#define FV_COMM_ID_BYTES 128
+int fv_comm_unique_id(char id[FV_COMM_ID_BYTES]);
+int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_COMM_ID_BYTES]);
+int fv_comm_destroy(fv_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVHIP_H */

@@ -19,3 +19,11 @@ def oracle():
     from oracle import fv_oracle
 
     return fv_oracle
+
+
+@pytest.fixture(scope="session")
+def fv():
+    """The product package (finitevolume.jl_amd/), loaded as `fvamd`; needs libfvhip.so."""
+    from __graft_entry__ import load_package
+
+    return load_package()

@@ -1,0 +1,245 @@
+"""GPU parity: SpMV, reductions, steady Jacobi-PCG and implicit stepping through
+the C ABI vs the CPU oracle.  Floating-point bar (BASELINE.json north_star): heads
+within 1e-8 relative of the CPU reference, with the device PCG run to rtol 1e-12
+and the oracle solved directly (SURVEY.md §7 risk 2)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from tests import refcases
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HEAD_RTOL = 1e-8
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _box(fv, ns, seed=0, sigma=1.5):
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    coords, nb, aol, vol = fv.regulargrid(mins, maxs, list(ns))
+    rng = np.random.default_rng(seed)
+    logk = np.log(1e-5) + sigma * rng.standard_normal(len(vol))
+    K = np.exp(fv.nodehycos2neighborhycos(nb, logk, True))
+    left = np.nonzero(coords[0] == mins[0])[0] + 1
+    right = np.nonzero(coords[0] == maxs[0])[0] + 1
+    dn = np.sort(np.r_[left, right]).astype(np.int64)
+    dh = np.where(np.isin(dn, left), 1.0, 0.0)
+    return coords, nb, aol, vol, K, dn, dh
+
+
+@pytest.mark.parametrize("ns", [(3, 4, 5), (20, 19, 18), (64, 33, 7)])
+def test_spmv_and_dot_match_oracle(fv, oracle, ns):
+    coords, nb, aol, vol, K, dn, dh = _box(fv, ns)
+    src = np.zeros(len(vol))
+    p = fv.Problem.create(nb, aol, len(vol), dn).assemble(K, src, dh)
+    oA = oracle.assembleA(nb[:, 0], nb[:, 1], aol, K, src, dn, dh)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(p.n)
+    y = p.spmv(x)
+    oy = oA.matvec(x)
+    assert np.allclose(y, oy, rtol=0, atol=1e-14 * np.abs(oA.nzval).max() * np.abs(x).max() * 8)
+    # shifted operator (A + sigma*D) x
+    p.transient_begin(0.1, vol, np.zeros(len(vol)))
+    freenode, _ = p.free_maps()
+    D = 0.1 * vol[freenode]
+    ys = p.spmv(x, sigma=0.25)
+    assert np.allclose(ys, oy + 0.25 * D * x, rtol=1e-13, atol=1e-22)
+    z = rng.standard_normal(p.n)
+    assert math.isclose(p.dot(x, z), float(np.dot(x, z)), rel_tol=1e-12, abs_tol=1e-12)
+
+
+def test_spmv_long_and_short_rows(fv, oracle):
+    """Rows longer than the 8-lane group (hub nodes) and single-entry rows."""
+    rng = np.random.default_rng(2)
+    N = 300
+    hub = np.full(120, 1)
+    n1 = np.r_[hub, rng.integers(2, N + 1, 500)]
+    n2 = np.r_[np.arange(2, 122), rng.integers(2, N + 1, 500)]
+    keep = n1 != n2
+    n1, n2 = n1[keep], n2[keep]
+    aol = rng.random(len(n1)) + 0.5
+    K = rng.random(len(n1)) + 0.5
+    dn = np.array([N], np.int64)
+    dh = np.array([1.0])
+    src = np.zeros(N)
+    nb = np.stack([n1, n2], 1)
+    for lpr_case in range(1):
+        p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+        oA = oracle.assembleA(n1, n2, aol, K, src, dn, dh)
+        x = rng.standard_normal(p.n)
+        assert np.allclose(p.spmv(x), oA.matvec(x), rtol=1e-13, atol=1e-13)
+
+
+def test_chain4_solvediffusion(fv):
+    """test/runtests.jl:4-16"""
+    c = refcases.chain4()
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    h, ch, A, b, freenode = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"])
+    assert refcases.isapprox(h, c["expected"])
+    assert ch.isconverged and list(freenode) == [False, True, True, False]
+    assert len(ch.data["resnorm"]) == ch.iters
+
+
+@pytest.mark.parametrize("ns,sigma", [((10, 10, 10), 3.0), ((24, 20, 16), 1.0), ((40, 40, 12), 0.0)])
+def test_box_steady_heads_vs_direct(fv, oracle, ns, sigma):
+    """examples/box_model BCs (ex.jl:29-37) scaled down; heads within 1e-8 of a direct solve."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, ns, sigma=sigma)
+    src = np.zeros(len(vol))
+    head, ch, A, b, freenode = fv.solvediffusion(nb, aol, K, src, dn, dh, maxiter=20000, rtol=1e-13)
+    assert ch.isconverged
+    ohead = oracle.solvediffusion(nb[:, 0], nb[:, 1], aol, K, src, dn, dh, solver="direct")[0]
+    assert relerr(head, ohead) < HEAD_RTOL
+    assert head.min() >= -1e-9 and head.max() <= 1 + 1e-9  # ex_piml_data.jl:49-51
+    # true residual of the returned solution
+    r = A.toscipy() @ head[freenode] - b
+    assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-11
+    # residual history is monotone-ish and ends below tolerance
+    assert ch.data["resnorm"][-1] <= 1e-13 * np.linalg.norm(b) * 1.0000001
+
+
+def test_steady_maxiter_reports_nonconvergence(fv):
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (12, 12, 12), sigma=3.0)
+    head, ch, *_ = fv.solvediffusion(nb, aol, K, np.zeros(len(vol)), dn, dh, maxiter=3, rtol=1e-14)
+    assert not ch.isconverged and ch.iters == 3
+
+
+def test_fourfractures_steady_vs_direct_and_pflotran(fv, oracle):
+    d = np.load(os.path.join(GOLDEN, "fourfractures.npz"))
+    nb = np.stack([d["node1"], d["node2"]], 1)
+    src = np.zeros(2106)
+    head, ch, A, b, fn = fv.solvediffusion(nb, d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], maxiter=20000, rtol=1e-13)
+    assert ch.isconverged
+    ohead = oracle.solvediffusion(d["node1"], d["node2"], d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], solver="direct")[0]
+    assert relerr(head, ohead) < HEAD_RTOL
+    assert relerr(head, d["pflotran_h"]) < 1.1e-2  # loose cross-code check, SURVEY §8c item 5
+
+
+def test_fixed_steps_vs_oracle_direct(fv, oracle):
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (14, 12, 10), sigma=1.0)
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    u0 = np.full(N, 0.5)
+    us, ts = fv.backwardeulerintegrate(u0, (0.0, 500.0), 0.1, vol, nb, aol, K, src, dn, dh, stepper=fv.fixedbackwardeulerstep, dt0=100.0, rtol=1e-13)
+    ous, ots = oracle.backwardeulerintegrate(u0, (0.0, 500.0), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=100.0, linearsolver=oracle.directlinearsolver)
+    assert ts == ots and len(us) == 6
+    for u, ou in zip(us, ous):
+        assert relerr(u, ou) < HEAD_RTOL
+    # the same through the all-device loop (fv_transient_run_fixed)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+    st = p.transient_begin(0.1, vol, u0)
+    iters, info, ms = p.run_fixed(st, 100.0, 5, rtol=1e-13)
+    assert relerr(st.node_values(), ous[-1]) < HEAD_RTOL and (iters > 0).all() and info.converged
+
+
+def test_time_dependent_getb_method(fv, oracle):
+    """transient.jl:165-174: caller supplies the volume-scaled b(t)."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (8, 8, 6), sigma=0.5)
+    N = len(vol)
+    src = np.zeros(N)
+    u0 = np.zeros(N)
+    ob = oracle.assembleb(nb[:, 0], nb[:, 1], aol, K, src, dn, dh)
+    freenode, n2f = oracle.getfreenodes(N, dn)
+    bhat = ob / (0.1 * vol[freenode])
+    getb = lambda t: bhat * (1 + 0.5 * math.sin(t / 50.0))  # noqa: E731
+    us, ts = fv.backwardeulerintegrate(u0, (0.0, 200.0), getb, 0.1, vol, nb, aol, K, src, dn, dh, stepper=fv.fixedbackwardeulerstep, dt0=50.0, rtol=1e-13)
+    ous, ots = oracle.backwardeulerintegrate(u0, (0.0, 200.0), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, getb=getb, stepper=oracle.fixedbackwardeulerstep, dt0=50.0, linearsolver=oracle.directlinearsolver)
+    assert ts == ots
+    assert relerr(us[-1], ous[-1]) < HEAD_RTOL
+
+
+@pytest.mark.parametrize("loghyco,analytic", [(0.0, lambda t: 1 - math.exp(-t)), (1.0, lambda t: (1 - math.exp(-math.e * t)) / math.e)])
+def test_onenode_logconductivity_adaptive(fv, loghyco, analytic):
+    """test/onenodeadjoint.jl:29-44 with the default (adaptive) stepper"""
+    c = refcases.onenode(loghyco)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    us, ts = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, atol=c["atol"], dt0=c["dt0"])
+    assert ts[-1] == 1.0 and len(ts) > 5
+    for u, t in zip(us, ts):
+        assert u[0] == 0.0
+        assert abs(u[1] - analytic(t)) <= 1e-4 * max(abs(u[1]), abs(analytic(t)))
+
+
+def test_ode_diagonal_decay_generic_entry(fv):
+    """test/ode.jl:8-19 through the generic integrator: sparse SPD A uploaded as CSC"""
+    v = np.array([1.0, 2.0, 3.0])
+    A = fv.SparseMatrixCSC(3, 3, np.array([1, 2, 3, 4]), np.array([1, 2, 3]), v.copy())
+    ys, ts = fv.backwardeulerintegrate(np.ones(3), A, np.zeros(3), 0.0001, 0.0, 2.0, atol=1e-8)
+    assert ts[-1] == 2.0
+    for y, t in zip(ys, ts):
+        assert np.allclose(y, np.exp(-v * t), atol=1e-4, rtol=0)
+
+
+def test_ode_growth_generic_entry(fv):
+    """test/ode.jl:21-29"""
+    A = fv.SparseMatrixCSC(1, 1, np.array([1, 2]), np.array([1]), np.array([-1.0]))
+    ys, ts = fv.backwardeulerintegrate(np.zeros(1), A, np.ones(1), 0.0001, 0.0, 1.0, atol=1e-8)
+    for y, t in zip(ys, ts):
+        assert abs(y[0] - (math.exp(t) - 1)) <= 1e-4
+
+
+def test_ode_dense_user_linearsolver_seam(fv):
+    """test/ode.jl:31-40: dense non-symmetric A with linearsolver = A \\ b stays on the host seam"""
+    s7 = math.sqrt(7)
+
+    def y(t, c1=1, c2=2):
+        e = math.exp(-t / 4)
+        a = np.array([1, 0.75]) * math.cos(s7 * t / 4) - np.array([0, -s7 / 4]) * math.sin(s7 * t / 4)
+        b = np.array([1, 0.75]) * math.sin(s7 * t / 4) + np.array([0, -s7 / 4]) * math.cos(s7 * t / 4)
+        return c1 * e * a + c2 * e * b
+
+    A = -np.array([[0.5, -1.0], [1.0, -1.0]])
+    calls = []
+
+    def linearsolver(A, b, x0):
+        calls.append(1)
+        return np.linalg.solve(A, b)
+
+    ys, ts = fv.backwardeulerintegrate(y(0), A, np.zeros(2), 1e-4, 0.0, 1e2, atol=1e-8, linearsolver=linearsolver)
+    assert ts[-1] == 1e2 and len(calls) > 10
+    for yy, t in zip(ys, ts):
+        assert np.linalg.norm(yy - y(t)) <= 1e-4
+
+
+def test_nonpositive_dt_raises(fv):
+    A = fv.SparseMatrixCSC(1, 1, np.array([1, 2]), np.array([1]), np.array([1.0]))
+    with pytest.raises(fv.FVError, match="time step must be positive"):
+        fv.backwardeulerintegrate(np.zeros(1), A, np.ones(1), 0.0, 0.0, 1.0)
+    p = fv.Problem.from_csc(A)
+    st = p.transient_begin(1.0, None, None)
+    with pytest.raises(fv.FVError, match="time step must be positive"):
+        p.step(st, st, -1.0)
+
+
+def test_callback_invoked_per_step(fv):
+    c = refcases.onenode(0.0)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    seen = []
+    us, ts = fv.backwardeulerintegrate(c["u0"], (0.0, 0.5), c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, stepper=fv.fixedbackwardeulerstep, dt0=0.1, callback=lambda t, dt: seen.append((t, dt)))
+    assert len(seen) == len(ts) - 1 and seen[0] == (0.0, 0.1)
+
+
+@pytest.mark.slow
+def test_theis_and_thiem(fv, oracle):
+    """test/theis.jl:52-65 with the reference's settings (atol=1e-4, dt0=60, 10 days)."""
+    grid = lambda a, b, n: (lambda r: (r[0], r[1][:, 0], r[1][:, 1], r[2], r[3]))(fv.regulargrid(a, b, n))  # noqa: E731
+    c = refcases.theis(grid)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    usteady, ch, A, b, freenode = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], maxiter=20000)
+    solver = fv.DevicePCG(rtol=1e-12, maxiter=2000)
+    us, ts = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], atol=c["atol"], dt0=c["dt0"], linearsolver=solver)
+    assert ts[-1] == c["tspan"][1]
+    th = [refcases.theisdrawdown(ts[-1], r, c["T"], c["S"], c["Q"]) for r in c["rs"]]
+    assert refcases.isapprox(th, -us[-1][c["goodnodes"]] + c["steadyhead"], atol=1e-4, rtol=2e-2)
+    tm = [refcases.thiemdrawdown(r, c["T"], c["Q"], c["sidelength"]) for r in c["rs"]]
+    assert refcases.isapprox(tm, -usteady[c["goodnodes"]] + c["steadyhead"], atol=1e-4, rtol=2e-2)
+    # against the oracle with exact solves: same step sequence, heads within 1e-8
+    ous, ots = oracle.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], c["node1"], c["node2"], c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], atol=c["atol"], dt0=c["dt0"], linearsolver=oracle.directlinearsolver)
+    assert len(ts) == len(ots) and np.allclose(ts, ots, rtol=0, atol=0)
+    assert relerr(us[-1], ous[-1]) < HEAD_RTOL
+    assert solver.solves > 3000
