@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — DoF-updates/s of the implicit transient hot path on MI355X.
+
+A "step" is one backward-Euler time step of the whole grid: RHS build + the
+Jacobi-PCG solve of (D/dt + A) u+ = D u/dt + b, everything resident in HBM.
+Workload (BASELINE.json configs[4] / the 10^8-cell target of
+`north_star`): structured box of ns^3 cells (default 464^3 = 9.99e7), 1000 x 1000
+x 100 m, K = 1e-5 m/s, Ss = 0.1, Dirichlet head 1e3 on the four lateral faces,
+u0 = 1e3, one pumping well (-1e-3 m^3/s) down the centre column, fixed dt = 60 s,
+PCG rtol 1e-10.  Grid, connectivity and CSR are generated/assembled on the device.
+
+    python bench.py --gpus 1 --steps 20 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  value = cells x steps / seconds, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+
+
+def box_setup(ns, i1_lo=None, i1_hi=None):
+    """Lateral-Dirichlet box of the transient configs.  Returns mins, maxs, dirichlet nodes (1-based), sources."""
+    n1, n2, n3 = ns
+    N = n1 * n2 * n3
+    i1 = np.arange(n1)
+    i2 = np.arange(n2)
+    lat = np.zeros((n1, n2), bool)
+    lat[0, :] = lat[-1, :] = True
+    lat[:, 0] = lat[:, -1] = True
+    cols = np.nonzero(lat.ravel())[0]  # (i1,i2) columns on the lateral boundary
+    dn = (cols[:, None] * n3 + np.arange(n3)[None, :]).ravel() + 1
+    dn.sort()
+    sources = np.zeros(N)
+    c1, c2 = n1 // 2, n2 // 2
+    well = (c1 * n2 + c2) * n3 + np.arange(n3)
+    Q = 1e-3
+    sources[well] = -2 * Q / (2 * n3 - 2)  # theis.jl:40-42 weighting along the column
+    sources[well[0]] = sources[well[-1]] = -Q / (2 * n3 - 2)
+    return dn.astype(np.int64), sources
+
+
+def spacing_box(ns, ref_ns=464):
+    """Box extents that keep the cell size of the 464^3 / 1000x1000x100 m configuration."""
+    hx = 1000.0 / (ref_ns - 1)
+    hz = 100.0 / (ref_ns - 1)
+    return [0.0, 0.0, 0.0], [hx * (ns[0] - 1), hx * (ns[1] - 1), hz * (ns[2] - 1)]
+
+
+def cpu_baseline(dt, rtol):
+    """The oracle (CPU restatement of the reference: assembleA/b, scalebyvolume!,
+    fixedbackwardeulerstep!, IterativeSolvers-style CG) timed on ONE host core on a
+    bounded sample of the same workload: same cell size / K / Ss / dt / BCs, 160^3
+    cells, 16 steps.  Only the stepping loop is timed, as for the GPU."""
+    from oracle import fv_oracle as o
+
+    ns = [160, 160, 160]
+    steps = 16
+    mins, maxs = spacing_box(ns)
+    _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
+    dn, src = box_setup(ns)
+    dh = np.full(len(dn), 1e3)
+    K = np.full(len(aol), 1e-5)
+    Ss = 0.1
+    freenodes, n2f = o.getfreenodes(len(vol), dn)
+    f2n = o.freenodei2nodei(n2f)
+    A = o.assembleA(n1, n2, aol, K, src, dn, dh)
+    b = o.assembleb(n1, n2, aol, K, src, dn, dh)
+    o.scalebyvolume_A(A, Ss * vol, f2n)
+    b = o.scalebyvolume_b(b, Ss * vol, f2n)
+    u0 = np.full(A.n, 1e3)
+    iters = []
+
+    def solver(Am, rhs, x0):
+        x, ch = o.cg(Am, rhs, x0=x0, tol=rtol, maxiter=1000)
+        iters.append(ch.iters)
+        return x
+
+    t0 = time.perf_counter()
+    us, ts = o.backwardeulerintegrate_generic(u0, A, b, dt, 0.0, dt * steps, stepper=o.fixedbackwardeulerstep, linearsolver=solver)
+    sec = time.perf_counter() - t0
+    N = len(vol)
+    return {
+        "value": N * steps / sec,
+        "unit": "DoF-updates/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "oracle (C restatement of the reference path, unpreconditioned CG rtol %.0e) on %dx%dx%d cells x %d steps, same cell size/K/Ss/dt/BCs; %.1f s; %.1f CG iters/step" % (rtol, ns[0], ns[1], ns[2], steps, sec, float(np.mean(iters))),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ns", type=int, default=464, help="cells per dimension of the box (464 -> 9.99e7 cells)")
+    ap.add_argument("--dt", type=float, default=60.0)
+    ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--maxiter", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print("bench.py: --gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus, file=sys.stderr)
+            sys.exit(2)
+    from __graft_entry__ import load_package
+
+    fv = load_package()
+    if world > 1:
+        from bench_dist import run_distributed
+
+        return run_distributed(fv, args, world, rank)
+
+    ctx = fv.default_context()
+    name, cus, mem = ctx.device_info()
+    ns = [args.ns] * 3
+    mins, maxs = spacing_box(ns)
+    dn, src = box_setup(ns)
+    t_setup = time.perf_counter()
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+    t_symbolic = time.perf_counter() - t_setup
+    t1 = time.perf_counter()
+    p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    t_assemble = time.perf_counter() - t1
+    state = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    t_setup = time.perf_counter() - t_setup
+
+    # warmup steps (untimed)
+    if args.warmup > 0:
+        p.run_fixed(state, args.dt, args.warmup, args.rtol, args.maxiter)
+    if not args.no_profile:
+        p.profile(True)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iters, info, dev_ms = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
+    ctx.synchronize()
+    sec = time.perf_counter() - t0
+    prof = p.profile_get() if not args.no_profile else None
+    p.profile(False)
+
+    value = p.N * args.steps / sec
+    # algorithmic bytes of the dominant kernel, SpMV with the D/dt shift and p.q epilogue:
+    # vals 8 + colind 4 per entry; rowptr 4 + x 8 + y 8 + D 8 per row   
+    spmv_bytes = 12 * p.nnz + 28 * p.n
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "kernel": "spmv_kernel<8,2,true> (K1: q=(A+D/dt)p, p.q)", "algorithmic_bytes_per_launch": spmv_bytes}
+    kern = {}
+    if prof and prof["spmv_dot"][1] > 0:
+        ms, cnt = prof["spmv_dot"]
+        ach = spmv_bytes / (ms / cnt * 1e-3) / 1e9
+        roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_ms=ms / cnt, launches=cnt)
+        for k, bytes_ in (("update", 56 * p.n), ("pupdate", 32 * p.n)):
+            kms, kc = prof[k]
+            if kc:
+                kern[k] = {"avg_ms": kms / kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
+    tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile))
+            roof["traffic"] = t.get(str(args.ns))
+        except Exception:
+            pass
+
+    out = {
+        "metric": "DoF-updates/s (cells x steps) implicit transient; SpMV HBM GB/s vs peak",
+        "value": value,
+        "unit": "DoF-updates/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": sec / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %d^3 box (%.3g cells), transient, fixed dt=%gs, Jacobi-PCG rtol %.0e, lateral Dirichlet + centre well (SURVEY 8d / BASELINE configs[4] on one GPU)" % (args.ns, p.N, args.dt, args.rtol),
+            "cells": p.N, "unknowns": p.n, "nnz": p.nnz, "faces": p.F,
+            "pcg_iters_per_step": float(np.mean(iters)), "pcg_iters_total": int(np.sum(iters)),
+            "last_relres": info.relres, "converged": bool(info.converged),
+            "device": name, "compute_units": cus,
+            "setup_s": {"grid+symbolic": t_symbolic, "assemble": t_assemble, "total": t_setup},
+            "device_ms_total": dev_ms,
+            "other_kernels": kern,
+        },
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

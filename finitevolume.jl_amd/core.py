@@ -244,6 +244,18 @@ class Problem:
         self.check(load().fv_bench_spmv(self.handle, float(sigma), int(reps), C.byref(ms)))
         return ms.value
 
+    def profile(self, on=True):
+        self.check(load().fv_profile_enable(self.handle, int(bool(on))))
+
+    def profile_get(self):
+        """{kernel: (total_ms, launches)} measured with HIP events around every PCG launch."""
+        out = {}
+        for k, name in enumerate(("spmv_dot", "update", "pupdate")):
+            ms, cnt = C.c_double(), C.c_int64()
+            self.check(load().fv_profile_get(self.handle, k, C.byref(ms), C.byref(cnt)))
+            out[name] = (ms.value, cnt.value)
+        return out
+
     # ---- transient
     def transient_begin(self, Ss, volumes, u0_nodes):
         v = af64(volumes) if volumes is not None else None

@@ -371,7 +371,8 @@ int fv_build_symbolic(fv_problem *p)
     }
     FV_TRY(p->rowptr.alloc(ctx, (size_t)n + 1));
     FV_TRY(fv_exclusive_scan_i32(ctx, rowcnt.p, p->rowptr.p, n, &p->nnz));
-    FV_TRY(p->colind.alloc(ctx, (size_t)p->nnz));
+    FV_TRY(p->colind.alloc(ctx, (size_t)p->nnz + 2)); // +2: the stream SpMV reads entry pairs
+    FV_TRY(p->colind.zero(ctx));
     FV_TRY(p->diagpos.alloc(ctx, (size_t)n));
     DevBuf<uint8_t> mark;
     FV_TRY(mark.alloc(ctx, (size_t)p->nnz));
@@ -497,6 +498,7 @@ extern "C" int fv_assemble(fv_problem *p, int64_t nK, const double *conductiviti
     }
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->assembled = true;
+    p->assemble_epoch++;
     return FV_OK;
 }
 
@@ -515,7 +517,8 @@ static int finish_problem(fv_problem *p, const int64_t *dirichletnodes)
         FV_TRY(fv_narrow_indices(ctx, w.p, p->dnodes0.p, p->ndir, 1, p->N, &bad));
     }
     FV_TRY(fv_build_symbolic(p));
-    FV_TRY(p->vals.alloc(ctx, (size_t)p->nnz));
+    FV_TRY(p->vals.alloc(ctx, (size_t)p->nnz + 2));
+    FV_TRY(p->vals.zero(ctx));
     FV_TRY(p->b.alloc(ctx, (size_t)p->n));
     FV_TRY(p->diagA.alloc(ctx, (size_t)p->n));
     FV_TRY(p->cond.alloc(ctx, (size_t)p->F));
@@ -811,8 +814,8 @@ extern "C" int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t 
     p->from_csc = true;
     int rc = FV_OK;
     do {
-        if ((rc = p->rowptr.alloc(ctx, (size_t)n + 1)) || (rc = p->colind.alloc(ctx, (size_t)nnz)) ||
-            (rc = p->vals.alloc(ctx, (size_t)nnz)) || (rc = p->diagpos.alloc(ctx, (size_t)n)) ||
+        if ((rc = p->rowptr.alloc(ctx, (size_t)n + 1)) || (rc = p->colind.alloc(ctx, (size_t)nnz + 2)) ||
+            (rc = p->colind.zero(ctx)) || (rc = p->vals.alloc(ctx, (size_t)nnz + 2)) || (rc = p->vals.zero(ctx)) || (rc = p->diagpos.alloc(ctx, (size_t)n)) ||
             (rc = p->diagA.alloc(ctx, (size_t)n)) || (rc = p->b.alloc(ctx, (size_t)n)) || (rc = p->nodemap.alloc(ctx, (size_t)n)) ||
             (rc = p->f2n.alloc(ctx, (size_t)n)) || (rc = p->dheads.alloc(ctx, 1)))
             break;

@@ -118,9 +118,19 @@ struct fv_problem {
     DevBuf<uint32_t> inc_face; // E: face<<1 | end, ascending per row == face order
     DevBuf<uint32_t> inc_slot; // E: bit31 = first contribution to its slot; low bits = slot - rowptr[row]; 0x7fffffff = other end is Dirichlet
     DevBuf<int32_t> rowptr, colind, diagpos;
+    // SpMV traversal: 64-row groups listed band by band, plane after plane (empty = natural order)
+    DevBuf<int32_t> group_order;
+    bool order_built = false;
+    int64_t order_stride = 0;
 
     // numeric
     DevBuf<double> cond, vals, b, diagA, dheads;
+
+    // fixed-dt runs: copy of vals with sigma*D folded into the stored diagonal
+    DevBuf<double> vals_shifted;
+    double shifted_sigma = 0.0;
+    int64_t shifted_epoch = -1, assemble_epoch = 0;
+    int fold_ok = -1; // -1 unknown, 0 some free row stores no diagonal, 1 ok
 
     // transient
     double Ss = 1.0;
@@ -135,11 +145,20 @@ struct fv_problem {
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;
 
+    // optional per-kernel timing of the PCG loop (fv_profile_enable): HIP event pairs
+    // around every K1/K2/K3 launch on the launch stream, harvested at each poll.
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev; // 6 per iteration of a chunk
+    double prof_ms[3] = {0, 0, 0};   // spmv_dot, update, pupdate
+    int64_t prof_launches[3] = {0, 0, 0};
+
     ~fv_problem()
     {
         for (double *s : slots)
             if (s)
                 (void)hipFree(s);
+        for (hipEvent_t e : prof_ev)
+            (void)hipEventDestroy(e);
     }
 };
 
@@ -164,8 +183,8 @@ int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev); 
 int fv_pcg_prepare(fv_problem *p);
 // Solve (A + sigma*D) x = rhs, x holds the initial guess (x0_zero: treat as zeros).
 int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool x0_zero, double rtol, int64_t maxiter,
-                 fv_solve_info *info, bool time_it);
-int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null);
+                 fv_solve_info *info, bool time_it, bool fold_shift = false);
+int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false);
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);
 int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double *out_host);

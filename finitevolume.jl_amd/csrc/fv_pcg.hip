@@ -122,6 +122,148 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_kernel(int64_t n, const int32_t
     }
 }
 
+// ------------------------------------------------------------------ SpMV, wave-private CSR-stream (the production form)
+// Each WAVE owns one group of 64 consecutive rows per pass, hence one contiguous
+// range of vals/colind.  That range is streamed with lane-contiguous 16-byte
+// (vals) and 8-byte (colind) loads that do not depend on the individual row
+// pointers; the products v*x[col] are staged in the wave's own LDS tile and each
+// lane then sums its row in column order.  rowptr, colind, vals, y (and D) are
+// fully coalesced HBM streams; only the x gather is irregular.  There is no block
+// barrier in the loop: the 32 waves of a CU drift through their load / gather /
+// reduce phases independently and cover each other's latency, and the row
+// pointers of the next pass are prefetched one pass ahead.
+//
+// Traffic, not latency, bounds this kernel (measured: time = L2-miss bytes / ~5
+// TB/s for every variant), so the traversal matters: `order` lists the row groups
+// band by band and, inside a band, plane after plane (see build_group_order), and
+// every XCD sweeps its own contiguous part of that list.  A group's +plane x
+// lines are then still in that XCD's 4 MiB L2 when the same band of the next
+// plane needs them as centre and -plane arms, instead of being fetched 3 times.
+template <int WT, bool DOT>
+__global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const int32_t *__restrict__ rowptr,
+                                                                 const int32_t *__restrict__ colind, const double *__restrict__ vals,
+                                                                 const double *__restrict__ x, double *__restrict__ y,
+                                                                 const double *__restrict__ shift, double sigma,
+                                                                 double *__restrict__ partials, const PcgScalars *__restrict__ scal,
+                                                                 const int32_t *__restrict__ order)
+{
+    constexpr int NIT = WT / 128; // entry pairs per lane
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double prod_all[WPB][WT + 2];
+    __shared__ double smem[4];
+    if (scal && scal->done)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *prod = prod_all[wave];
+    const int64_t ngroups = (n + 63) >> 6;
+    // position space: XCD share xs of [0, ngroups) is swept in passes of (G/8)*WPB consecutive positions
+    const int64_t per_xcd = (ngroups + 7) >> 3;
+    const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xend = (xbase + per_xcd < ngroups) ? xbase + per_xcd : ngroups;
+    int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave;
+    double dacc = 0.0;
+    int64_t group = 0;
+    int32_t s = 0, e = 0;
+    if (pos < xend) {
+        group = order ? order[pos] : pos;
+        const int64_t row = (group << 6) + lane;
+        if (row < n) {
+            s = rowptr[row];
+            e = rowptr[row + 1];
+        }
+    }
+    for (; pos < xend; pos += pstride) {
+        const int64_t r0 = group << 6;
+        const int nr = (int)((n - r0 < 64) ? (n - r0) : 64);
+        const int32_t my_s = s, my_e = e;
+        const int32_t k0 = __builtin_amdgcn_readfirstlane(my_s);
+        const int32_t k1 = __builtin_amdgcn_readlane(my_e, nr - 1);
+        const int32_t ka = k0 & ~1; // 16-byte aligned start of the streamed range
+        // prefetch the next group's row pointers
+        s = 0;
+        e = 0;
+        if (pos + pstride < xend) {
+            group = order ? order[pos + pstride] : pos + pstride;
+            const int64_t nrow = (group << 6) + lane;
+            if (nrow < n) {
+                s = rowptr[nrow];
+                e = rowptr[nrow + 1];
+            }
+        }
+        const int64_t row = r0 + lane;
+        double sum = 0.0;
+        if (k1 - ka <= WT) {
+            double2 v[NIT];
+            int2 c[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int32_t j = ka + 2 * (lane + it * 64);
+                if (j < k1) { // vals/colind carry two padding entries past nnz
+                    v[it] = *reinterpret_cast<const double2 *>(vals + j);
+                    c[it] = *reinterpret_cast<const int2 *>(colind + j);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int32_t j = ka + 2 * (lane + it * 64);
+                if (j < k1) {
+                    double2 pr;
+                    pr.x = v[it].x * x[c[it].x];
+                    pr.y = v[it].y * x[c[it].y];
+                    *reinterpret_cast<double2 *>(prod + (j - ka)) = pr;
+                }
+            }
+            // the wave's own LDS writes must land before other lanes read them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int32_t k = my_s - ka, ke = my_e - ka; k < ke; k++)
+                sum += prod[k];
+            __builtin_amdgcn_wave_barrier(); // reads done before the next pass overwrites the tile
+        } else { // rare: more than WT entries in 64 rows; each lane walks its own row
+            for (int32_t k = my_s; k < my_e; k++)
+                sum += vals[k] * x[colind[k]];
+        }
+        if (lane < nr) {
+            const double xr = (shift || DOT) ? x[row] : 0.0;
+            if (shift)
+                sum += sigma * shift[row] * xr;
+            y[row] = sum;
+            if (DOT)
+                dacc += xr * sum;
+        }
+    }
+    if (DOT) {
+        const double tsum = block_sum(dacc, smem);
+        if (threadIdx.x == 0)
+            partials[blockIdx.x] = tsum;
+    }
+}
+
+// Tuning knobs (fv_tune) for in-process A/B: 0 = SpMV form (1 lanes-per-row, 2 wave stream),
+// 1 = unroll of the lanes-per-row form, 2 = use the plane-blocked traversal order (0/1),
+// 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1)
+static int g_spmv_form = 2;
+static int g_spmv_unroll = 2;
+static int g_use_order = 1;
+int g_fold_shift = 1;
+
+extern "C" int fv_tune(int key, int value)
+{
+    if (key == 0 && (value == 1 || value == 2))
+        g_spmv_form = value;
+    else if (key == 1 && (value == 2 || value == 4 || value == 8))
+        g_spmv_unroll = value;
+    else if (key == 2 && (value == 0 || value == 1))
+        g_use_order = value;
+    else if (key == 3 && (value == 0 || value == 1))
+        g_fold_shift = value;
+    else
+        return FV_ERR_ARG;
+    return FV_OK;
+}
+
 // lanes per row from the mean row length: 8 covers the 7-point stencil in one pass
 static int spmv_lpr(const fv_problem *p)
 {
@@ -129,12 +271,18 @@ static int spmv_lpr(const fv_problem *p)
     return avg >= 11.0 ? 16 : (avg <= 4.0 ? 4 : 8);
 }
 
+constexpr int STREAM_RB = 256; // rows per block per pass of the wave-stream form (4 waves x 64)
+
 int fv_spmv_grid(fv_problem *p)
 {
     // a multiple of 8 (XCD shares), at most one partial per block
-    const int lpr = spmv_lpr(p);
-    const int rpb = (FV_BLOCK / lpr) * 2;
-    int64_t g = (p->n + rpb - 1) / rpb;
+    int64_t g;
+    if (g_spmv_form == 2)
+        g = (p->n + STREAM_RB - 1) / STREAM_RB;
+    else {
+        const int rpb = (FV_BLOCK / spmv_lpr(p)) * g_spmv_unroll;
+        g = (p->n + rpb - 1) / rpb;
+    }
     g = ((g + 7) / 8) * 8;
     if (g > FV_MAX_PARTIALS)
         g = FV_MAX_PARTIALS;
@@ -143,37 +291,143 @@ int fv_spmv_grid(fv_problem *p)
     return (int)g;
 }
 
-// y = (A + sigma*D) x ; partials != NULL also emits per-block partial sums of x.y.
-// use_done: honour the PCG early-exit flag.
-static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double sigma, double *partials, bool use_done)
+// A matrix whose rows mostly reach `stride` rows ahead (the +i1 neighbour of a
+// structured grid) is traversed band by band: for each band of BAND in-plane row
+// offsets, plane after plane.  Returned as a list of 64-row group ids.
+static int build_group_order(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
+    p->order_built = true;
+    const int64_t n = p->n;
+    if (n < (1 << 20) || p->nnz == 0)
+        return FV_OK; // small: x stays cache-resident anyway
+    // estimate the far stride from the middle row, then count how many rows agree
+    int32_t rp[2] = {0, 0};
+    FV_HIP(ctx, hipMemcpy(rp, p->rowptr.p + n / 2, sizeof rp, hipMemcpyDeviceToHost));
+    if (rp[1] <= rp[0])
+        return FV_OK;
+    int32_t lastcol = 0;
+    FV_HIP(ctx, hipMemcpy(&lastcol, p->colind.p + (rp[1] - 1), sizeof lastcol, hipMemcpyDeviceToHost));
+    const int64_t stride = (int64_t)lastcol - n / 2;
+    if (stride < 32768 || stride > n / 4)
+        return FV_OK; // near-diagonal band (natural order is fine) or no plane structure
+    extern int fv_count_far_stride(fv_problem *, int64_t, int64_t *);
+    int64_t agree = 0;
+    FV_TRY(fv_count_far_stride(p, stride, &agree));
+    if (agree < (n - stride) * 8 / 10)
+        return FV_OK;
+    constexpr int64_t BAND = 8192;
+    const int64_t ngroups = (n + 63) >> 6;
+    std::vector<int32_t> order;
+    order.reserve((size_t)ngroups);
+    const int64_t nplanes = (n + stride - 1) / stride;
+    for (int64_t b0 = 0; b0 < stride; b0 += BAND) {
+        const int64_t b1 = (b0 + BAND < stride) ? b0 + BAND : stride;
+        for (int64_t pl = 0; pl < nplanes; pl++) {
+            const int64_t lo = pl * stride + b0;
+            int64_t hi = pl * stride + b1;
+            if (hi > n)
+                hi = n;
+            if (lo >= hi)
+                continue;
+            for (int64_t g = (lo + 63) >> 6; (g << 6) < hi; g++) // groups whose first row lies in [lo, hi)
+                order.push_back((int32_t)g);
+        }
+    }
+    if ((int64_t)order.size() != ngroups) { // group 0 starts at row 0 in band 0: every group is counted exactly once
+        fv_set_error(ctx, "internal: group order covers %zu of %lld groups", order.size(), (long long)ngroups);
+        return FV_ERR_STATE;
+    }
+    FV_TRY(p->group_order.alloc(ctx, (size_t)ngroups));
+    FV_HIP(ctx, hipMemcpy(p->group_order.p, order.data(), (size_t)ngroups * sizeof(int32_t), hipMemcpyHostToDevice));
+    p->order_stride = stride;
+    return FV_OK;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void far_stride_kernel(int64_t n, const int32_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ colind, int64_t stride,
+                                                               unsigned long long *__restrict__ count)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    bool hit = false;
+    if (r < n) {
+        const int32_t e = rowptr[r + 1];
+        hit = e > rowptr[r] && (int64_t)colind[e - 1] - r == stride;
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+int fv_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree)
+{
+    fv_ctx *ctx = p->ctx;
+    DevBuf<unsigned long long> cnt;
+    FV_TRY(cnt.alloc(ctx, 1));
+    FV_TRY(cnt.zero(ctx));
+    hipLaunchKernelGGL(far_stride_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p, stride,
+                       cnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    unsigned long long h = 0;
+    FV_HIP(ctx, hipMemcpyAsync(&h, cnt.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *agree = (int64_t)h;
+    return FV_OK;
+}
+
+// y = (A + sigma*D) x ; partials != NULL also emits per-block partial sums of x.y.
+// use_done: honour the PCG early-exit flag.  vals_override: a value array with the
+// shift already folded into the diagonal (then sigma must be passed as 0).
+static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double sigma, double *partials, bool use_done,
+                            const double *vals_override = nullptr)
+{
+    fv_ctx *ctx = p->ctx;
+    if (!p->order_built)
+        FV_TRY(build_group_order(p));
     const int G = fv_spmv_grid(p);
     const double *shift = (sigma != 0.0) ? p->D.p : nullptr;
     const PcgScalars *scal = use_done ? p->scal.p : nullptr;
-    const int lpr = spmv_lpr(p);
-#define FV_SPMV_CASE(L)                                                                                                 \
-    if (partials)                                                                                                       \
-        hipLaunchKernelGGL((spmv_kernel<L, 2, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p,       \
-                           p->colind.p, p->vals.p, x, y, shift, sigma, partials, scal);                                 \
-    else                                                                                                                \
-        hipLaunchKernelGGL((spmv_kernel<L, 2, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p,      \
-                           p->colind.p, p->vals.p, x, y, shift, sigma, partials, scal);
-    if (lpr == 4) {
-        FV_SPMV_CASE(4)
-    } else if (lpr == 8) {
-        FV_SPMV_CASE(8)
+    const double *vals = vals_override ? vals_override : p->vals.p;
+    const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
+#define FV_SPMV_ARGS p->n, p->rowptr.p, p->colind.p, vals, x, y, shift, sigma, partials, scal
+    if (g_spmv_form == 2) {
+        if (partials)
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+        else
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
     } else {
-        FV_SPMV_CASE(16)
-    }
+        const int lpr = spmv_lpr(p);
+#define FV_SPMV_CASE(L, UU)                                                                                              \
+    if (partials)                                                                                                        \
+        hipLaunchKernelGGL((spmv_kernel<L, UU, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS);            \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((spmv_kernel<L, UU, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS);
+        if (lpr == 4) {
+            FV_SPMV_CASE(4, 2)
+        } else if (lpr == 16) {
+            FV_SPMV_CASE(16, 2)
+        } else if (g_spmv_unroll == 8) {
+            FV_SPMV_CASE(8, 8)
+        } else if (g_spmv_unroll == 4) {
+            FV_SPMV_CASE(8, 4)
+        } else {
+            FV_SPMV_CASE(8, 2)
+        }
 #undef FV_SPMV_CASE
+    }
+#undef FV_SPMV_ARGS
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
 
-int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null)
+static int ensure_folded(fv_problem *p, double sigma, const double **out);
+
+int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold)
 {
-    return spmv_launch_impl(p, x, y, sigma, partials_or_null, false);
+    const double *folded = nullptr;
+    if (fold && sigma != 0.0)
+        FV_TRY(ensure_folded(p, sigma, &folded));
+    return spmv_launch_impl(p, x, y, folded ? 0.0 : sigma, partials_or_null, false, folded);
 }
 
 // ------------------------------------------------------------------ PCG vector kernels
@@ -362,8 +616,59 @@ int fv_pcg_prepare(fv_problem *p)
     return FV_OK;
 }
 
+// vals_shifted = vals with sigma*D added to every stored diagonal entry
+__global__ __launch_bounds__(FV_BLOCK) void fold_shift_kernel(int64_t n, const int32_t *__restrict__ diagpos, const double *__restrict__ D,
+                                                               double sigma, double *__restrict__ vals_shifted, int *__restrict__ missing)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    const int32_t dp = diagpos[r];
+    if (dp >= 0)
+        vals_shifted[dp] += sigma * D[r];
+    else
+        *missing = 1;
+}
+
+extern int g_fold_shift;
+
+// Returns the folded value array for this sigma (building it if needed), or nullptr when folding is not possible.
+static int ensure_folded(fv_problem *p, double sigma, const double **out)
+{
+    fv_ctx *ctx = p->ctx;
+    *out = nullptr;
+    if (!g_fold_shift || p->fold_ok == 0 || p->nnz == 0)
+        return FV_OK;
+    if (p->vals_shifted.p && p->shifted_sigma == sigma && p->shifted_epoch == p->assemble_epoch) {
+        *out = p->vals_shifted.p;
+        return FV_OK;
+    }
+    if (!p->vals_shifted.p)
+        FV_TRY(p->vals_shifted.alloc(ctx, (size_t)p->nnz + 2));
+    FV_HIP(ctx, hipMemcpyAsync(p->vals_shifted.p, p->vals.p, ((size_t)p->nnz + 2) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    DevBuf<int> miss;
+    FV_TRY(miss.alloc(ctx, 1));
+    FV_TRY(miss.zero(ctx));
+    hipLaunchKernelGGL(fold_shift_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->diagpos.p, p->D.p, sigma,
+                       p->vals_shifted.p, miss.p);
+    FV_LAUNCH_CHECK(ctx);
+    int h = 0;
+    FV_HIP(ctx, hipMemcpyAsync(&h, miss.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h) { // a free row without a stored diagonal cannot carry the shift
+        p->fold_ok = 0;
+        p->vals_shifted.release();
+        return FV_OK;
+    }
+    p->fold_ok = 1;
+    p->shifted_sigma = sigma;
+    p->shifted_epoch = p->assemble_epoch;
+    *out = p->vals_shifted.p;
+    return FV_OK;
+}
+
 int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool x0_zero, double rtol, int64_t maxiter,
-                 fv_solve_info *info, bool time_it)
+                 fv_solve_info *info, bool time_it, bool fold_shift)
 {
     fv_ctx *ctx = p->ctx;
     FV_TRY(fv_pcg_prepare(p));
@@ -378,6 +683,10 @@ int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool
     const int64_t n = p->n;
     const int Gs = fv_spmv_grid(p);
     const int Gv = vec_grid(n);
+    const double *folded = nullptr;
+    if (fold_shift && sigma != 0.0)
+        FV_TRY(ensure_folded(p, sigma, &folded));
+    const double sig_mv = folded ? 0.0 : sigma; // the SpMV's own shift is off when the diagonal already carries it
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const double *Dp = (sigma != 0.0) ? p->D.p : nullptr;
@@ -386,7 +695,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool
         hipLaunchKernelGGL(pcg_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, rhs, (const double *)nullptr, p->diagA.p, Dp,
                            sigma, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
     } else {
-        FV_TRY(spmv_launch_impl(p, x, p->q.p, sigma, nullptr, false));
+        FV_TRY(spmv_launch_impl(p, x, p->q.p, sig_mv, nullptr, false, folded));
         hipLaunchKernelGGL(pcg_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, rhs, (const double *)p->q.p, p->diagA.p, Dp,
                            sigma, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
     }
@@ -398,26 +707,55 @@ int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool
     int64_t it = 0;
     int64_t chunk = 4;
     bool polled = false;
+    constexpr int64_t MAX_CHUNK = 32;
+    if (p->profile && p->prof_ev.empty()) {
+        p->prof_ev.resize((size_t)(6 * MAX_CHUNK));
+        for (hipEvent_t &e : p->prof_ev)
+            FV_HIP(ctx, hipEventCreate(&e));
+    }
+#define FV_PROF(idx)                                                                                            \
+    if (p->profile)                                                                                             \
+    FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * k + (idx))], ctx->stream))
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
+        int32_t iters_before = 0;
+        if (p->profile && polled)
+            iters_before = hs->iters;
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
-            FV_TRY(spmv_launch_impl(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true));
+            FV_PROF(0);
+            FV_TRY(spmv_launch_impl(p, p->pvec.p, p->q.p, sig_mv, p->part_pq.p, true, folded));
+            FV_PROF(1);
+            FV_PROF(2);
             hipLaunchKernelGGL(pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, x, p->r.p, p->pvec.p, p->q.p,
                                p->minv.p, p->part_pq.p, Gs, p->scal.p, p->part_rz.p, p->part_rr.p);
+            FV_PROF(3);
+            FV_PROF(4);
             hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,
                                p->part_rz.p, p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap);
+            FV_PROF(5);
         }
         FV_LAUNCH_CHECK(ctx);
         it += m;
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         polled = true;
+        if (p->profile) { // only launches that did real work (not the post-convergence no-ops)
+            const int64_t live = (int64_t)hs->iters - iters_before;
+            for (int64_t k = 0; k < m && k < live; k++)
+                for (int c = 0; c < 3; c++) {
+                    float ms = 0.f;
+                    FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k + 2 * c)], p->prof_ev[(size_t)(6 * k + 2 * c + 1)]));
+                    p->prof_ms[c] += ms;
+                    p->prof_launches[c]++;
+                }
+        }
         if (hs->done)
             break;
-        if (chunk < 32)
+        if (chunk < MAX_CHUNK)
             chunk *= 2;
     }
+#undef FV_PROF
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (!polled) {

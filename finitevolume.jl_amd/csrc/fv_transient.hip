@@ -286,7 +286,7 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
 }
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
-                     int64_t maxiter, fv_solve_info *info, bool time_it)
+                     int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
@@ -299,7 +299,7 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
                            bhat_dev, p->b.p, p->rhs.p, p->tmp.p);
         FV_LAUNCH_CHECK(ctx);
     }
-    FV_TRY(fv_pcg_solve(p, p->tmp.p, p->rhs.p, 1.0 / dt, false, rtol, maxiter, info, time_it));
+    FV_TRY(fv_pcg_solve(p, p->tmp.p, p->rhs.p, 1.0 / dt, false, rtol, maxiter, info, time_it, fold_shift));
     if (mode == FV_STEP_ADJOINT && p->n > 0) {
         hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, p->tmp.p);
         FV_LAUNCH_CHECK(ctx);
@@ -348,7 +348,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     fv_solve_info inf = {};
     int rc = FV_OK;
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
-        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false);
+        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
     }
@@ -400,10 +400,10 @@ extern "C" int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *
         FV_TRY(need_transient(p, "fv_bench_spmv with sigma != 0"));
     FV_TRY(fv_pcg_prepare(p));
     // the PCG's own kernel: SpMV with the p.q epilogue, on the resident search direction
-    FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p)); // warm
+    FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true)); // warm (and fold the shift if enabled)
     FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int32_t i = 0; i < reps; i++)
-        FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p));
+        FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true));
     FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     FV_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;
@@ -422,4 +422,29 @@ extern "C" int fv_dot(fv_problem *p, const double *a_free, const double *b_free,
     FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, a_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
     FV_HIP(ctx, hipMemcpyAsync(p->rhs.p, b_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
     return fv_dot_device(p, p->tmp.p, p->rhs.p, out);
+}
+
+// Per-kernel timing of the PCG loop with HIP events on the launch stream.
+extern "C" int fv_profile_enable(fv_problem *p, int on)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    p->profile = on != 0;
+    for (int c = 0; c < 3; c++) {
+        p->prof_ms[c] = 0;
+        p->prof_launches[c] = 0;
+    }
+    return FV_OK;
+}
+
+// kernel 0: spmv_dot (K1), 1: update (K2), 2: pupdate (K3)
+extern "C" int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches)
+{
+    if (!p || kernel < 0 || kernel > 2)
+        return FV_ERR_ARG;
+    if (total_ms)
+        *total_ms = p->prof_ms[kernel];
+    if (launches)
+        *launches = p->prof_launches[kernel];
+    return FV_OK;
 }

@@ -177,6 +177,13 @@ int fv_spmv(fv_problem *p, const double *x_free, double sigma, double *y_free);
  * average launch duration from HIP events on the launch stream. */
 int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms);
 int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *out);
+/* Time every PCG kernel launch with HIP event pairs on the launch stream (for the
+ * roofline figures of bench.py).  kernel: 0 = SpMV+dot, 1 = x/r update, 2 = p update. */
+/* Process-wide kernel selection for A/B measurements.  key 0: SpMV form (0 = CSR-stream
+ * through LDS, the default; 1 = lanes-per-row); key 1: unroll of the lanes-per-row form (2, 4, 8). */
+int fv_tune(int key, int value);
+int fv_profile_enable(fv_problem *p, int on);
+int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""A/B the SpMV variants in ONE process (interleaved rounds) on the bench workload.
+usage: python tools/tune_spmv.py [ns] [rounds]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+import bench  # noqa: E402
+
+fv = load_package()
+ns_ = int(sys.argv[1]) if len(sys.argv) > 1 else 464
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+ns = [ns_] * 3
+mins, maxs = bench.spacing_box(ns)
+dn, src = bench.box_setup(ns)
+p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+p.transient_begin(0.1, None, np.full(p.N, 1e3))
+lib = fv.load()
+bytes_ = 12 * p.nnz + 28 * p.n
+# name, form, order, fold
+variants = [("wstream+order+fold", 2, 1, 1), ("wstream+order", 2, 1, 0), ("wstream natural", 2, 0, 0), ("lpr8 U2", 1, 0, 0)]
+
+
+def select(form, order, fold):
+    lib.fv_tune(0, form)
+    lib.fv_tune(2, order)
+    lib.fv_tune(3, fold)
+
+
+res = {v[0]: [] for v in variants}
+rng = np.random.default_rng(0)
+x = rng.standard_normal(p.n)
+ref = None
+for name, form, order, fold in variants:  # correctness of every variant against the first
+    select(form, order, fold)
+    y = p.spmv(x, sigma=1 / 60.0)
+    if ref is None:
+        ref = y
+    else:
+        err = np.abs(y - ref).max() / np.abs(ref).max()
+        assert err < 1e-13, (name, err)
+for r in range(rounds):
+    for name, form, order, fold in variants:
+        select(form, order, fold)
+        res[name].append(p.bench_spmv(1 / 60.0, 10))
+for name, v in res.items():
+    v = np.array(v)
+    print("%-20s median %.3f ms  min %.3f ms  -> %.0f GB/s (median), %.1f%% of 8 TB/s" % (name, np.median(v), v.min(), bytes_ / np.median(v) / 1e6, bytes_ / np.median(v) / 1e6 / 80))
