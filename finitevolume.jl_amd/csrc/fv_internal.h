@@ -131,6 +131,9 @@ struct fv_problem {
     double shifted_sigma = 0.0;
     int64_t shifted_epoch = -1, assemble_epoch = 0;
     int fold_ok = -1; // -1 unknown, 0 some free row stores no diagonal, 1 ok
+    bool minv_valid = false; // cached Jacobi diagonal 1/(diag(A) + sigma D)
+    double minv_sigma = 0.0;
+    int64_t minv_epoch = -1;
 
     // transient
     double Ss = 1.0;
@@ -181,9 +184,20 @@ int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev); 
 
 // ---- fv_pcg.hip
 int fv_pcg_prepare(fv_problem *p);
-// Solve (A + sigma*D) x = rhs, x holds the initial guess (x0_zero: treat as zeros).
-int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool x0_zero, double rtol, int64_t maxiter,
-                 fv_solve_info *info, bool time_it, bool fold_shift = false);
+// The linear system handed to the PCG: (A + sigma*D) x = rhs.
+struct PcgSystem {
+    double sigma = 0.0;
+    const double *rhs = nullptr; // explicit right-hand side; for implicit_step: b' (nullptr = 0)
+    bool x0_zero = false;        // explicit form only: start from zeros
+    // implicit time step from the state held in x:  rhs = b' + D x0/dt  (b' = D*rhs if b_times_D),
+    // sigma must be 1/dt.  The initial residual is then b' - A x0 and no rhs vector is formed.
+    bool implicit_step = false;
+    bool b_times_D = false;
+    double dt = 0.0;
+    bool fold_shift = false; // use the copy of vals with sigma*D folded into the diagonal (fixed-dt runs)
+};
+// x holds the initial guess on entry and the solution on return.
+int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false);
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);

@@ -433,24 +433,44 @@ int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, doub
 // ------------------------------------------------------------------ PCG vector kernels
 __device__ inline int64_t vec_stride() { return (int64_t)gridDim.x * FV_BLOCK; }
 
-// r = rhs - q (q = (A + sigma D) x0, or absent when x0 = 0); M^-1 = 1/(diag(A) + sigma D);
-// p = M^-1 r; per-block partials of r.M^-1 r, r.r, rhs.rhs
+// r = rhs - q with q = (A + sigma D) x0 (absent when x0 = 0), for an explicit
+// right-hand side; or, for an implicit time step from the state x0 itself,
+//      rhs = b' + D x0/dt ,  q = A x0 (unshifted)  =>  r = b' - q
+// (the D x0/dt terms of rhs and of the shifted operator cancel, so the step needs
+// neither a materialised rhs nor the shift in its first SpMV).  b' is the assembled
+// b, or D*bhat when the caller supplies the volume-scaled bhat of the reference.
+// Also M^-1 = 1/(diag(A) + sigma D) (skipped when cached), p = M^-1 r and the
+// per-block partials of r.M^-1 r, r.r, rhs.rhs.
+template <bool IMPLICIT>
 __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const double *__restrict__ rhs, const double *__restrict__ q,
                                                              const double *__restrict__ diagA, const double *__restrict__ D,
-                                                             double sigma, double *__restrict__ r, double *__restrict__ pv,
+                                                             double sigma, double dt, int b_times_D, const double *__restrict__ x0,
+                                                             int compute_minv, double *__restrict__ r, double *__restrict__ pv,
                                                              double *__restrict__ minv, double *__restrict__ part_rz,
                                                              double *__restrict__ part_rr, double *__restrict__ part_bb)
 {
     __shared__ double smem[4];
     double arz = 0.0, arr = 0.0, abb = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
-        const double bi = rhs[i];
-        const double ri = q ? bi - q[i] : bi;
-        const double d = D ? diagA[i] + sigma * D[i] : diagA[i];
-        const double mi = 1.0 / d;
+        double bi = rhs ? rhs[i] : 0.0; // explicit rhs, or b' of the implicit step (absent = 0)
+        double ri;
+        if (IMPLICIT) {
+            const double di = D[i];
+            if (b_times_D)
+                bi *= di;
+            ri = bi - q[i];
+            bi += di * (x0[i] / dt); // the right-hand side this step solves for (norm only)
+        } else
+            ri = q ? bi - q[i] : bi;
+        double mi;
+        if (compute_minv) {
+            const double d = D ? diagA[i] + sigma * D[i] : diagA[i];
+            mi = 1.0 / d;
+            minv[i] = mi;
+        } else
+            mi = minv[i];
         const double zi = mi * ri;
         r[i] = ri;
-        minv[i] = mi;
         pv[i] = zi;
         arz += ri * zi;
         arr += ri * ri;
@@ -557,7 +577,8 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     const double rzn = reduce_partials(part_rz, nparts, smem);
     const double rrn = reduce_partials(part_rr, nparts, smem);
     const double beta = rzn / scal->rz[it & 1];
-    const int64_t n2 = n >> 1;
+    const bool converged = rrn <= scal->tol2; // same value in every block: the search direction is not needed any more
+    const int64_t n2 = converged ? 0 : (n >> 1);
     const double2 *r2 = reinterpret_cast<const double2 *>(r);
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
     double2 *p2 = reinterpret_cast<double2 *>(pv);
@@ -568,7 +589,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
         pvv.y = mv.y * rv.y + beta * pvv.y;
         p2[i] = pvv;
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!converged && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
         pv[i] = minv[i] * r[i] + beta * pv[i];
     }
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
         scal->iters = it + 1;
         if (hist && it < hist_cap)
             hist[it] = sqrt(rrn);
-        if (rrn <= scal->tol2)
+        if (converged)
             scal->done = 1;
     }
 }
@@ -667,8 +688,7 @@ static int ensure_folded(fv_problem *p, double sigma, const double **out)
     return FV_OK;
 }
 
-int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool x0_zero, double rtol, int64_t maxiter,
-                 fv_solve_info *info, bool time_it, bool fold_shift)
+int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it)
 {
     fv_ctx *ctx = p->ctx;
     FV_TRY(fv_pcg_prepare(p));
@@ -676,7 +696,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool
         maxiter = 0;
     if (maxiter > 0x7ffffff0LL)
         maxiter = 0x7ffffff0LL;
-    if (sigma != 0.0 && !p->D.p) {
+    const double sigma = sys.sigma;
+    if ((sigma != 0.0 || sys.implicit_step) && !p->D.p) {
         fv_set_error(ctx, "fv_pcg_solve: shifted operator requested before fv_transient_begin");
         return FV_ERR_STATE;
     }
@@ -684,20 +705,33 @@ int fv_pcg_solve(fv_problem *p, double *x, const double *rhs, double sigma, bool
     const int Gs = fv_spmv_grid(p);
     const int Gv = vec_grid(n);
     const double *folded = nullptr;
-    if (fold_shift && sigma != 0.0)
+    if (sys.fold_shift && sigma != 0.0)
         FV_TRY(ensure_folded(p, sigma, &folded));
     const double sig_mv = folded ? 0.0 : sigma; // the SpMV's own shift is off when the diagonal already carries it
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     const double *Dp = (sigma != 0.0) ? p->D.p : nullptr;
-    if (x0_zero) {
+    // the Jacobi diagonal only depends on (sigma, assembled values): keep it across the steps of a fixed-dt run
+    const int compute_minv = !(p->minv_valid && p->minv_sigma == sigma && p->minv_epoch == p->assemble_epoch);
+    p->minv_valid = true;
+    p->minv_sigma = sigma;
+    p->minv_epoch = p->assemble_epoch;
+    if (sys.implicit_step) {
+        // r0 = b' - A x0: plain (unshifted, unfolded) SpMV
+        FV_TRY(spmv_launch_impl(p, x, p->q.p, 0.0, nullptr, false, nullptr));
+        hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
+                           (const double *)p->D.p, sigma, sys.dt, (int)sys.b_times_D, (const double *)x, compute_minv, p->r.p, p->pvec.p,
+                           p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+    } else if (sys.x0_zero) {
         FV_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * sizeof(double), ctx->stream));
-        hipLaunchKernelGGL(pcg_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, rhs, (const double *)nullptr, p->diagA.p, Dp,
-                           sigma, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+        hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)nullptr, p->diagA.p,
+                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
+                           p->part_rr.p, p->part_bb.p);
     } else {
         FV_TRY(spmv_launch_impl(p, x, p->q.p, sig_mv, nullptr, false, folded));
-        hipLaunchKernelGGL(pcg_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, rhs, (const double *)p->q.p, p->diagA.p, Dp,
-                           sigma, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+        hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
+                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
+                           p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, p->part_rz.p, p->part_rr.p, p->part_bb.p,

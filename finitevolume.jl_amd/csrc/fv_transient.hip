@@ -76,7 +76,10 @@ extern "C" int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol
         p->hist.p = nullptr;
         p->hist_cap = 0;
     }
-    const int rc = fv_pcg_solve(p, x, p->b.p, 0.0, x0_free == nullptr, rtol, maxiter, &local, true);
+    PcgSystem sys;
+    sys.rhs = p->b.p;
+    sys.x0_zero = x0_free == nullptr;
+    const int rc = fv_pcg_solve(p, x, sys, rtol, maxiter, &local, true);
     p->hist.p = saved_hist;
     p->hist_cap = saved_cap;
     FV_TRY(rc);
@@ -119,6 +122,8 @@ extern "C" int fv_transient_begin(fv_problem *p, double Ss, const double *volume
     FV_TRY(fv_pcg_prepare(p));
     FV_TRY(p->D.alloc(ctx, (size_t)p->n + 2));
     p->Ss = Ss;
+    p->minv_valid = false; // D changes: cached Jacobi diagonal and folded values are stale
+    p->shifted_epoch = -1;
     DevBuf<double> dvol;
     const double *vol = nullptr;
     if (volumes) {
@@ -257,32 +262,17 @@ extern "C" int fv_state_norm2_diff(fv_problem *p, int32_t a, int32_t b, double *
 }
 
 // ------------------------------------------------------------------ one implicit step (a11)
-// forward:  rhs = D*(bhat + u/dt)         (bhat = volume-scaled b of the reference, transient.jl:71)
-//           rhs = b + D*(u/dt)            (bhat absent: the assembled, unscaled b)
-// adjoint:  the state is g = D w;  rhs = bhat + g/dt, initial guess w = g/D, afterwards g+ = D w+
-__global__ __launch_bounds__(FV_BLOCK) void step_rhs_kernel(int64_t n, int mode, double dt, const double *__restrict__ u,
-                                                             const double *__restrict__ D, const double *__restrict__ bhat,
-                                                             const double *__restrict__ b, double *__restrict__ rhs,
-                                                             double *__restrict__ x)
-{
-    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
-    if (i >= n)
-        return;
-    const double ui = u[i], di = D[i];
-    if (mode == FV_STEP_FORWARD) {
-        rhs[i] = bhat ? di * (bhat[i] + ui / dt) : b[i] + di * (ui / dt);
-        x[i] = ui;
-    } else {
-        rhs[i] = (bhat ? bhat[i] : 0.0) + ui / dt;
-        x[i] = ui / di;
-    }
-}
-
-__global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double *__restrict__ D, double *__restrict__ x)
+// forward:  (D/dt + A) u+ = b' + D u/dt with b' = b (assembled) or D*bhat (bhat = the
+//           volume-scaled b of the reference, transient.jl:71); initial guess u.
+// adjoint:  the state is g = D w;  (D/dt + A) w+ = bhat + D w/dt, initial guess w = g/D,
+//           afterwards g+ = D w+   (transpose(A_scaled) of transient.jl:193).
+// Solved in place in the destination slot; no right-hand side vector is formed
+// (see pcg_init_kernel<true>).
+__global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double *__restrict__ D, double *__restrict__ x, int divide)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (i < n)
-        x[i] *= D[i];
+        x[i] = divide ? x[i] / D[i] : x[i] * D[i];
 }
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
@@ -293,18 +283,26 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
         fv_set_error(ctx, "time step must be positive"); // transient.jl:68-70
         return FV_ERR_DT;
     }
-    // the solve runs in tmp so that src == dst is allowed
-    if (p->n > 0) {
-        hipLaunchKernelGGL(step_rhs_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, mode, dt, usrc, p->D.p,
-                           bhat_dev, p->b.p, p->rhs.p, p->tmp.p);
+    if (usrc != udst)
+        FV_HIP(ctx, hipMemcpyAsync(udst, usrc, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    PcgSystem sys;
+    sys.sigma = 1.0 / dt;
+    sys.dt = dt;
+    sys.implicit_step = true;
+    sys.fold_shift = fold_shift;
+    if (mode == FV_STEP_FORWARD) {
+        sys.rhs = bhat_dev ? bhat_dev : p->b.p;
+        sys.b_times_D = bhat_dev != nullptr;
+    } else {
+        sys.rhs = bhat_dev; // may be null: zero forcing
+        hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 1);
         FV_LAUNCH_CHECK(ctx);
     }
-    FV_TRY(fv_pcg_solve(p, p->tmp.p, p->rhs.p, 1.0 / dt, false, rtol, maxiter, info, time_it, fold_shift));
-    if (mode == FV_STEP_ADJOINT && p->n > 0) {
-        hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, p->tmp.p);
+    FV_TRY(fv_pcg_solve(p, udst, sys, rtol, maxiter, info, time_it));
+    if (mode == FV_STEP_ADJOINT) {
+        hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 0);
         FV_LAUNCH_CHECK(ctx);
     }
-    FV_HIP(ctx, hipMemcpyAsync(udst, p->tmp.p, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     return FV_OK;
 }
 
