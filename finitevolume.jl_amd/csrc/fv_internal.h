@@ -147,6 +147,7 @@ struct fv_problem {
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;
+    int64_t last_iters = 0; // iterations of the previous solve: sizes the first launch chunk of the next one
 
     // optional per-kernel timing of the PCG loop (fv_profile_enable): HIP event pairs
     // around every K1/K2/K3 launch on the launch stream, harvested at each poll.

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_kernel(int64_t n, const int32_t
 // every XCD sweeps its own contiguous part of that list.  A group's +plane x
 // lines are then still in that XCD's 4 MiB L2 when the same band of the next
 // plane needs them as centre and -plane arms, instead of being fetched 3 times.
-template <int WT, bool DOT>
+template <int WT, bool DOT, bool NT>
 __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const int32_t *__restrict__ rowptr,
                                                                  const int32_t *__restrict__ colind, const double *__restrict__ vals,
                                                                  const double *__restrict__ x, double *__restrict__ y,
@@ -200,8 +200,15 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
             for (int it = 0; it < NIT; it++) {
                 const int32_t j = ka + 2 * (lane + it * 64);
                 if (j < k1) { // vals/colind carry two padding entries past nnz
-                    v[it] = *reinterpret_cast<const double2 *>(vals + j);
-                    c[it] = *reinterpret_cast<const int2 *>(colind + j);
+                    if (NT) { // read-once streams: ask the caches not to keep them, so the x lines survive in L2
+                        v[it].x = __builtin_nontemporal_load(vals + j);
+                        v[it].y = __builtin_nontemporal_load(vals + j + 1);
+                        c[it].x = __builtin_nontemporal_load(colind + j);
+                        c[it].y = __builtin_nontemporal_load(colind + j + 1);
+                    } else {
+                        v[it] = *reinterpret_cast<const double2 *>(vals + j);
+                        c[it] = *reinterpret_cast<const int2 *>(colind + j);
+                    }
                 }
             }
 #pragma unroll
@@ -229,7 +236,10 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
             const double xr = (shift || DOT) ? x[row] : 0.0;
             if (shift)
                 sum += sigma * shift[row] * xr;
-            y[row] = sum;
+            if (NT)
+                __builtin_nontemporal_store(sum, y + row);
+            else
+                y[row] = sum;
             if (DOT)
                 dacc += xr * sum;
         }
@@ -243,10 +253,11 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
 
 // Tuning knobs (fv_tune) for in-process A/B: 0 = SpMV form (1 lanes-per-row, 2 wave stream),
 // 1 = unroll of the lanes-per-row form, 2 = use the plane-blocked traversal order (0/1),
-// 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1)
+// 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1)
 static int g_spmv_form = 2;
 static int g_spmv_unroll = 2;
 static int g_use_order = 1;
+static int g_nt = 1;
 int g_fold_shift = 1;
 
 extern "C" int fv_tune(int key, int value)
@@ -259,6 +270,8 @@ extern "C" int fv_tune(int key, int value)
         g_use_order = value;
     else if (key == 3 && (value == 0 || value == 1))
         g_fold_shift = value;
+    else if (key == 4 && (value == 0 || value == 1))
+        g_nt = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -277,7 +290,7 @@ int fv_spmv_grid(fv_problem *p)
 {
     // a multiple of 8 (XCD shares), at most one partial per block
     int64_t g;
-    if (g_spmv_form == 2)
+    if (g_spmv_form >= 2)
         g = (p->n + STREAM_RB - 1) / STREAM_RB;
     else {
         const int rpb = (FV_BLOCK / spmv_lpr(p)) * g_spmv_unroll;
@@ -354,9 +367,16 @@ __global__ __launch_bounds__(FV_BLOCK) void far_stride_kernel(int64_t n, const i
         const int32_t e = rowptr[r + 1];
         hit = e > rowptr[r] && (int64_t)colind[e - 1] - r == stride;
     }
+    __shared__ int wcount[FV_BLOCK / 64];
     const unsigned long long m = __ballot(hit);
-    if ((threadIdx.x & 63) == 0 && m)
-        atomicAdd(count, (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0)
+        wcount[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int c = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        if (c)
+            atomicAdd(count, (unsigned long long)c);
+    }
 }
 
 int fv_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree)
@@ -391,10 +411,14 @@ static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double si
     const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
 #define FV_SPMV_ARGS p->n, p->rowptr.p, p->colind.p, vals, x, y, shift, sigma, partials, scal
     if (g_spmv_form == 2) {
-        if (partials)
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+        if (partials && g_nt)
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+        else if (partials)
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+        else if (g_nt)
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
         else
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
     } else {
         const int lpr = spmv_lpr(p);
 #define FV_SPMV_CASE(L, UU)                                                                                              \
@@ -739,9 +763,14 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
-    int64_t chunk = 4;
-    bool polled = false;
     constexpr int64_t MAX_CHUNK = 32;
+    // Launches past convergence are no-ops (the done flag), but they still cost a few microseconds each and
+    // show up as zero-work kernels in traces, so the first chunk is sized by the previous solve on this
+    // problem (consecutive time steps need about the same number of iterations) and later chunks double.
+    int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
+    if (chunk > MAX_CHUNK)
+        chunk = MAX_CHUNK;
+    bool polled = false;
     if (p->profile && p->prof_ev.empty()) {
         p->prof_ev.resize((size_t)(6 * MAX_CHUNK));
         for (hipEvent_t &e : p->prof_ev)
@@ -796,6 +825,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    p->last_iters = hs->iters;
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;

@@ -22,22 +22,23 @@ p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
 p.transient_begin(0.1, None, np.full(p.N, 1e3))
 lib = fv.load()
 bytes_ = 12 * p.nnz + 28 * p.n
-# name, form, order, fold
-variants = [("wstream+order+fold", 2, 1, 1), ("wstream+order", 2, 1, 0), ("wstream natural", 2, 0, 0), ("lpr8 U2", 1, 0, 0)]
+# name, form, order, fold, nt
+variants = [("wstream+order+fold+nt", 2, 1, 1, 1), ("wstream+order+fold", 2, 1, 1, 0), ("wstream+fold", 2, 0, 1, 0), ("wstream", 2, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0)]
 
 
-def select(form, order, fold):
+def select(form, order, fold, nt=0):
     lib.fv_tune(0, form)
     lib.fv_tune(2, order)
     lib.fv_tune(3, fold)
+    lib.fv_tune(4, nt)
 
 
 res = {v[0]: [] for v in variants}
 rng = np.random.default_rng(0)
 x = rng.standard_normal(p.n)
 ref = None
-for name, form, order, fold in variants:  # correctness of every variant against the first
-    select(form, order, fold)
+for name, form, order, fold, nt in variants:  # correctness of every variant against the first
+    select(form, order, fold, nt)
     y = p.spmv(x, sigma=1 / 60.0)
     if ref is None:
         ref = y
@@ -45,9 +46,9 @@ for name, form, order, fold in variants:  # correctness of every variant against
         err = np.abs(y - ref).max() / np.abs(ref).max()
         assert err < 1e-13, (name, err)
 for r in range(rounds):
-    for name, form, order, fold in variants:
-        select(form, order, fold)
+    for name, form, order, fold, nt in variants:
+        select(form, order, fold, nt)
         res[name].append(p.bench_spmv(1 / 60.0, 10))
 for name, v in res.items():
     v = np.array(v)
-    print("%-20s median %.3f ms  min %.3f ms  -> %.0f GB/s (median), %.1f%% of 8 TB/s" % (name, np.median(v), v.min(), bytes_ / np.median(v) / 1e6, bytes_ / np.median(v) / 1e6 / 80))
+    print("%-24s median %.3f ms  min %.3f ms  -> %.0f GB/s (median), %.1f%% of 8 TB/s" % (name, np.median(v), v.min(), bytes_ / np.median(v) / 1e6, bytes_ / np.median(v) / 1e6 / 80))
