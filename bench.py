@@ -120,7 +120,7 @@ def main():
     from __graft_entry__ import load_package
 
     fv = load_package()
-    if world > 1:
+    if world > 1 or os.environ.get("FV_BENCH_FORCE_DIST") == "1":  # the env var rehearses the multi-GPU driver with one rank
         from bench_dist import run_distributed
 
         return run_distributed(fv, args, world, rank)

@@ -97,6 +97,12 @@ SIGNATURES = {
     "fv_comm_unique_id": (C.c_int, [C.c_char_p]),
     "fv_comm_init": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p]),
     "fv_comm_destroy": (C.c_int, [c_ctx]),
+    "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
+    "fv_dist_plan_sizes": (C.c_int, [c_prob] + [P(C.c_int64)] * 7),
+    "fv_dist_get_plan": (C.c_int, [c_prob] + [_i64p] * 7),
+    "fv_dist_run_fixed": (C.c_int, [c_prob, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_void_p, P(SolveInfo), P(C.c_double)]),
+    "fv_dist_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
+    "fv_dist_state_get": (C.c_int, [c_prob, _f64p]),
 }
 
 _lib = None

@@ -57,3 +57,45 @@ extern "C" int fv_comm_destroy(fv_ctx *ctx)
     ctx->rank = 0;
     return FV_OK;
 }
+
+// Halo exchange of one vector: ship sendbuf (grouped by destination) and receive
+// every peer's contribution straight into the halo slots (recv_base, grouped by
+// owner).  One grouped ncclSend/ncclRecv batch on `stream`; over xGMI these are
+// point-to-point transfers between the two neighbouring slabs of a structured grid.
+int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream)
+{
+    if (d->nranks <= 1)
+        return FV_OK;
+    if (!ctx->comm || ctx->nranks != d->nranks || ctx->rank != d->rank) {
+        fv_set_error(ctx, "distributed problem (%d ranks) without a matching communicator: call fv_comm_init first", d->nranks);
+        return FV_ERR_COMM;
+    }
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    FV_NCCL(ctx, ncclGroupStart());
+    int64_t soff = 0, roff = 0;
+    for (int q = 0; q < d->nranks; q++) {
+        const int64_t sc = d->send_counts[(size_t)q], rcnt = d->recv_counts[(size_t)q];
+        if (q != d->rank) {
+            if (sc > 0)
+                FV_NCCL(ctx, ncclSend(sendbuf + soff, (size_t)sc, ncclDouble, q, comm, stream));
+            if (rcnt > 0)
+                FV_NCCL(ctx, ncclRecv(recv_base + roff, (size_t)rcnt, ncclDouble, q, comm, stream));
+        }
+        soff += sc;
+        roff += rcnt;
+    }
+    FV_NCCL(ctx, ncclGroupEnd());
+    return FV_OK;
+}
+
+int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream)
+{
+    if (d->nranks <= 1)
+        return FV_OK;
+    if (!ctx->comm || ctx->nranks != d->nranks) {
+        fv_set_error(ctx, "distributed problem (%d ranks) without a matching communicator: call fv_comm_init first", d->nranks);
+        return FV_ERR_COMM;
+    }
+    FV_NCCL(ctx, ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, stream));
+    return FV_OK;
+}

@@ -100,9 +100,25 @@ struct PcgScalars {
     int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN)
 };
 
+// Plan and buffers of a row block in a distributed run (built by fv_dist_setup).
+struct fv_dist {
+    int nranks = 1, rank = 0;
+    int64_t lo = 0, hi = 0, nhalo = 0, nsend = 0, entry_lo = 0, n_int = 0, n_bnd = 0;
+    std::vector<int64_t> bounds, recv_counts, send_counts; // per rank
+    DevBuf<int32_t> halo_cols;  // global column of every halo slot, ascending
+    DevBuf<int32_t> send_idx;   // local rows to ship, grouped by destination rank, ascending
+    DevBuf<int32_t> groups_int; // 64-row groups that touch no halo slot
+    DevBuf<int32_t> groups_bnd; // the others
+    DevBuf<double> sendbuf;
+    DevBuf<double> red;   // 8 scalars: all-reduce buffer
+    DevBuf<double> part2; // per-block partials of the boundary SpMV pass
+};
+
 struct fv_problem {
     fv_ctx *ctx = nullptr;
     int64_t N = 0, F = 0, n = 0, nnz = 0, ndir = 0, E = 0;
+    int64_t nhalo = 0;             // row block of a distributed operator: halo slots appended to every vector
+    fv_dist *dist = nullptr;       // plan + buffers of the distributed run (fv_dist.hip)
     bool from_grid = false, from_csc = false, assembled = false, transient_ready = false;
     int64_t ns[3] = {0, 0, 0};
 
@@ -163,6 +179,7 @@ struct fv_problem {
                 (void)hipFree(s);
         for (hipEvent_t e : prof_ev)
             (void)hipEventDestroy(e);
+        delete dist;
     }
 };
 
@@ -203,6 +220,10 @@ int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, doub
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);
 int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double *out_host);
+
+// ---- fv_comm.hip (RCCL); all are no-ops for a single rank
+int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream);
+int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream);
 
 // copy helper: dst/src may be host or device
 inline int fv_copy(fv_ctx *ctx, void *dst, const void *src, size_t bytes)

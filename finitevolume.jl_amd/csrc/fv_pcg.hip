@@ -145,7 +145,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
                                                                  const double *__restrict__ x, double *__restrict__ y,
                                                                  const double *__restrict__ shift, double sigma,
                                                                  double *__restrict__ partials, const PcgScalars *__restrict__ scal,
-                                                                 const int32_t *__restrict__ order)
+                                                                 const int32_t *__restrict__ order, int64_t npos)
 {
     constexpr int NIT = WT / 128; // entry pairs per lane
     constexpr int WPB = FV_BLOCK / 64;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
         return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *prod = prod_all[wave];
-    const int64_t ngroups = (n + 63) >> 6;
+    const int64_t ngroups = npos; // positions to visit: all 64-row groups, or the entries of `order`
     // position space: XCD share xs of [0, ngroups) is swept in passes of (G/8)*WPB consecutive positions
     const int64_t per_xcd = (ngroups + 7) >> 3;
     const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
@@ -398,27 +398,44 @@ int fv_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree)
 // y = (A + sigma*D) x ; partials != NULL also emits per-block partial sums of x.y.
 // use_done: honour the PCG early-exit flag.  vals_override: a value array with the
 // shift already folded into the diagonal (then sigma must be passed as 0).
+// order_override/npos_override: visit only the listed 64-row groups (distributed interior / boundary passes).
 static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double sigma, double *partials, bool use_done,
-                            const double *vals_override = nullptr)
+                            const double *vals_override = nullptr, const int32_t *order_override = nullptr,
+                            int64_t npos_override = -1, int *grid_out = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     if (!p->order_built)
         FV_TRY(build_group_order(p));
-    const int G = fv_spmv_grid(p);
+    int G = fv_spmv_grid(p);
+    if (npos_override >= 0) { // a grid sized for the listed groups (4 per block), multiple of 8
+        int64_t g = ((npos_override + 3) / 4 + 7) / 8 * 8;
+        if (g < 8)
+            g = 8;
+        if (g < G)
+            G = (int)g;
+    }
+    if (grid_out)
+        *grid_out = G;
     const double *shift = (sigma != 0.0) ? p->D.p : nullptr;
     const PcgScalars *scal = use_done ? p->scal.p : nullptr;
     const double *vals = vals_override ? vals_override : p->vals.p;
     const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
+    int64_t npos = (p->n + 63) >> 6;
+    if (npos_override >= 0) {
+        order = order_override;
+        npos = npos_override;
+    }
+    const bool stream_form = g_spmv_form == 2 || npos_override >= 0;
 #define FV_SPMV_ARGS p->n, p->rowptr.p, p->colind.p, vals, x, y, shift, sigma, partials, scal
-    if (g_spmv_form == 2) {
+    if (stream_form) {
         if (partials && g_nt)
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order, npos);
         else if (partials)
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, true, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order, npos);
         else if (g_nt)
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, true>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order, npos);
         else
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order);
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, FV_SPMV_ARGS, order, npos);
     } else {
         const int lpr = spmv_lpr(p);
 #define FV_SPMV_CASE(L, UU)                                                                                              \
@@ -643,7 +660,7 @@ int fv_pcg_prepare(fv_problem *p)
     fv_ctx *ctx = p->ctx;
     if (p->r.p)
         return FV_OK;
-    const size_t n = (size_t)p->n + 2; // +2: the double2 tail never reads past the allocation
+    const size_t n = (size_t)p->n + (size_t)p->nhalo + 2; // +2: the double2 tail never reads past the allocation; halo slots of a row block
     FV_TRY(p->r.alloc(ctx, n));
     FV_TRY(p->pvec.alloc(ctx, n));
     FV_TRY(p->q.alloc(ctx, n));
@@ -916,4 +933,211 @@ int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double
     FV_TRY(reduce_to_host(p, G, &s));
     *out_host = sqrt(s);
     return FV_OK;
+}
+
+// ------------------------------------------------------------------ distributed fixed-step run (row blocks over RCCL)
+// Same three kernels per iteration as the single-GPU solve; the differences are
+//   - p's halo slots are refreshed before every SpMV: pack kernel -> grouped
+//     ncclSend/ncclRecv on the second stream, overlapped with the SpMV over the
+//     interior row groups; the boundary groups run after the halo has landed;
+//   - the per-block partials are summed to device scalars and all-reduced
+//     (p.q: 1 double; r.M^-1 r and r.r: one 2-double message), and K2/K3 read the
+//     reduced scalars instead of re-reducing partials.
+// Every rank sees bit-identical scalars, so all ranks take the same branches and
+// enqueue the same collectives.
+__global__ __launch_bounds__(FV_BLOCK) void dist_pack_kernel(int64_t nsend, const int32_t *__restrict__ idx, const double *__restrict__ x,
+                                                              double *__restrict__ buf)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < nsend)
+        buf[i] = x[idx[i]];
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void dist_sum2_kernel(const double *__restrict__ a, int na, const double *__restrict__ b, int nb,
+                                                              double *__restrict__ out)
+{
+    __shared__ double smem[4];
+    const double ta = reduce_partials(a, na, smem);
+    const double tb = nb > 0 ? reduce_partials(b, nb, smem) : 0.0;
+    if (threadIdx.x == 0)
+        *out = ta + tb;
+}
+
+static int dist_exchange_begin(fv_problem *p, double *xext)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    if (d->nranks <= 1)
+        return FV_OK;
+    if (d->nsend > 0) {
+        hipLaunchKernelGGL(dist_pack_kernel, dim3(fv_blocks(d->nsend)), dim3(FV_BLOCK), 0, ctx->stream, d->nsend, d->send_idx.p, xext,
+                           d->sendbuf.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_HIP(ctx, hipEventRecord(ctx->ev_comp, ctx->stream));
+    FV_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_comp, 0));
+    FV_TRY(fv_comm_halo_exchange(ctx, d, d->sendbuf.p, xext + p->n, ctx->stream2));
+    FV_HIP(ctx, hipEventRecord(ctx->ev_halo, ctx->stream2));
+    return FV_OK;
+}
+
+static int dist_exchange_wait(fv_problem *p)
+{
+    if (p->dist->nranks <= 1)
+        return FV_OK;
+    FV_HIP(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->ctx->ev_halo, 0));
+    return FV_OK;
+}
+
+// y = (A + sigma D) x on the row block; with want_dot the local x.y lands in red[0] (not yet all-reduced)
+static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const double *folded, bool want_dot, bool use_done)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    int Ga = 0, Gb = 0;
+    FV_TRY(dist_exchange_begin(p, xext));
+    FV_TRY(spmv_launch_impl(p, xext, y, sigma, want_dot ? p->part_pq.p : nullptr, use_done, folded, d->groups_int.p, d->n_int, &Ga));
+    FV_TRY(dist_exchange_wait(p));
+    if (d->n_bnd > 0)
+        FV_TRY(spmv_launch_impl(p, xext, y, sigma, want_dot ? d->part2.p : nullptr, use_done, folded, d->groups_bnd.p, d->n_bnd, &Gb));
+    if (want_dot) {
+        hipLaunchKernelGGL(dist_sum2_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_pq.p, Ga,
+                           (const double *)d->part2.p, d->n_bnd > 0 ? Gb : 0, d->red.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    return FV_OK;
+}
+
+static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    const int64_t n = p->n;
+    const int Gv = vec_grid(n);
+    const double sigma = 1.0 / dt;
+    const double *folded = nullptr;
+    FV_TRY(ensure_folded(p, sigma, &folded));
+    const double sig_mv = folded ? 0.0 : sigma;
+    const int compute_minv = !(p->minv_valid && p->minv_sigma == sigma && p->minv_epoch == p->assemble_epoch);
+    p->minv_valid = true;
+    p->minv_sigma = sigma;
+    p->minv_epoch = p->assemble_epoch;
+    double *red = d->red.p;
+    // r0 = b - A u (unshifted), rhs norm from b + D u/dt
+    FV_TRY(dist_spmv(p, u, p->q.p, 0.0, nullptr, false, false));
+    hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
+                       p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, p->r.p, p->pvec.p, p->minv.p,
+                       p->part_rz.p, p->part_rr.p, p->part_bb.p);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_bb.p, Gv, red + 3);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 3, ctx->stream));
+    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 1), (const double *)(red + 2),
+                       (const double *)(red + 3), 1, rtol, p->scal.p);
+    FV_LAUNCH_CHECK(ctx);
+    PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
+    int64_t it = 0;
+    int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
+    if (chunk > 32)
+        chunk = 32;
+    while (it < maxiter) {
+        const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
+        for (int64_t k = 0; k < m; k++) {
+            const int iter = (int)(it + k);
+            FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
+            hipLaunchKernelGGL(pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, u, p->r.p, p->pvec.p, p->q.p, p->minv.p,
+                               (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
+            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
+            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
+            FV_LAUNCH_CHECK(ctx);
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 2, ctx->stream));
+            hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,
+                               (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0);
+            FV_LAUNCH_CHECK(ctx);
+        }
+        it += m;
+        FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hs->done)
+            break;
+        if (chunk < 32)
+            chunk *= 2;
+    }
+    if (it == 0) {
+        FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    p->last_iters = hs->iters;
+    if (info) {
+        info->converged = hs->done == 1;
+        info->iters = hs->iters;
+        info->bnorm = sqrt(hs->bnorm2);
+        info->relres = hs->bnorm2 > 0 ? sqrt(hs->rr / hs->bnorm2) : sqrt(hs->rr);
+        info->solve_ms = 0.0;
+        info->resnorm_len = 0;
+    }
+    return FV_OK;
+}
+
+extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, double rtol, int64_t maxiter, int32_t *iters_per_step,
+                                 fv_solve_info *last_info, double *total_ms)
+{
+    if (!p || !p->dist || nsteps < 0)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!(dt > 0)) {
+        fv_set_error(ctx, "time step must be positive");
+        return FV_ERR_DT;
+    }
+    hipEvent_t e0, e1;
+    FV_HIP(ctx, hipEventCreate(&e0));
+    FV_HIP(ctx, hipEventCreate(&e1));
+    FV_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    fv_solve_info inf = {};
+    int rc = FV_OK;
+    for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
+        rc = dist_step(p, p->slots[0], dt, rtol, maxiter, &inf);
+        if (iters_per_step)
+            iters_per_step[s] = inf.iters;
+    }
+    if (rc == FV_OK) {
+        float ms = 0.f;
+        if (hipEventRecord(e1, ctx->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess ||
+            hipEventElapsedTime(&ms, e0, e1) != hipSuccess) {
+            fv_set_error(ctx, "event timing failed");
+            rc = FV_ERR_HIP;
+        }
+        if (total_ms)
+            *total_ms = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (last_info)
+        *last_info = inf;
+    return rc;
+}
+
+// one distributed SpMV on host data (tests): y_local = (A + sigma D) x, x_local has nloc entries
+extern "C" int fv_dist_spmv(fv_problem *p, const double *x_local, double sigma, double *y_local)
+{
+    if (!p || !p->dist || !x_local || !y_local)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(fv_pcg_prepare(p));
+    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, x_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(dist_spmv(p, p->tmp.p, p->rhs.p, sigma, nullptr, false, false));
+    return fv_copy(ctx, y_local, p->rhs.p, (size_t)p->n * sizeof(double));
+}
+
+// local slice of the state (slot 0), nloc values
+extern "C" int fv_dist_state_get(fv_problem *p, double *u_local)
+{
+    if (!p || !p->dist || !u_local)
+        return FV_ERR_ARG;
+    FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
+    return fv_copy(p->ctx, u_local, p->slots[0], (size_t)p->n * sizeof(double));
 }

@@ -1,0 +1,88 @@
+"""One-process-per-GPU runs: RCCL communicator bootstrap and row-block problems.
+
+torch.distributed is used only as the control plane (rendezvous, broadcasting the
+RCCL unique id, barriers); the data plane — halo exchange and the PCG all-reduces —
+is RCCL called directly from libfvhip.so on HIP streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import SolveInfo, load, ptr
+from .core import Problem
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(_lib.FV_COMM_ID_BYTES)
+    _lib.check(load().fv_comm_unique_id(buf))
+    return buf.raw
+
+
+def comm_init(ctx, nranks, rank, uid):
+    ctx.check(load().fv_comm_init(ctx.handle, int(nranks), int(rank), C.create_string_buffer(uid, _lib.FV_COMM_ID_BYTES)))
+
+
+def comm_init_from_torch(ctx):
+    """Rank 0 creates the RCCL id; torch.distributed (any backend) broadcasts it."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm_init(ctx, world, rank, box[0])
+    return rank, world
+
+
+class RowBlock:
+    """A rank's contiguous range of free rows (fv_dist_setup)."""
+
+    def __init__(self, global_problem, nranks, rank):
+        h = _lib.c_prob()
+        global_problem.check(load().fv_dist_setup(global_problem.handle, int(nranks), int(rank), C.byref(h)))
+        self.handle, self.ctx = h, global_problem.ctx
+        self.nranks, self.rank = int(nranks), int(rank)
+        v = [C.c_int64() for _ in range(7)]
+        self.ctx.check(load().fv_dist_plan_sizes(h, *[C.byref(x) for x in v]))
+        self.lo, self.hi, self.nnz, self.nhalo, self.nsend, self.n_int, self.n_bnd = [x.value for x in v]
+        self.nloc = self.hi - self.lo
+
+    def plan(self):
+        rp = np.empty(self.nloc + 1, np.int64)
+        ci = np.empty(self.nnz, np.int64)
+        hc = np.empty(self.nhalo, np.int64)
+        rc = np.empty(self.nranks, np.int64)
+        sc = np.empty(self.nranks, np.int64)
+        si = np.empty(self.nsend, np.int64)
+        gb = np.empty(self.n_bnd, np.int64)
+        self.ctx.check(load().fv_dist_get_plan(self.handle, ptr(rp), ptr(ci), ptr(hc), ptr(rc), ptr(sc), ptr(si), ptr(gb)))
+        return dict(rowptr=rp, colind=ci, halo_cols=hc, recv_counts=rc, send_counts=sc, send_idx=si, groups_bnd=gb)
+
+    def run_fixed(self, dt, nsteps, rtol, maxiter=1000):
+        iters = np.zeros(max(int(nsteps), 1), np.int32)
+        info = SolveInfo()
+        ms = C.c_double()
+        self.ctx.check(load().fv_dist_run_fixed(self.handle, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
+        return iters[: int(nsteps)], info, ms.value
+
+    def spmv(self, x_local, sigma=0.0):
+        x = _lib.af64(x_local)
+        y = np.empty(self.nloc, np.float64)
+        self.ctx.check(load().fv_dist_spmv(self.handle, ptr(x), float(sigma), ptr(y)))
+        return y
+
+    def state(self):
+        u = np.empty(self.nloc, np.float64)
+        self.ctx.check(load().fv_dist_state_get(self.handle, ptr(u)))
+        return u
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            load().fv_problem_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -191,6 +191,28 @@ int fv_comm_unique_id(char id[FV_COMM_ID_BYTES]);
 int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_COMM_ID_BYTES]);
 int fv_comm_destroy(fv_ctx *ctx);
 
+/* Row-block partition for one-process-per-GPU runs (no reference counterpart:
+ * FiniteVolume.jl is single-process).  Call on a global problem after fv_assemble
+ * and fv_transient_begin: rank `rank` of `nranks` gets a NEW problem holding its
+ * contiguous range of free rows ([r*n/nranks, (r+1)*n/nranks)), columns renumbered
+ * [local | halo]; the global problem can be destroyed afterwards.  State slot 0 of
+ * the block is the rank's slice of the global slot 0. */
+int fv_dist_setup(fv_problem *global, int nranks, int rank, fv_problem **block);
+int fv_dist_plan_sizes(fv_problem *block, int64_t *lo, int64_t *hi, int64_t *nnz_loc, int64_t *nhalo, int64_t *nsend,
+                       int64_t *n_interior_groups, int64_t *n_boundary_groups);
+/* The plan, 0-based (device convention): local CSR, global column of every halo slot,
+ * per-rank receive/send counts, the concatenated send list (local rows) and the
+ * 64-row groups that touch the halo.  Any pointer may be NULL. */
+int fv_dist_get_plan(fv_problem *block, int64_t *rowptr_loc, int64_t *colind_loc, int64_t *halo_cols, int64_t *recv_counts,
+                     int64_t *send_counts, int64_t *send_idx, int64_t *groups_bnd);
+/* fixedbackwardeulerstep! x nsteps on the row block; halo exchange by grouped
+ * ncclSend/ncclRecv on a second stream (overlapping the interior SpMV) and the PCG
+ * scalars by ncclAllReduce.  Collective: every rank must call it with the same arguments. */
+int fv_dist_run_fixed(fv_problem *block, double dt, int64_t nsteps, double rtol, int64_t maxiter, int32_t *iters_per_step,
+                      fv_solve_info *last_info, double *total_ms);
+int fv_dist_spmv(fv_problem *block, const double *x_local, double sigma, double *y_local); /* collective */
+int fv_dist_state_get(fv_problem *block, double *u_local);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,3 +243,64 @@ def test_theis_and_thiem(fv, oracle):
     assert len(ts) == len(ots) and np.allclose(ts, ots, rtol=0, atol=0)
     assert relerr(us[-1], ous[-1]) < HEAD_RTOL
     assert solver.solves > 3000
+
+
+# ------------------------------------------------------------------ multi-GPU plan and single-rank RCCL path
+def _dist_case(fv, ns=(12, 9, 7)):
+    import bench
+
+    mins, maxs = bench.spacing_box(list(ns))
+    dn, src = bench.box_setup(list(ns))
+    p = fv.Problem.regulargrid(mins, maxs, list(ns), dn)
+    rng = np.random.default_rng(0)
+    K = 1e-5 * np.exp(rng.standard_normal(p.F))
+    p.assemble(K, src, np.full(len(dn), 1e3))
+    u0 = np.full(p.N, 1e3)
+    u0 += rng.standard_normal(p.N)
+    st = p.transient_begin(0.1, None, u0)
+    return p, st
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_device_partition_plan_matches_host_planner(fv, nranks):
+    from fvamd import dist, partition
+
+    p, st = _dist_case(fv)
+    A = p.csc()
+    rowptr, colind = A.colptr - 1, A.rowval - 1
+    u_global = st.free_values()
+    for rank in range(nranks):
+        blk = dist.RowBlock(p, nranks, rank)
+        want = partition.plan(rowptr, colind, nranks, rank)
+        got = blk.plan()
+        assert (blk.lo, blk.hi) == (want["lo"], want["hi"])
+        assert np.array_equal(got["rowptr"], want["rowptr"])
+        assert np.array_equal(got["colind"], want["colind"])
+        assert np.array_equal(got["halo_cols"], want["halo_cols"])
+        assert np.array_equal(got["recv_counts"], want["recv_counts"])
+        assert got["send_counts"].tolist() == [len(s) for s in want["send_idx"]]
+        assert np.array_equal(got["send_idx"], np.concatenate(want["send_idx"]) if blk.nsend else np.empty(0, np.int64))
+        bgroups = np.unique(np.nonzero(want["boundary_rows"])[0] // 64)
+        assert np.array_equal(got["groups_bnd"], bgroups)
+        assert blk.n_int + blk.n_bnd == (blk.nloc + 63) // 64
+        assert np.array_equal(blk.state(), u_global[blk.lo : blk.hi])
+
+
+def test_single_rank_rccl_path_matches_plain_run(fv):
+    """nranks = 1 through the distributed driver (RCCL communicator of one rank:
+    all-reduce + empty halo) must reproduce the single-GPU loop."""
+    from fvamd import dist
+
+    p, st = _dist_case(fv, (16, 12, 10))
+    ctx = p.ctx
+    dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
+    blk = dist.RowBlock(p, 1, 0)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(p.n)
+    assert np.allclose(blk.spmv(x, 0.01), p.spmv(x, 0.01), rtol=1e-14, atol=1e-20)
+    it_d, info_d, _ = blk.run_fixed(3600.0, 4, 1e-12)
+    it_s, info_s, _ = p.run_fixed(st, 3600.0, 4, 1e-12)
+    assert info_d.converged and info_s.converged
+    assert np.array_equal(it_d, it_s)
+    assert relerr(blk.state(), st.free_values()) < 1e-12
+    fv.load().fv_comm_destroy(ctx.handle)
