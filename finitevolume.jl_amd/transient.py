@@ -122,45 +122,44 @@ def _norm_diff(a, b):
 
 
 def backwardeulertwostep(rhs, A, getb, u_k, t, dt, linearsolver, atol, onestep=None):
-    """transient.jl:78-87"""
-    if onestep is None:
-        onestep = backwardeuleronestep(rhs, A, getb(t), u_k, dt, linearsolver, atol)
-    twostep1 = backwardeuleronestep(rhs, A, getb(t), u_k, 0.5 * dt, linearsolver, atol)
-    twostep = backwardeuleronestep(rhs, A, getb(t + 0.5 * dt), twostep1, 0.5 * dt, linearsolver, atol)
-    err = _norm_diff(onestep, twostep)
-    if err < atol:
-        return twostep, dt, err < atol / 4
-    return twostep1, 0.5 * dt, False
+    """Step doubling (transient.jl:78-87): one full step against two half steps; the
+    two-half-step state is accepted when they agree to atol (and the step may grow when
+    they agree to atol/4), otherwise the first half step is handed back."""
+    full = onestep if onestep is not None else backwardeuleronestep(rhs, A, getb(t), u_k, dt, linearsolver, atol)
+    half = 0.5 * dt
+    firsthalf = backwardeuleronestep(rhs, A, getb(t), u_k, half, linearsolver, atol)
+    secondhalf = backwardeuleronestep(rhs, A, getb(t + half), firsthalf, half, linearsolver, atol)
+    mismatch = _norm_diff(full, secondhalf)
+    if mismatch < atol:
+        return secondhalf, dt, mismatch < atol / 4
+    return firsthalf, half, False
 
 
 def adaptivebackwardeulerstep(rhs, A, getb, u_k, t, dt, linearsolver, atol, callback):
-    """transient.jl:89-121"""
+    """transient.jl:89-121: try the requested dt; when it is rejected, cover it with accepted
+    sub-steps — halve on rejection, double when the error is below atol/4, never overshoot —
+    and reuse a rejected trial's half-step state as the next trial's full step."""
     callback(t, dt)
-    u_new, laststeptime, increasestepsize = backwardeulertwostep(rhs, A, getb, u_k, t, dt, linearsolver, atol)
-    if laststeptime < dt:  # it couldn't take the step we asked, so try taking smaller steps
-        laststepfailed = True
-        elapsedtime = 0.0
-        u_elapsedtime = u_k
-        targetdt = laststeptime
-        while elapsedtime < dt:
-            callback(t, dt)
-            if laststepfailed:  # reuse u_new as the onestep part
-                u_new, laststeptime, increasestepsize = backwardeulertwostep(rhs, A, getb, u_elapsedtime, t + elapsedtime, targetdt, linearsolver, atol, u_new)
-            else:
-                u_new, laststeptime, increasestepsize = backwardeulertwostep(rhs, A, getb, u_elapsedtime, t + elapsedtime, targetdt, linearsolver, atol)
-            if laststeptime == targetdt:
-                elapsedtime += laststeptime
-                u_elapsedtime = u_new
-                if increasestepsize:
-                    targetdt = 2 * laststeptime
-                laststepfailed = False
-            elif laststeptime < targetdt:
-                targetdt = laststeptime
-                laststepfailed = True
-            else:
-                raise FVError(_lib.FV_ERR_STATE, "Code is broken -- laststeptime should never be greater than targetdt")
-            targetdt = min(targetdt, dt - elapsedtime)  # don't overshoot
-    return u_new, laststeptime, increasestepsize
+    state, taken, grow = backwardeulertwostep(rhs, A, getb, u_k, t, dt, linearsolver, atol)
+    if not taken < dt:
+        return state, taken, grow
+    covered, base, want, reuse = 0.0, u_k, taken, True
+    while covered < dt:
+        callback(t, dt)
+        state, taken, grow = backwardeulertwostep(rhs, A, getb, base, t + covered, want, linearsolver, atol, state if reuse else None)
+        if taken == want:
+            covered += taken
+            base = state
+            reuse = False
+            if grow:
+                want = 2 * taken
+        elif taken < want:
+            want = taken
+            reuse = True
+        else:
+            raise FVError(_lib.FV_ERR_STATE, "Code is broken -- laststeptime should never be greater than targetdt")
+        want = min(want, dt - covered)
+    return state, taken, grow
 
 
 def fixedbackwardeulerstep(rhs, A, getb, u_k, t, dt, linearsolver, atol, callback):
