@@ -304,3 +304,56 @@ def test_single_rank_rccl_path_matches_plain_run(fv):
     assert np.array_equal(it_d, it_s)
     assert relerr(blk.state(), st.free_values()) < 1e-12
     fv.load().fv_comm_destroy(ctx.handle)
+
+
+# ------------------------------------------------------------------ adjoint on the device operator
+def test_onenode_adjoint_lambda(fv):
+    """test/onenodeadjoint.jl:51-66: adjointintegrate re-enters the hot path with transpose(A)."""
+    from scipy.integrate import quad
+
+    sigma2 = 0.01**2
+    c = refcases.onenode(0.0)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    uobs = lambda t: 1 - math.exp(-t)  # noqa: E731  (observations: analytic solution for loghyco = 0)
+    # forward model at the perturbed parameters (loghyco + 1)
+    us, ts = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"] + 1, c["sources"], c["dnodes"], c["dheads"], None, True, atol=c["atol"], dt0=c["dt0"])
+    uc = fv.getcontinuoussolution(us, ts)
+    dgdu = lambda t: np.array([2 * sigma2 * (uc(t)[1] - uobs(t))])  # noqa: E731  (transientadjointutils.jl:13-21, one observed free node)
+    lambdas, ts_l = fv.adjointintegrate(dgdu, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"] + 1, c["sources"], c["dnodes"], c["dheads"], None, True, atol=c["atol"], dt0=c["dt0"])
+    u_init = lambda s: (1 - math.exp(-math.e * s)) / math.e  # noqa: E731
+    f = lambda s: 2 * sigma2 * (u_init(s) - uobs(s))  # noqa: E731
+    T = c["tspan"][1]
+    gamma = lambda t: math.exp(-math.e * t) * quad(lambda s: math.exp(math.e * s) * f(T - s), 0, t)[0]  # noqa: E731
+    assert ts_l[0] == 0.0 and ts_l[-1] == T and len(ts_l) > 5
+    for lam, t in zip(lambdas, ts_l):
+        want = gamma(T - t)
+        assert abs(lam[0] - want) <= max(1e-7, 1e-4 * max(abs(lam[0]), abs(want)))
+
+
+def test_adjoint_step_matches_transposed_scaled_operator(fv, oracle):
+    """FV_STEP_ADJOINT solves (I/dt + A D^-1) g+ = g/dt + bhat: checked against a dense solve with unequal volumes."""
+    rng = np.random.default_rng(7)
+    ns = (5, 4, 3)
+    coords, nb, aol, vol = fv.regulargrid([0.0, 0.0, 0.0], [4.0, 3.0, 2.0], list(ns))
+    K = rng.random(len(aol)) + 0.5
+    dn = np.array([1, len(vol)], np.int64)
+    dh = np.array([1.0, 0.0])
+    vol = vol * (1 + rng.random(len(vol)))  # make D non-uniform so that A D^-1 is NOT symmetric
+    p = fv.Problem.create(nb, aol, len(vol), dn).assemble(K, np.zeros(len(vol)), dh)
+    st = p.transient_begin(0.3, vol, None)
+    g0 = rng.standard_normal(p.n)
+    bhat = rng.standard_normal(p.n)
+    st.set_free(g0)
+    dst = p.new_state()
+    dt = 0.7
+    p.step(st, dst, dt, bhat, mode=1, rtol=1e-14, maxiter=500)
+    A = p.csc().toscipy().toarray()
+    freenode, _ = p.free_maps()
+    D = 0.3 * vol[freenode]
+    M = np.eye(p.n) / dt + A @ np.diag(1 / D)  # transpose of (I/dt + D^-1 A)
+    want = np.linalg.solve(M, g0 / dt + bhat)
+    assert relerr(dst.free_values(), want) < 1e-11
+    # and the forward mode against (I/dt + D^-1 A) u+ = u/dt + bhat
+    p.step(st, dst, dt, bhat, mode=0, rtol=1e-14, maxiter=500)
+    Mf = np.eye(p.n) / dt + np.diag(1 / D) @ A
+    assert relerr(dst.free_values(), np.linalg.solve(Mf, g0 / dt + bhat)) < 1e-11

@@ -1,0 +1,67 @@
+"""CPU: the host-side seams of the integrator and the adjoint hooks, exercised with a
+user-supplied linearsolver and host matrices exactly as the reference's tests do
+(test/ode.jl:31-40, test/odeadjoint.jl).  No GPU is touched on this path."""
+import math
+
+import numpy as np
+
+
+def test_odeadjoint_closed_form(fv):
+    """test/odeadjoint.jl: d/dp of ∫x dt with dx/dt = b x, x(0) = a"""
+    a, b, T = 1.0, 2.0, 1.0
+    p = [a, b]
+    x = lambda t: np.array([p[0] * math.exp(p[1] * t)])  # noqa: E731
+    lam = lambda t: (1 - math.exp(p[1] * (T - t))) / b  # noqa: E731
+    grad = np.array([1 / p[1] * (math.exp(p[1] * T) - 1), -p[0] / p[1] ** 2 * (math.exp(p[1] * T) - 1) + p[0] / p[1] * math.exp(p[1] * T) * T])
+    A = np.full((1, 1), p[1])
+    linearsolver = lambda A, b, x0: np.linalg.solve(A, b)  # noqa: E731
+    xs, ts_x = fv.backwardeulerintegrate(x(0), -A, lambda t: np.zeros(1), 1e-5, 0.0, T, linearsolver=linearsolver, atol=1e-8)
+    assert ts_x[-1] == T
+    X = np.array([v[0] for v in xs])
+    Xe = np.array([x(t)[0] for t in ts_x])
+    assert np.linalg.norm(X - Xe) <= 1e-4 * max(np.linalg.norm(X), np.linalg.norm(Xe))
+    lambdas, ts_l = fv.adjointintegrate(-A, lambda t: -np.ones(1), (0.0, T), dt0=1e-5, linearsolver=linearsolver, atol=1e-8)
+    assert ts_l[0] == 0.0 and ts_l[-1] == T  # returned in terms of lambda: time runs forward again
+    L = np.array([v[0] for v in lambdas])
+    Le = np.array([lam(t) for t in ts_l])
+    assert np.linalg.norm(L - Le) <= 1e-4 * max(np.linalg.norm(L), np.linalg.norm(Le))
+    xc = fv.getcontinuoussolution(xs, ts_x)
+    lambdac = fv.getcontinuoussolution(lambdas, ts_l)
+    assert abs(xc(0.5 * (ts_x[3] + ts_x[4]))[0] - 0.5 * (xs[3][0] + xs[4][0])) < 1e-14
+    dx0dp = np.array([[-1.0], [0.0]])
+
+    def dfdp(t):
+        r = np.zeros((2, 1))
+        r[1, 0] = -xc(t)[0]
+        return r
+
+    g = fv.gradientintegrate(lambdac, dx0dp, lambda t: np.zeros(2), dfdp, (0.0, T))
+    assert np.linalg.norm(g - grad) <= 1e-4 * np.linalg.norm(grad)
+
+
+def test_diagonalupdate_and_scalebyvolume_host_objects(fv):
+    """transient.jl:1-48 on host matrices (the objects a user linearsolver receives)."""
+    A = fv.SparseMatrixCSC(3, 3, np.array([1, 3, 5, 6]), np.array([1, 2, 1, 2, 3]), np.array([4.0, -1.0, -1.0, 4.0, 2.0]))
+    fv.diagonalupdate(A, 0.5)
+    assert A.nzval.tolist() == [4.5, -1.0, -1.0, 4.5, 2.5]
+    fv.diagonalupdate(A, -0.5)
+    assert A.nzval.tolist() == [4.0, -1.0, -1.0, 4.0, 2.0]
+    M = np.eye(2)
+    fv.diagonalupdate(M, 2.0)
+    assert M.tolist() == [[3.0, 0.0], [0.0, 3.0]]
+    vols = np.array([2.0, 10.0, 4.0, 8.0])
+    f2n = np.array([1, 3, 4])  # free index -> node
+    fv.scalebyvolume(A, vols, f2n)  # row scaling, transient.jl:19
+    assert A.nzval.tolist() == [2.0, -0.25, -0.5, 1.0, 0.25]
+    b = np.array([2.0, 4.0, 8.0])
+    fv.scalebyvolume(b, vols, f2n)
+    assert b.tolist() == [1.0, 1.0, 1.0]
+
+
+def test_getcontinuoussolution_bounds(fv):
+    import pytest
+
+    uc = fv.getcontinuoussolution([np.zeros(2), np.ones(2)], [0.0, 2.0])
+    assert uc(0.5).tolist() == [0.25, 0.25] and uc(2.0).tolist() == [1.0, 1.0]
+    with pytest.raises(IndexError):
+        uc(2.5)
