@@ -281,13 +281,13 @@ extern "C" int fv_dist_setup(fv_problem *pg, int nranks, int rank, fv_problem **
         if ((rc = fv_pcg_prepare(pl)))
             break;
         double *s0 = nullptr;
-        if (hipMalloc((void **)&s0, ((size_t)nloc + (size_t)nhalo + 2) * sizeof(double)) != hipSuccess) {
+        if (hipMalloc((void **)&s0, ((size_t)nloc + (size_t)nhalo + FV_VEC_PAD) * sizeof(double)) != hipSuccess) {
             rc = FV_ERR_NOMEM;
             break;
         }
         pl->slots.push_back(s0);
         pl->slot_used.push_back(1);
-        if (hipMemsetAsync(s0, 0, ((size_t)nloc + (size_t)nhalo + 2) * sizeof(double), ctx->stream) != hipSuccess ||
+        if (hipMemsetAsync(s0, 0, ((size_t)nloc + (size_t)nhalo + FV_VEC_PAD) * sizeof(double), ctx->stream) != hipSuccess ||
             (nloc > 0 && hipMemcpyAsync(s0, pg->slots[0] + lo, (size_t)nloc * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = FV_ERR_HIP;

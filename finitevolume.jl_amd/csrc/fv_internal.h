@@ -13,6 +13,7 @@
 
 constexpr int FV_BLOCK = 256;        // 4 waves of 64
 constexpr int FV_MAX_PARTIALS = 2048; // 8 blocks/CU x 256 CUs: one partial per block
+constexpr int FV_VEC_PAD = 32;        // slack behind every vector (double2 tails read past n)
 
 struct fv_ctx {
     int device = 0;

@@ -272,6 +272,7 @@ extern "C" int fv_tune(int key, int value)
         g_fold_shift = value;
     else if (key == 4 && (value == 0 || value == 1))
         g_nt = value;
+
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -660,7 +661,7 @@ int fv_pcg_prepare(fv_problem *p)
     fv_ctx *ctx = p->ctx;
     if (p->r.p)
         return FV_OK;
-    const size_t n = (size_t)p->n + (size_t)p->nhalo + 2; // +2: the double2 tail never reads past the allocation; halo slots of a row block
+    const size_t n = (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD; // slack for double2 tails and whole x lines; halo slots of a row block
     FV_TRY(p->r.alloc(ctx, n));
     FV_TRY(p->pvec.alloc(ctx, n));
     FV_TRY(p->q.alloc(ctx, n));

@@ -38,7 +38,7 @@ static int slot_new(fv_problem *p, int32_t *slot)
             return FV_OK;
         }
     double *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, ((size_t)p->n + (size_t)p->nhalo + 2) * sizeof(double));
+    hipError_t e = hipMalloc((void **)&d, ((size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD) * sizeof(double));
     if (e != hipSuccess) {
         fv_set_error(p->ctx, "hipMalloc of a state vector failed: %s", hipGetErrorString(e));
         return FV_ERR_NOMEM;

@@ -22,23 +22,24 @@ p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
 p.transient_begin(0.1, None, np.full(p.N, 1e3))
 lib = fv.load()
 bytes_ = 12 * p.nnz + 28 * p.n
-# name, form, order, fold, nt
-variants = [("wstream+order+fold+nt", 2, 1, 1, 1), ("wstream+order+fold", 2, 1, 1, 0), ("wstream+fold", 2, 0, 1, 0), ("wstream", 2, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0)]
+# name, form, order, fold, nt, stage
+variants = [("staged-x+order+fold+nt", 2, 1, 1, 1, 1), ("staged-x+fold+nt", 2, 0, 1, 1, 1), ("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
 
 
-def select(form, order, fold, nt=0):
+def select(form, order, fold, nt, stage):
     lib.fv_tune(0, form)
     lib.fv_tune(2, order)
     lib.fv_tune(3, fold)
     lib.fv_tune(4, nt)
+    lib.fv_tune(5, stage)
 
 
 res = {v[0]: [] for v in variants}
 rng = np.random.default_rng(0)
 x = rng.standard_normal(p.n)
 ref = None
-for name, form, order, fold, nt in variants:  # correctness of every variant against the first
-    select(form, order, fold, nt)
+for name, *knobs in variants:  # correctness of every variant against the last (lanes-per-row)
+    select(*knobs)
     y = p.spmv(x, sigma=1 / 60.0)
     if ref is None:
         ref = y
@@ -46,8 +47,8 @@ for name, form, order, fold, nt in variants:  # correctness of every variant aga
         err = np.abs(y - ref).max() / np.abs(ref).max()
         assert err < 1e-13, (name, err)
 for r in range(rounds):
-    for name, form, order, fold, nt in variants:
-        select(form, order, fold, nt)
+    for name, *knobs in variants:
+        select(*knobs)
         res[name].append(p.bench_spmv(1 / 60.0, 10))
 for name, v in res.items():
     v = np.array(v)
