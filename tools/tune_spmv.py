@@ -23,7 +23,7 @@ p.transient_begin(0.1, None, np.full(p.N, 1e3))
 lib = fv.load()
 bytes_ = 12 * p.nnz + 28 * p.n
 # name, form, order, fold, nt, stage
-variants = [("staged-x+order+fold+nt", 2, 1, 1, 1, 1), ("staged-x+fold+nt", 2, 0, 1, 1, 1), ("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
+variants = [("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream+fold+nt", 2, 0, 1, 1, 0), ("wstream+fold", 2, 0, 1, 0, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
 
 
 def select(form, order, fold, nt, stage):
@@ -31,7 +31,6 @@ def select(form, order, fold, nt, stage):
     lib.fv_tune(2, order)
     lib.fv_tune(3, fold)
     lib.fv_tune(4, nt)
-    lib.fv_tune(5, stage)
 
 
 res = {v[0]: [] for v in variants}
