@@ -167,7 +167,7 @@ def main():
             kms, kc = prof[k]
             if kc:
                 kern[k] = {"avg_ms": kms / kc, "launches": kc}
-                if kms / kc > 0.05 * 32 * p.n / 5e9 * 1e3:  # the last p-update of a solve is skipped on convergence: no bandwidth figure for no-ops
+                if kms / kc > 0.05 * (32 * p.n / 5e12 * 1e3):  # the last p-update of a solve is skipped on convergence: no bandwidth figure for no-ops
                     kern[k]["GB/s"] = bytes_ / (kms / kc * 1e-3) / 1e9
     tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
     if os.path.exists(tfile):

@@ -139,13 +139,25 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_kernel(int64_t n, const int32_t
 // every XCD sweeps its own contiguous part of that list.  A group's +plane x
 // lines are then still in that XCD's 4 MiB L2 when the same band of the next
 // plane needs them as centre and -plane arms, instead of being fetched 3 times.
-template <int WT, bool DOT, bool NT>
+// Optional epilogue that turns the first SpMV of an implicit step (q = A u) into the whole PCG set-up
+// (see pcg_init_kernel<true>): r = b' - q, p = M^-1 r and the three partial sums, without writing q.
+struct StepInitEpilogue {
+    const double *bprime; // b' (may be null = 0)
+    const double *D;
+    const double *diagA;
+    double *minv, *r, *pv;
+    double *part_rz, *part_rr, *part_bb;
+    double sigma, dt;
+    int b_times_D, compute_minv;
+};
+
+template <int WT, bool DOT, bool NT, bool INIT = false>
 __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const int32_t *__restrict__ rowptr,
                                                                  const int32_t *__restrict__ colind, const double *__restrict__ vals,
                                                                  const double *__restrict__ x, double *__restrict__ y,
                                                                  const double *__restrict__ shift, double sigma,
                                                                  double *__restrict__ partials, const PcgScalars *__restrict__ scal,
-                                                                 const int32_t *__restrict__ order, int64_t npos)
+                                                                 const int32_t *__restrict__ order, int64_t npos, StepInitEpilogue epi = {})
 {
     constexpr int NIT = WT / 128; // entry pairs per lane
     constexpr int WPB = FV_BLOCK / 64;
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
     const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
     const int64_t xend = (xbase + per_xcd < ngroups) ? xbase + per_xcd : ngroups;
     int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave;
-    double dacc = 0.0;
+    double dacc = 0.0, arr = 0.0, abb = 0.0; // INIT: dacc = r.M^-1 r
     int64_t group = 0;
     int32_t s = 0, e = 0;
     if (pos < xend) {
@@ -232,7 +244,28 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
             for (int32_t k = my_s; k < my_e; k++)
                 sum += vals[k] * x[colind[k]];
         }
-        if (lane < nr) {
+        if (INIT) {
+            if (lane < nr) { // sum = (A u)_row
+                const double di = epi.D[row];
+                double bi = epi.bprime ? epi.bprime[row] : 0.0;
+                if (epi.b_times_D)
+                    bi *= di;
+                const double ri = bi - sum;
+                bi += di * (x[row] / epi.dt);
+                double mi;
+                if (epi.compute_minv) {
+                    mi = 1.0 / (epi.diagA[row] + epi.sigma * di);
+                    epi.minv[row] = mi;
+                } else
+                    mi = epi.minv[row];
+                const double zi = mi * ri;
+                epi.r[row] = ri;
+                epi.pv[row] = zi;
+                dacc += ri * zi;
+                arr += ri * ri;
+                abb += bi * bi;
+            }
+        } else if (lane < nr) {
             const double xr = (shift || DOT) ? x[row] : 0.0;
             if (shift)
                 sum += sigma * shift[row] * xr;
@@ -244,7 +277,16 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
                 dacc += xr * sum;
         }
     }
-    if (DOT) {
+    if (INIT) {
+        const double t0 = block_sum(dacc, smem);
+        const double t1 = block_sum(arr, smem);
+        const double t2 = block_sum(abb, smem);
+        if (threadIdx.x == 0) {
+            epi.part_rz[blockIdx.x] = t0;
+            epi.part_rr[blockIdx.x] = t1;
+            epi.part_bb[blockIdx.x] = t2;
+        }
+    } else if (DOT) {
         const double tsum = block_sum(dacc, smem);
         if (threadIdx.x == 0)
             partials[blockIdx.x] = tsum;
@@ -253,11 +295,13 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
 
 // Tuning knobs (fv_tune) for in-process A/B: 0 = SpMV form (1 lanes-per-row, 2 wave stream),
 // 1 = unroll of the lanes-per-row form, 2 = use the plane-blocked traversal order (0/1),
-// 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1)
+// 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1),
+// 5 = fuse the PCG set-up of an implicit step into its first SpMV (0/1)
 static int g_spmv_form = 2;
 static int g_spmv_unroll = 2;
 static int g_use_order = 1;
 static int g_nt = 1;
+static int g_fuse_init = 1;
 int g_fold_shift = 1;
 
 extern "C" int fv_tune(int key, int value)
@@ -272,6 +316,8 @@ extern "C" int fv_tune(int key, int value)
         g_fold_shift = value;
     else if (key == 4 && (value == 0 || value == 1))
         g_nt = value;
+    else if (key == 5 && (value == 0 || value == 1))
+        g_fuse_init = value;
 
     else
         return FV_ERR_ARG;
@@ -758,7 +804,36 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->minv_valid = true;
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
-    if (sys.implicit_step) {
+    int Ginit = Gv; // number of per-block partials the set-up produced
+    if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
+        // r0 = b' - A x0 and the whole set-up in the epilogue of one plain (unshifted, unfolded) SpMV
+        if (!p->order_built)
+            FV_TRY(build_group_order(p));
+        StepInitEpilogue epi;
+        epi.bprime = sys.rhs;
+        epi.D = p->D.p;
+        epi.diagA = p->diagA.p;
+        epi.minv = p->minv.p;
+        epi.r = p->r.p;
+        epi.pv = p->pvec.p;
+        epi.part_rz = p->part_rz.p;
+        epi.part_rr = p->part_rr.p;
+        epi.part_bb = p->part_bb.p;
+        epi.sigma = sigma;
+        epi.dt = sys.dt;
+        epi.b_times_D = (int)sys.b_times_D;
+        epi.compute_minv = compute_minv;
+        const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
+        Ginit = Gs;
+        if (g_nt)
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, true, true>), dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, n, p->rowptr.p,
+                               p->colind.p, p->vals.p, (const double *)x, (double *)nullptr, (const double *)nullptr, 0.0, (double *)nullptr,
+                               (const PcgScalars *)nullptr, order, (n + 63) >> 6, epi);
+        else
+            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, false, true>), dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, n, p->rowptr.p,
+                               p->colind.p, p->vals.p, (const double *)x, (double *)nullptr, (const double *)nullptr, 0.0, (double *)nullptr,
+                               (const PcgScalars *)nullptr, order, (n + 63) >> 6, epi);
+    } else if (sys.implicit_step) {
         // r0 = b' - A x0: plain (unshifted, unfolded) SpMV
         FV_TRY(spmv_launch_impl(p, x, p->q.p, 0.0, nullptr, false, nullptr));
         hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
@@ -777,7 +852,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     FV_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, p->part_rz.p, p->part_rr.p, p->part_bb.p,
-                       Gv, rtol, p->scal.p);
+                       Ginit, rtol, p->scal.p);
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
