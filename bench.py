@@ -153,11 +153,13 @@ def main():
     p.profile(False)
 
     value = p.N * args.steps / sec
-    # algorithmic bytes of the dominant kernel, SpMV with the D/dt shift and p.q epilogue:
-    # vals 8 + colind 4 per entry; rowptr 4 + x 8 + y 8 + D 8 per row   
-    spmv_bytes = 12 * p.nnz + 28 * p.n
+    # algorithmic bytes of the dominant kernel, the PCG SpMV q = (A + D/dt) p with the p.q epilogue, in
+    # SURVEY.md §8d's CSR accounting: vals 8 + colind 4 per entry; rowptr 4 + x 8 + y 8 per row.  The fixed-dt
+    # run folds D/dt into the stored diagonal, so the "+8 n if the shift vector is read separately" does not apply.
+    spmv_bytes = 12 * p.nnz + 20 * p.n
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": "spmv_kernel<8,2,true> (K1: q=(A+D/dt)p, p.q)", "algorithmic_bytes_per_launch": spmv_bytes}
+            "kernel": "K1 q=(A+D/dt)p with p.q: spmv_dia_kernel<true,true,false> (+ spmv_wstream_kernel<512,true,true> on the non-grid-like slices)",
+            "algorithmic_bytes_per_launch": spmv_bytes}
     kern = {}
     if prof and prof["spmv_dot"][1] > 0:
         ms, cnt = prof["spmv_dot"]

@@ -210,3 +210,26 @@ int fv_exclusive_scan_i32(fv_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FV_OK;
 }
+
+// ------------------------------------------------------------------ stream compaction
+__global__ __launch_bounds__(FV_BLOCK) void compact_kernel(int64_t n, const int32_t *__restrict__ flag, const int32_t *__restrict__ scan,
+                                                            int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n && flag[i])
+        out[scan[i]] = (int32_t)i;
+}
+
+// out[] <- ascending indices i with flag[i] != 0 (flags must be 0/1); *count = how many
+int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count)
+{
+    DevBuf<int32_t> scan;
+    FV_TRY(scan.alloc(ctx, (size_t)n + 1));
+    FV_TRY(fv_exclusive_scan_i32(ctx, flag, scan.p, n, count));
+    if (*count > 0 && out) {
+        hipLaunchKernelGGL(compact_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, flag, scan.p, out);
+        FV_LAUNCH_CHECK(ctx);
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return FV_OK;
+}

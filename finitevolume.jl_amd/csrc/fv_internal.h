@@ -140,6 +140,15 @@ struct fv_problem {
     bool order_built = false;
     int64_t order_stride = 0;
 
+    // sliced-DIA copy of the grid-like slices (fv_pcg.hip): per 64-row slice the distinct column offsets
+    // (0 = slice stays with the CSR kernel), the lists of DIA slices / CSR groups, lane-major values
+    DevBuf<uint8_t> sl_noff;
+    DevBuf<int32_t> sl_off, dia_list, csr_list;
+    DevBuf<double> dia_vals;
+    int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
+    double dia_tag = 0.0;
+    bool dia_built = false;
+
     // numeric
     DevBuf<double> cond, vals, b, diagA, dheads;
 
@@ -198,6 +207,7 @@ int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes_host_or_dev);
 int fv_build_symbolic(fv_problem *p);
 int fv_widen_indices(fv_ctx *ctx, const int32_t *src, int64_t *dst, int64_t n, int64_t add);
 int fv_narrow_indices(fv_ctx *ctx, const int64_t *src, int32_t *dst, int64_t n, int64_t lo, int64_t hi, int *bad);
+int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count); // ascending indices of the set flags
 int fv_scatter_nodes(fv_problem *p, const double *ufree_dev, double *head_dev); // freenodes2nodes on device buffers
 int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev);  // u[freenodes]
 

@@ -149,6 +149,7 @@ struct StepInitEpilogue {
     double *part_rz, *part_rr, *part_bb;
     double sigma, dt;
     int b_times_D, compute_minv;
+    int q_shifted; // the SpMV used the shifted operator: r = rhs - q instead of b' - q
 };
 
 template <int WT, bool DOT, bool NT, bool INIT = false>
@@ -250,8 +251,9 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
                 double bi = epi.bprime ? epi.bprime[row] : 0.0;
                 if (epi.b_times_D)
                     bi *= di;
-                const double ri = bi - sum;
-                bi += di * (x[row] / epi.dt);
+                const double rhsv = bi + di * (x[row] / epi.dt);
+                const double ri = epi.q_shifted ? rhsv - sum : bi - sum;
+                bi = rhsv;
                 double mi;
                 if (epi.compute_minv) {
                     mi = 1.0 / (epi.diagA[row] + epi.sigma * di);
@@ -296,12 +298,13 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
 // Tuning knobs (fv_tune) for in-process A/B: 0 = SpMV form (1 lanes-per-row, 2 wave stream),
 // 1 = unroll of the lanes-per-row form, 2 = use the plane-blocked traversal order (0/1),
 // 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1),
-// 5 = fuse the PCG set-up of an implicit step into its first SpMV (0/1)
+// 5 = fuse the PCG set-up of an implicit step into its first SpMV (0/1), 6 = sliced-DIA form for grid-like slices (0/1)
 static int g_spmv_form = 2;
 static int g_spmv_unroll = 2;
 static int g_use_order = 1;
 static int g_nt = 1;
 static int g_fuse_init = 1;
+static int g_use_dia = 1;
 int g_fold_shift = 1;
 
 extern "C" int fv_tune(int key, int value)
@@ -318,6 +321,8 @@ extern "C" int fv_tune(int key, int value)
         g_nt = value;
     else if (key == 5 && (value == 0 || value == 1))
         g_fuse_init = value;
+    else if (key == 6 && (value == 0 || value == 1))
+        g_use_dia = value;
 
     else
         return FV_ERR_ARG;
@@ -508,6 +513,378 @@ static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double si
     return FV_OK;
 }
 
+// ------------------------------------------------------------------ sliced-DIA form of the grid-like part
+// A 64-row slice of a grid-structured matrix has only a handful of distinct column
+// offsets (col - row): 7 for the 7-point stencil, also across line ends and next to
+// Dirichlet cells, where some rows merely lack some of them.  For every slice with at
+// most DIA_K distinct offsets the values are kept a second time lane-major,
+//      sval[(slice_pos*DIA_K + k)*64 + lane] = A[row, row + off_k]   (0 where absent),
+// and the SpMV needs no column indices, no row pointers, no LDS and no cross-lane
+// reduction: lane = row, every value load and every x load of a step is one contiguous
+// 512-byte access.  Entry traffic drops from 12 to 8 bytes.  Slices with more offsets
+// (irregular meshes, rows longer than DIA_K) stay with the CSR wave-stream kernel, which
+// then runs over the list of remaining 64-row groups.  The terms of a row are summed in
+// ascending column order, exactly like the CSR kernels.
+constexpr int DIA_K = 8;
+
+__global__ __launch_bounds__(FV_BLOCK) void dia_pattern_kernel(int64_t n, const int32_t *__restrict__ rowptr,
+                                                                const int32_t *__restrict__ colind, uint8_t *__restrict__ sl_noff,
+                                                                int32_t *__restrict__ sl_off, int32_t *__restrict__ is_dia,
+                                                                int32_t *__restrict__ is_csr)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nslices = (n + 63) >> 6;
+    const int64_t sl = (int64_t)blockIdx.x * WPB + wave;
+    if (sl >= nslices)
+        return;
+    const int64_t row = (sl << 6) + lane;
+    int32_t o[DIA_K];
+    int len = 0;
+    int32_t k0 = 0;
+    if (row < n) {
+        k0 = rowptr[row];
+        len = rowptr[row + 1] - k0;
+    }
+#pragma unroll
+    for (int k = 0; k < DIA_K; k++)
+        o[k] = (k < len && k < DIA_K) ? (int32_t)((int64_t)colind[k0 + k] - row) : 0x7fffffff;
+    const bool toolong = __any(len > DIA_K);
+    int32_t last = -0x7fffffff - 1;
+    int count = 0;
+    bool ok = !toolong;
+    int32_t found[DIA_K];
+    while (ok) { // distinct offsets of the slice in ascending order
+        int32_t m = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (o[k] > last && o[k] < m)
+                m = o[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int32_t t = __shfl_xor(m, off, 64);
+            m = t < m ? t : m;
+        }
+        if (m == 0x7fffffff)
+            break;
+        if (count == DIA_K) {
+            ok = false;
+            break;
+        }
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (k == count)
+                found[k] = m;
+        count++;
+        last = m;
+    }
+    if (count == 0)
+        ok = false; // nothing stored in this slice: leave it to the CSR kernel (which writes the zeros)
+    if (lane == 0) {
+        sl_noff[sl] = ok ? (uint8_t)count : 0;
+        is_dia[sl] = ok ? 1 : 0;
+        is_csr[sl] = ok ? 0 : 1;
+    }
+    if (ok && lane < DIA_K) {
+        int32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (k == lane && k < count)
+                v = found[k];
+        sl_off[sl * DIA_K + lane] = v;
+    }
+}
+
+// sval <- the (possibly diagonal-folded) CSR values, lane-major per slice
+__global__ __launch_bounds__(FV_BLOCK) void dia_fill_kernel(int64_t n, int64_t ndia, const int32_t *__restrict__ dia_list,
+                                                             const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+                                                             const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                             const double *__restrict__ vals, double *__restrict__ sval)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pos = (int64_t)blockIdx.x * WPB + wave;
+    if (pos >= ndia)
+        return;
+    const int64_t sl = dia_list[pos];
+    const int64_t row = (sl << 6) + lane;
+    const int noff = sl_noff[sl];
+    int32_t ptr = 0, end = 0;
+    if (row < n) {
+        ptr = rowptr[row];
+        end = rowptr[row + 1];
+    }
+    for (int k = 0; k < noff; k++) {
+        const int32_t off = sl_off[sl * DIA_K + k];
+        double v = 0.0;
+        if (ptr < end && (int64_t)colind[ptr] - row == off) {
+            v = vals[ptr];
+            ptr++;
+        }
+        sval[(pos * DIA_K + k) * 64 + lane] = v;
+    }
+}
+
+template <bool DOT, bool NT, bool INIT>
+__global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t ndia, const int32_t *__restrict__ dia_list,
+                                                             const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+                                                             const double *__restrict__ sval, const double *__restrict__ x,
+                                                             double *__restrict__ y, const double *__restrict__ shift, double sigma,
+                                                             double *__restrict__ partials, const PcgScalars *__restrict__ scal,
+                                                             StepInitEpilogue epi)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double smem[4];
+    if (scal && scal->done)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per_xcd = (ndia + 7) >> 3;
+    const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xend = (xbase + per_xcd < ndia) ? xbase + per_xcd : ndia;
+    double dacc = 0.0, arr = 0.0, abb = 0.0;
+    for (int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave; pos < xend; pos += pstride) {
+        const int64_t sl = dia_list[pos];
+        const int64_t row = (sl << 6) + lane;
+        const int noff = __builtin_amdgcn_readfirstlane((int)sl_noff[sl]);
+        const int32_t offs = (lane < DIA_K) ? sl_off[sl * DIA_K + lane] : 0;
+        const double *sv = sval + pos * (DIA_K * 64) + lane;
+        double v[DIA_K], xv[DIA_K];
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++) {
+            v[k] = 0.0;
+            xv[k] = 0.0;
+            if (k < noff) {
+                const int32_t off = __builtin_amdgcn_readlane(offs, k);
+                int64_t c = row + off;
+                c = c < 0 ? 0 : (c >= n ? n - 1 : c); // absent entries (value 0) near the ends may point outside
+                v[k] = NT ? __builtin_nontemporal_load(sv + k * 64) : sv[k * 64];
+                xv[k] = x[c];
+            }
+        }
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (k < noff)
+                sum += v[k] * xv[k];
+        if (row < n) {
+            if (INIT) {
+                const double di = epi.D[row];
+                double bi = epi.bprime ? epi.bprime[row] : 0.0;
+                if (epi.b_times_D)
+                    bi *= di;
+                const double rhs = bi + di * (x[row] / epi.dt);
+                const double ri = epi.q_shifted ? rhs - sum : bi - sum;
+                double mi;
+                if (epi.compute_minv) {
+                    mi = 1.0 / (epi.diagA[row] + epi.sigma * di);
+                    epi.minv[row] = mi;
+                } else
+                    mi = epi.minv[row];
+                const double zi = mi * ri;
+                epi.r[row] = ri;
+                epi.pv[row] = zi;
+                dacc += ri * zi;
+                arr += ri * ri;
+                abb += rhs * rhs;
+            } else {
+                const double xr = (shift || DOT) ? x[row] : 0.0;
+                if (shift)
+                    sum += sigma * shift[row] * xr;
+                if (NT)
+                    __builtin_nontemporal_store(sum, y + row);
+                else
+                    y[row] = sum;
+                if (DOT)
+                    dacc += xr * sum;
+            }
+        }
+    }
+    if (INIT) {
+        const double t0 = block_sum(dacc, smem);
+        const double t1 = block_sum(arr, smem);
+        const double t2 = block_sum(abb, smem);
+        if (threadIdx.x == 0) {
+            epi.part_rz[blockIdx.x] = t0;
+            epi.part_rr[blockIdx.x] = t1;
+            epi.part_bb[blockIdx.x] = t2;
+        }
+    } else if (DOT) {
+        const double tsum = block_sum(dacc, smem);
+        if (threadIdx.x == 0)
+            partials[blockIdx.x] = tsum;
+    }
+}
+
+int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count); // fv_ctx.hip
+
+static int build_dia(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    p->dia_built = true;
+    p->ndia = 0;
+    p->ncsr_groups = (p->n + 63) >> 6;
+    const int64_t ns = (p->n + 63) >> 6;
+    if (ns == 0 || p->nnz == 0 || p->n < 4096)
+        return FV_OK; // tiny problems are launch-bound: one kernel is better than two
+    DevBuf<int32_t> fd, fc;
+    FV_TRY(p->sl_noff.alloc(ctx, (size_t)ns));
+    FV_TRY(p->sl_off.alloc(ctx, (size_t)ns * DIA_K));
+    FV_TRY(fd.alloc(ctx, (size_t)ns));
+    FV_TRY(fc.alloc(ctx, (size_t)ns));
+    hipLaunchKernelGGL(dia_pattern_kernel, dim3(fv_blocks(ns, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p,
+                       p->sl_noff.p, p->sl_off.p, fd.p, fc.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(p->dia_list.alloc(ctx, (size_t)ns));
+    FV_TRY(p->csr_list.alloc(ctx, (size_t)ns));
+    FV_TRY(fv_compact_flags(ctx, fd.p, ns, p->dia_list.p, &p->ndia));
+    FV_TRY(fv_compact_flags(ctx, fc.p, ns, p->csr_list.p, &p->ncsr_groups));
+    if (p->ndia * 2 < ns) { // mostly irregular: keep the pure CSR form
+        p->ndia = 0;
+        p->ncsr_groups = ns;
+        p->dia_list.release();
+        p->csr_list.release();
+        p->sl_noff.release();
+        p->sl_off.release();
+        return FV_OK;
+    }
+    FV_TRY(p->dia_vals.alloc(ctx, (size_t)p->ndia * DIA_K * 64));
+    p->dia_epoch = -1;
+    return FV_OK;
+}
+
+// lane-major values for the current assembly; src_tag identifies the source array (0 = plain, else the folded sigma)
+static int ensure_dia_vals(fv_problem *p, const double *src, double src_tag)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->dia_epoch == p->assemble_epoch && p->dia_tag == src_tag)
+        return FV_OK;
+    hipLaunchKernelGGL(dia_fill_kernel, dim3(fv_blocks(p->ndia, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->ndia, p->dia_list.p,
+                       p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, p->dia_vals.p);
+    FV_LAUNCH_CHECK(ctx);
+    p->dia_epoch = p->assemble_epoch;
+    p->dia_tag = src_tag;
+    return FV_OK;
+}
+
+enum { SPMV_PLAIN = 0, SPMV_DOT = 1, SPMV_INIT = 2 };
+
+static int stream_grid(int64_t npos)
+{
+    int64_t g = ((npos + 3) / 4 + 7) / 8 * 8; // 4 groups per block and pass, multiple of 8 (XCD shares)
+    if (g < 8)
+        g = 8;
+    if (g > FV_MAX_PARTIALS)
+        g = FV_MAX_PARTIALS;
+    return (int)g;
+}
+
+// One launch of the CSR wave-stream kernel over `npos` 64-row groups (all of them in `order`, or the listed ones).
+static int launch_wstream(fv_problem *p, int G, const double *vals, const double *x, double *y, const double *shift, double sigma,
+                          int mode, double *partials, const PcgScalars *scal, const int32_t *order, int64_t npos, const StepInitEpilogue &epi)
+{
+    fv_ctx *ctx = p->ctx;
+#define FV_WS(D_, N_, I_)                                                                                                            \
+    hipLaunchKernelGGL((spmv_wstream_kernel<512, D_, N_, I_>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p, \
+                       vals, x, y, shift, sigma, partials, scal, order, npos, epi)
+    if (mode == SPMV_INIT) {
+        if (g_nt)
+            FV_WS(false, true, true);
+        else
+            FV_WS(false, false, true);
+    } else if (mode == SPMV_DOT) {
+        if (g_nt)
+            FV_WS(true, true, false);
+        else
+            FV_WS(true, false, false);
+    } else {
+        if (g_nt)
+            FV_WS(false, true, false);
+        else
+            FV_WS(false, false, false);
+    }
+#undef FV_WS
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+static StepInitEpilogue offset_epilogue(StepInitEpilogue e, int off)
+{
+    e.part_rz += off;
+    e.part_rr += off;
+    e.part_bb += off;
+    return e;
+}
+
+// y = (A + sigma*D) x over the whole operator.  mode SPMV_DOT also leaves per-block partials of x.y in
+// `partials`; SPMV_INIT runs the step set-up epilogue instead of writing y.  `vals_override`: value array
+// with the shift already folded into the diagonal (sigma must then be 0).  *nparts = partials written.
+static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const double *vals_override, int mode, double *partials,
+                      const StepInitEpilogue *epi_in, bool use_done, int *nparts)
+{
+    fv_ctx *ctx = p->ctx;
+    if (!p->order_built)
+        FV_TRY(build_group_order(p));
+    if (!p->dia_built)
+        FV_TRY(build_dia(p));
+    const double *shift = (sigma != 0.0) ? p->D.p : nullptr;
+    const PcgScalars *scal = use_done ? p->scal.p : nullptr;
+    const double *vals = vals_override ? vals_override : p->vals.p;
+    StepInitEpilogue epi = epi_in ? *epi_in : StepInitEpilogue{};
+    const int64_t ngroups = (p->n + 63) >> 6;
+    if (g_spmv_form != 2) { // lanes-per-row form (A/B only): no epilogues
+        if (mode == SPMV_INIT) {
+            fv_set_error(ctx, "internal: fused set-up needs the stream form");
+            return FV_ERR_STATE;
+        }
+        int G = 0;
+        FV_TRY(spmv_launch_impl(p, x, y, sigma, mode == SPMV_DOT ? partials : nullptr, use_done, vals_override, nullptr, -1, &G));
+        if (nparts)
+            *nparts = G;
+        return FV_OK;
+    }
+    if (g_use_dia && p->ndia > 0) {
+        FV_TRY(ensure_dia_vals(p, vals, vals_override ? p->shifted_sigma : 0.0));
+        const int GA = stream_grid(p->ndia);
+#define FV_DIA(D_, N_, I_)                                                                                                        \
+    hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->ndia, p->dia_list.p, p->sl_noff.p, \
+                       p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, partials, scal, epi)
+        if (mode == SPMV_INIT) {
+            if (g_nt)
+                FV_DIA(false, true, true);
+            else
+                FV_DIA(false, false, true);
+        } else if (mode == SPMV_DOT) {
+            if (g_nt)
+                FV_DIA(true, true, false);
+            else
+                FV_DIA(true, false, false);
+        } else {
+            if (g_nt)
+                FV_DIA(false, true, false);
+            else
+                FV_DIA(false, false, false);
+        }
+#undef FV_DIA
+        FV_LAUNCH_CHECK(ctx);
+        int GB = 0;
+        if (p->ncsr_groups > 0) {
+            GB = stream_grid(p->ncsr_groups);
+            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GA : nullptr, scal, p->csr_list.p, p->ncsr_groups,
+                                  offset_epilogue(epi, GA)));
+        }
+        if (nparts)
+            *nparts = GA + GB;
+        return FV_OK;
+    }
+    const int G = stream_grid(ngroups);
+    const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
+    FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, order, ngroups, epi));
+    if (nparts)
+        *nparts = G;
+    return FV_OK;
+}
+
 static int ensure_folded(fv_problem *p, double sigma, const double **out);
 
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold)
@@ -515,7 +892,7 @@ int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, doub
     const double *folded = nullptr;
     if (fold && sigma != 0.0)
         FV_TRY(ensure_folded(p, sigma, &folded));
-    return spmv_launch_impl(p, x, y, folded ? 0.0 : sigma, partials_or_null, false, folded);
+    return spmv_apply(p, x, y, folded ? 0.0 : sigma, folded, partials_or_null ? SPMV_DOT : SPMV_PLAIN, partials_or_null, nullptr, false, nullptr);
 }
 
 // ------------------------------------------------------------------ PCG vector kernels
@@ -714,10 +1091,11 @@ int fv_pcg_prepare(fv_problem *p)
     FV_TRY(p->minv.alloc(ctx, n));
     FV_TRY(p->rhs.alloc(ctx, n));
     FV_TRY(p->tmp.alloc(ctx, n));
-    FV_TRY(p->part_pq.alloc(ctx, FV_MAX_PARTIALS));
-    FV_TRY(p->part_rz.alloc(ctx, FV_MAX_PARTIALS));
-    FV_TRY(p->part_rr.alloc(ctx, FV_MAX_PARTIALS));
-    FV_TRY(p->part_bb.alloc(ctx, FV_MAX_PARTIALS));
+    // two launches (sliced-DIA part + CSR part) may each leave up to FV_MAX_PARTIALS partials
+    FV_TRY(p->part_pq.alloc(ctx, 2 * FV_MAX_PARTIALS));
+    FV_TRY(p->part_rz.alloc(ctx, 2 * FV_MAX_PARTIALS));
+    FV_TRY(p->part_rr.alloc(ctx, 2 * FV_MAX_PARTIALS));
+    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_MAX_PARTIALS));
     FV_TRY(p->scal.alloc(ctx, 1));
     FV_TRY(p->scal.zero(ctx));
     FV_TRY(p->pvec.zero(ctx));
@@ -790,7 +1168,6 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         return FV_ERR_STATE;
     }
     const int64_t n = p->n;
-    const int Gs = fv_spmv_grid(p);
     const int Gv = vec_grid(n);
     const double *folded = nullptr;
     if (sys.fold_shift && sigma != 0.0)
@@ -806,10 +1183,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->minv_epoch = p->assemble_epoch;
     int Ginit = Gv; // number of per-block partials the set-up produced
     if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
-        // r0 = b' - A x0 and the whole set-up in the epilogue of one plain (unshifted, unfolded) SpMV
-        if (!p->order_built)
-            FV_TRY(build_group_order(p));
-        StepInitEpilogue epi;
+        // the whole set-up in the epilogue of ONE SpMV: with the folded matrix q = (A + sigma D) x0 and
+        // r0 = rhs - q; otherwise q = A x0 (plain) and r0 = b' - q (the D x0/dt terms cancel)
+        StepInitEpilogue epi{};
         epi.bprime = sys.rhs;
         epi.D = p->D.p;
         epi.diagA = p->diagA.p;
@@ -823,19 +1199,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         epi.dt = sys.dt;
         epi.b_times_D = (int)sys.b_times_D;
         epi.compute_minv = compute_minv;
-        const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
-        Ginit = Gs;
-        if (g_nt)
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, true, true>), dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, n, p->rowptr.p,
-                               p->colind.p, p->vals.p, (const double *)x, (double *)nullptr, (const double *)nullptr, 0.0, (double *)nullptr,
-                               (const PcgScalars *)nullptr, order, (n + 63) >> 6, epi);
-        else
-            hipLaunchKernelGGL((spmv_wstream_kernel<512, false, false, true>), dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, n, p->rowptr.p,
-                               p->colind.p, p->vals.p, (const double *)x, (double *)nullptr, (const double *)nullptr, 0.0, (double *)nullptr,
-                               (const PcgScalars *)nullptr, order, (n + 63) >> 6, epi);
+        epi.q_shifted = folded ? 1 : 0;
+        FV_TRY(spmv_apply(p, x, nullptr, 0.0, folded, SPMV_INIT, nullptr, &epi, false, &Ginit));
     } else if (sys.implicit_step) {
         // r0 = b' - A x0: plain (unshifted, unfolded) SpMV
-        FV_TRY(spmv_launch_impl(p, x, p->q.p, 0.0, nullptr, false, nullptr));
+        FV_TRY(spmv_apply(p, x, p->q.p, 0.0, nullptr, SPMV_PLAIN, nullptr, nullptr, false, nullptr));
         hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
                            (const double *)p->D.p, sigma, sys.dt, (int)sys.b_times_D, (const double *)x, compute_minv, p->r.p, p->pvec.p,
                            p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
@@ -845,7 +1213,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
                            p->part_rr.p, p->part_bb.p);
     } else {
-        FV_TRY(spmv_launch_impl(p, x, p->q.p, sig_mv, nullptr, false, folded));
+        FV_TRY(spmv_apply(p, x, p->q.p, sig_mv, folded, SPMV_PLAIN, nullptr, nullptr, false, nullptr));
         hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
                            Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
                            p->part_rr.p, p->part_bb.p);
@@ -880,11 +1248,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
             FV_PROF(0);
-            FV_TRY(spmv_launch_impl(p, p->pvec.p, p->q.p, sig_mv, p->part_pq.p, true, folded));
+            int npq = 0;
+            FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
             FV_PROF(1);
             FV_PROF(2);
             hipLaunchKernelGGL(pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, x, p->r.p, p->pvec.p, p->q.p,
-                               p->minv.p, p->part_pq.p, Gs, p->scal.p, p->part_rz.p, p->part_rr.p);
+                               p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
             FV_PROF(3);
             FV_PROF(4);
             hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,

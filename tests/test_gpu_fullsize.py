@@ -91,7 +91,7 @@ def test_watertable_like_216_cubed_transient(fv):
     # linearity holds to the solver tolerance, which is relative to the HEADS (|u| ~ 1e3, drawdowns ~ 1e-2)
     assert np.linalg.norm(draw[1] - 2 * draw[0]) / (1e3 * np.sqrt(p.n)) < 1e-9
     assert np.linalg.norm(draw[1] - 2 * draw[0]) / np.linalg.norm(draw[1]) < 1e-4
-    assert draw[0].min() > -1e-9  # pumping only lowers heads
+    assert draw[0].min() > -1e-8  # pumping only lowers heads (up to the solver tolerance, 1e-12 of |u| ~ 1e3 per step)
 
 
 def test_fractures_like_5M_irregular_csr(fv):

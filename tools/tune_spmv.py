@@ -21,16 +21,17 @@ p = fv.Problem.regulargrid(mins, maxs, ns, dn)
 p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
 p.transient_begin(0.1, None, np.full(p.N, 1e3))
 lib = fv.load()
-bytes_ = 12 * p.nnz + 28 * p.n
-# name, form, order, fold, nt, stage
-variants = [("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream+fold+nt", 2, 0, 1, 1, 0), ("wstream+fold", 2, 0, 1, 0, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
+bytes_ = 12 * p.nnz + 20 * p.n  # CSR accounting with the shift folded (variants that read D move 8 n more)
+# name, form, order, fold, nt, dia
+variants = [("sliced-DIA+fold+nt", 2, 1, 1, 1, 1), ("sliced-DIA+fold", 2, 1, 1, 0, 1), ("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
 
 
-def select(form, order, fold, nt, stage):
+def select(form, order, fold, nt, dia):
     lib.fv_tune(0, form)
     lib.fv_tune(2, order)
     lib.fv_tune(3, fold)
     lib.fv_tune(4, nt)
+    lib.fv_tune(6, dia)
 
 
 res = {v[0]: [] for v in variants}
