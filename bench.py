@@ -120,6 +120,10 @@ def main():
     from __graft_entry__ import load_package
 
     fv = load_package()
+    for kv in os.environ.get("FV_TUNE", "").split(","):  # A/B knobs of libfvhip (fv_tune), e.g. FV_TUNE=5=0,6=0
+        if "=" in kv:
+            k, v = kv.split("=")
+            fv.load().fv_tune(int(k), int(v))
     if world > 1 or os.environ.get("FV_BENCH_FORCE_DIST") == "1":  # the env var rehearses the multi-GPU driver with one rank
         from bench_dist import run_distributed
 

@@ -102,6 +102,7 @@ SIGNATURES = {
     "fv_dist_get_plan": (C.c_int, [c_prob] + [_i64p] * 7),
     "fv_dist_run_fixed": (C.c_int, [c_prob, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_void_p, P(SolveInfo), P(C.c_double)]),
     "fv_dist_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
+    "fv_dist_spmv_halo": (C.c_int, [c_prob, _f64p, _f64p, C.c_double, _f64p]),
     "fv_dist_state_get": (C.c_int, [c_prob, _f64p]),
 }
 

@@ -113,6 +113,10 @@ struct fv_dist {
     DevBuf<double> sendbuf;
     DevBuf<double> red;   // 8 scalars: all-reduce buffer
     DevBuf<double> part2; // per-block partials of the boundary SpMV pass
+    // interior / boundary groups split by storage form (built at the first distributed SpMV)
+    DevBuf<int32_t> int_dia, int_csr, bnd_dia, bnd_csr;
+    int64_t n_int_dia = 0, n_int_csr = 0, n_bnd_dia = 0, n_bnd_csr = 0;
+    bool split_built = false;
 };
 
 struct fv_problem {
@@ -143,7 +147,7 @@ struct fv_problem {
     // sliced-DIA copy of the grid-like slices (fv_pcg.hip): per 64-row slice the distinct column offsets
     // (0 = slice stays with the CSR kernel), the lists of DIA slices / CSR groups, lane-major values
     DevBuf<uint8_t> sl_noff;
-    DevBuf<int32_t> sl_off, dia_list, csr_list;
+    DevBuf<int32_t> sl_off, dia_list, csr_list, dia_pos;
     DevBuf<double> dia_vals;
     int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
     double dia_tag = 0.0;

@@ -303,7 +303,7 @@ static int g_spmv_form = 2;
 static int g_spmv_unroll = 2;
 static int g_use_order = 1;
 static int g_nt = 1;
-static int g_fuse_init = 1;
+static int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 static int g_use_dia = 1;
 int g_fold_shift = 1;
 
@@ -614,20 +614,22 @@ __global__ __launch_bounds__(FV_BLOCK) void dia_fill_kernel(int64_t n, int64_t n
         ptr = rowptr[row];
         end = rowptr[row + 1];
     }
-    for (int k = 0; k < noff; k++) {
+    for (int k = 0; k < noff; k++) { // rows are short (<= DIA_K) and, in a row block, not necessarily sorted (halo columns)
         const int32_t off = sl_off[sl * DIA_K + k];
         double v = 0.0;
-        if (ptr < end && (int64_t)colind[ptr] - row == off) {
-            v = vals[ptr];
-            ptr++;
-        }
+        for (int32_t j = ptr; j < end; j++)
+            if ((int64_t)colind[j] - row == off) {
+                v = vals[j];
+                break;
+            }
         sval[(pos * DIA_K + k) * 64 + lane] = v;
     }
 }
 
 template <bool DOT, bool NT, bool INIT>
-__global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t ndia, const int32_t *__restrict__ dia_list,
-                                                             const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+__global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t ncols, int64_t ndia, const int32_t *__restrict__ dia_list,
+                                                             const int32_t *__restrict__ dia_pos, const uint8_t *__restrict__ sl_noff,
+                                                             const int32_t *__restrict__ sl_off,
                                                              const double *__restrict__ sval, const double *__restrict__ x,
                                                              double *__restrict__ y, const double *__restrict__ shift, double sigma,
                                                              double *__restrict__ partials, const PcgScalars *__restrict__ scal,
@@ -648,7 +650,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
         const int64_t row = (sl << 6) + lane;
         const int noff = __builtin_amdgcn_readfirstlane((int)sl_noff[sl]);
         const int32_t offs = (lane < DIA_K) ? sl_off[sl * DIA_K + lane] : 0;
-        const double *sv = sval + pos * (DIA_K * 64) + lane;
+        const double *sv = sval + (int64_t)dia_pos[sl] * (DIA_K * 64) + lane; // the list may be any subset of the DIA slices
         double v[DIA_K], xv[DIA_K];
 #pragma unroll
         for (int k = 0; k < DIA_K; k++) {
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
             if (k < noff) {
                 const int32_t off = __builtin_amdgcn_readlane(offs, k);
                 int64_t c = row + off;
-                c = c < 0 ? 0 : (c >= n ? n - 1 : c); // absent entries (value 0) near the ends may point outside
+                c = c < 0 ? 0 : (c >= ncols ? ncols - 1 : c); // absent entries (value 0) near the ends may point outside; ncols = n + halo slots
                 v[k] = NT ? __builtin_nontemporal_load(sv + k * 64) : sv[k * 64];
                 xv[k] = x[c];
             }
@@ -716,7 +718,12 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
     }
 }
 
-int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count); // fv_ctx.hip
+__global__ __launch_bounds__(FV_BLOCK) void dia_pos_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, int32_t *__restrict__ dia_pos)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < ndia)
+        dia_pos[dia_list[i]] = (int32_t)i;
+}
 
 static int build_dia(fv_problem *p)
 {
@@ -749,6 +756,9 @@ static int build_dia(fv_problem *p)
         return FV_OK;
     }
     FV_TRY(p->dia_vals.alloc(ctx, (size_t)p->ndia * DIA_K * 64));
+    FV_TRY(p->dia_pos.alloc(ctx, (size_t)ns));
+    hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, p->dia_list.p, p->dia_pos.p);
+    FV_LAUNCH_CHECK(ctx);
     p->dia_epoch = -1;
     return FV_OK;
 }
@@ -819,8 +829,16 @@ static StepInitEpilogue offset_epilogue(StepInitEpilogue e, int off)
 // y = (A + sigma*D) x over the whole operator.  mode SPMV_DOT also leaves per-block partials of x.y in
 // `partials`; SPMV_INIT runs the step set-up epilogue instead of writing y.  `vals_override`: value array
 // with the shift already folded into the diagonal (sigma must then be 0).  *nparts = partials written.
+// Subset of the operator's 64-row groups for the distributed interior / boundary passes.
+struct GroupSubset {
+    const int32_t *dia = nullptr; // DIA slices of the subset
+    int64_t ndia = 0;
+    const int32_t *csr = nullptr; // its CSR groups
+    int64_t ncsr = 0;
+};
+
 static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const double *vals_override, int mode, double *partials,
-                      const StepInitEpilogue *epi_in, bool use_done, int *nparts)
+                      const StepInitEpilogue *epi_in, bool use_done, int *nparts, const GroupSubset *subset = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     if (!p->order_built)
@@ -843,12 +861,25 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
             *nparts = G;
         return FV_OK;
     }
+    if (subset && !(g_use_dia && p->ndia > 0)) { // subset of a pure-CSR operator: everything is in subset->csr
+        const int G = stream_grid(subset->ncsr);
+        if (subset->ncsr > 0)
+            FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, subset->csr, subset->ncsr, epi));
+        if (nparts)
+            *nparts = subset->ncsr > 0 ? G : 0;
+        return FV_OK;
+    }
     if (g_use_dia && p->ndia > 0) {
         FV_TRY(ensure_dia_vals(p, vals, vals_override ? p->shifted_sigma : 0.0));
-        const int GA = stream_grid(p->ndia);
+        const int32_t *dlist = subset ? subset->dia : p->dia_list.p;
+        const int64_t dcount = subset ? subset->ndia : p->ndia;
+        const int32_t *clist = subset ? subset->csr : p->csr_list.p;
+        const int64_t ccount = subset ? subset->ncsr : p->ncsr_groups;
+        const int GA = dcount > 0 ? stream_grid(dcount) : 0;
 #define FV_DIA(D_, N_, I_)                                                                                                        \
-    hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->ndia, p->dia_list.p, p->sl_noff.p, \
+    hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, dcount, dlist, p->dia_pos.p, p->sl_noff.p, \
                        p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, partials, scal, epi)
+        if (dcount > 0) {
         if (mode == SPMV_INIT) {
             if (g_nt)
                 FV_DIA(false, true, true);
@@ -865,12 +896,13 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
             else
                 FV_DIA(false, false, false);
         }
+        }
 #undef FV_DIA
         FV_LAUNCH_CHECK(ctx);
         int GB = 0;
-        if (p->ncsr_groups > 0) {
-            GB = stream_grid(p->ncsr_groups);
-            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GA : nullptr, scal, p->csr_list.p, p->ncsr_groups,
+        if (ccount > 0) {
+            GB = stream_grid(ccount);
+            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GA : nullptr, scal, clist, ccount,
                                   offset_epilogue(epi, GA)));
         }
         if (nparts)
@@ -910,7 +942,7 @@ template <bool IMPLICIT>
 __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const double *__restrict__ rhs, const double *__restrict__ q,
                                                              const double *__restrict__ diagA, const double *__restrict__ D,
                                                              double sigma, double dt, int b_times_D, const double *__restrict__ x0,
-                                                             int compute_minv, double *__restrict__ r, double *__restrict__ pv,
+                                                             int compute_minv, int q_shifted, double *__restrict__ r, double *__restrict__ pv,
                                                              double *__restrict__ minv, double *__restrict__ part_rz,
                                                              double *__restrict__ part_rr, double *__restrict__ part_bb)
 {
@@ -923,8 +955,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const dou
             const double di = D[i];
             if (b_times_D)
                 bi *= di;
-            ri = bi - q[i];
-            bi += di * (x0[i] / dt); // the right-hand side this step solves for (norm only)
+            const double rhsv = bi + di * (x0[i] / dt); // the right-hand side this step solves for
+            ri = q_shifted ? rhsv - q[i] : bi - q[i];  // q = (A + sigma D) x0 or A x0
+            bi = rhsv;
         } else
             ri = q ? bi - q[i] : bi;
         double mi;
@@ -1092,7 +1125,7 @@ int fv_pcg_prepare(fv_problem *p)
     FV_TRY(p->rhs.alloc(ctx, n));
     FV_TRY(p->tmp.alloc(ctx, n));
     // two launches (sliced-DIA part + CSR part) may each leave up to FV_MAX_PARTIALS partials
-    FV_TRY(p->part_pq.alloc(ctx, 2 * FV_MAX_PARTIALS));
+    FV_TRY(p->part_pq.alloc(ctx, 4 * FV_MAX_PARTIALS)); // distributed: interior + boundary pass, each DIA + CSR
     FV_TRY(p->part_rz.alloc(ctx, 2 * FV_MAX_PARTIALS));
     FV_TRY(p->part_rr.alloc(ctx, 2 * FV_MAX_PARTIALS));
     FV_TRY(p->part_bb.alloc(ctx, 2 * FV_MAX_PARTIALS));
@@ -1202,20 +1235,21 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         epi.q_shifted = folded ? 1 : 0;
         FV_TRY(spmv_apply(p, x, nullptr, 0.0, folded, SPMV_INIT, nullptr, &epi, false, &Ginit));
     } else if (sys.implicit_step) {
-        // r0 = b' - A x0: plain (unshifted, unfolded) SpMV
-        FV_TRY(spmv_apply(p, x, p->q.p, 0.0, nullptr, SPMV_PLAIN, nullptr, nullptr, false, nullptr));
+        // q = A x0 (plain) or, when the folded matrix is in use, (A + sigma D) x0 — never alternate between the two
+        // value arrays inside a run (the lane-major copy would be rebuilt every time)
+        FV_TRY(spmv_apply(p, x, p->q.p, 0.0, folded, SPMV_PLAIN, nullptr, nullptr, false, nullptr));
         hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
-                           (const double *)p->D.p, sigma, sys.dt, (int)sys.b_times_D, (const double *)x, compute_minv, p->r.p, p->pvec.p,
-                           p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+                           (const double *)p->D.p, sigma, sys.dt, (int)sys.b_times_D, (const double *)x, compute_minv, folded ? 1 : 0, p->r.p,
+                           p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
     } else if (sys.x0_zero) {
         FV_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)nullptr, p->diagA.p,
-                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
+                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, 0, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
                            p->part_rr.p, p->part_bb.p);
     } else {
         FV_TRY(spmv_apply(p, x, p->q.p, sig_mv, folded, SPMV_PLAIN, nullptr, nullptr, false, nullptr));
         hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->q.p, p->diagA.p,
-                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
+                           Dp, sigma, 0.0, 0, (const double *)nullptr, compute_minv, 0, p->r.p, p->pvec.p, p->minv.p, p->part_rz.p,
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
@@ -1435,19 +1469,95 @@ static int dist_exchange_wait(fv_problem *p)
 }
 
 // y = (A + sigma D) x on the row block; with want_dot the local x.y lands in red[0] (not yet all-reduced)
-static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const double *folded, bool want_dot, bool use_done)
+// split a list of 64-row groups into those stored as DIA slices and those left to the CSR kernel
+__global__ __launch_bounds__(FV_BLOCK) void list_form_flags_kernel(int64_t m, const int32_t *__restrict__ list, const uint8_t *__restrict__ sl_noff,
+                                                                    int32_t *__restrict__ fd, int32_t *__restrict__ fc)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= m)
+        return;
+    const int dia = sl_noff ? (sl_noff[list[i]] > 0) : 0;
+    fd[i] = dia;
+    fc[i] = !dia;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void list_gather_kernel(int64_t m, const int32_t *__restrict__ idx, const int32_t *__restrict__ list,
+                                                                int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < m)
+        out[i] = list[idx[i]];
+}
+
+static int split_list(fv_problem *p, const int32_t *list, int64_t m, DevBuf<int32_t> &out_dia, int64_t *ndia, DevBuf<int32_t> &out_csr,
+                      int64_t *ncsr)
+{
+    fv_ctx *ctx = p->ctx;
+    *ndia = 0;
+    *ncsr = 0;
+    FV_TRY(out_dia.alloc(ctx, (size_t)m));
+    FV_TRY(out_csr.alloc(ctx, (size_t)m));
+    if (m <= 0)
+        return FV_OK;
+    DevBuf<int32_t> fd, fc, idx;
+    FV_TRY(fd.alloc(ctx, (size_t)m));
+    FV_TRY(fc.alloc(ctx, (size_t)m));
+    FV_TRY(idx.alloc(ctx, (size_t)m));
+    const uint8_t *noff = (g_use_dia && p->ndia > 0) ? p->sl_noff.p : nullptr;
+    hipLaunchKernelGGL(list_form_flags_kernel, dim3(fv_blocks(m)), dim3(FV_BLOCK), 0, ctx->stream, m, list, noff, fd.p, fc.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_compact_flags(ctx, fd.p, m, idx.p, ndia));
+    if (*ndia > 0)
+        hipLaunchKernelGGL(list_gather_kernel, dim3(fv_blocks(*ndia)), dim3(FV_BLOCK), 0, ctx->stream, *ndia, idx.p, list, out_dia.p);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FV_TRY(fv_compact_flags(ctx, fc.p, m, idx.p, ncsr));
+    if (*ncsr > 0)
+        hipLaunchKernelGGL(list_gather_kernel, dim3(fv_blocks(*ncsr)), dim3(FV_BLOCK), 0, ctx->stream, *ncsr, idx.p, list, out_csr.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+static int dist_build_split(fv_problem *p)
+{
+    fv_dist *d = p->dist;
+    if (!p->dia_built)
+        FV_TRY(build_dia(p));
+    FV_TRY(split_list(p, d->groups_int.p, d->n_int, d->int_dia, &d->n_int_dia, d->int_csr, &d->n_int_csr));
+    FV_TRY(split_list(p, d->groups_bnd.p, d->n_bnd, d->bnd_dia, &d->n_bnd_dia, d->bnd_csr, &d->n_bnd_csr));
+    d->split_built = true;
+    return FV_OK;
+}
+
+// y = (A + sigma D) x on the row block; with want_dot the local x.y lands in red[0] (not yet all-reduced).
+// skip_exchange: the halo slots of xext were filled by the caller (single-GPU rehearsal of the boundary pass).
+static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const double *folded, bool want_dot, bool use_done,
+                     bool skip_exchange = false)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
-    int Ga = 0, Gb = 0;
-    FV_TRY(dist_exchange_begin(p, xext));
-    FV_TRY(spmv_launch_impl(p, xext, y, sigma, want_dot ? p->part_pq.p : nullptr, use_done, folded, d->groups_int.p, d->n_int, &Ga));
-    FV_TRY(dist_exchange_wait(p));
+    if (!d->split_built)
+        FV_TRY(dist_build_split(p));
+    const int mode = want_dot ? SPMV_DOT : SPMV_PLAIN;
+    GroupSubset interior, boundary;
+    interior.dia = d->int_dia.p;
+    interior.ndia = d->n_int_dia;
+    interior.csr = d->int_csr.p;
+    interior.ncsr = d->n_int_csr;
+    boundary.dia = d->bnd_dia.p;
+    boundary.ndia = d->n_bnd_dia;
+    boundary.csr = d->bnd_csr.p;
+    boundary.ncsr = d->n_bnd_csr;
+    int na = 0, nb = 0;
+    if (!skip_exchange)
+        FV_TRY(dist_exchange_begin(p, xext));
+    FV_TRY(spmv_apply(p, xext, y, sigma, folded, mode, want_dot ? p->part_pq.p : nullptr, nullptr, use_done, &na, &interior));
+    if (!skip_exchange)
+        FV_TRY(dist_exchange_wait(p));
     if (d->n_bnd > 0)
-        FV_TRY(spmv_launch_impl(p, xext, y, sigma, want_dot ? d->part2.p : nullptr, use_done, folded, d->groups_bnd.p, d->n_bnd, &Gb));
+        FV_TRY(spmv_apply(p, xext, y, sigma, folded, mode, want_dot ? p->part_pq.p + na : nullptr, nullptr, use_done, &nb, &boundary));
     if (want_dot) {
-        hipLaunchKernelGGL(dist_sum2_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_pq.p, Ga,
-                           (const double *)d->part2.p, d->n_bnd > 0 ? Gb : 0, d->red.p);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_pq.p, na + nb, d->red.p);
         FV_LAUNCH_CHECK(ctx);
     }
     return FV_OK;
@@ -1468,10 +1578,10 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     double *red = d->red.p;
-    // r0 = b - A u (unshifted), rhs norm from b + D u/dt
-    FV_TRY(dist_spmv(p, u, p->q.p, 0.0, nullptr, false, false));
+    // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
+    FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
     hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
-                       p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, p->r.p, p->pvec.p, p->minv.p,
+                       p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p, p->minv.p,
                        p->part_rz.p, p->part_rr.p, p->part_bb.p);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
@@ -1575,6 +1685,22 @@ extern "C" int fv_dist_spmv(fv_problem *p, const double *x_local, double sigma, 
     FV_TRY(fv_pcg_prepare(p));
     FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, x_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
     FV_TRY(dist_spmv(p, p->tmp.p, p->rhs.p, sigma, nullptr, false, false));
+    return fv_copy(ctx, y_local, p->rhs.p, (size_t)p->n * sizeof(double));
+}
+
+// Rehearsal of the interior + boundary passes on one GPU: the caller supplies the halo values a peer
+// would have sent (nhalo doubles, in halo-slot order); no communication happens.
+extern "C" int fv_dist_spmv_halo(fv_problem *p, const double *x_local, const double *halo_values, double sigma, double *y_local)
+{
+    if (!p || !p->dist || !x_local || !y_local || (p->nhalo > 0 && !halo_values))
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(fv_pcg_prepare(p));
+    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, x_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    if (p->nhalo > 0)
+        FV_HIP(ctx, hipMemcpyAsync(p->tmp.p + p->n, halo_values, (size_t)p->nhalo * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(dist_spmv(p, p->tmp.p, p->rhs.p, sigma, nullptr, true, false, true));
     return fv_copy(ctx, y_local, p->rhs.p, (size_t)p->n * sizeof(double));
 }
 

@@ -71,6 +71,13 @@ class RowBlock:
         self.ctx.check(load().fv_dist_spmv(self.handle, ptr(x), float(sigma), ptr(y)))
         return y
 
+    def spmv_halo(self, x_local, halo_values, sigma=0.0):
+        """Interior + boundary SpMV passes with caller-supplied halo values (no communication)."""
+        x, h = _lib.af64(x_local), _lib.af64(halo_values)
+        y = np.empty(self.nloc, np.float64)
+        self.ctx.check(load().fv_dist_spmv_halo(self.handle, ptr(x), ptr(h) if self.nhalo else None, float(sigma), ptr(y)))
+        return y
+
     def state(self):
         u = np.empty(self.nloc, np.float64)
         self.ctx.check(load().fv_dist_state_get(self.handle, ptr(u)))

@@ -211,6 +211,9 @@ int fv_dist_get_plan(fv_problem *block, int64_t *rowptr_loc, int64_t *colind_loc
 int fv_dist_run_fixed(fv_problem *block, double dt, int64_t nsteps, double rtol, int64_t maxiter, int32_t *iters_per_step,
                       fv_solve_info *last_info, double *total_ms);
 int fv_dist_spmv(fv_problem *block, const double *x_local, double sigma, double *y_local); /* collective */
+/* Same kernels (interior pass + boundary pass) with the halo values supplied by the caller instead of
+ * received from peers: lets one GPU rehearse any rank of an N-way partition.  Not a collective. */
+int fv_dist_spmv_halo(fv_problem *block, const double *x_local, const double *halo_values, double sigma, double *y_local);
 int fv_dist_state_get(fv_problem *block, double *u_local);
 
 #ifdef __cplusplus
