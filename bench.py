@@ -59,12 +59,12 @@ def spacing_box(ns, ref_ns=464):
 def cpu_baseline(dt, rtol):
     """The oracle (CPU restatement of the reference: assembleA/b, scalebyvolume!,
     fixedbackwardeulerstep!, IterativeSolvers-style CG) timed on ONE host core on a
-    bounded sample of the same workload: same cell size / K / Ss / dt / BCs, 160^3
-    cells, 16 steps.  Only the stepping loop is timed, as for the GPU."""
+    bounded sample of the same workload: same cell size / K / Ss / dt / BCs, 256^3
+    cells, 30 steps (10-20 s of CPU).  Only the stepping loop is timed, as for the GPU."""
     from oracle import fv_oracle as o
 
-    ns = [160, 160, 160]
-    steps = 16
+    ns = [256, 256, 256]
+    steps = 30
     mins, maxs = spacing_box(ns)
     _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
     dn, src = box_setup(ns)
