@@ -14,25 +14,44 @@ from .core import DeviceMatrix, _assembled_problem, af64
 from .transient import DeviceOperator, _integrate_generic, backwardeulerintegrate
 
 
-def getcontinuoussolution(us, ts, val=None):
-    """transient.jl:176-186: piecewise-linear-in-time interpolant of the stored states.
-    Returns uc(t) -> vector (Gridded(Linear())); with val=2 an itp(i, t) of the 2-D form."""
-    ts = np.asarray(ts, dtype=np.float64)
-    U = np.stack([np.asarray(u, dtype=np.float64) for u in us], axis=0)  # (nt, n)
-    if np.any(np.diff(ts) <= 0):
-        raise ValueError("knot-vectors must be unique and sorted in increasing order")
+class LinearInterpolant:
+    """uc(t) -> vector: the Gridded(Linear()) interpolant of transient.jl:176-180.  The knots (`ts`) and the stored
+    states (`U`, one row per knot) stay readable so quadratures of products can be done exactly."""
 
-    def uc(t):
+    def __init__(self, us, ts):
+        self.ts = np.asarray(ts, dtype=np.float64)
+        self.U = np.stack([np.asarray(u, dtype=np.float64) for u in us], axis=0)  # (nt, n)
+        if np.any(np.diff(self.ts) <= 0):
+            raise ValueError("knot-vectors must be unique and sorted in increasing order")
+
+    def __call__(self, t):
+        ts = self.ts
         if t < ts[0] or t > ts[-1]:
             raise IndexError("BoundsError: attempt to interpolate at t = %r outside [%r, %r]" % (t, ts[0], ts[-1]))
         k = int(np.searchsorted(ts, t, side="right")) - 1
         k = min(max(k, 0), len(ts) - 2)
         w = (t - ts[k]) / (ts[k + 1] - ts[k])
-        return (1.0 - w) * U[k] + w * U[k + 1]
+        return (1.0 - w) * self.U[k] + w * self.U[k + 1]
 
-    if val == 2:
-        return lambda i, t: uc(t)[int(i) - 1]
-    return uc
+    def at(self, tq):
+        """all components at the times tq -> (len(tq), n)"""
+        tq = np.asarray(tq, dtype=np.float64)
+        k = np.clip(np.searchsorted(self.ts, tq, side="right") - 1, 0, len(self.ts) - 2)
+        w = ((tq - self.ts[k]) / (self.ts[k + 1] - self.ts[k]))[:, None]
+        return (1.0 - w) * self.U[k] + w * self.U[k + 1]
+
+
+class LinearInterpolant2(LinearInterpolant):
+    """itp(i, t): the (NoInterp(), Gridded(Linear())) form of transient.jl:182-186 (i is 1-based)."""
+
+    def __call__(self, i, t):
+        return LinearInterpolant.__call__(self, t)[int(i) - 1]
+
+
+def getcontinuoussolution(us, ts, val=None):
+    """transient.jl:176-186: piecewise-linear-in-time interpolant of the stored states.
+    Returns uc(t) -> vector (Gridded(Linear())); with val=2 an itp(i, t) of the 2-D form."""
+    return LinearInterpolant2(us, ts) if val == 2 else LinearInterpolant(us, ts)
 
 
 def adjointintegrate(*args, **kwargs):
@@ -80,9 +99,229 @@ def gradientintegrate(lambdac_or_lambda0, du0dp, dgdp, dfdp_or_integral, tspan, 
     limit = int(kwargs.get("maxevals", 10**7) // 21 + 1) if "maxevals" in kwargs else 10000
     if callable(lambdac_or_lambda0):
         lambdac, dfdp = lambdac_or_lambda0, dfdp_or_integral
-        I2, _ = quad_vec(lambda t: np.asarray(dfdp(t)) @ np.asarray(lambdac(t)), tspan[0], tspan[1], limit=limit)
+
+        def dfdp_lambda(t):
+            M = dfdp(t)
+            if not hasattr(M, "tocsr"):  # dense array; scipy sparse matrices multiply as they are
+                M = np.asarray(M)
+            return np.asarray(M @ np.asarray(lambdac(t))).ravel()
+
+        I2, _ = quad_vec(dfdp_lambda, tspan[0], tspan[1], limit=limit)
         lambda0 = np.asarray(lambdac(0))
     else:
         lambda0, I2 = af64(lambdac_or_lambda0), af64(dfdp_or_integral)
     I1, _ = quad_vec(lambda t: np.asarray(dgdp(t), dtype=np.float64), tspan[0], tspan[1], limit=limit)
     return du0dp @ lambda0 + I1 + I2  # du0dp may be a dense array or a scipy sparse matrix (spzeros in the reference)
+
+
+# ------------------------------------------------------------------ src/transientadjointutils.jl (host-side glue, API kept)
+def _parameter_jacobians(ueval_free, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity):
+    """b_p - A_px as an (np x nfree) scipy CSR matrix, p = [conductivities; sources; dirichletheads].
+
+    Stands in for the LinearAdjoints-generated assembleb_p / assembleA_px called at
+    transientadjointutils.jl:27-28 (that package is not in the reference tree; the derivative of
+    the assembly at FiniteVolume.jl:75-139 is written out here): per face i with conductance
+    c_i = K[m]*aol_i or exp(K[m])*aol_i,
+      free-free:        d(Ax)_f1/dK_m = dc (x_f1 - x_f2),  d(Ax)_f2/dK_m = dc (x_f2 - x_f1)
+      one free end f:   d(Ax)_f/dK_m  = dc x_f ;  db_f/dK_m = dc*dhead ;  db_f/ddhead_j = c_i
+      db_f/dsource_node(f) = 1."""
+    import scipy.sparse as sp
+
+    from .core import _metaindex_array, _split_neighbors, getfreenodes, getnodei2dirichleti
+
+    n1, n2 = _split_neighbors(neighbors)
+    aol, K, dh = af64(areasoverlengths), af64(conductivities), af64(dirichletheads)
+    N, F, nK, ndir = len(sources), len(n1), len(K), len(dh)
+    freenode, n2f = getfreenodes(N, dirichletnodes)
+    n2d = getnodei2dirichleti(np.zeros(N), dirichletnodes)
+    nfree = int(freenode.sum())
+    mi = _metaindex_array(metaindex, F)
+    m = (mi - 1) if mi is not None else np.arange(F)
+    c = np.exp(K[m]) * aol if logtransformconductivity else K[m] * aol
+    dc = c if logtransformconductivity else aol
+    a, b = n1 - 1, n2 - 1
+    fa, fb = n2f[a] - 1, n2f[b] - 1  # -2 where Dirichlet
+    x = af64(ueval_free)
+    rows, cols, vals = [], [], []
+
+    def add(r, cidx, v):
+        rows.append(r)
+        cols.append(cidx)
+        vals.append(v)
+
+    both = freenode[a] & freenode[b]
+    add(m[both], fa[both], -dc[both] * (x[fa[both]] - x[fb[both]]))
+    add(m[both], fb[both], -dc[both] * (x[fb[both]] - x[fa[both]]))
+    onlya = freenode[a] & ~freenode[b]
+    add(m[onlya], fa[onlya], dc[onlya] * dh[n2d[b[onlya]] - 1] - dc[onlya] * x[fa[onlya]])
+    add(nK + N + n2d[b[onlya]] - 1, fa[onlya], c[onlya])
+    onlyb = ~freenode[a] & freenode[b]
+    add(m[onlyb], fb[onlyb], dc[onlyb] * dh[n2d[a[onlyb]] - 1] - dc[onlyb] * x[fb[onlyb]])
+    add(nK + N + n2d[a[onlyb]] - 1, fb[onlyb], c[onlyb])
+    freenodes_idx = np.nonzero(freenode)[0]
+    add(nK + freenodes_idx, n2f[freenodes_idx] - 1, np.ones(nfree))
+    M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(nK + N + ndir, nfree)).tocsr()
+    return M, freenode, n2f
+
+
+def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, **kwargs):
+    """transientadjointutils.jl:1-55 -> g, dgdu, dfdp, dgdp, du0dp, G."""
+    import scipy.sparse as sp
+    from scipy.integrate import quad
+
+    from .core import getfreenodes
+
+    nK, N, ndir = len(conductivities), len(sources), len(dirichletheads)
+    freenodes, n2f = getfreenodes(len(u0), dirichletnodes)
+    f2n = np.empty(int(freenodes.sum()), np.int64)  # free index (1-based) -> node (1-based), the Dict of :3
+    f2n[n2f[freenodes] - 1] = np.nonzero(freenodes)[0] + 1
+    nfree = len(f2n)
+    vols = Ss * af64(volumes)
+
+    def g(u, t):
+        uo, ue = uobs(t), u(t)
+        return float(sum(sigma(i, t) ** 2 * (ue[f2n[i - 1] - 1] - uo[f2n[i - 1] - 1]) ** 2 for i in obsfreenodes))
+
+    def dgdu(u, t):
+        uo, ue = uobs(t), u(t)
+        result = np.zeros(nfree)
+        for i in obsfreenodes:
+            result[i - 1] = 2 * sigma(i, t) ** 2 * (ue[f2n[i - 1] - 1] - uo[f2n[i - 1] - 1])
+        return result
+
+    def split(p):
+        p = af64(p)
+        return p[:nK], p[nK : nK + N], p[nK + N : nK + N + ndir]
+
+    def dfdp(u, t, p):
+        pK, ps, pd = split(p)
+        ueval = np.asarray(u(t))[freenodes]
+        M, _, _ = _parameter_jacobians(ueval, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity)
+        # scalebyvolume!(transpose(...), Ss*volumes, ...) of transient.jl:25-34 divides the entries of free unknown i by
+        # volumes[i] — indexed by the FREE index, without the free->node map (the reference's behaviour, kept as is)
+        return M @ sp.diags(1.0 / vols[:nfree])
+
+    dgdpval = np.zeros(nK + N + ndir)
+
+    def dgdp(u, t, p):
+        return dgdpval
+
+    du0dp = sp.csr_matrix((nK + N + ndir, nfree))
+
+    def G(p):
+        limit = max(300 // 21, 50)  # quadgk(...; maxevals=3*10^2, order=21) in the reference
+        if callable(p):
+            return quad(lambda t: g(p, t), tspan[0], tspan[1], limit=limit)[0]
+        pK, ps, pd = split(p)
+        us_p, ts_p = backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity, **kwargs)
+        uc_p = getcontinuoussolution(us_p, ts_p)
+        # the integrand is piecewise smooth between the stored steps: integrate interval by interval
+        return float(sum(quad(lambda t: g(uc_p, t), a, b, limit=limit)[0] for a, b in zip(ts_p[:-1], ts_p[1:])))
+
+    return g, dgdu, dfdp, dgdp, du0dp, G
+
+
+class FVErrorNotSupported(Exception):
+    """error("not supported"), FiniteVolume.jl:363"""
+
+
+def _simpleintegrate(fs, ts):
+    """FiniteVolume.jl:262-269 — the trapezoid rule over the stored knots."""
+    fs, ts = np.asarray(fs, dtype=np.float64), np.asarray(ts, dtype=np.float64)
+    w = np.empty(len(ts))
+    w[0], w[-1] = 0.5 * (ts[1] - ts[0]), 0.5 * (ts[-1] - ts[-2])
+    w[1:-1] = 0.5 * (ts[2:] - ts[:-2])
+    return w @ fs
+
+
+def _product_integrals(lam, u2, nodes, freeidx, tspan):
+    """The integral over tspan of lambda_f(t) * u_node(t) for each (node, free index) pair — integrateproduct of
+    FiniteVolume.jl:277-285 (QuadGK there).  Both factors are piecewise linear, so with the knots of both in hand
+    Simpson's rule on the merged grid is exact; an opaque u2(i, t) is integrated by Gauss-Kronrod between lambda's knots."""
+    lo, hi = float(tspan[0]), float(tspan[1])
+    if isinstance(u2, LinearInterpolant):
+        knots = np.unique(np.concatenate([lam.ts, u2.ts, [lo, hi]]))
+        knots = knots[(knots >= lo) & (knots <= hi)]
+        a, b = knots[:-1], knots[1:]
+        mid = 0.5 * (a + b)
+        out = np.zeros(len(nodes))
+        La, Lm, Lb = lam.at(a)[:, freeidx], lam.at(mid)[:, freeidx], lam.at(b)[:, freeidx]
+        Ua, Um, Ub = u2.at(a)[:, nodes], u2.at(mid)[:, nodes], u2.at(b)[:, nodes]
+        out = ((b - a) / 6.0) @ (La * Ua + 4.0 * Lm * Um + Lb * Ub)
+        return out
+    from scipy.integrate import quad
+
+    knots = [lo] + [float(t) for t in lam.ts if lo < t < hi] + [hi]
+    return np.array([sum(quad(lambda t: lam(t)[f] * u2(n + 1, t), a, b)[0] for a, b in zip(knots[:-1], knots[1:])) for n, f in zip(nodes, freeidx)])
+
+
+def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, complete=False):
+    """transientadjointutils.jl:57-63 -> FiniteVolume.jl:271-377 (integrateb_pmA_pxlambda): the integral over tspan of
+    dfdp(t) * lambda(t) with lambda piecewise linear over ts_lambda and u2 = getcontinuoussolution(us, ts, 2).
+
+    The default follows the reference's hand-unrolled routine term by term, i.e. exactly the terms it carries:
+      * sources:          trapz(lambda_f) / (Ss*volumes[node])                               (:327-336)
+      * free|Dirichlet faces only: c*dhead*trapz(lambda_f)/(Ss*volumes[f]) into K and c*trapz(lambda_f)/(Ss*volumes[f])
+        into the Dirichlet head, plus  + c * integral(lambda_f * u_node) / (Ss*volumes[f])   into K   (:339-360)
+        with volumes indexed by the FREE index f there, and the u term entering with a plus sign;
+      * no free|free face terms; logtransformconductivity=false raises "not supported"       (:362-363).
+    complete=True instead integrates the full Jacobian (b_p - A_px, every face, the D^-1 scaling of dfdp in
+    getadjointfunctions) by Gauss-Kronrod between lambda's knots — the quantity gradientintegrate(lambdac, ..., dfdp)
+    integrates."""
+    from .core import _metaindex_array, _split_neighbors, getfreenodes, getnodei2dirichleti
+
+    if not logtransformconductivity:
+        raise FVErrorNotSupported("not supported")
+    nK, N, ndir = len(conductivities), len(sources), len(dirichletheads)
+    pv = af64(p)
+    pK, ps, pd = pv[:nK], pv[nK : nK + N], pv[nK + N : nK + N + ndir]
+    vols = Ss * af64(volumes)
+    freenode, n2f = getfreenodes(N, dirichletnodes)
+    lam = LinearInterpolant(lambdas, ts_lambda)
+    if complete:
+        import inspect
+
+        import scipy.sparse as sp
+        from scipy.integrate import quad_vec
+
+        if isinstance(u2, LinearInterpolant):
+            uc = lambda t: LinearInterpolant.__call__(u2, t)  # noqa: E731
+        elif len(inspect.signature(u2).parameters) == 1:
+            uc = u2
+        else:
+            uc = lambda t: np.array([u2(i, t) for i in range(1, N + 1)])  # noqa: E731
+
+        def integrand(t):
+            M, _, _ = _parameter_jacobians(np.asarray(uc(t))[freenode], neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, True)
+            return (M @ sp.diags(1.0 / vols[: M.shape[1]])) @ lam(t)
+
+        total = np.zeros(nK + N + ndir)
+        knots = sorted(set(float(t) for t in ts_lambda if tspan[0] <= t <= tspan[1]) | {float(tspan[0]), float(tspan[1])})
+        for a, b in zip(knots[:-1], knots[1:]):
+            total += quad_vec(integrand, a, b, limit=20)[0]
+        return total
+
+    n1, n2 = _split_neighbors(neighbors)
+    aol = af64(areasoverlengths)
+    F = len(n1)
+    n2d = getnodei2dirichleti(np.zeros(N), dirichletnodes)
+    mi = _metaindex_array(metaindex, F)
+    m = (mi - 1) if mi is not None else np.arange(F)
+    c = np.exp(pK[m]) * aol
+    lamint = _simpleintegrate(lambdas, ts_lambda)
+    result = np.zeros(nK + N + ndir)
+    free_idx = np.nonzero(freenode)[0]
+    result[nK + free_idx] += lamint[n2f[free_idx] - 1] / vols[free_idx]
+    a, b = n1 - 1, n2 - 1
+    for fr, di in ((a, b), (b, a)):  # (free end, Dirichlet end) of the faces with exactly one free end
+        sel = freenode[fr] & ~freenode[di]
+        f = n2f[fr[sel]] - 1
+        d = n2d[di[sel]] - 1
+        cs, msel = c[sel], m[sel]
+        nodes = fr[sel]
+        un, inv = np.unique(nodes, return_inverse=True)  # the reference memoises the product integral per node
+        prod = _product_integrals(lam, u2, un, n2f[un] - 1, tspan)[inv] if len(un) else np.zeros(0)
+        scale = 1.0 / vols[f]  # volumes[nodei2freenodei[node]]: the free index, as the reference writes it
+        np.add.at(result, msel, cs * pd[d] * lamint[f] * scale + cs * prod * scale)
+        np.add.at(result, nK + N + d, cs * lamint[f] * scale)
+    return result

@@ -44,6 +44,8 @@ extern "C" int fv_ctx_create(int device, fv_ctx **out)
     ctx->num_cus = prop.multiProcessorCount;
     ctx->total_mem = (int64_t)prop.totalGlobalMem;
     ctx->name = prop.name;
+    if (ctx->name.empty())
+        ctx->name = prop.gcnArchName; // some ROCm builds leave the marketing name blank
     FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
     FV_HIP(ctx, hipEventCreate(&ctx->ev0));

@@ -376,3 +376,139 @@ def test_virtual_ranks_interior_and_boundary_passes(fv, ns, nranks):
             y = blk.spmv_halo(x[blk.lo : blk.hi], x[plan["halo_cols"]], sigma)
             assert np.allclose(y, y_global[blk.lo : blk.hi], rtol=1e-13, atol=1e-18), (rank, sigma)
             assert blk.n_bnd > 0 or nranks == 1
+
+
+def test_onenode_adjoint_gradient_vs_finite_differences(fv):
+    """test/onenodeadjoint.jl:51-75: getadjointfunctions + adjointintegrate + gradientintegrate vs central FD of G."""
+    sigma = lambda i, t: 0.01  # noqa: E731
+    c = refcases.onenode(0.0)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    kw = dict(atol=c["atol"], dt0=c["dt0"])
+    us, ts = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, **kw)
+    uobs = fv.getcontinuoussolution(us, ts)
+    p0 = np.r_[c["K"] + 1, c["sources"], c["dheads"]]
+    us_i, ts_i = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"] + 1, c["sources"], c["dnodes"], c["dheads"], None, True, **kw)
+    uc_init = fv.getcontinuoussolution(us_i, ts_i)
+    freenodes, n2f = fv.getfreenodes(2, c["dnodes"])
+    obsfreenodes = [int(n2f[1])]
+    g, dgdu, dfdp, dgdp, du0dp, G = fv.getadjointfunctions(sigma, obsfreenodes, uobs, c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, **kw)
+    assert g(uobs, 0.5) == 0
+    shifted = lambda t: uobs(t) + 1  # noqa: E731
+    assert dgdu(shifted, 0.5).tolist() == [2 * 0.01**2]
+    lambdas, ts_l = fv.adjointintegrate(lambda t: dgdu(uc_init, t), c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"] + 1, c["sources"], c["dnodes"], c["dheads"], None, True, **kw)
+    lambdac = fv.getcontinuoussolution(lambdas, ts_l)
+    dGdp = fv.gradientintegrate(lambdac, du0dp, lambda t: dgdp(uc_init, t, p0), lambda t: dfdp(uc_init, t, p0), c["tspan"], maxevals=300, order=21)
+    # the same integral through integratedfdplambda: complete=True integrates the whole Jacobian; the default keeps the
+    # reference's hand-unrolled terms (FiniteVolume.jl:271-377), which agree on the source and Dirichlet-head entries
+    uc_init2 = fv.getcontinuoussolution(us_i, ts_i, 2)
+    idl = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, complete=True)
+    dGdp2 = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc_init, t, p0), idl, c["tspan"])
+    idl_ref = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True)
+    assert np.allclose(idl_ref[[2, 3]], idl[[2, 3]], rtol=1e-6, atol=0)
+    # ... and carry the u term of the conductivity entry with the opposite sign (dhead = 0 here: that is the whole entry)
+    assert abs(idl_ref[0] + idl[0]) <= 1e-6 * abs(idl[0])
+    deltap = 1e-6
+    for i in (0, 2, 3):  # importantindices = [1, 3, 4] of the reference (1-based)
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += deltap
+        pm[i] -= deltap
+        fd = (G(pp) - G(pm)) / (2 * deltap)
+        assert abs(fd - dGdp[i]) <= 1e-2 * max(abs(fd), abs(dGdp[i])), (i, fd, dGdp[i])
+        assert abs(dGdp2[i] - dGdp[i]) <= 1e-3 * abs(dGdp[i]) + 1e-14
+
+
+def test_parameter_jacobians_vs_finite_differences_of_the_oracle_assembly(fv, oracle):
+    """b_p - A_px (the LinearAdjoints-generated pair called at transientadjointutils.jl:27-28) against central
+    finite differences of the oracle's assembleb - assembleA*x, with a metaindex, both conductivity forms."""
+    import sys
+
+    adj = sys.modules[fv.__name__ + ".adjoint"]
+    rng = np.random.default_rng(7)
+    # 3 x 4 lattice of nodes, faces along both directions, three conductivity zones, two Dirichlet nodes
+    n1, n2 = [], []
+    for i in range(3):
+        for j in range(4):
+            k = i * 4 + j + 1
+            if j < 3:
+                n1.append(k), n2.append(k + 1)
+            if i < 2:
+                n1.append(k), n2.append(k + 4)
+    n1, n2 = np.array(n1), np.array(n2)
+    F, N = len(n1), 12
+    aol = rng.uniform(0.5, 2.0, F)
+    meta = rng.integers(1, 4, F)
+    dn = np.array([1, 7])
+    dh = np.array([3.0, -1.5])
+    src = rng.normal(size=N)
+    src[dn - 1] = 0.0  # FiniteVolume.jl:26: no source at a Dirichlet node
+    x = rng.normal(size=N - 2)
+    nb = np.stack([n1, n2], 1)
+    for logk in (False, True):
+        K = rng.uniform(0.2, 1.5, 3)
+        p0 = np.r_[K, src, dh]
+
+        def resid(p):
+            Kp, sp_, dp = p[:3], p[3 : 3 + N], p[3 + N :]
+            A = oracle.assembleA(n1, n2, aol, Kp, sp_, dn, dp, meta, logk).toscipy()
+            return oracle.assembleb(n1, n2, aol, Kp, sp_, dn, dp, meta, logk) - A @ x
+
+        M, freenode, n2f = adj._parameter_jacobians(x, nb, aol, K, src, dn, dh, meta, logk)
+        M = M.toarray()
+        assert M.shape == (3 + N + 2, N - 2)
+        h = 1e-6
+        for i in range(len(p0)):
+            if i - 3 in dn - 1:  # a Dirichlet node's source slot cannot be perturbed (it must stay zero)
+                continue
+            pp, pm = p0.copy(), p0.copy()
+            pp[i] += h
+            pm[i] -= h
+            fd = (resid(pp) - resid(pm)) / (2 * h)
+            assert np.allclose(M[i], fd, rtol=1e-7, atol=1e-8), (logk, i)
+        # Dirichlet nodes' own source entries have no effect
+        assert not M[3 + dn - 1].any()
+
+
+def test_theisadjoint_gradient_vs_finite_differences(fv):
+    """test/theisadjoint.jl:12-84: 25 x 25 x 2 grid, forward x2 + adjoint on the device stepper, integratedfdplambda,
+    gradient against central finite differences of G on the 20 largest entries (rtol 1e-3 there and here)."""
+    atol, steadyhead, side, thick = 1e-4, 0.0, 50.0, 10.0
+    mins, maxs, ns = [-side, -side, 0.0], [side, side, thick], [25, 25, 2]
+    meanloghyco, Q, Ss = math.log(1e-5), 1e-3, 0.1
+    sigma = lambda i, t: 0.03  # noqa: E731
+    coords, neighbors, aol, volumes = fv.regulargrid(mins, maxs, ns)
+    F, N = len(aol), coords.shape[1]
+    loghycos = np.full(F, meanloghyco + 1)
+    center = np.nonzero((coords[0] == 0) & (coords[1] == 0))[0]
+    assert len(center) == 2
+    sources = np.zeros(N)
+    sources[center] = -2 * Q / (2 * len(center) - 2)
+    sources[center[0]] = sources[center[-1]] = -Q / (2 * len(center) - 2)
+    dmask = np.hypot(coords[0], coords[1]) - side >= 0
+    dnodes = np.nonzero(dmask)[0] + 1
+    dheads = np.full(len(dnodes), steadyhead)
+    u0 = np.full(N, steadyhead)
+    tspan = (0.0, 60 * 60 * 24 * 1e1)
+    meta = lambda i: i  # noqa: E731
+    kw = dict(atol=atol, dt0=60.0)
+    us, ts = fv.backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, aol, loghycos, sources, dnodes, dheads, meta, True, **kw)
+    uobs = fv.getcontinuoussolution(us, ts)
+    K0 = np.full(F, meanloghyco)
+    p0 = np.r_[K0, sources, dheads]
+    us_i, ts_i = fv.backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    uc_init = fv.getcontinuoussolution(us_i, ts_i)
+    uc_init2 = fv.getcontinuoussolution(us_i, ts_i, 2)
+    freenodes, n2f = fv.getfreenodes(N, dnodes)
+    obsfreenodes = [int(n2f[i]) for i in center]
+    g, dgdu, dfdp, dgdp, du0dp, G = fv.getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    lambdas, ts_l = fv.adjointintegrate(lambda t: dgdu(uc_init, t), tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    idl = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True)
+    dGdp = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc_init, t, p0), idl, tspan, maxevals=300, order=21)
+    assert dGdp.shape == (F + N + len(dnodes),)
+    important = np.argsort(-np.abs(dGdp), kind="stable")[:20]
+    deltap = 1e-4
+    for i in important:
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += deltap
+        pm[i] -= deltap
+        x1 = (G(pp) - G(pm)) / (2 * deltap)
+        assert abs(x1 - dGdp[i]) <= 1e-3 * max(abs(x1), abs(dGdp[i])), (int(i), x1, dGdp[i])

@@ -65,3 +65,11 @@ def test_getcontinuoussolution_bounds(fv):
     assert uc(0.5).tolist() == [0.25, 0.25] and uc(2.0).tolist() == [1.0, 1.0]
     with pytest.raises(IndexError):
         uc(2.5)
+
+
+def test_integratedfdplambda_rejects_plain_conductivity(fv):
+    """FiniteVolume.jl:363 error("not supported")"""
+    import pytest
+
+    with pytest.raises(Exception, match="not supported"):
+        fv.integratedfdplambda(lambda t: np.zeros(2), np.zeros(4), [np.zeros(1)] * 2, [0.0, 1.0], (0.0, 1.0), 1.0, np.ones(2), np.array([[1, 2]]), np.ones(1), np.ones(1), np.zeros(2), np.array([1]), np.zeros(1), None, False)
