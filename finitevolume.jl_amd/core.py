@@ -309,6 +309,13 @@ class DeviceVector:
         self.problem.check(load().fv_state_get_nodes(self.problem.handle, self.slot, ptr(out)))
         return out
 
+    def set_nodes(self, u_nodes):
+        u_ = af64(u_nodes)
+        if len(u_) != self.problem.N:
+            raise ValueError("set_nodes wants one value per node (%d), got %d" % (self.problem.N, len(u_)))
+        self.problem.check(load().fv_state_set_nodes(self.problem.handle, self.slot, ptr(u_)))
+        return self
+
     def set_free(self, u):
         u_ = af64(u)
         self.problem.check(load().fv_state_set_free(self.problem.handle, self.slot, ptr(u_)))

@@ -170,6 +170,7 @@ struct fv_problem {
     DevBuf<double> D; // Ss * volumes[free]
     std::vector<double *> slots;
     std::vector<char> slot_used;
+    int32_t pingpong_slot = -1; // hidden state vector the fixed-dt run alternates with the caller's slot
 
     // PCG workspace
     DevBuf<double> r, pvec, q, minv, rhs, tmp;
@@ -228,9 +229,18 @@ struct PcgSystem {
     bool b_times_D = false;
     double dt = 0.0;
     bool fold_shift = false; // use the copy of vals with sigma*D folded into the diagonal (fixed-dt runs)
+    // fixed-dt runs, ping-pong state: when x_next is set the first iteration writes x + alpha p THERE and the solve
+    // continues in place in x_next (the solution is in x_next iff info->iters > 0, x is then untouched = the old state).
+    double *x_next = nullptr;
+    // residual carry-over: the workspace r still holds the final recurrence residual of the previous step of the same
+    // system (same sigma, same b'), whose initial state was carry_prev.  Then
+    //     r0 = rhs_new - (A + sigma D) x = r + sigma D (x - carry_prev)
+    // and the step needs no SpMV for its initial residual.
+    const double *carry_prev = nullptr;
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
+int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false);
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);

@@ -306,6 +306,7 @@ static int g_nt = 1;
 static int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 static int g_use_dia = 1;
 int g_fold_shift = 1;
+extern int g_carry_refresh; // fv_transient.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -323,7 +324,8 @@ extern "C" int fv_tune(int key, int value)
         g_fuse_init = value;
     else if (key == 6 && (value == 0 || value == 1))
         g_use_dia = value;
-
+    else if (key == 7 && value >= 0)
+        g_carry_refresh = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -984,6 +986,61 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const dou
     }
 }
 
+// K0' — set-up of an implicit step from the previous step's final residual (PcgSystem::carry_prev): with the same
+// operator and b', rhs_new - rhs_old = sigma D (x - x_prev), so r0 = r_final + sigma D (x - x_prev) needs no SpMV.
+// Everything else as pcg_init_kernel<true>: p = M^-1 r0 and the partials of r.M^-1 r, r.r, rhs.rhs with
+// rhs = b' + D x/dt.  Streams: r, D, x, x_prev, b', M^-1 in; r, p out (64 B per row).
+__global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, const double *__restrict__ bprime, const double *__restrict__ D,
+                                                                   double dt, const double *__restrict__ x, const double *__restrict__ xprev,
+                                                                   const double *__restrict__ minv, double *__restrict__ r,
+                                                                   double *__restrict__ pv, double *__restrict__ part_rz,
+                                                                   double *__restrict__ part_rr, double *__restrict__ part_bb)
+{
+    __shared__ double smem[4];
+    double arz = 0.0, arr = 0.0, abb = 0.0;
+    const int64_t n2 = n >> 1;
+    const double2 *b2 = reinterpret_cast<const double2 *>(bprime);
+    const double2 *D2 = reinterpret_cast<const double2 *>(D);
+    const double2 *x2 = reinterpret_cast<const double2 *>(x);
+    const double2 *o2 = reinterpret_cast<const double2 *>(xprev);
+    const double2 *m2 = reinterpret_cast<const double2 *>(minv);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    double2 *p2 = reinterpret_cast<double2 *>(pv);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
+        const double2 dv = D2[i], xv = x2[i], ov = o2[i], mv = m2[i];
+        double2 rv = r2[i];
+        rv.x += dv.x * ((xv.x - ov.x) / dt);
+        rv.y += dv.y * ((xv.y - ov.y) / dt);
+        const double hx = bv.x + dv.x * (xv.x / dt), hy = bv.y + dv.y * (xv.y / dt);
+        const double zx = mv.x * rv.x, zy = mv.y * rv.y;
+        r2[i] = rv;
+        p2[i] = make_double2(zx, zy);
+        arz += rv.x * zx + rv.y * zy;
+        arr += rv.x * rv.x + rv.y * rv.y;
+        abb += hx * hx + hy * hy;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double ri = r[i] + D[i] * ((x[i] - xprev[i]) / dt);
+        const double hi = (bprime ? bprime[i] : 0.0) + D[i] * (x[i] / dt);
+        const double zi = minv[i] * ri;
+        r[i] = ri;
+        pv[i] = zi;
+        arz += ri * zi;
+        arr += ri * ri;
+        abb += hi * hi;
+    }
+    const double t0 = block_sum(arz, smem);
+    const double t1 = block_sum(arr, smem);
+    const double t2 = block_sum(abb, smem);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+        part_bb[blockIdx.x] = t2;
+    }
+}
+
 __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const double *__restrict__ part_rz,
                                                                       const double *__restrict__ part_rr,
                                                                       const double *__restrict__ part_bb, int nparts, double rtol,
@@ -1005,8 +1062,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const doubl
     }
 }
 
-// K2
-__global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it, double *__restrict__ x, double *__restrict__ r,
+// K2.  SPLIT: the iterate is read from xin and written to x (first iteration of a ping-pong step), else in place.
+template <bool SPLIT>
+__global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it, const double *xin, double *x, double *__restrict__ r,
                                                                const double *__restrict__ pv, const double *__restrict__ q,
                                                                const double *__restrict__ minv, const double *__restrict__ part_pq,
                                                                int npq, PcgScalars *__restrict__ scal, double *__restrict__ part_rz,
@@ -1027,12 +1085,13 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it,
     double arz = 0.0, arr = 0.0;
     const int64_t n2 = n >> 1;
     double2 *x2 = reinterpret_cast<double2 *>(x);
+    const double2 *xi2 = SPLIT ? reinterpret_cast<const double2 *>(xin) : x2;
     double2 *r2 = reinterpret_cast<double2 *>(r);
     const double2 *p2 = reinterpret_cast<const double2 *>(pv);
     const double2 *q2 = reinterpret_cast<const double2 *>(q);
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
-        double2 xv = x2[i], rv = r2[i];
+        double2 xv = xi2[i], rv = r2[i];
         const double2 pvv = p2[i], qv = q2[i], mv = m2[i];
         xv.x += alpha * pvv.x;
         xv.y += alpha * pvv.y;
@@ -1045,7 +1104,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it,
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double xi = x[i] + alpha * pv[i];
+        const double xi = (SPLIT ? xin[i] : x[i]) + alpha * pv[i];
         const double ri = r[i] - alpha * q[i];
         x[i] = xi;
         r[i] = ri;
@@ -1215,7 +1274,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     int Ginit = Gv; // number of per-block partials the set-up produced
-    if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
+    if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
+        hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
+                           (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
+                           p->part_bb.p);
+    } else if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
         // the whole set-up in the epilogue of ONE SpMV: with the folded matrix q = (A + sigma D) x0 and
         // r0 = rhs - q; otherwise q = A x0 (plain) and r0 = b' - q (the D x0/dt terms cancel)
         StepInitEpilogue epi{};
@@ -1286,8 +1349,13 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
             FV_PROF(1);
             FV_PROF(2);
-            hipLaunchKernelGGL(pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, x, p->r.p, p->pvec.p, p->q.p,
-                               p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
+            if (iter == 0 && sys.x_next)
+                hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)x, sys.x_next,
+                                   p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
+            else
+                hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)nullptr,
+                                   sys.x_next ? sys.x_next : x, p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p,
+                                   p->part_rz.p, p->part_rr.p);
             FV_PROF(3);
             FV_PROF(4);
             hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,
@@ -1563,7 +1631,9 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     return FV_OK;
 }
 
-static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info)
+// x_next / carry_prev: the ping-pong state and the residual carry-over of PcgSystem, same meaning.
+static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info, double *x_next = nullptr,
+                     const double *carry_prev = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
@@ -1578,11 +1648,18 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     double *red = d->red.p;
-    // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
-    FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
-    hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
-                       p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p, p->minv.p,
-                       p->part_rz.p, p->part_rr.p, p->part_bb.p);
+    if (carry_prev && !compute_minv) {
+        // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
+        hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->D.p, dt,
+                           (const double *)u, carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
+                           p->part_bb.p);
+    } else {
+        // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
+        FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
+        hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
+                           p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
+                           p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+    }
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
     hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_bb.p, Gv, red + 3);
@@ -1602,8 +1679,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             const int iter = (int)(it + k);
             FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
             FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
-            hipLaunchKernelGGL(pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, u, p->r.p, p->pvec.p, p->q.p, p->minv.p,
-                               (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
+            if (iter == 0 && x_next)
+                hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)u, x_next, p->r.p,
+                                   p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
+            else
+                hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)nullptr,
+                                   x_next ? x_next : u, p->r.p, p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p,
+                                   p->part_rz.p, p->part_rr.p);
             hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
             hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
             FV_LAUNCH_CHECK(ctx);
@@ -1653,10 +1735,32 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     FV_HIP(ctx, hipEventRecord(e0, ctx->stream));
     fv_solve_info inf = {};
     int rc = FV_OK;
+    // ping-pong state + residual carry-over, as in fv_transient_run_fixed (identical decisions on every rank:
+    // they depend only on the step index and on the all-reduced iteration count)
+    const int64_t refresh = g_carry_refresh;
+    const bool pingpong = refresh > 0 && nsteps >= 2;
+    if (pingpong && p->pingpong_slot < 0)
+        rc = fv_slot_new(p, &p->pingpong_slot);
+    double *u = p->slots[0];
+    double *alt = (pingpong && rc == FV_OK) ? p->slots[(size_t)p->pingpong_slot] : nullptr;
+    const double *prev = nullptr;
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
-        rc = dist_step(p, p->slots[0], dt, rtol, maxiter, &inf);
+        const bool carry = prev != nullptr && (s % refresh) != 0;
+        rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
+        if (pingpong && rc == FV_OK) {
+            prev = u;
+            if (inf.iters > 0) {
+                double *t = u;
+                u = alt;
+                alt = t;
+            }
+        }
+    }
+    if (pingpong && rc == FV_OK) {
+        p->slots[0] = u;
+        p->slots[(size_t)p->pingpong_slot] = alt;
     }
     if (rc == FV_OK) {
         float ms = 0.f;

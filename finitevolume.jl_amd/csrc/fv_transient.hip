@@ -29,7 +29,7 @@ static int slot_ptr(fv_problem *p, int32_t slot, double **out)
     return FV_OK;
 }
 
-static int slot_new(fv_problem *p, int32_t *slot)
+int fv_slot_new(fv_problem *p, int32_t *slot)
 {
     for (size_t i = 0; i < p->slots.size(); i++)
         if (!p->slot_used[i]) {
@@ -138,7 +138,7 @@ extern "C" int fv_transient_begin(fv_problem *p, double Ss, const double *volume
     }
     if (p->slots.empty()) {
         int32_t s0;
-        FV_TRY(slot_new(p, &s0));
+        FV_TRY(fv_slot_new(p, &s0));
     }
     p->slot_used[0] = 1;
     if (u0_nodes) {
@@ -170,7 +170,7 @@ extern "C" int fv_state_alloc(fv_problem *p, int32_t *slot)
         return FV_ERR_ARG;
     FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
     FV_TRY(need_transient(p, "fv_state_alloc"));
-    return slot_new(p, slot);
+    return fv_slot_new(p, slot);
 }
 
 extern "C" int fv_state_free(fv_problem *p, int32_t slot)
@@ -275,8 +275,11 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
         x[i] = divide ? x[i] / D[i] : x[i] * D[i];
 }
 
+int g_carry_refresh = 32; // fv_tune key 7: 0 = every step computes its residual with an SpMV
+
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
-                     int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false)
+                     int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
+                     const double *carry_prev = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
@@ -290,6 +293,8 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.dt = dt;
     sys.implicit_step = true;
     sys.fold_shift = fold_shift;
+    sys.x_next = x_next;
+    sys.carry_prev = carry_prev;
     if (mode == FV_STEP_FORWARD) {
         sys.rhs = bhat_dev ? bhat_dev : p->b.p;
         sys.b_times_D = bhat_dev != nullptr;
@@ -345,10 +350,41 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     FV_HIP(ctx, hipEventRecord(e0, ctx->stream));
     fv_solve_info inf = {};
     int rc = FV_OK;
+    // Fixed dt, constant b: the step's system differs from the previous one only by sigma D (u_new - u_old) on the
+    // right-hand side, so the initial residual follows from the previous step's final residual without an SpMV
+    // (PcgSystem::carry_prev).  The state ping-pongs between the caller's slot and a hidden one so that u_old stays
+    // readable at no extra traffic; every g_carry_refresh steps the residual is recomputed from scratch (b' - A u), which
+    // bounds the drift between the carried recurrence residual and the true one.
+    const int64_t refresh = g_carry_refresh;
+    const bool pingpong = refresh > 0 && nsteps >= 2;
+    double *alt = nullptr;
+    if (pingpong) {
+        if (p->pingpong_slot < 0)
+            rc = fv_slot_new(p, &p->pingpong_slot);
+        if (rc == FV_OK) {
+            FV_TRY(slot_ptr(p, slot, &u)); // slot_new may have reallocated the table
+            alt = p->slots[(size_t)p->pingpong_slot];
+        }
+    }
+    const double *prev = nullptr; // state the last solve started from, while p->r holds that solve's final residual
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
-        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2);
+        const bool carry = prev != nullptr && (s % refresh) != 0;
+        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
+        if (pingpong && rc == FV_OK) {
+            if (inf.iters > 0) { // the new state is in alt, u still holds the old one
+                prev = u;
+                double *t = u;
+                u = alt;
+                alt = t;
+            } else
+                prev = u; // converged on entry: state unchanged, zero increment
+        }
+    }
+    if (pingpong && rc == FV_OK) { // hand the buffers back: the caller's slot owns the current state
+        p->slots[(size_t)slot] = u;
+        p->slots[(size_t)p->pingpong_slot] = alt;
     }
     if (rc == FV_OK) {
         hipError_t e = hipEventRecord(e1, ctx->stream);

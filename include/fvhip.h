@@ -179,8 +179,13 @@ int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms);
 int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *out);
 /* Time every PCG kernel launch with HIP event pairs on the launch stream (for the
  * roofline figures of bench.py).  kernel: 0 = SpMV+dot, 1 = x/r update, 2 = p update. */
-/* Process-wide kernel selection for A/B measurements.  key 0: SpMV form (0 = CSR-stream
- * through LDS, the default; 1 = lanes-per-row); key 1: unroll of the lanes-per-row form (2, 4, 8). */
+/* Process-wide kernel selection for A/B measurements (defaults in brackets).
+ *   0: CSR SpMV form, 2 = wave-private CSR-stream [2], 1 = lanes-per-row;  1: unroll of the lanes-per-row form (2, 4, 8)
+ *   2: plane-blocked group order [1];  3: fold sigma*D into a diagonal copy for fixed-dt runs [1]
+ *   4: non-temporal matrix streams [1];  5: fuse the step set-up into the first SpMV's epilogue [0]
+ *   6: sliced-DIA SpMV for grid-like 64-row slices [1]
+ *   7: fixed-dt runs carry the residual from step to step and recompute it from scratch every `value` steps [32];
+ *      0 = every step computes its initial residual with an SpMV */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);

@@ -298,8 +298,9 @@ def test_single_rank_rccl_path_matches_plain_run(fv):
     rng = np.random.default_rng(3)
     x = rng.standard_normal(p.n)
     assert np.allclose(blk.spmv(x, 0.01), p.spmv(x, 0.01), rtol=1e-14, atol=1e-20)
-    it_d, info_d, _ = blk.run_fixed(3600.0, 4, 1e-12)
-    it_s, info_s, _ = p.run_fixed(st, 3600.0, 4, 1e-12)
+    # 40 steps: crosses a refresh of the carried residual (every 32 steps) in both drivers
+    it_d, info_d, _ = blk.run_fixed(3600.0, 40, 1e-12)
+    it_s, info_s, _ = p.run_fixed(st, 3600.0, 40, 1e-12)
     assert info_d.converged and info_s.converged
     assert np.array_equal(it_d, it_s)
     assert relerr(blk.state(), st.free_values()) < 1e-12
@@ -512,3 +513,52 @@ def test_theisadjoint_gradient_vs_finite_differences(fv):
         pm[i] -= deltap
         x1 = (G(pp) - G(pm)) / (2 * deltap)
         assert abs(x1 - dGdp[i]) <= 1e-3 * max(abs(x1), abs(dGdp[i])), (int(i), x1, dGdp[i])
+
+
+def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle):
+    """fv_transient_run_fixed: carrying the residual from step to step (fv_tune key 7, refreshed every 32 steps; here
+    also every 5) gives the heads of the run that recomputes b' - A u every step, and the oracle's (direct solves),
+    over 70 steps that cross refresh boundaries, with several PCG iterations per step."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (15, 13, 11), sigma=1.0)  # odd n: exercises the scalar tails
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    u0 = np.full(N, 0.5)
+    nsteps, dt = 70, 40.0
+    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, nsteps * dt), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=dt, linearsolver=oracle.directlinearsolver)
+    lib = fv.load()
+    heads, its = {}, {}
+    try:
+        for refresh in (0, 32, 5):
+            assert lib.fv_tune(7, refresh) == 0
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+            st = p.transient_begin(0.1, vol, u0)
+            a, info, _ = p.run_fixed(st, dt, 30, rtol=1e-13)  # two calls: the second starts from a fresh residual again
+            b, info, _ = p.run_fixed(st, dt, nsteps - 30, rtol=1e-13)
+            assert info.converged
+            heads[refresh], its[refresh] = st.node_values(), np.r_[a, b]
+            # another state of the same problem is not disturbed by the hidden ping-pong vector
+            st2 = p.new_state()
+            st2.set_nodes(u0)
+            p.run_fixed(st2, dt, 3, rtol=1e-13)
+            assert relerr(st2.node_values(), ous[3]) < HEAD_RTOL
+            assert relerr(st.node_values(), ous[nsteps]) < HEAD_RTOL
+    finally:
+        lib.fv_tune(7, 32)
+    assert (its[0] > 1).all()
+    for refresh in (32, 5):
+        assert relerr(heads[refresh], heads[0]) < 1e-11
+        assert np.abs(its[refresh] - its[0]).max() <= 1
+
+
+def test_run_fixed_at_steady_state_takes_zero_iterations(fv):
+    """A state that already solves every step (no sources, u0 = the uniform Dirichlet head): each solve converges on
+    entry, the ping-pong must leave the state where it is."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (9, 8, 7), sigma=0.0)
+    N = len(vol)
+    dh = np.full(len(dn), 2.5)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, np.zeros(N), dh)
+    st = p.transient_begin(0.1, vol, np.full(N, 2.5))
+    iters, info, _ = p.run_fixed(st, 10.0, 6, rtol=1e-10)
+    assert (iters == 0).all() and info.converged
+    assert np.array_equal(st.node_values(), np.full(N, 2.5))
