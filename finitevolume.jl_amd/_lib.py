@@ -92,6 +92,10 @@ SIGNATURES = {
     "fv_bench_spmv": (C.c_int, [c_prob, C.c_double, C.c_int32, P(C.c_double)]),
     "fv_dot": (C.c_int, [c_prob, _f64p, _f64p, P(C.c_double)]),
     "fv_tune": (C.c_int, [C.c_int, C.c_int]),
+    "fv_precond_set": (C.c_int, [c_prob, C.c_int]),
+    "fv_amg_configure": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_int]),
+    "fv_amg_info": (C.c_int, [c_prob, P(C.c_int32), _i64p, _i64p, C.c_int32]),
+    "fv_amg_apply": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
     "fv_profile_enable": (C.c_int, [c_prob, C.c_int]),
     "fv_profile_get": (C.c_int, [c_prob, C.c_int, P(C.c_double), P(C.c_int64)]),
     "fv_comm_unique_id": (C.c_int, [C.c_char_p]),

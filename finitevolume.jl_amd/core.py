@@ -227,6 +227,30 @@ class Problem:
         ch = ConvergenceHistory(info, hist[: info.resnorm_len].copy() if hist is not None else None)
         return head, res, ch
 
+    PRECONDITIONERS = {"jacobi": 0, "amg": 1}
+
+    def set_preconditioner(self, kind):
+        """"jacobi" (default) or "amg": the aggregation-AMG V-cycle that stands where the reference uses
+        AlgebraicMultigrid.ruge_stuben (FiniteVolume.jl:159-161)."""
+        if kind not in self.PRECONDITIONERS:
+            raise ValueError("preconditioner must be one of %s" % sorted(self.PRECONDITIONERS))
+        self.check(load().fv_precond_set(self.handle, self.PRECONDITIONERS[kind]))
+        return self
+
+    def amg_info(self):
+        """(rows, nnz) per level of the AMG hierarchy (built on demand)."""
+        nl = C.c_int32()
+        rows = np.zeros(32, np.int64)
+        nnz = np.zeros(32, np.int64)
+        self.check(load().fv_amg_info(self.handle, C.byref(nl), ptr(rows), ptr(nnz), 32))
+        return rows[: nl.value].copy(), nnz[: nl.value].copy()
+
+    def amg_apply(self, r, sigma=0.0):
+        r_ = af64(r)
+        z = np.empty(self.n, np.float64)
+        self.check(load().fv_amg_apply(self.handle, ptr(r_), float(sigma), ptr(z)))
+        return z
+
     def spmv(self, x, sigma=0.0):
         x_ = af64(x)
         y = np.empty(self.n, np.float64)
@@ -382,14 +406,17 @@ def freenodes2nodes(result, sources, dirichletnodes, dirichletheads, ctx=None):
     return head, freenode, n2f
 
 
-def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None):
+def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None, preconditioner="jacobi"):
     """FiniteVolume.jl:157-165 -> head, ch, A, b, freenode.
 
-    The reference preconditions CG with Ruge-Stuben AMG; this build runs
-    Jacobi-PCG on the GPU (BASELINE.json north_star), so `maxiter` counts Jacobi-PCG
-    iterations.  As in the reference, non-convergence is reported through
-    ch.isconverged, not raised."""
+    The reference preconditions CG with Ruge-Stuben AMG.  Here the default is the Jacobi-PCG of
+    BASELINE.json's north_star (`maxiter` then counts Jacobi-PCG iterations); preconditioner="amg"
+    selects the aggregation-AMG V-cycle (fv_precond_set), which is what high-contrast or anisotropic
+    steady problems want.  As in the reference, non-convergence is reported through ch.isconverged,
+    not raised."""
     p = _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, None, False, ctx)
+    if preconditioner != "jacobi":
+        p.set_preconditioner(preconditioner)
     head, _, ch = p.solve_steady(None, rtol, maxiter)
     freenode, _ = p.free_maps()
     return head, ch, DeviceMatrix(p, p.csc()), p.b(), freenode

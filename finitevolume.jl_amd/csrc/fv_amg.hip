@@ -1,0 +1,982 @@
+// Aggregation-based algebraic multigrid preconditioner for the PCG (SPD M-matrix-like operators).
+//
+// Stands where the reference calls AlgebraicMultigrid.ruge_stuben + aspreconditioner
+// (/root/reference/src/FiniteVolume.jl:159-161): one V(1,1) cycle per CG iteration.  The
+// construction is not Ruge-Stuben but plain (unsmoothed) aggregation, chosen because every phase
+// of it is a data-parallel pass over CSR rows with no sequential colouring:
+//
+//   setup, per level: three passes of pairwise matching ("handshake": every unmatched row names its
+//     strongest unmatched neighbour, mutual choices become pairs; leftovers join the pair of their
+//     strongest matched neighbour), each followed by the Galerkin product with the piecewise-constant
+//     prolongation, which for such a P is a merge of the member rows with columns renamed — one
+//     thread per coarse row, sorted by column, duplicates summed in a fixed order.  No floating-point
+//     atomics anywhere: the hierarchy and every cycle are bit-reproducible.
+//   cycle: x = w D^-1 b ; t = A x ; b_c = P^T (b - t) ; recurse ; x += P x_c ; t = A x ;
+//     x += w D^-1 (b - t).  Same w before and after, so the preconditioner is symmetric.  The coarsest
+//     level (<= 1024 rows) is solved with an explicit inverse computed once by Gauss-Jordan on the device.
+//   The storage term of the implicit step is carried along exactly: P^T D P is diagonal (sums of D over
+//     the aggregates), so level l applies A_l + sigma D_l and only the Jacobi diagonals and the coarsest
+//     inverse depend on sigma.
+//
+// Everything is HBM-bound streaming like the rest of the library; level 0 uses the problem's own SpMV
+// (sliced-DIA / CSR-stream), the coarse levels a lanes-per-row CSR kernel.
+#include "fv_internal.h"
+#include "fv_device.h"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+
+namespace {
+
+struct AmgLevel {
+    int64_t n = 0, nnz = 0, nc = 0;
+    // operator (level 0: views of the problem's arrays)
+    const int32_t *rowptr = nullptr, *colind = nullptr;
+    const double *vals = nullptr, *D = nullptr;
+    DevBuf<int32_t> o_rowptr, o_colind;
+    DevBuf<double> o_vals, o_D;
+    DevBuf<double> diag, dinv;
+    // transfer to the next level
+    DevBuf<int32_t> agg;         // n: coarse index, -1 = not represented below (row without couplings)
+    DevBuf<int32_t> memptr, mem; // nc+1 / members of every aggregate, ascending
+    // cycle workspace
+    DevBuf<double> x, b, t;
+};
+
+} // namespace
+
+struct fv_amg {
+    std::vector<AmgLevel *> lev;
+    DevBuf<double> inv;  // coarsest inverse (nco x nco), row-major
+    DevBuf<double> gjrow, gjcol;
+    int64_t nco = 0;
+    bool dense = false;
+    double sigma = NAN;       // the sigma dinv / inv were built for
+    int64_t epoch = -1;       // assemble_epoch of the hierarchy
+    int64_t storage_epoch = -1; // which fv_transient_begin the aggregated D belongs to
+    bool fold = false;        // level-0 SpMVs use the folded value array (fixed-dt runs), as the PCG around them
+    DevBuf<double> z;         // preconditioned residual of the PCG
+    ~fv_amg()
+    {
+        for (AmgLevel *l : lev)
+            delete l;
+    }
+};
+
+void fv_amg_free(fv_amg *a) { delete a; }
+
+// tunables (fv_amg_configure)
+static double g_theta = 0.25; // a coupling is strong when -a_ij >= theta * max_k(-a_ik)
+static double g_omega = 2.0 / 3.0;
+static int g_passes = 3;      // pairwise passes per level
+static int g_rounds = 6;      // handshake rounds per pass
+static int g_coarse_max = 1024;
+static int g_coarse_sweeps = 12; // Jacobi sweeps on a coarsest level too large for the dense inverse
+
+extern "C" int fv_amg_configure(double theta, double omega, int passes, int rounds)
+{
+    if (!(theta > 0 && theta <= 1) || !(omega > 0 && omega < 1) || passes < 1 || passes > 4 || rounds < 1 || rounds > 16)
+        return FV_ERR_ARG;
+    g_theta = theta;
+    g_omega = omega;
+    g_passes = passes;
+    g_rounds = rounds;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ setup kernels
+constexpr int32_t AMG_UNMATCHED = -1, AMG_ISOLATED = -2;
+
+// Preference of row i for neighbour j: the octave of the coupling strength first, then a hash that is symmetric in
+// (i, j).  Ranking by the raw strength makes the handshake crawl: wherever strengths vary monotonically every row names
+// its uphill neighbour and only the top of each chain pairs up per round; with octaves + a symmetric hash two
+// neighbours often rank each other first, and 6 rounds match almost everything (which also keeps the aggregates of
+// high-conductivity regions from snowballing through the leftover rule).
+__device__ inline uint64_t amg_pref(double s, int32_t i, int32_t j)
+{
+    const uint32_t lo = (uint32_t)(i < j ? i : j), hi = (uint32_t)(i < j ? j : i);
+    uint32_t h = lo * 0x9E3779B1u ^ hi * 0x85EBCA77u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 12;
+    h *= 0x297A2D39u;
+    h ^= h >> 15;
+    const uint64_t octave = ((uint64_t)__double_as_longlong(s) >> 52) & 0x7ffu;
+    return (octave << 32) | h;
+}
+
+// every unmatched row names its preferred strong unmatched neighbour (strong: -a_ij >= theta * the row's strongest
+// coupling), -1 if there is none; rows without any negative off-diagonal are marked isolated
+__global__ __launch_bounds__(FV_BLOCK) void amg_pick_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                             const double *__restrict__ vals, const int32_t *__restrict__ partner,
+                                                             int32_t *__restrict__ cand, double theta)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    if (partner[i] != AMG_UNMATCHED) {
+        cand[i] = -1;
+        return;
+    }
+    double maxoff = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int32_t j = colind[k];
+        if (j != i && j < n && -vals[k] > maxoff)
+            maxoff = -vals[k];
+    }
+    if (!(maxoff > 0.0)) {
+        cand[i] = AMG_ISOLATED;
+        return;
+    }
+    const double cut = theta * maxoff;
+    uint64_t bestp = 0;
+    int32_t best = -1;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int32_t j = colind[k];
+        if (j == i || j >= n)
+            continue;
+        const double s = -vals[k];
+        if (s >= cut && s > 0.0 && partner[j] == AMG_UNMATCHED) {
+            const uint64_t pr = amg_pref(s, (int32_t)i, j);
+            if (best < 0 || pr > bestp || (pr == bestp && j < best)) {
+                bestp = pr;
+                best = j;
+            }
+        }
+    }
+    cand[i] = best;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_match_kernel(int64_t n, const int32_t *__restrict__ cand, int32_t *__restrict__ partner)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n || partner[i] != AMG_UNMATCHED)
+        return;
+    const int32_t c = cand[i];
+    if (c == AMG_ISOLATED)
+        partner[i] = AMG_ISOLATED;
+    else if (c >= 0 && cand[c] == (int32_t)i)
+        partner[i] = c;
+}
+
+// root of every row's aggregate: pairs -> the smaller index; leftovers join the pair of their strongest matched
+// neighbour (if strong enough) or stay alone; isolated rows get -1.  isroot feeds the numbering scan.
+__global__ __launch_bounds__(FV_BLOCK) void amg_root_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                             const double *__restrict__ vals, const int32_t *__restrict__ partner,
+                                                             int32_t *__restrict__ rootof, int32_t *__restrict__ isroot, double theta)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const int32_t pi = partner[i];
+    int32_t root;
+    if (pi >= 0)
+        root = pi < (int32_t)i ? pi : (int32_t)i;
+    else if (pi == AMG_ISOLATED)
+        root = -1;
+    else {
+        double maxoff = 0.0, bestv = 0.0;
+        int32_t best = -1;
+        for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+            const int32_t j = colind[k];
+            if (j == i || j >= n)
+                continue;
+            const double s = -vals[k];
+            if (s > maxoff)
+                maxoff = s;
+            if (s > 0.0 && partner[j] >= 0 && (s > bestv || (s == bestv && j < best))) {
+                bestv = s;
+                best = j;
+            }
+        }
+        if (best >= 0 && bestv >= theta * maxoff) {
+            const int32_t pj = partner[best];
+            root = pj < best ? pj : best;
+        } else
+            root = (int32_t)i;
+    }
+    rootof[i] = root;
+    isroot[i] = root == (int32_t)i;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_number_kernel(int64_t n, const int32_t *__restrict__ rootof, const int32_t *__restrict__ cidx,
+                                                               int32_t *__restrict__ agg)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        agg[i] = rootof[i] < 0 ? -1 : cidx[rootof[i]];
+}
+
+// agg_out[i] = next[agg_out[i]] (composition of two aggregation maps; -1 stays -1)
+__global__ __launch_bounds__(FV_BLOCK) void amg_compose_kernel(int64_t n, int32_t *__restrict__ agg, const int32_t *__restrict__ next)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n) {
+        const int32_t a = agg[i];
+        agg[i] = a < 0 ? -1 : next[a];
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_count_kernel(int64_t n, const int32_t *__restrict__ agg, int32_t *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n && agg[i] >= 0)
+        atomicAdd(&cnt[agg[i]], 1);
+}
+
+// sort keys of the member lists: the aggregate, rows without one last
+__global__ __launch_bounds__(FV_BLOCK) void amg_member_keys_kernel(int64_t n, const int32_t *__restrict__ agg, uint32_t nc, uint32_t *__restrict__ key,
+                                                                    int32_t *__restrict__ idx)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n) {
+        key[i] = agg[i] < 0 ? nc : (uint32_t)agg[i];
+        idx[i] = (int32_t)i;
+    }
+}
+
+// Galerkin product with a piecewise-constant P, step 1: every stored entry (i, j, v) becomes (agg[i] * nc + agg[j], v);
+// entries of rows or columns without an aggregate get the largest key and fall off the end of the sort
+__global__ __launch_bounds__(FV_BLOCK) void amg_expand_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                               const int32_t *__restrict__ agg, uint64_t nc, uint64_t *__restrict__ key)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const int32_t I = agg[i];
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int32_t j = colind[k];
+        const int32_t c = (j < n) ? agg[j] : -1;
+        key[k] = (I < 0 || c < 0) ? nc * nc : (uint64_t)I * nc + (uint64_t)c;
+    }
+}
+
+// step 2, after the stable sort: head[k] = 1 where a new (row, column) starts
+__global__ __launch_bounds__(FV_BLOCK) void amg_heads_kernel(int64_t m, const uint64_t *__restrict__ key, uint64_t invalid, int32_t *__restrict__ head)
+{
+    const int64_t k = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (k < m)
+        head[k] = (key[k] != invalid && (k == 0 || key[k] != key[k - 1])) ? 1 : 0;
+}
+
+// step 3: one thread per run sums it front to back (= the order of the fine entries: the sort is stable), writes the
+// coarse entry and counts it for its row
+__global__ __launch_bounds__(FV_BLOCK) void amg_runs_kernel(int64_t m, const uint64_t *__restrict__ key, const double *__restrict__ val,
+                                                             const int32_t *__restrict__ head, const int32_t *__restrict__ pos, uint64_t nc,
+                                                             int32_t *__restrict__ colind_c, double *__restrict__ vals_c,
+                                                             int32_t *__restrict__ rowcnt)
+{
+    const int64_t k = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (k >= m || !head[k])
+        return;
+    const uint64_t kk = key[k];
+    double s = val[k];
+    for (int64_t q = k + 1; q < m && key[q] == kk; q++)
+        s += val[q];
+    const int32_t o = pos[k];
+    colind_c[o] = (int32_t)(kk % nc);
+    vals_c[o] = s;
+    atomicAdd(&rowcnt[(int32_t)(kk / nc)], 1);
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_aggD_kernel(int64_t nc, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
+                                                             const double *__restrict__ D, double *__restrict__ Dc)
+{
+    const int64_t I = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (I >= nc)
+        return;
+    double s = 0.0;
+    for (int32_t k = memptr[I]; k < memptr[I + 1]; k++)
+        s += D[mem[k]];
+    Dc[I] = s;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_diag_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                             const double *__restrict__ vals, double *__restrict__ diag)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    double d = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++)
+        if (colind[k] == (int32_t)i)
+            d += vals[k];
+    diag[i] = d;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_dinv_kernel(int64_t n, const double *__restrict__ diag, const double *__restrict__ D, double sigma,
+                                                             double *__restrict__ dinv)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n) {
+        const double d = diag[i] + (D ? sigma * D[i] : 0.0);
+        dinv[i] = d > 0.0 ? 1.0 / d : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------ cycle kernels
+// y = (A + sigma D) x, LPR lanes per row (coarse levels: irregular rows of ~10-30 entries)
+template <int LPR>
+__global__ __launch_bounds__(FV_BLOCK) void amg_spmv_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                             const double *__restrict__ vals, const double *__restrict__ x,
+                                                             double *__restrict__ y, const double *__restrict__ D, double sigma)
+{
+    const int64_t row = (int64_t)blockIdx.x * (FV_BLOCK / LPR) + threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    double s = 0.0;
+    if (row < n) {
+        const int32_t e = rowptr[row + 1];
+        for (int32_t k = rowptr[row] + sub; k < e; k += LPR)
+            s += vals[k] * x[colind[k]];
+    }
+#pragma unroll
+    for (int off = LPR / 2; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, LPR);
+    if (sub == 0 && row < n) {
+        if (D)
+            s += sigma * D[row] * x[row];
+        y[row] = s;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_smooth0_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ b, double omega,
+                                                                double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        x[i] = omega * dinv[i] * b[i];
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_smooth_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ b,
+                                                               const double *__restrict__ t, double omega, double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        x[i] += omega * dinv[i] * (b[i] - t[i]);
+}
+
+// b_c[I] = sum over the members of (b - t): 8 lanes per aggregate (aggregates of a high-conductivity region can have
+// thousands of members), fixed lane partition + shuffle tree, so the sum order is fixed
+__global__ __launch_bounds__(FV_BLOCK) void amg_restrict_kernel(int64_t nc, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
+                                                                 const double *__restrict__ b, const double *__restrict__ t,
+                                                                 double *__restrict__ bc)
+{
+    const int64_t I = (int64_t)blockIdx.x * (FV_BLOCK / 8) + threadIdx.x / 8;
+    const int sub = threadIdx.x % 8;
+    double s = 0.0;
+    if (I < nc) {
+        const int32_t e = memptr[I + 1];
+        for (int32_t k = memptr[I] + sub; k < e; k += 8) {
+            const int32_t m = mem[k];
+            s += b[m] - t[m];
+        }
+    }
+    s += __shfl_xor(s, 4, 8);
+    s += __shfl_xor(s, 2, 8);
+    s += __shfl_xor(s, 1, 8);
+    if (sub == 0 && I < nc)
+        bc[I] = s;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_prolong_kernel(int64_t n, const int32_t *__restrict__ agg, const double *__restrict__ xc,
+                                                                double *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n) {
+        const int32_t a = agg[i];
+        if (a >= 0)
+            x[i] += xc[a];
+    }
+}
+
+// ------------------------------------------------------------------ coarsest level: explicit inverse by Gauss-Jordan
+__global__ __launch_bounds__(FV_BLOCK) void amg_dense_fill_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                   const double *__restrict__ vals, const double *__restrict__ D, double sigma,
+                                                                   double *__restrict__ M)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++)
+        M[i * n + colind[k]] += vals[k]; // one thread per row: no race
+    if (D)
+        M[i * n + i] += sigma * D[i];
+}
+
+// step k, phase 1: save row k and column k
+__global__ __launch_bounds__(FV_BLOCK) void amg_gj_save_kernel(int64_t n, int64_t k, const double *__restrict__ M, double *__restrict__ rowk,
+                                                                double *__restrict__ colk)
+{
+    const int64_t j = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (j < n) {
+        rowk[j] = M[k * n + j];
+        colk[j] = M[j * n + k];
+    }
+}
+
+// step k, phase 2: in-place Gauss-Jordan update of the whole matrix (no pivoting: the matrix is SPD)
+__global__ __launch_bounds__(FV_BLOCK) void amg_gj_update_kernel(int64_t n, int64_t k, double *__restrict__ M, const double *__restrict__ rowk,
+                                                                  const double *__restrict__ colk)
+{
+    const int64_t j = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n)
+        return;
+    const double piv = rowk[k];
+    const double ip = 1.0 / piv;
+    double v;
+    if (i == k)
+        v = (j == k) ? ip : rowk[j] * ip;
+    else if (j == k)
+        v = -colk[i] * ip;
+    else
+        v = M[i * n + j] - colk[i] * rowk[j] * ip;
+    M[i * n + j] = v;
+}
+
+// y = Minv b, one wave per row
+__global__ __launch_bounds__(FV_BLOCK) void amg_gemv_kernel(int64_t n, const double *__restrict__ M, const double *__restrict__ b, double *__restrict__ y)
+{
+    const int64_t row = (int64_t)blockIdx.x * (FV_BLOCK / 64) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    if (row < n)
+        for (int64_t j = lane; j < n; j += 64)
+            s += M[row * n + j] * b[j];
+    s = wave_sum(s);
+    if (lane == 0 && row < n)
+        y[row] = s;
+}
+
+// ------------------------------------------------------------------ host side: hierarchy
+static int amg_level_spmv(fv_ctx *ctx, const AmgLevel *L, const double *x, double *y, double sigma)
+{
+    const double *D = (sigma != 0.0) ? L->D : nullptr;
+    const double avg = L->n > 0 ? (double)L->nnz / (double)L->n : 0.0;
+    if (avg > 12.0)
+        hipLaunchKernelGGL(amg_spmv_kernel<16>, dim3(fv_blocks(L->n, FV_BLOCK / 16)), dim3(FV_BLOCK), 0, ctx->stream, L->n, L->rowptr, L->colind,
+                           L->vals, x, y, D, sigma);
+    else
+        hipLaunchKernelGGL(amg_spmv_kernel<8>, dim3(fv_blocks(L->n, FV_BLOCK / 8)), dim3(FV_BLOCK), 0, ctx->stream, L->n, L->rowptr, L->colind,
+                           L->vals, x, y, D, sigma);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+// One pairwise pass on the CSR (n, rowptr, colind, vals): agg (n entries) and the number of aggregates.
+static int amg_pairwise(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int32_t *colind, const double *vals, DevBuf<int32_t> &agg,
+                        int64_t *nc)
+{
+    DevBuf<int32_t> partner, cand, rootof, isroot, cidx;
+    FV_TRY(partner.alloc(ctx, (size_t)n));
+    FV_TRY(cand.alloc(ctx, (size_t)n));
+    FV_TRY(rootof.alloc(ctx, (size_t)n));
+    FV_TRY(isroot.alloc(ctx, (size_t)n));
+    FV_TRY(cidx.alloc(ctx, (size_t)n + 1));
+    FV_TRY(agg.alloc(ctx, (size_t)n));
+    FV_HIP(ctx, hipMemsetAsync(partner.p, 0xff, (size_t)n * sizeof(int32_t), ctx->stream)); // AMG_UNMATCHED
+    const dim3 g(fv_blocks(n)), b(FV_BLOCK);
+    for (int r = 0; r < g_rounds; r++) {
+        hipLaunchKernelGGL(amg_pick_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, (const int32_t *)partner.p, cand.p, g_theta);
+        hipLaunchKernelGGL(amg_match_kernel, g, b, 0, ctx->stream, n, (const int32_t *)cand.p, partner.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(amg_root_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, (const int32_t *)partner.p, rootof.p, isroot.p, g_theta);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_exclusive_scan_i32(ctx, isroot.p, cidx.p, n, nc));
+    hipLaunchKernelGGL(amg_number_kernel, g, b, 0, ctx->stream, n, (const int32_t *)rootof.p, (const int32_t *)cidx.p, agg.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+static unsigned amg_bits(uint64_t maxval)
+{
+    unsigned b = 1;
+    while (b < 64 && (maxval >> b) != 0)
+        b++;
+    return b;
+}
+
+// stable LSD radix sort of (key, value) pairs (rocPRIM): the one library primitive of the set-up.  Stability is what
+// keeps every later sum in a fixed order.
+template <class K, class V>
+static int amg_sort_pairs(fv_ctx *ctx, const K *kin, K *kout, const V *vin, V *vout, size_t count, unsigned end_bit)
+{
+    size_t bytes = 0;
+    FV_HIP(ctx, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, count, 0u, end_bit, ctx->stream));
+    DevBuf<char> tmp;
+    FV_TRY(tmp.alloc(ctx, bytes));
+    FV_HIP(ctx, rocprim::radix_sort_pairs((void *)tmp.p, bytes, kin, kout, vin, vout, count, 0u, end_bit, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+// members of every aggregate, ascending (CSR-like: memptr, mem)
+static int amg_members(fv_ctx *ctx, int64_t n, const int32_t *agg, int64_t nc, DevBuf<int32_t> &memptr, DevBuf<int32_t> &mem)
+{
+    DevBuf<int32_t> cnt, idx;
+    DevBuf<uint32_t> key, key2;
+    FV_TRY(cnt.alloc(ctx, (size_t)nc + 1));
+    FV_TRY(cnt.zero(ctx));
+    FV_TRY(memptr.alloc(ctx, (size_t)nc + 1));
+    hipLaunchKernelGGL(amg_count_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, agg, cnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    int64_t total = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, cnt.p, memptr.p, nc, &total));
+    FV_TRY(key.alloc(ctx, (size_t)n));
+    FV_TRY(key2.alloc(ctx, (size_t)n));
+    FV_TRY(idx.alloc(ctx, (size_t)n));
+    FV_TRY(mem.alloc(ctx, (size_t)n)); // the first `total` entries are the lists; rows without an aggregate trail behind
+    hipLaunchKernelGGL(amg_member_keys_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, agg, (uint32_t)nc, key.p, idx.p);
+    FV_LAUNCH_CHECK(ctx);
+    return amg_sort_pairs<uint32_t, int32_t>(ctx, key.p, key2.p, idx.p, mem.p, (size_t)n, amg_bits((uint64_t)nc));
+}
+
+// Galerkin coarse operator P^T A P for the aggregation `agg`: CSR with sorted columns + aggregated storage diagonal
+static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *D,
+                        const int32_t *agg, int64_t nc, const int32_t *memptr, const int32_t *mem, DevBuf<int32_t> &rowptr_c,
+                        DevBuf<int32_t> &colind_c, DevBuf<double> &vals_c, DevBuf<double> &Dc, int64_t *nnz_c)
+{
+    DevBuf<uint64_t> key, key2;
+    DevBuf<double> val2;
+    DevBuf<int32_t> head, pos, rowcnt;
+    FV_TRY(key.alloc(ctx, (size_t)nnz));
+    FV_TRY(key2.alloc(ctx, (size_t)nnz));
+    FV_TRY(val2.alloc(ctx, (size_t)nnz));
+    const uint64_t unc = (uint64_t)nc;
+    hipLaunchKernelGGL(amg_expand_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, rowptr, colind, agg, unc, key.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY((amg_sort_pairs<uint64_t, double>(ctx, key.p, key2.p, vals, val2.p, (size_t)nnz, amg_bits(unc * unc))));
+    key.release();
+    FV_TRY(head.alloc(ctx, (size_t)nnz));
+    FV_TRY(pos.alloc(ctx, (size_t)nnz + 1));
+    hipLaunchKernelGGL(amg_heads_kernel, dim3(fv_blocks(nnz)), dim3(FV_BLOCK), 0, ctx->stream, nnz, (const uint64_t *)key2.p, unc * unc, head.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_exclusive_scan_i32(ctx, head.p, pos.p, nnz, nnz_c));
+    FV_TRY(colind_c.alloc(ctx, (size_t)*nnz_c));
+    FV_TRY(vals_c.alloc(ctx, (size_t)*nnz_c));
+    FV_TRY(rowcnt.alloc(ctx, (size_t)nc + 1));
+    FV_TRY(rowcnt.zero(ctx));
+    hipLaunchKernelGGL(amg_runs_kernel, dim3(fv_blocks(nnz)), dim3(FV_BLOCK), 0, ctx->stream, nnz, (const uint64_t *)key2.p, (const double *)val2.p,
+                       (const int32_t *)head.p, (const int32_t *)pos.p, unc, colind_c.p, vals_c.p, rowcnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(rowptr_c.alloc(ctx, (size_t)nc + 1));
+    int64_t check = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, rowcnt.p, rowptr_c.p, nc, &check));
+    if (check != *nnz_c) {
+        fv_set_error(ctx, "AMG Galerkin product: row counts (%lld) and entries (%lld) disagree", (long long)check, (long long)*nnz_c);
+        return FV_ERR_STATE;
+    }
+    if (D) {
+        FV_TRY(Dc.alloc(ctx, (size_t)nc));
+        hipLaunchKernelGGL(amg_aggD_kernel, dim3(fv_blocks(nc)), dim3(FV_BLOCK), 0, ctx->stream, nc, memptr, mem, D, Dc.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
+static bool amg_verbose() { return getenv("FV_AMG_VERBOSE") != nullptr; }
+static double amg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+static int amg_build(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    const double t_start = amg_now();
+    if (p->dist || p->nhalo) {
+        fv_set_error(ctx, "the AMG preconditioner is not available for row blocks of a distributed operator");
+        return FV_ERR_STATE;
+    }
+    fv_amg_free(p->amg);
+    p->amg = new fv_amg();
+    fv_amg *a = p->amg;
+    AmgLevel *L = new AmgLevel();
+    a->lev.push_back(L);
+    L->n = p->n;
+    L->nnz = p->nnz;
+    L->rowptr = p->rowptr.p;
+    L->colind = p->colind.p;
+    L->vals = p->vals.p;
+    L->D = p->D.p; // may be null (steady solve before fv_transient_begin)
+    for (int depth = 0; depth < 24; depth++) {
+        L = a->lev.back();
+        if (L->n <= g_coarse_max)
+            break;
+        // passes of pairwise aggregation, each on the Galerkin operator of the previous one
+        DevBuf<int32_t> cur_rowptr, cur_colind, agg_total;
+        DevBuf<double> cur_vals, cur_D;
+        const int32_t *rp = L->rowptr, *ci = L->colind;
+        const double *va = L->vals, *Dp = L->D;
+        int64_t ncur = L->n, nnz_cur = L->nnz;
+        bool stalled = false;
+        for (int pass = 0; pass < g_passes; pass++) {
+            DevBuf<int32_t> agg, memptr, mem, nrp, nci;
+            DevBuf<double> nva, nD;
+            int64_t nc = 0, nnzc = 0;
+            const double tp0 = amg_now();
+            FV_TRY(amg_pairwise(ctx, ncur, rp, ci, va, agg, &nc));
+            if (amg_verbose())
+                fprintf(stderr, "[amg] level %zu pass %d: %lld rows -> %lld aggregates (matching %.3f s)\n", a->lev.size() - 1, pass, (long long)ncur,
+                        (long long)nc, amg_now() - tp0);
+            if (nc == 0 || nc > (int64_t)(0.95 * (double)ncur)) {
+                stalled = pass == 0;
+                break;
+            }
+            FV_TRY(amg_members(ctx, ncur, agg.p, nc, memptr, mem));
+            const double tg0 = amg_now();
+            FV_TRY(amg_galerkin(ctx, ncur, nnz_cur, rp, ci, va, Dp, agg.p, nc, memptr.p, mem.p, nrp, nci, nva, nD, &nnzc));
+            if (amg_verbose())
+                fprintf(stderr, "[amg]   Galerkin: nnz %lld -> %lld (%.3f s)\n", (long long)nnz_cur, (long long)nnzc, amg_now() - tg0);
+            if (pass == 0) {
+                std::swap(agg_total.p, agg.p);
+                std::swap(agg_total.n, agg.n);
+            } else {
+                hipLaunchKernelGGL(amg_compose_kernel, dim3(fv_blocks(L->n)), dim3(FV_BLOCK), 0, ctx->stream, L->n, agg_total.p,
+                                   (const int32_t *)agg.p);
+                FV_LAUNCH_CHECK(ctx);
+                FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+            std::swap(cur_rowptr.p, nrp.p), std::swap(cur_rowptr.n, nrp.n);
+            std::swap(cur_colind.p, nci.p), std::swap(cur_colind.n, nci.n);
+            std::swap(cur_vals.p, nva.p), std::swap(cur_vals.n, nva.n);
+            std::swap(cur_D.p, nD.p), std::swap(cur_D.n, nD.n);
+            rp = cur_rowptr.p;
+            ci = cur_colind.p;
+            va = cur_vals.p;
+            Dp = L->D ? cur_D.p : nullptr;
+            ncur = nc;
+            nnz_cur = nnzc;
+            if (ncur <= g_coarse_max)
+                break;
+        }
+        if (stalled || ncur == L->n || !agg_total.p)
+            break; // cannot coarsen further: this level is the coarsest
+        AmgLevel *C = new AmgLevel();
+        C->n = ncur;
+        C->nnz = nnz_cur;
+        std::swap(C->o_rowptr.p, cur_rowptr.p), std::swap(C->o_rowptr.n, cur_rowptr.n);
+        std::swap(C->o_colind.p, cur_colind.p), std::swap(C->o_colind.n, cur_colind.n);
+        std::swap(C->o_vals.p, cur_vals.p), std::swap(C->o_vals.n, cur_vals.n);
+        std::swap(C->o_D.p, cur_D.p), std::swap(C->o_D.n, cur_D.n);
+        C->rowptr = C->o_rowptr.p;
+        C->colind = C->o_colind.p;
+        C->vals = C->o_vals.p;
+        C->D = L->D ? C->o_D.p : nullptr;
+        L->nc = ncur;
+        std::swap(L->agg.p, agg_total.p), std::swap(L->agg.n, agg_total.n);
+        FV_TRY(amg_members(ctx, L->n, L->agg.p, L->nc, L->memptr, L->mem));
+        FV_TRY(C->x.alloc(ctx, (size_t)C->n));
+        FV_TRY(C->b.alloc(ctx, (size_t)C->n));
+        a->lev.push_back(C);
+    }
+    for (AmgLevel *l : a->lev) {
+        FV_TRY(l->diag.alloc(ctx, (size_t)l->n));
+        FV_TRY(l->dinv.alloc(ctx, (size_t)l->n));
+        FV_TRY(l->t.alloc(ctx, (size_t)l->n + FV_VEC_PAD));
+        hipLaunchKernelGGL(amg_diag_kernel, dim3(fv_blocks(l->n)), dim3(FV_BLOCK), 0, ctx->stream, l->n, l->rowptr, l->colind, l->vals, l->diag.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    AmgLevel *last = a->lev.back();
+    a->nco = last->n;
+    a->dense = last->n <= 2 * (int64_t)g_coarse_max && last->n > 0; // also a tiny problem as a whole: the "cycle" is then the exact inverse
+    if (a->dense) {
+        FV_TRY(a->inv.alloc(ctx, (size_t)(a->nco * a->nco)));
+        FV_TRY(a->gjrow.alloc(ctx, (size_t)a->nco));
+        FV_TRY(a->gjcol.alloc(ctx, (size_t)a->nco));
+    }
+    FV_TRY(a->z.alloc(ctx, (size_t)p->n + FV_VEC_PAD));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    a->epoch = p->assemble_epoch;
+    a->storage_epoch = p->storage_epoch;
+    a->sigma = NAN;
+    if (amg_verbose())
+        fprintf(stderr, "[amg] hierarchy of %zu levels, coarsest %lld rows (%s), %.3f s\n", a->lev.size(), (long long)a->nco,
+                a->dense ? "dense inverse" : "Jacobi sweeps", amg_now() - t_start);
+    return FV_OK;
+}
+
+// Jacobi diagonals of every level and the coarsest inverse for this sigma
+static int amg_set_sigma(fv_problem *p, double sigma)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_amg *a = p->amg;
+    if (a->sigma == sigma)
+        return FV_OK;
+    const double t_sig = amg_now();
+    if (sigma != 0.0 && !a->lev[0]->D) {
+        fv_set_error(ctx, "AMG hierarchy was built without the storage term; call fv_transient_begin before selecting it for shifted solves");
+        return FV_ERR_STATE;
+    }
+    for (AmgLevel *l : a->lev) {
+        hipLaunchKernelGGL(amg_dinv_kernel, dim3(fv_blocks(l->n)), dim3(FV_BLOCK), 0, ctx->stream, l->n, (const double *)l->diag.p,
+                           sigma != 0.0 ? l->D : (const double *)nullptr, sigma, l->dinv.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    if (a->dense) {
+        const AmgLevel *l = a->lev.back();
+        const int64_t m = a->nco;
+        FV_HIP(ctx, hipMemsetAsync(a->inv.p, 0, (size_t)(m * m) * sizeof(double), ctx->stream));
+        hipLaunchKernelGGL(amg_dense_fill_kernel, dim3(fv_blocks(m)), dim3(FV_BLOCK), 0, ctx->stream, m, l->rowptr, l->colind, l->vals,
+                           sigma != 0.0 ? l->D : (const double *)nullptr, sigma, a->inv.p);
+        FV_LAUNCH_CHECK(ctx);
+        const dim3 g2(fv_blocks(m), (unsigned)m);
+        for (int64_t k = 0; k < m; k++) {
+            hipLaunchKernelGGL(amg_gj_save_kernel, dim3(fv_blocks(m)), dim3(FV_BLOCK), 0, ctx->stream, m, k, (const double *)a->inv.p, a->gjrow.p,
+                               a->gjcol.p);
+            hipLaunchKernelGGL(amg_gj_update_kernel, g2, dim3(FV_BLOCK), 0, ctx->stream, m, k, a->inv.p, (const double *)a->gjrow.p,
+                               (const double *)a->gjcol.p);
+        }
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    a->sigma = sigma;
+    if (amg_verbose())
+        fprintf(stderr, "[amg] diagonals + coarsest inverse for sigma = %g: %.3f s\n", sigma, amg_now() - t_sig);
+    return FV_OK;
+}
+
+int fv_amg_prepare(fv_problem *p, double sigma)
+{
+    if (!p->amg || p->amg->epoch != p->assemble_epoch || p->amg->storage_epoch != p->storage_epoch)
+        FV_TRY(amg_build(p));
+    return amg_set_sigma(p, sigma);
+}
+
+// x_l = V(b_l) on level l (x, b: the level's vectors; level 0: the caller's)
+static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_amg *a = p->amg;
+    AmgLevel *L = a->lev[l];
+    const dim3 g(fv_blocks(L->n)), blk(FV_BLOCK);
+    if (l + 1 == a->lev.size()) { // coarsest
+        if (a->dense) {
+            hipLaunchKernelGGL(amg_gemv_kernel, dim3(fv_blocks(L->n, FV_BLOCK / 64)), blk, 0, ctx->stream, L->n, (const double *)a->inv.p, b, x);
+            FV_LAUNCH_CHECK(ctx);
+            return FV_OK;
+        }
+        // no dense inverse (single level, or coarsening stalled high): symmetric Jacobi sweeps
+        hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, x);
+        for (int s = 1; s < g_coarse_sweeps; s++) {
+            if (l == 0)
+                FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+            else
+                FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
+            hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
+        }
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    }
+    AmgLevel *C = a->lev[l + 1];
+    hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, x);
+    FV_LAUNCH_CHECK(ctx);
+    if (l == 0)
+        FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+    else
+        FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
+    hipLaunchKernelGGL(amg_restrict_kernel, dim3(fv_blocks(C->n, FV_BLOCK / 8)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
+                       (const int32_t *)L->mem.p, b, (const double *)L->t.p, C->b.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(amg_cycle(p, l + 1, C->b.p, C->x.p, sigma));
+    hipLaunchKernelGGL(amg_prolong_kernel, g, blk, 0, ctx->stream, L->n, (const int32_t *)L->agg.p, (const double *)C->x.p, x);
+    FV_LAUNCH_CHECK(ctx);
+    if (l == 0)
+        FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+    else
+        FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
+    hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma)
+{
+    FV_TRY(fv_amg_prepare(p, sigma));
+    p->amg->fold = false;
+    return amg_cycle(p, 0, r, z, sigma);
+}
+
+// ------------------------------------------------------------------ PCG driven by the V-cycle
+// The set-up (r0, ||rhs||^2, ||r0||^2, tol2, done) has been left in the workspace by fv_pcg_solve's own set-up path.
+__global__ __launch_bounds__(FV_BLOCK) void amg_dot_kernel(int64_t n, const double *__restrict__ a, const double *__restrict__ b,
+                                                            double *__restrict__ part)
+{
+    __shared__ double smem[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        acc += a[i] * b[i];
+    const double t = block_sum(acc, smem);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = t;
+}
+
+// first direction: rz0 = r.z, p = z
+__global__ __launch_bounds__(FV_BLOCK) void amg_pcg_start_kernel(int64_t n, const double *__restrict__ z, double *__restrict__ pv,
+                                                                  const double *__restrict__ part_rz, int nparts, PcgScalars *__restrict__ scal)
+{
+    __shared__ double smem[4];
+    const double rz = reduce_partials(part_rz, nparts, smem);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        pv[i] = z[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scal->rz[0] = rz;
+        scal->iters = 0;
+    }
+}
+
+// x += alpha p ; r -= alpha q ; partial r.r
+__global__ __launch_bounds__(FV_BLOCK) void amg_pcg_update_kernel(int64_t n, int it, double *__restrict__ x, double *__restrict__ r,
+                                                                   const double *__restrict__ pv, const double *__restrict__ q,
+                                                                   const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
+                                                                   double *__restrict__ part_rr)
+{
+    __shared__ double smem[4];
+    const double pq = reduce_partials(part_pq, npq, smem);
+    if (!(pq > 0.0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->pq = pq;
+            scal->done = 2;
+        }
+        return;
+    }
+    const double alpha = scal->rz[it & 1] / pq;
+    double arr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
+        const double ri = r[i] - alpha * q[i];
+        x[i] += alpha * pv[i];
+        r[i] = ri;
+        arr += ri * ri;
+    }
+    const double t = block_sum(arr, smem);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = t;
+        if (blockIdx.x == 0)
+            scal->pq = pq;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_pcg_check_kernel(int it, const double *__restrict__ part_rr, int nparts, PcgScalars *__restrict__ scal,
+                                                                  double *__restrict__ hist, int64_t hist_cap)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    const double rr = reduce_partials(part_rr, nparts, smem);
+    if (threadIdx.x == 0) {
+        scal->rr = rr;
+        scal->iters = it + 1;
+        if (hist && it < hist_cap)
+            hist[it] = sqrt(rr);
+        if (rr <= scal->tol2)
+            scal->done = 1;
+    }
+}
+
+// beta = r.z / (r.z)_old ; p = z + beta p
+__global__ __launch_bounds__(FV_BLOCK) void amg_pcg_direction_kernel(int64_t n, int it, const double *__restrict__ z, double *__restrict__ pv,
+                                                                      const double *__restrict__ part_rz, int nparts,
+                                                                      PcgScalars *__restrict__ scal)
+{
+    __shared__ double smem[4];
+    const double rzn = reduce_partials(part_rz, nparts, smem);
+    const double beta = rzn / scal->rz[it & 1];
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        pv[i] = z[i] + beta * pv[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        scal->rz[(it + 1) & 1] = rzn;
+}
+
+int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t maxiter, PcgScalars *hs)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t n = p->n;
+    const int Gv = vec_grid(n);
+    FV_TRY(fv_amg_prepare(p, sigma));
+    fv_amg *a = p->amg;
+    a->fold = fold;
+    FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hs->done || maxiter <= 0)
+        return FV_OK;
+    FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma));
+    hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p, p->part_rz.p);
+    hipLaunchKernelGGL(amg_pcg_start_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)a->z.p, p->pvec.p,
+                       (const double *)p->part_rz.p, Gv, p->scal.p);
+    FV_LAUNCH_CHECK(ctx);
+    for (int64_t it = 0; it < maxiter; it++) {
+        int npq = 0;
+        FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, fold, &npq));
+        hipLaunchKernelGGL(amg_pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, x, p->r.p, (const double *)p->pvec.p,
+                           (const double *)p->q.p, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rr.p);
+        hipLaunchKernelGGL(amg_pcg_check_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (int)it, (const double *)p->part_rr.p, Gv, p->scal.p,
+                           p->hist.p, p->hist_cap);
+        FV_LAUNCH_CHECK(ctx);
+        FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hs->done)
+            break;
+        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma));
+        hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p,
+                           p->part_rz.p);
+        hipLaunchKernelGGL(amg_pcg_direction_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, (const double *)a->z.p, p->pvec.p,
+                           (const double *)p->part_rz.p, Gv, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" int fv_precond_set(fv_problem *p, int kind)
+{
+    if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG))
+        return FV_ERR_ARG;
+    if (kind == FV_PRECOND_AMG && (p->dist || p->nhalo)) {
+        fv_set_error(p->ctx, "the AMG preconditioner is not available for row blocks of a distributed operator");
+        return FV_ERR_STATE;
+    }
+    p->precond = kind;
+    return FV_OK;
+}
+
+extern "C" int fv_amg_info(fv_problem *p, int32_t *nlevels, int64_t *rows, int64_t *nnz, int32_t cap)
+{
+    if (!p || !nlevels)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p->assembled) {
+        fv_set_error(ctx, "fv_amg_info: call fv_assemble first");
+        return FV_ERR_STATE;
+    }
+    FV_TRY(fv_pcg_prepare(p));
+    FV_TRY(fv_amg_prepare(p, 0.0));
+    *nlevels = (int32_t)p->amg->lev.size();
+    for (int32_t l = 0; l < *nlevels && l < cap; l++) {
+        if (rows)
+            rows[l] = p->amg->lev[(size_t)l]->n;
+        if (nnz)
+            nnz[l] = p->amg->lev[(size_t)l]->nnz;
+    }
+    return FV_OK;
+}
+
+// z = M^-1 r on host vectors (tests: symmetry and definiteness of the preconditioner)
+extern "C" int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_free)
+{
+    if (!p || !r_free || !z_free)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!p->assembled) {
+        fv_set_error(ctx, "fv_amg_apply: call fv_assemble first");
+        return FV_ERR_STATE;
+    }
+    FV_TRY(fv_pcg_prepare(p));
+    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, r_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_amg_apply_device(p, p->tmp.p, p->rhs.p, sigma));
+    return fv_copy(ctx, z_free, p->rhs.p, (size_t)p->n * sizeof(double));
+}

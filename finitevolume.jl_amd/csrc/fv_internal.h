@@ -119,6 +119,9 @@ struct fv_dist {
     bool split_built = false;
 };
 
+struct fv_amg; // fv_amg.hip
+void fv_amg_free(fv_amg *a);
+
 struct fv_problem {
     fv_ctx *ctx = nullptr;
     int64_t N = 0, F = 0, n = 0, nnz = 0, ndir = 0, E = 0;
@@ -170,7 +173,12 @@ struct fv_problem {
     DevBuf<double> D; // Ss * volumes[free]
     std::vector<double *> slots;
     std::vector<char> slot_used;
+    int64_t storage_epoch = 0;  // bumped by fv_transient_begin (D changed)
     int32_t pingpong_slot = -1; // hidden state vector the fixed-dt run alternates with the caller's slot
+
+    // preconditioner of the PCG: FV_PRECOND_JACOBI (fused into the vector kernels) or FV_PRECOND_AMG (fv_amg.hip)
+    int precond = 0;
+    fv_amg *amg = nullptr;
 
     // PCG workspace
     DevBuf<double> r, pvec, q, minv, rhs, tmp;
@@ -195,6 +203,7 @@ struct fv_problem {
         for (hipEvent_t e : prof_ev)
             (void)hipEventDestroy(e);
         delete dist;
+        fv_amg_free(amg);
     }
 };
 
@@ -241,10 +250,17 @@ struct PcgSystem {
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
-int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false);
+int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
+                   int *npartials = nullptr);
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);
 int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double *out_host);
+
+// ---- fv_amg.hip
+int fv_amg_prepare(fv_problem *p, double sigma);
+int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma);
+// runs the V-cycle-preconditioned CG from the set-up left in the workspace (r, scal); x is updated in place
+int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t maxiter, PcgScalars *hs);
 
 // ---- fv_comm.hip (RCCL); all are no-ops for a single rank
 int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream);

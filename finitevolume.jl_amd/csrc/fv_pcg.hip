@@ -18,35 +18,7 @@
 // atomics), and a device-side `done` flag turns surplus launches into no-ops, so
 // the host polls convergence only once per chunk of iterations.
 #include "fv_internal.h"
-
-// ------------------------------------------------------------------ reductions
-__device__ inline double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-        v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// all threads of the 256-thread block get the sum; smem: 4 doubles
-__device__ inline double block_sum(double v, double *smem)
-{
-    v = wave_sum(v);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads(); // smem may still be read by a previous call
-    if (lane == 0)
-        smem[wave] = v;
-    __syncthreads();
-    return (smem[0] + smem[1]) + (smem[2] + smem[3]);
-}
-
-__device__ inline double reduce_partials(const double *__restrict__ part, int count, double *smem)
-{
-    double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += FV_BLOCK)
-        v += part[i];
-    return block_sum(v, smem);
-}
+#include "fv_device.h"
 
 // ------------------------------------------------------------------ SpMV
 // LPR lanes cooperate on one row (8 for the 7-point stencil: a wave64 covers 8
@@ -921,16 +893,15 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
 
 static int ensure_folded(fv_problem *p, double sigma, const double **out);
 
-int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold)
+int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold, int *npartials)
 {
     const double *folded = nullptr;
     if (fold && sigma != 0.0)
         FV_TRY(ensure_folded(p, sigma, &folded));
-    return spmv_apply(p, x, y, folded ? 0.0 : sigma, folded, partials_or_null ? SPMV_DOT : SPMV_PLAIN, partials_or_null, nullptr, false, nullptr);
+    return spmv_apply(p, x, y, folded ? 0.0 : sigma, folded, partials_or_null ? SPMV_DOT : SPMV_PLAIN, partials_or_null, nullptr, false, npartials);
 }
 
 // ------------------------------------------------------------------ PCG vector kernels
-__device__ inline int64_t vec_stride() { return (int64_t)gridDim.x * FV_BLOCK; }
 
 // r = rhs - q with q = (A + sigma D) x0 (absent when x0 = 0), for an explicit
 // right-hand side; or, for an implicit time step from the state x0 itself,
@@ -1161,15 +1132,6 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     }
 }
 
-static int vec_grid(int64_t n)
-{
-    int64_t g = (n / 2 + FV_BLOCK - 1) / FV_BLOCK;
-    if (g < 1)
-        g = 1;
-    if (g > FV_MAX_PARTIALS)
-        g = FV_MAX_PARTIALS;
-    return (int)g;
-}
 
 int fv_pcg_prepare(fv_problem *p)
 {
@@ -1322,13 +1284,22 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
     constexpr int64_t MAX_CHUNK = 32;
+    bool polled = false;
+    if (p->precond == FV_PRECOND_AMG) {
+        if (sys.x_next) {
+            fv_set_error(ctx, "fv_pcg_solve: the ping-pong state is a Jacobi-path feature");
+            return FV_ERR_STATE;
+        }
+        FV_TRY(fv_amg_pcg_loop(p, x, sigma, folded != nullptr, maxiter, hs));
+        polled = true;
+        maxiter = 0; // skip the Jacobi loop below
+    }
     // Launches past convergence are no-ops (the done flag), but they still cost a few microseconds each and
     // show up as zero-work kernels in traces, so the first chunk is sized by the previous solve on this
     // problem (consecutive time steps need about the same number of iterations) and later chunks double.
     int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
     if (chunk > MAX_CHUNK)
         chunk = MAX_CHUNK;
-    bool polled = false;
     if (p->profile && p->prof_ev.empty()) {
         p->prof_ev.resize((size_t)(6 * MAX_CHUNK));
         for (hipEvent_t &e : p->prof_ev)

@@ -123,6 +123,7 @@ extern "C" int fv_transient_begin(fv_problem *p, double Ss, const double *volume
     FV_TRY(p->D.alloc(ctx, (size_t)p->n + 2));
     p->Ss = Ss;
     p->minv_valid = false; // D changes: cached Jacobi diagonal and folded values are stale
+    p->storage_epoch++;    // ... and so is the aggregated storage term of an AMG hierarchy
     p->shifted_epoch = -1;
     DevBuf<double> dvol;
     const double *vol = nullptr;
@@ -356,7 +357,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     // readable at no extra traffic; every g_carry_refresh steps the residual is recomputed from scratch (b' - A u), which
     // bounds the drift between the carried recurrence residual and the true one.
     const int64_t refresh = g_carry_refresh;
-    const bool pingpong = refresh > 0 && nsteps >= 2;
+    const bool pingpong = refresh > 0 && nsteps >= 2 && p->precond == FV_PRECOND_JACOBI;
     double *alt = nullptr;
     if (pingpong) {
         if (p->pingpong_slot < 0)

@@ -179,6 +179,24 @@ int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms);
 int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *out);
 /* Time every PCG kernel launch with HIP event pairs on the launch stream (for the
  * roofline figures of bench.py).  kernel: 0 = SpMV+dot, 1 = x/r update, 2 = p update. */
+/* ---------------------------------------------------------------- preconditioner of the PCG
+ * FV_PRECOND_JACOBI (default): diagonal scaling fused into the PCG's vector kernels.
+ * FV_PRECOND_AMG: one V(1,1) cycle of an aggregation-based algebraic multigrid per iteration — the role
+ * AlgebraicMultigrid.ruge_stuben + aspreconditioner play at FiniteVolume.jl:159-161 (solvediffusion).  The hierarchy
+ * is built on the device at the first solve after fv_assemble (and again after the next fv_assemble /
+ * fv_transient_begin); it carries the storage term, so shifted solves (implicit steps) can use it as well.
+ * Not available for row blocks of a distributed run. */
+#define FV_PRECOND_JACOBI 0
+#define FV_PRECOND_AMG 1
+int fv_precond_set(fv_problem *p, int kind);
+/* theta: strength threshold of the matching (0.25); omega: Jacobi damping of the smoother (2/3); passes: pairwise
+ * passes per level (3 -> aggregates of ~8-10); rounds: handshake rounds per pass (6).  Process-wide. */
+int fv_amg_configure(double theta, double omega, int passes, int rounds);
+/* Builds the hierarchy if needed; rows[l], nnz[l] for l < min(*nlevels, cap). */
+int fv_amg_info(fv_problem *p, int32_t *nlevels, int64_t *rows, int64_t *nnz, int32_t cap);
+/* z = M^-1 r: one cycle on host vectors over the free cells (tests: symmetry, definiteness). */
+int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_free);
+
 /* Process-wide kernel selection for A/B measurements (defaults in brackets).
  *   0: CSR SpMV form, 2 = wave-private CSR-stream [2], 1 = lanes-per-row;  1: unroll of the lanes-per-row form (2, 4, 8)
  *   2: plane-blocked group order [1];  3: fold sigma*D into a diagonal copy for fixed-dt runs [1]

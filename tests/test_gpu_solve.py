@@ -562,3 +562,84 @@ def test_run_fixed_at_steady_state_takes_zero_iterations(fv):
     iters, info, _ = p.run_fixed(st, 10.0, 6, rtol=1e-10)
     assert (iters == 0).all() and info.converged
     assert np.array_equal(st.node_values(), np.full(N, 2.5))
+
+
+# ------------------------------------------------------------------ aggregation-AMG preconditioner
+def _aniso_box(fv, ns, sigma=3.0):
+    """the box_model geometry (100 x 100 x 10 m: flat cells, z couplings ~100x the lateral ones) with a smooth log-K field"""
+    from tests import workloads
+
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    coords, nb, aol, vol = fv.regulargrid(mins, maxs, list(ns))
+    logk = np.log(1e-5) + sigma * workloads.smooth_gaussian_field(ns, seed=0, radius_cells=(4, 4, 4))
+    K = fv.nodehycos2neighborhycos(nb, logk, True)
+    dn, dh = workloads.box_model_dirichlet(ns)
+    return nb, aol, vol, K, dn, dh
+
+
+def test_amg_preconditioned_solve_matches_direct_and_beats_jacobi(fv, oracle):
+    ns = (24, 22, 20)
+    nb, aol, vol, K, dn, dh = _aniso_box(fv, ns)
+    N = len(vol)
+    src = np.zeros(N)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh, None, True)
+    head_j, res_j, ch_j = p.solve_steady(None, 1e-10, 20000)
+    p.set_preconditioner("amg")
+    rows, nnz = p.amg_info()
+    assert rows[0] == p.n and nnz[0] == p.nnz and len(rows) >= 2
+    assert (np.diff(rows) < 0).all() and rows[-1] <= 2048
+    head_a, res_a, ch_a = p.solve_steady(None, 1e-10, 400)
+    assert ch_j.isconverged and ch_a.isconverged
+    assert ch_a.iters * 5 < ch_j.iters, (ch_a.iters, ch_j.iters)
+    ohead = oracle.solvediffusion(nb[:, 0], nb[:, 1], aol, np.exp(K), src, dn, dh, solver="direct")[0]
+    assert relerr(head_a, ohead) < HEAD_RTOL and relerr(head_j, ohead) < HEAD_RTOL
+    hist = ch_a.data["resnorm"]
+    assert len(hist) == ch_a.iters and hist[-1] <= 1e-10 * np.linalg.norm(p.b()) * 1.0000001
+    # bit-reproducible: no floating-point atomics in the set-up or the cycle
+    p2 = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh, None, True).set_preconditioner("amg")
+    head_b, res_b, ch_b = p2.solve_steady(None, 1e-10, 400)
+    assert np.array_equal(res_a, res_b) and np.array_equal(hist, ch_b.data["resnorm"])
+    # the public wrapper
+    head_w, ch_w, *_ = fv.solvediffusion(nb, aol, np.exp(K), src, dn, dh, maxiter=400, rtol=1e-10, preconditioner="amg")
+    assert ch_w.isconverged and relerr(head_w, ohead) < HEAD_RTOL
+
+
+def test_amg_cycle_is_symmetric_positive_definite(fv):
+    ns = (20, 12, 9)
+    nb, aol, vol, K, dn, dh = _aniso_box(fv, ns, sigma=2.0)
+    N = len(vol)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, np.zeros(N), dh, None, True)
+    p.transient_begin(0.1, vol, np.zeros(N))
+    rng = np.random.default_rng(5)
+    for sigma in (0.0, 1e-3):
+        x, y = rng.standard_normal(p.n), rng.standard_normal(p.n)
+        Mx, My = p.amg_apply(x, sigma), p.amg_apply(y, sigma)
+        assert abs(y @ Mx - x @ My) <= 1e-12 * (np.linalg.norm(x) * np.linalg.norm(My))
+        assert x @ Mx > 0 and y @ My > 0
+
+
+def test_amg_tiny_problem_uses_the_exact_inverse(fv, oracle):
+    """n <= 1024: the whole 'hierarchy' is the dense inverse, PCG converges in one iteration"""
+    c = refcases.chain4()
+    p = fv.Problem.create(np.stack([c["node1"], c["node2"]], 1), c["aol"], 4, c["dnodes"]).assemble(c["K"], c["sources"], c["dheads"])
+    p.set_preconditioner("amg")
+    head, res, ch = p.solve_steady(None, 1e-12, 10)
+    assert ch.isconverged and ch.iters <= 2
+    assert np.allclose(head, [1, 2 / 3, 1 / 3, 0], atol=1e-14)
+
+
+def test_amg_in_implicit_steps_matches_jacobi_steps(fv):
+    """the hierarchy carries the storage term (P^T D P is diagonal): large-dt implicit steps through run_fixed"""
+    ns = (18, 16, 12)
+    nb, aol, vol, K, dn, dh = _aniso_box(fv, ns, sigma=2.0)
+    N = len(vol)
+    src = np.zeros(N)
+    out = {}
+    for kind in ("jacobi", "amg"):
+        p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh, None, True).set_preconditioner(kind)
+        st = p.transient_begin(0.1, vol, np.zeros(N))
+        iters, info, _ = p.run_fixed(st, 3.0e4, 6, rtol=1e-12, maxiter=20000)
+        assert info.converged
+        out[kind] = (st.node_values(), iters)
+    assert relerr(out["amg"][0], out["jacobi"][0]) < 1e-9
+    assert out["amg"][1].sum() * 3 < out["jacobi"][1].sum()
