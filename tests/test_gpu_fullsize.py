@@ -63,6 +63,17 @@ def test_box_model_256_cubed_steady(fv):
     assert head.min() >= -1e-6 and head.max() <= 1 + 1e-6  # maximum principle (ex_piml_data.jl:49-51)
     r = p.spmv(res) - p.b()
     assert np.linalg.norm(r) / np.linalg.norm(p.b()) < 1e-7
+    # the aggregation-AMG V-cycle in the preconditioner's seat (the reference: Ruge-Stuben AMG) converges inside the
+    # reference's maxiter = 400 and lands on the same heads
+    p.set_preconditioner("amg")
+    rows, nnz = p.amg_info()
+    assert rows[0] == p.n and rows[-1] <= 2048 and nnz.sum() < 1.5 * nnz[0]
+    head_a, res_a, ch_a = p.solve_steady(None, 1e-8, 400, want_resnorm=False)
+    print("box_model 256^3 sigma=3: AMG-PCG iterations to rtol 1e-8:", ch_a.iters, "converged", ch_a.isconverged, "ms", ch_a.solve_ms, "levels", rows.tolist())
+    assert ch_a.isconverged and ch_a.iters < 400
+    ra = p.spmv(res_a) - p.b()
+    assert np.linalg.norm(ra) / np.linalg.norm(p.b()) < 1e-7
+    assert np.abs(head_a - head).max() < 1e-5  # both are rtol 1e-8 solves of a system with condition ~1e9
 
 
 def test_watertable_like_216_cubed_transient(fv):
@@ -111,6 +122,17 @@ def test_fractures_like_5M_irregular_csr(fv):
     assert head.min() >= 1e6 - 1e-3 and head.max() <= 2e6 + 1e-3
     r = p.spmv(res) - p.b()
     assert np.linalg.norm(r) / np.linalg.norm(p.b()) < 1e-9
+    print("fractures-like 5M: Jacobi-PCG iterations to rtol 1e-10:", ch.iters, "ms", ch.solve_ms)
+    # the same solve with the AMG V-cycle (irregular rows, aol spread over four decades)
+    p.set_preconditioner("amg")
+    rows, nnz = p.amg_info()
+    head_a, res_a, ch_a = p.solve_steady(None, 1e-10, 400, want_resnorm=False)
+    print("fractures-like 5M: AMG-PCG iterations:", ch_a.iters, "converged", ch_a.isconverged, "ms", ch_a.solve_ms, "levels", rows.tolist(), "nnz", nnz.tolist())
+    assert ch_a.isconverged and ch_a.iters < ch.iters
+    ra = p.spmv(res_a) - p.b()
+    assert np.linalg.norm(ra) / np.linalg.norm(p.b()) < 1e-9
+    assert np.abs(head_a - head).max() < 1e-6 * 2e6  # two rtol 1e-10 solves of an ill-conditioned system (measured: 1.6e-7 relative)
+    p.set_preconditioner("jacobi")
     # transient relaxation from a flat state towards that steady state
     st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
     it, info, ms = p.run_fixed(st, 1e-3, 20, 1e-10)
