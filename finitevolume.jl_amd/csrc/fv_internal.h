@@ -182,6 +182,8 @@ struct fv_problem {
 
     // PCG workspace
     DevBuf<double> r, pvec, q, minv, rhs, tmp;
+    DevBuf<double> pnext;    // p' of a speculatively prepared next step (swapped with pvec when used)
+    bool spec_valid = false; // r, pnext and the upper halves of part_rz/rr/bb hold the next step's set-up
     DevBuf<double> part_pq, part_rz, part_rr, part_bb;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
@@ -246,6 +248,9 @@ struct PcgSystem {
     //     r0 = rhs_new - (A + sigma D) x = r + sigma D (x - carry_prev)
     // and the step needs no SpMV for its initial residual.
     const double *carry_prev = nullptr;
+    // speculate: the first K2 of this step may also prepare the next step's set-up (pcg_update_spec_kernel) when the
+    // previous solve took one iteration; use_spec: start from such a prepared set-up if the previous solve left one.
+    bool speculate = false, use_spec = false;
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);

@@ -278,7 +278,7 @@ static int g_nt = 1;
 static int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 static int g_use_dia = 1;
 int g_fold_shift = 1;
-extern int g_carry_refresh; // fv_transient.hip
+extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -298,6 +298,8 @@ extern "C" int fv_tune(int key, int value)
         g_use_dia = value;
     else if (key == 7 && value >= 0)
         g_carry_refresh = value;
+    else if (key == 8 && (value == 0 || value == 1))
+        g_carry_speculate = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -1092,12 +1094,104 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it,
     }
 }
 
-// K3
-__global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it, const double *__restrict__ r,
-                                                                const double *__restrict__ minv, double *__restrict__ pv,
-                                                                const double *__restrict__ part_rz, const double *__restrict__ part_rr,
-                                                                int nparts, PcgScalars *__restrict__ scal, double *__restrict__ hist,
-                                                                int64_t hist_cap)
+// K2S — the first K2 of a fixed-dt step that is expected to converge in this iteration (the previous step did):
+// besides alpha, x_out = x_in + alpha p, r -= alpha q and the partials of the convergence test, it prepares the NEXT
+// step the way pcg_carry_init_kernel would: r0' = r + D (x_out - x_in)/dt is what it leaves in r, p' = M^-1 r0' goes to
+// pnext, and the partials of r0'.M^-1 r0', r0'.r0', rhs'.rhs' (rhs' = b' + D x_out/dt) to the spec_* arrays.  If the
+// step does converge here, the next step starts straight at its K1 (80 B/row instead of 56 + 64).  If it does not,
+// pcg_pupdate_kernel<true> takes the D (x_out - x_in)/dt term out of r again before it builds the next direction.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, const double *__restrict__ xin, double *__restrict__ xout,
+                                                                    double *__restrict__ r, const double *__restrict__ pv,
+                                                                    const double *__restrict__ q, const double *__restrict__ minv,
+                                                                    const double *__restrict__ D, const double *__restrict__ bprime, double dt,
+                                                                    const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
+                                                                    double *__restrict__ part_rz, double *__restrict__ part_rr,
+                                                                    double *__restrict__ pnext, double *__restrict__ spec_rz,
+                                                                    double *__restrict__ spec_rr, double *__restrict__ spec_bb)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    const double pq = reduce_partials(part_pq, npq, smem);
+    if (!(pq > 0.0)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->pq = pq;
+            scal->done = 2;
+        }
+        return;
+    }
+    const double alpha = scal->rz[0] / pq;
+    double arz = 0.0, arr = 0.0, srz = 0.0, srr = 0.0, sbb = 0.0;
+    const int64_t n2 = n >> 1;
+    const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
+    double2 *xo2 = reinterpret_cast<double2 *>(xout);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(pv);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    const double2 *m2 = reinterpret_cast<const double2 *>(minv);
+    const double2 *D2 = reinterpret_cast<const double2 *>(D);
+    const double2 *b2 = reinterpret_cast<const double2 *>(bprime);
+    double2 *pn2 = reinterpret_cast<double2 *>(pnext);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        const double2 xv = xi2[i], pvv = p2[i], qv = q2[i], mv = m2[i], dv = D2[i];
+        const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
+        double2 rv = r2[i];
+        const double xnx = xv.x + alpha * pvv.x, xny = xv.y + alpha * pvv.y;
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        arz += rv.x * (mv.x * rv.x) + rv.y * (mv.y * rv.y);
+        arr += rv.x * rv.x + rv.y * rv.y;
+        // the next step's set-up, on the increment as stored (x_out - x_in after rounding, like K0')
+        const double cx = rv.x + dv.x * ((xnx - xv.x) / dt), cy = rv.y + dv.y * ((xny - xv.y) / dt);
+        const double hx = bv.x + dv.x * (xnx / dt), hy = bv.y + dv.y * (xny / dt);
+        const double zx = mv.x * cx, zy = mv.y * cy;
+        xo2[i] = make_double2(xnx, xny);
+        r2[i] = make_double2(cx, cy);
+        pn2[i] = make_double2(zx, zy);
+        srz += cx * zx + cy * zy;
+        srr += cx * cx + cy * cy;
+        sbb += hx * hx + hy * hy;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double xn = xin[i] + alpha * pv[i];
+        const double ri = r[i] - alpha * q[i];
+        arz += ri * (minv[i] * ri);
+        arr += ri * ri;
+        const double c = ri + D[i] * ((xn - xin[i]) / dt);
+        const double h = (bprime ? bprime[i] : 0.0) + D[i] * (xn / dt);
+        const double z = minv[i] * c;
+        xout[i] = xn;
+        r[i] = c;
+        pnext[i] = z;
+        srz += c * z;
+        srr += c * c;
+        sbb += h * h;
+    }
+    const double t0 = block_sum(arz, smem);
+    const double t1 = block_sum(arr, smem);
+    const double t2 = block_sum(srz, smem);
+    const double t3 = block_sum(srr, smem);
+    const double t4 = block_sum(sbb, smem);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+        spec_rz[blockIdx.x] = t2;
+        spec_rr[blockIdx.x] = t3;
+        spec_bb[blockIdx.x] = t4;
+        if (blockIdx.x == 0)
+            scal->pq = pq;
+    }
+}
+
+// K3.  UNSPEC: the K2 before it was pcg_update_spec_kernel and the step did not converge there: r carries the next
+// step's D (x_out - x_in)/dt term, which is taken out again here (same expression, same operands).
+template <bool UNSPEC>
+__global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it, double *__restrict__ r, const double *__restrict__ minv,
+                                                                double *__restrict__ pv, const double *__restrict__ part_rz,
+                                                                const double *__restrict__ part_rr, int nparts, PcgScalars *__restrict__ scal,
+                                                                double *__restrict__ hist, int64_t hist_cap, const double *__restrict__ xin,
+                                                                const double *__restrict__ xout, const double *__restrict__ D, double dt)
 {
     __shared__ double smem[4];
     if (scal->done)
@@ -1107,11 +1201,21 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     const double beta = rzn / scal->rz[it & 1];
     const bool converged = rrn <= scal->tol2; // same value in every block: the search direction is not needed any more
     const int64_t n2 = converged ? 0 : (n >> 1);
-    const double2 *r2 = reinterpret_cast<const double2 *>(r);
+    double2 *r2 = reinterpret_cast<double2 *>(r);
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
     double2 *p2 = reinterpret_cast<double2 *>(pv);
+    const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
+    const double2 *xo2 = reinterpret_cast<const double2 *>(xout);
+    const double2 *D2 = reinterpret_cast<const double2 *>(D);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
-        const double2 rv = r2[i], mv = m2[i];
+        double2 rv = r2[i];
+        const double2 mv = m2[i];
+        if (UNSPEC) {
+            const double2 a = xi2[i], b = xo2[i], dv = D2[i];
+            rv.x -= dv.x * ((b.x - a.x) / dt);
+            rv.y -= dv.y * ((b.y - a.y) / dt);
+            r2[i] = rv;
+        }
         double2 pvv = p2[i];
         pvv.x = mv.x * rv.x + beta * pvv.x;
         pvv.y = mv.y * rv.y + beta * pvv.y;
@@ -1119,7 +1223,12 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     }
     if (!converged && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        pv[i] = minv[i] * r[i] + beta * pv[i];
+        double ri = r[i];
+        if (UNSPEC) {
+            ri -= D[i] * ((xout[i] - xin[i]) / dt);
+            r[i] = ri;
+        }
+        pv[i] = minv[i] * ri + beta * pv[i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         scal->rz[(it + 1) & 1] = rzn;
@@ -1131,7 +1240,6 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
             scal->done = 1;
     }
 }
-
 
 int fv_pcg_prepare(fv_problem *p)
 {
@@ -1236,7 +1344,22 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     int Ginit = Gv; // number of per-block partials the set-up produced
-    if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
+    // speculative set-up left behind by the previous step's K2S (pcg_update_spec_kernel): r, p' and the partials are ready
+    const bool use_spec = sys.use_spec && p->spec_valid && sys.implicit_step && !compute_minv;
+    p->spec_valid = false;
+    // ... and whether this step's first K2 should prepare the next step the same way
+    const bool speculate = sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
+                           p->precond == FV_PRECOND_JACOBI && p->last_iters == 1 && maxiter > 0;
+    if (speculate && !p->pnext.p)
+        FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+    const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
+    if (use_spec) {
+        std::swap(p->pvec.p, p->pnext.p);
+        std::swap(p->pvec.n, p->pnext.n);
+        in_rz += FV_MAX_PARTIALS;
+        in_rr += FV_MAX_PARTIALS;
+        in_bb += FV_MAX_PARTIALS;
+    } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
         hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
                            (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
                            p->part_bb.p);
@@ -1278,8 +1401,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, p->part_rz.p, p->part_rr.p, p->part_bb.p,
-                       Ginit, rtol, p->scal.p);
+    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p);
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
@@ -1320,7 +1442,13 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
             FV_PROF(1);
             FV_PROF(2);
-            if (iter == 0 && sys.x_next)
+            const bool spec = iter == 0 && speculate;
+            if (spec)
+                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
+                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
+                                   sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p, p->pnext.p,
+                                   p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS, p->part_bb.p + FV_MAX_PARTIALS);
+            else if (iter == 0 && sys.x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)x, sys.x_next,
                                    p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
             else
@@ -1329,8 +1457,14 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                                    p->part_rz.p, p->part_rr.p);
             FV_PROF(3);
             FV_PROF(4);
-            hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,
-                               p->part_rz.p, p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap);
+            if (spec)
+                hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
+                                   (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt);
+            else
+                hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
+                                   (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0.0);
             FV_PROF(5);
         }
         FV_LAUNCH_CHECK(ctx);
@@ -1361,6 +1495,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
+    p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
@@ -1661,8 +1796,9 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
             FV_LAUNCH_CHECK(ctx);
             FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 2, ctx->stream));
-            hipLaunchKernelGGL(pcg_pupdate_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, p->minv.p, p->pvec.p,
-                               (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0);
+            hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
+                               p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
+                               (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0.0);
             FV_LAUNCH_CHECK(ctx);
         }
         it += m;

@@ -277,10 +277,11 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
 }
 
 int g_carry_refresh = 32; // fv_tune key 7: 0 = every step computes its residual with an SpMV
+int g_carry_speculate = 1; // fv_tune key 8: the first K2 of a step also prepares the next step (pcg_update_spec_kernel)
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
                      int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
-                     const double *carry_prev = nullptr)
+                     const double *carry_prev = nullptr, bool speculate = false)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
@@ -296,6 +297,8 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.fold_shift = fold_shift;
     sys.x_next = x_next;
     sys.carry_prev = carry_prev;
+    sys.speculate = speculate;              // prepare the next step inside this step's first K2 ...
+    sys.use_spec = carry_prev != nullptr;   // ... and start from such a set-up when the residual may be carried
     if (mode == FV_STEP_FORWARD) {
         sys.rhs = bhat_dev ? bhat_dev : p->b.p;
         sys.b_times_D = bhat_dev != nullptr;
@@ -370,7 +373,8 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     const double *prev = nullptr; // state the last solve started from, while p->r holds that solve's final residual
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         const bool carry = prev != nullptr && (s % refresh) != 0;
-        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr);
+        rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,
+                       pingpong && g_carry_speculate && s + 1 < nsteps);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
         if (pingpong && rc == FV_OK) {

@@ -515,40 +515,52 @@ def test_theisadjoint_gradient_vs_finite_differences(fv):
         assert abs(x1 - dGdp[i]) <= 1e-3 * max(abs(x1), abs(dGdp[i])), (int(i), x1, dGdp[i])
 
 
-def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle):
-    """fv_transient_run_fixed: carrying the residual from step to step (fv_tune key 7, refreshed every 32 steps; here
-    also every 5) gives the heads of the run that recomputes b' - A u every step, and the oracle's (direct solves),
-    over 70 steps that cross refresh boundaries, with several PCG iterations per step."""
+@pytest.mark.parametrize("schedule", ["several_iterations", "one_iteration", "one_then_several"])
+def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle, schedule):
+    """fv_transient_run_fixed: carrying the residual from step to step (fv_tune key 7: refresh period) and preparing the
+    next step inside a one-iteration step's vector update (key 8) give the heads of the run that recomputes b' - A u
+    every step, and the oracle's (direct solves), over two calls of 30 + 40 steps that cross refresh boundaries.
+    dt = 40: several PCG iterations per step (never speculates); dt = 2^-10: one per step (the bench's regime, every step
+    speculates); 2^-10 then 40: the first step of the second call speculates and misses (pcg_pupdate_kernel<true>)."""
     coords, nb, aol, vol, K, dn, dh = _box(fv, (15, 13, 11), sigma=1.0)  # odd n: exercises the scalar tails
     N = len(vol)
     src = np.zeros(N)
     src[N // 2] = -1e-4
     u0 = np.full(N, 0.5)
-    nsteps, dt = 70, 40.0
-    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, nsteps * dt), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=dt, linearsolver=oracle.directlinearsolver)
+    dts = {"several_iterations": (40.0, 40.0), "one_iteration": (0.0009765625, 0.0009765625), "one_then_several": (0.0009765625, 40.0)}[schedule]
+    rtol = 1e-13
+    ous1, _ = oracle.backwardeulerintegrate(u0, (0.0, 30 * dts[0]), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=dts[0], linearsolver=oracle.directlinearsolver)
+    ous2, _ = oracle.backwardeulerintegrate(ous1[-1], (0.0, 40 * dts[1]), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=dts[1], linearsolver=oracle.directlinearsolver)
     lib = fv.load()
     heads, its = {}, {}
     try:
-        for refresh in (0, 32, 5):
-            assert lib.fv_tune(7, refresh) == 0
+        for refresh, spec in ((0, 0), (32, 1), (32, 0), (5, 1)):
+            assert lib.fv_tune(7, refresh) == 0 and lib.fv_tune(8, spec) == 0
             p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
             st = p.transient_begin(0.1, vol, u0)
-            a, info, _ = p.run_fixed(st, dt, 30, rtol=1e-13)  # two calls: the second starts from a fresh residual again
-            b, info, _ = p.run_fixed(st, dt, nsteps - 30, rtol=1e-13)
-            assert info.converged
-            heads[refresh], its[refresh] = st.node_values(), np.r_[a, b]
+            a, info, _ = p.run_fixed(st, dts[0], 30, rtol=rtol)
+            assert info.converged and relerr(st.node_values(), ous1[-1]) < HEAD_RTOL
+            b, info, _ = p.run_fixed(st, dts[1], 40, rtol=rtol)  # the second call starts from a fresh residual again
+            assert info.converged and relerr(st.node_values(), ous2[-1]) < HEAD_RTOL
+            heads[(refresh, spec)], its[(refresh, spec)] = st.node_values(), np.r_[a, b]
             # another state of the same problem is not disturbed by the hidden ping-pong vector
             st2 = p.new_state()
             st2.set_nodes(u0)
-            p.run_fixed(st2, dt, 3, rtol=1e-13)
-            assert relerr(st2.node_values(), ous[3]) < HEAD_RTOL
-            assert relerr(st.node_values(), ous[nsteps]) < HEAD_RTOL
+            p.run_fixed(st2, dts[0], 3, rtol=rtol)
+            assert relerr(st2.node_values(), ous1[3]) < HEAD_RTOL
     finally:
         lib.fv_tune(7, 32)
-    assert (its[0] > 1).all()
-    for refresh in (32, 5):
-        assert relerr(heads[refresh], heads[0]) < 1e-11
-        assert np.abs(its[refresh] - its[0]).max() <= 1
+        lib.fv_tune(8, 1)
+    base = its[(0, 0)]
+    if schedule == "several_iterations":
+        assert (base > 1).all()
+    elif schedule == "one_iteration":
+        assert (base == 1).all()
+    else:
+        assert (base[:30] == 1).all() and (base[30:] > 1).all()
+    for key in ((32, 1), (32, 0), (5, 1)):
+        assert relerr(heads[key], heads[(0, 0)]) < 1e-11
+        assert np.abs(its[key] - base).max() <= 1
 
 
 def test_run_fixed_at_steady_state_takes_zero_iterations(fv):
