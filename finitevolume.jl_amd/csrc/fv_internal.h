@@ -151,6 +151,7 @@ struct fv_problem {
     // (0 = slice stays with the CSR kernel), the lists of DIA slices / CSR groups, lane-major values
     DevBuf<uint8_t> sl_noff;
     DevBuf<int32_t> sl_off, dia_list, csr_list, dia_pos;
+    DevBuf<int32_t> dia_list_ord; // the DIA slices in traversal order (plane-blocked), when the operator has a plane stride
     DevBuf<double> dia_vals;
     int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
     double dia_tag = 0.0;

@@ -20,6 +20,8 @@
 #include "fv_internal.h"
 #include "fv_device.h"
 
+#include <cstdlib>
+
 // ------------------------------------------------------------------ SpMV
 // LPR lanes cooperate on one row (8 for the 7-point stencil: a wave64 covers 8
 // consecutive rows, whose ~56 stored entries are contiguous in vals/colind, so a
@@ -277,6 +279,8 @@ static int g_use_order = 1;
 static int g_nt = 1;
 static int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 static int g_use_dia = 1;
+static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9)
+static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 
@@ -300,6 +304,10 @@ extern "C" int fv_tune(int key, int value)
         g_carry_refresh = value;
     else if (key == 8 && (value == 0 || value == 1))
         g_carry_speculate = value;
+    else if (key == 9 && (value == 0 || value == 1))
+        g_march = value;
+    else if (key == 10 && value >= 0 && value <= 16)
+        g_march_segs = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -357,7 +365,9 @@ static int build_group_order(fv_problem *p)
     FV_TRY(fv_count_far_stride(p, stride, &agree));
     if (agree < (n - stride) * 8 / 10)
         return FV_OK;
-    constexpr int64_t BAND = 8192;
+    int64_t BAND = 8192; // rows per band: ~18 grid lines of the 464^3 box; FV_BAND overrides (experiments)
+    if (const char *e = getenv("FV_BAND"))
+        BAND = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : BAND;
     const int64_t ngroups = (n + 63) >> 6;
     std::vector<int32_t> order;
     order.reserve((size_t)ngroups);
@@ -694,11 +704,146 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
     }
 }
 
+// Sliced-DIA SpMV for operators with a plane stride (structured grids), marching along the plane direction.
+// A wave owns a "pencil": the slices s0, s0 + step, s0 + 2 step, ... with step = (stride - shift) / 64 and
+// shift = stride mod 64, i.e. the same 64 in-plane positions (moving by `shift` rows per plane) of consecutive planes.
+// Then the -plane arm of the current slice is the previous slice's centre and the +plane arm is the next slice's
+// centre, both moved by `shift` lanes: they are taken from registers (wave shuffle), only the `shift` lanes that
+// fall off the end are loaded.  Every x line is therefore fetched once for the three plane-direction uses, however
+// short-lived it is in L2 (a 4 MiB L2 turns over in ~6 us at this rate, far less than the time between planes in any
+// slice-by-slice traversal).  Work items are (pencil, segment of `seglen` plane steps); XCD k owns the segments
+// [k m, (k+1) m) and its resident waves march through neighbouring pencils of one segment together, so the in-plane
+// arms (+-1, +-line) are shared through L2 as before.
+template <bool DOT, bool NT>
+__global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int shift, int64_t stride,
+                                                                   int seglen, int segs_per_xcd, const int32_t *__restrict__ dia_pos,
+                                                                   const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+                                                                   const double *__restrict__ sval, const double *__restrict__ x,
+                                                                   double *__restrict__ y, const double *__restrict__ dshift, double sigma,
+                                                                   double *__restrict__ partials, const PcgScalars *__restrict__ scal)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double smem[4];
+    if (scal && scal->done)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t wstride = (int64_t)(gridDim.x >> 3) * WPB;    // waves of this XCD
+    const int64_t nitems = (int64_t)segs_per_xcd * step;         // (segment, pencil) pairs of this XCD
+    double dacc = 0.0;
+    for (int64_t item = (int64_t)(blockIdx.x >> 3) * WPB + wave; item < nitems; item += wstride) {
+        const int64_t seg = (int64_t)xcd * segs_per_xcd + item / step;
+        const int64_t pc = item % step;
+        int64_t sl = pc + seg * seglen * step;
+        if (sl >= nslices)
+            continue;
+        // rows and columns fit int32 (device indices are int32): keeps the address arithmetic in one register
+        const int32_t nc32 = (int32_t)ncols, st32 = (int32_t)stride;
+        double prevc = 0.0, curc, nextc;
+        {
+            const int32_t r0 = (int32_t)(sl << 6) + lane;
+            curc = r0 < nc32 ? x[r0] : 0.0;
+        }
+        bool have_prev = false;
+        // the slice's metadata is fetched one step ahead too, so that a step waits for one memory round trip
+        // (values + arms), not three (pattern -> offsets -> values)
+        int nx_noff = (int)sl_noff[sl];
+        int32_t nx_offs = (lane < DIA_K) ? sl_off[sl * DIA_K + lane] : 0;
+        int32_t nx_pos = dia_pos[sl];
+        for (int k = 0; k < seglen && sl < nslices; k++, sl += step) {
+            const int32_t row = (int32_t)(sl << 6) + lane;
+            const int64_t nsl = sl + step;
+            const bool have_next = nsl < nslices;
+            const int noff = __builtin_amdgcn_readfirstlane(nx_noff);
+            const int32_t offs = nx_offs;
+            const int64_t pos = __builtin_amdgcn_readfirstlane(nx_pos);
+            {
+                const int32_t rn = (int32_t)(nsl << 6) + lane;
+                nextc = (have_next && rn < nc32) ? x[rn] : 0.0;
+                if (have_next && k + 1 < seglen) {
+                    nx_noff = (int)sl_noff[nsl];
+                    nx_offs = (lane < DIA_K) ? sl_off[nsl * DIA_K + lane] : 0;
+                    nx_pos = dia_pos[nsl];
+                }
+            }
+            if (noff > 0) {
+                const double *sv = sval + pos * (DIA_K * 64) + lane;
+                double sum = 0.0;
+#pragma unroll
+                for (int j = 0; j < DIA_K; j++) {
+                    if (j < noff) {
+                        const int32_t off = __builtin_amdgcn_readlane(offs, j);
+                        const double v = NT ? __builtin_nontemporal_load(sv + j * 64) : sv[j * 64];
+                        double xv;
+                        if (off == 0)
+                            xv = curc;
+                        else if (off == -st32 && have_prev) {
+                            xv = __shfl(prevc, (lane - shift) & 63, 64);
+                            if (lane < shift) {
+                                int32_t c = row - st32;
+                                c = c < 0 ? 0 : c;
+                                xv = x[c];
+                            }
+                        } else if (off == st32 && have_next) {
+                            xv = __shfl(nextc, (lane + shift) & 63, 64);
+                            if (lane + shift >= 64) {
+                                int32_t c = row + st32;
+                                c = c >= nc32 ? nc32 - 1 : c;
+                                xv = x[c];
+                            }
+                        } else {
+                            int32_t c = row + off; // |off| <= stride < n/4: no overflow
+                            c = c < 0 ? 0 : (c >= nc32 ? nc32 - 1 : c);
+                            xv = x[c];
+                        }
+                        sum += v * xv;
+                    }
+                }
+                if (row < n) {
+                    if (dshift)
+                        sum += sigma * dshift[row] * curc;
+                    if (NT)
+                        __builtin_nontemporal_store(sum, y + row);
+                    else
+                        y[row] = sum;
+                    if (DOT)
+                        dacc += curc * sum;
+                }
+            }
+            prevc = curc;
+            curc = nextc;
+            have_prev = true;
+        }
+    }
+    if (DOT) {
+        const double tsum = block_sum(dacc, smem);
+        if (threadIdx.x == 0)
+            partials[blockIdx.x] = tsum;
+    }
+}
+
 __global__ __launch_bounds__(FV_BLOCK) void dia_pos_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, int32_t *__restrict__ dia_pos)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (i < ndia)
         dia_pos[dia_list[i]] = (int32_t)i;
+}
+
+// traversal order of the DIA slices: the plane-blocked group order (build_group_order) restricted to the DIA slices
+__global__ __launch_bounds__(FV_BLOCK) void dia_order_flag_kernel(int64_t ng, const int32_t *__restrict__ order, const uint8_t *__restrict__ sl_noff,
+                                                                   int32_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < ng)
+        flag[i] = sl_noff[order[i]] > 0;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void dia_order_gather_kernel(int64_t m, const int32_t *__restrict__ idx, const int32_t *__restrict__ order,
+                                                                     int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < m)
+        out[i] = order[idx[i]];
 }
 
 static int build_dia(fv_problem *p)
@@ -736,6 +881,23 @@ static int build_dia(fv_problem *p)
     hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, p->dia_list.p, p->dia_pos.p);
     FV_LAUNCH_CHECK(ctx);
     p->dia_epoch = -1;
+    if (p->group_order.p) { // walk the slices band by band, plane after plane: the +-plane x arms are then re-used while still in L2
+        DevBuf<int32_t> flag, idx;
+        FV_TRY(flag.alloc(ctx, (size_t)ns));
+        FV_TRY(idx.alloc(ctx, (size_t)ns));
+        hipLaunchKernelGGL(dia_order_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const int32_t *)p->group_order.p,
+                           (const uint8_t *)p->sl_noff.p, flag.p);
+        FV_LAUNCH_CHECK(ctx);
+        int64_t cnt = 0;
+        FV_TRY(fv_compact_flags(ctx, flag.p, ns, idx.p, &cnt));
+        if (cnt == p->ndia) {
+            FV_TRY(p->dia_list_ord.alloc(ctx, (size_t)cnt));
+            hipLaunchKernelGGL(dia_order_gather_kernel, dim3(fv_blocks(cnt)), dim3(FV_BLOCK), 0, ctx->stream, cnt, (const int32_t *)idx.p,
+                               (const int32_t *)p->group_order.p, p->dia_list_ord.p);
+            FV_LAUNCH_CHECK(ctx);
+            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
     return FV_OK;
 }
 
@@ -847,7 +1009,7 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
     }
     if (g_use_dia && p->ndia > 0) {
         FV_TRY(ensure_dia_vals(p, vals, vals_override ? p->shifted_sigma : 0.0));
-        const int32_t *dlist = subset ? subset->dia : p->dia_list.p;
+        const int32_t *dlist = subset ? subset->dia : ((g_use_order && p->dia_list_ord.p) ? p->dia_list_ord.p : p->dia_list.p);
         const int64_t dcount = subset ? subset->ndia : p->ndia;
         const int32_t *clist = subset ? subset->csr : p->csr_list.p;
         const int64_t ccount = subset ? subset->ncsr : p->ncsr_groups;
@@ -855,7 +1017,59 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
 #define FV_DIA(D_, N_, I_)                                                                                                        \
     hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, dcount, dlist, p->dia_pos.p, p->sl_noff.p, \
                        p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, partials, scal, epi)
-        if (dcount > 0) {
+        // structured grids: plane-marching form over the whole DIA part (not for subsets or the fused set-up)
+        const bool march = g_march && !subset && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0;
+        int GM = 0;
+        if (march) {
+            const int64_t ns = (p->n + 63) >> 6;
+            const int sh = (int)(p->order_stride % 64);
+            const int64_t step = (p->order_stride - sh) / 64;
+            const int64_t nk = (ns + step - 1) / step;                     // plane steps of the longest pencil
+            // m segments per XCD: a static partition pays for a partly filled last round of the XCD's resident waves, short
+            // segments pay for their start-up loads: the smallest m whose m * step (pencil, segment) items fill >= 95 % of
+            // whole rounds, else the best filling one
+            int segs_per_xcd = g_march_segs;
+            if (segs_per_xcd <= 0) {
+                double best = 0.0;
+                for (int m = 1; m <= 8; m++) {
+                    const int64_t items = (int64_t)m * step;
+                    int64_t gg = ((items + 3) / 4) * 8;
+                    if (gg > FV_MAX_PARTIALS)
+                        gg = FV_MAX_PARTIALS;
+                    const int64_t waves = gg / 8 * 4;
+                    const double eff = (double)items / (double)(((items + waves - 1) / waves) * waves);
+                    if (eff > best) {
+                        best = eff;
+                        segs_per_xcd = m;
+                    }
+                    if (eff >= 0.95)
+                        break;
+                }
+            }
+            const int seglen = (int)((nk + 8 * segs_per_xcd - 1) / (8 * segs_per_xcd));
+            const int64_t per_xcd = (int64_t)segs_per_xcd * step;
+            int64_t g = ((per_xcd + 3) / 4) * 8;
+            if (g > FV_MAX_PARTIALS)
+                g = FV_MAX_PARTIALS;
+            GM = (int)g;
+#define FV_MARCH(D_, N_)                                                                                                                      \
+    hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
+                       seglen, segs_per_xcd, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
+                       (const double *)p->dia_vals.p, x, y, shift, sigma, partials, scal)
+            if (mode == SPMV_DOT) {
+                if (g_nt)
+                    FV_MARCH(true, true);
+                else
+                    FV_MARCH(true, false);
+            } else {
+                if (g_nt)
+                    FV_MARCH(false, true);
+                else
+                    FV_MARCH(false, false);
+            }
+#undef FV_MARCH
+        }
+        if (dcount > 0 && !march) {
         if (mode == SPMV_INIT) {
             if (g_nt)
                 FV_DIA(false, true, true);
@@ -875,14 +1089,15 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
         }
 #undef FV_DIA
         FV_LAUNCH_CHECK(ctx);
+        const int GD = march ? GM : GA; // partials written by the DIA part
         int GB = 0;
         if (ccount > 0) {
             GB = stream_grid(ccount);
-            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GA : nullptr, scal, clist, ccount,
-                                  offset_epilogue(epi, GA)));
+            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GD : nullptr, scal, clist, ccount,
+                                  offset_epilogue(epi, GD)));
         }
         if (nparts)
-            *nparts = GA + GB;
+            *nparts = GD + GB;
         return FV_OK;
     }
     const int G = stream_grid(ngroups);

@@ -156,3 +156,51 @@ def test_synthetic_464_cubed_operator_identities(fv):
     ax, ay = p.spmv(x), p.spmv(y)
     assert np.linalg.norm(p.spmv(2.0 * x - 3.0 * y) - (2.0 * ax - 3.0 * ay)) / np.linalg.norm(ax) < 1e-13  # linearity
     assert abs(float(y @ ax) - float(x @ ay)) / (np.linalg.norm(x) * np.linalg.norm(ay)) < 1e-13  # symmetry
+
+
+def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
+    """>= 2^20 unknowns with a plane stride: the plane-marching sliced-DIA kernel (default), the slice-by-slice DIA
+    kernel and the CSR wave-stream form against a float64 CSR product on the host; the p.q epilogue against numpy."""
+    import scipy.sparse as sp
+
+    ns = [120, 100, 100]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    assert p.n >= 1 << 20
+    A = p.csc()
+    As = sp.csc_matrix((A.nzval, A.rowval - 1, A.colptr - 1), shape=(p.n, p.n)).tocsr()
+    _, _, _, vol = fv.regulargrid(mins, maxs, ns)
+    freenode, _ = p.free_maps()
+    D = 0.1 * vol[freenode]
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(p.n)
+    sigma = 1.0 / 60.0
+    ref = As @ x + sigma * D * x
+    scale = np.abs(ref).max()
+    lib = fv.load()
+    try:
+        for name, knobs in (("march", {9: 1, 6: 1}), ("march m=1", {9: 1, 10: 1}), ("march m=5", {9: 1, 10: 5}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
+            for k, v in knobs.items():
+                assert lib.fv_tune(k, v) == 0
+            y = p.spmv(x, sigma)
+            assert np.abs(y - ref).max() <= 1e-13 * scale, name
+            assert abs(p.dot(x, y) - x @ y) <= 1e-12 * abs(x @ y)
+            lib.fv_tune(10, 0)
+        # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
+        heads = {}
+        for name, knobs in (("march", {9: 1, 6: 1}), ("slices", {9: 0, 6: 1})):
+            for k, v in knobs.items():
+                lib.fv_tune(k, v)
+            st = p.new_state()
+            st.set_nodes(np.full(p.N, 1e3))
+            it, info, _ = p.run_fixed(st, 3600.0, 4, 1e-12)
+            assert info.converged
+            heads[name] = st.node_values()
+        assert np.abs(heads["march"] - heads["slices"]).max() <= 1e-9
+    finally:
+        lib.fv_tune(9, 1)
+        lib.fv_tune(6, 1)
+        lib.fv_tune(10, 0)

@@ -1,0 +1,20 @@
+"""time the PCG SpMV (sliced-DIA) of the bench operator for the FV_BAND given in the environment"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+import bench  # noqa: E402
+
+fv = load_package()
+ns = [int(sys.argv[1]) if len(sys.argv) > 1 else 464] * 3
+mins, maxs = bench.spacing_box(ns)
+dn, src = bench.box_setup(ns)
+p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+p.transient_begin(0.1, None, np.full(p.N, 1e3))
+t = [p.bench_spmv(1 / 60.0, 10) for _ in range(5)]
+print("FV_BAND=%s: median %.3f ms min %.3f ms" % (os.environ.get("FV_BAND", "default"), float(np.median(t)), min(t)), flush=True)

@@ -22,16 +22,21 @@ p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
 p.transient_begin(0.1, None, np.full(p.N, 1e3))
 lib = fv.load()
 bytes_ = 12 * p.nnz + 20 * p.n  # CSR accounting with the shift folded (variants that read D move 8 n more)
-# name, form, order, fold, nt, dia
-variants = [("sliced-DIA+fold+nt", 2, 1, 1, 1, 1), ("sliced-DIA+fold", 2, 1, 1, 0, 1), ("wstream+order+fold+nt", 2, 1, 1, 1, 0), ("wstream", 2, 0, 0, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0)]
+# name, form, order, fold, nt, dia, march (0 = off, m = segments per XCD)
+variants = [("DIA plane-marching auto", 2, 1, 1, 1, 1, -1), ("DIA plane-marching m=2", 2, 1, 1, 1, 1, 2), ("DIA plane-marching m=3", 2, 1, 1, 1, 1, 3),
+            ("DIA plane-marching m=7", 2, 1, 1, 1, 1, 7), ("sliced-DIA plane-blocked", 2, 1, 1, 1, 1, 0), ("sliced-DIA natural order", 2, 0, 1, 1, 1, 0),
+            ("wstream+order+fold+nt", 2, 1, 1, 1, 0, 0), ("lanes-per-row(8)", 1, 0, 0, 0, 0, 0)]
 
 
-def select(form, order, fold, nt, dia):
+def select(form, order, fold, nt, dia, march):
     lib.fv_tune(0, form)
     lib.fv_tune(2, order)
     lib.fv_tune(3, fold)
     lib.fv_tune(4, nt)
     lib.fv_tune(6, dia)
+    lib.fv_tune(9, 1 if march else 0)
+    if march:
+        lib.fv_tune(10, max(march, 0))  # -1: let the library choose the segment count
 
 
 res = {v[0]: [] for v in variants}
@@ -45,6 +50,7 @@ for name, *knobs in variants:  # correctness of every variant against the last (
         ref = y
     else:
         err = np.abs(y - ref).max() / np.abs(ref).max()
+        print("%-28s max rel diff to the first variant %.2e" % (name, err), flush=True)
         assert err < 1e-13, (name, err)
 for r in range(rounds):
     for name, *knobs in variants:
