@@ -294,7 +294,7 @@ extern "C" int fv_dist_setup(fv_problem *pg, int nranks, int rank, fv_problem **
             break;
         }
         pl->transient_ready = true;
-        if ((rc = d->red.alloc(ctx, 8)) || (rc = d->part2.alloc(ctx, FV_MAX_PARTIALS)))
+        if ((rc = d->red.alloc(ctx, 8)))
             break;
     } while (0);
     if (rc != FV_OK) {

@@ -112,7 +112,6 @@ struct fv_dist {
     DevBuf<int32_t> groups_bnd; // the others
     DevBuf<double> sendbuf;
     DevBuf<double> red;   // 8 scalars: all-reduce buffer
-    DevBuf<double> part2; // per-block partials of the boundary SpMV pass
     // interior / boundary groups split by storage form (built at the first distributed SpMV)
     DevBuf<int32_t> int_dia, int_csr, bnd_dia, bnd_csr;
     int64_t n_int_dia = 0, n_int_csr = 0, n_bnd_dia = 0, n_bnd_csr = 0;

@@ -1821,16 +1821,6 @@ __global__ __launch_bounds__(FV_BLOCK) void dist_pack_kernel(int64_t nsend, cons
         buf[i] = x[idx[i]];
 }
 
-__global__ __launch_bounds__(FV_BLOCK) void dist_sum2_kernel(const double *__restrict__ a, int na, const double *__restrict__ b, int nb,
-                                                              double *__restrict__ out)
-{
-    __shared__ double smem[4];
-    const double ta = reduce_partials(a, na, smem);
-    const double tb = nb > 0 ? reduce_partials(b, nb, smem) : 0.0;
-    if (threadIdx.x == 0)
-        *out = ta + tb;
-}
-
 static int dist_exchange_begin(fv_problem *p, double *xext)
 {
     fv_ctx *ctx = p->ctx;

@@ -205,7 +205,9 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *   7: fixed-dt runs carry the residual from step to step and recompute it from scratch every `value` steps [32];
  *      0 = every step computes its initial residual with an SpMV
  *   8: in such runs, after a one-iteration step, the first vector update of a step also prepares the next step's
- *      set-up, so a step is SpMV + one fused vector pass [1] */
+ *      set-up, so a step is SpMV + one fused vector pass [1]
+ *   9: plane-marching sliced-DIA SpMV on operators with a plane stride (structured grids) [1]
+ *  10: segments per XCD of that kernel, 0 = chosen per operator [0] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);

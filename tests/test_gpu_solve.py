@@ -117,6 +117,10 @@ def test_fourfractures_steady_vs_direct_and_pflotran(fv, oracle):
     ohead = oracle.solvediffusion(d["node1"], d["node2"], d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], solver="direct")[0]
     assert relerr(head, ohead) < HEAD_RTOL
     assert relerr(head, d["pflotran_h"]) < 1.1e-2  # loose cross-code check, SURVEY §8c item 5
+    # AMG on the irregular fracture mesh (aol spread over decades): the reference's maxiter = 400 suffices
+    head_a, ch_a, *_ = fv.solvediffusion(nb, d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], maxiter=400, rtol=1e-13, preconditioner="amg")
+    assert ch_a.isconverged and ch_a.iters < ch.iters
+    assert relerr(head_a, ohead) < HEAD_RTOL
 
 
 def test_fixed_steps_vs_oracle_direct(fv, oracle):
@@ -243,6 +247,10 @@ def test_theis_and_thiem(fv, oracle):
     assert len(ts) == len(ots) and np.allclose(ts, ots, rtol=0, atol=0)
     assert relerr(us[-1], ous[-1]) < HEAD_RTOL
     assert solver.solves > 3000
+    # the steady solve with the AMG V-cycle in the preconditioner's seat, as the reference runs it (maxiter = 400)
+    usteady_a, ch_a, *_ = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], preconditioner="amg")
+    assert ch_a.isconverged and ch_a.iters < ch.iters and ch_a.iters <= 60
+    assert refcases.isapprox(tm, -usteady_a[c["goodnodes"]] + c["steadyhead"], atol=1e-4, rtol=2e-2)
 
 
 # ------------------------------------------------------------------ multi-GPU plan and single-rank RCCL path
