@@ -279,6 +279,7 @@ static int g_use_order = 1;
 static int g_nt = 1;
 static int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 static int g_use_dia = 1;
+static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
@@ -308,6 +309,8 @@ extern "C" int fv_tune(int key, int value)
         g_march = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
+    else if (key == 11 && (value == 0 || value == 1))
+        g_dia_packed = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -585,7 +588,8 @@ __global__ __launch_bounds__(FV_BLOCK) void dia_pattern_kernel(int64_t n, const 
 __global__ __launch_bounds__(FV_BLOCK) void dia_fill_kernel(int64_t n, int64_t ndia, const int32_t *__restrict__ dia_list,
                                                              const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
-                                                             const double *__restrict__ vals, double *__restrict__ sval)
+                                                             const double *__restrict__ vals, const int32_t *__restrict__ dia_pos,
+                                                             double *__restrict__ sval)
 {
     constexpr int WPB = FV_BLOCK / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -593,6 +597,7 @@ __global__ __launch_bounds__(FV_BLOCK) void dia_fill_kernel(int64_t n, int64_t n
     if (pos >= ndia)
         return;
     const int64_t sl = dia_list[pos];
+    const int64_t base = dia_pos[sl];
     const int64_t row = (sl << 6) + lane;
     const int noff = sl_noff[sl];
     int32_t ptr = 0, end = 0;
@@ -608,7 +613,7 @@ __global__ __launch_bounds__(FV_BLOCK) void dia_fill_kernel(int64_t n, int64_t n
                 v = vals[j];
                 break;
             }
-        sval[(pos * DIA_K + k) * 64 + lane] = v;
+        sval[(base + k) * 64 + lane] = v;
     }
 }
 
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
         const int64_t row = (sl << 6) + lane;
         const int noff = __builtin_amdgcn_readfirstlane((int)sl_noff[sl]);
         const int32_t offs = (lane < DIA_K) ? sl_off[sl * DIA_K + lane] : 0;
-        const double *sv = sval + (int64_t)dia_pos[sl] * (DIA_K * 64) + lane; // the list may be any subset of the DIA slices
+        const double *sv = sval + (int64_t)dia_pos[sl] * 64 + lane; // dia_pos: start of the slice's values in units of 64 doubles (packed, no padding)
         double v[DIA_K], xv[DIA_K];
 #pragma unroll
         for (int k = 0; k < DIA_K; k++) {
@@ -767,7 +772,7 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                 }
             }
             if (noff > 0) {
-                const double *sv = sval + pos * (DIA_K * 64) + lane;
+                const double *sv = sval + pos * 64 + lane;
                 double sum = 0.0;
 #pragma unroll
                 for (int j = 0; j < DIA_K; j++) {
@@ -822,11 +827,21 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
     }
 }
 
-__global__ __launch_bounds__(FV_BLOCK) void dia_pos_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, int32_t *__restrict__ dia_pos)
+// values are packed: slice i of the list holds sl_noff lane-major blocks of 64 doubles, one after the other
+__global__ __launch_bounds__(FV_BLOCK) void dia_len_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, const uint8_t *__restrict__ sl_noff,
+                                                            int pad_to, int32_t *__restrict__ len)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (i < ndia)
-        dia_pos[dia_list[i]] = (int32_t)i;
+        len[i] = pad_to > 0 ? pad_to : sl_noff[dia_list[i]];
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void dia_pos_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, const int32_t *__restrict__ start,
+                                                            int32_t *__restrict__ dia_pos)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < ndia)
+        dia_pos[dia_list[i]] = start[i];
 }
 
 // traversal order of the DIA slices: the plane-blocked group order (build_group_order) restricted to the DIA slices
@@ -876,10 +891,22 @@ static int build_dia(fv_problem *p)
         p->sl_off.release();
         return FV_OK;
     }
-    FV_TRY(p->dia_vals.alloc(ctx, (size_t)p->ndia * DIA_K * 64));
-    FV_TRY(p->dia_pos.alloc(ctx, (size_t)ns));
-    hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, p->dia_list.p, p->dia_pos.p);
-    FV_LAUNCH_CHECK(ctx);
+    {
+        DevBuf<int32_t> len, start;
+        FV_TRY(len.alloc(ctx, (size_t)p->ndia));
+        FV_TRY(start.alloc(ctx, (size_t)p->ndia + 1));
+        hipLaunchKernelGGL(dia_len_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, (const int32_t *)p->dia_list.p,
+                           (const uint8_t *)p->sl_noff.p, g_dia_packed ? 0 : DIA_K, len.p);
+        FV_LAUNCH_CHECK(ctx);
+        int64_t nblocks = 0; // blocks of 64 doubles in all
+        FV_TRY(fv_exclusive_scan_i32(ctx, len.p, start.p, p->ndia, &nblocks));
+        FV_TRY(p->dia_vals.alloc(ctx, (size_t)nblocks * 64 + 64));
+        FV_TRY(p->dia_pos.alloc(ctx, (size_t)ns));
+        hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, (const int32_t *)p->dia_list.p,
+                           (const int32_t *)start.p, p->dia_pos.p);
+        FV_LAUNCH_CHECK(ctx);
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     p->dia_epoch = -1;
     if (p->group_order.p) { // walk the slices band by band, plane after plane: the +-plane x arms are then re-used while still in L2
         DevBuf<int32_t> flag, idx;
@@ -908,7 +935,7 @@ static int ensure_dia_vals(fv_problem *p, const double *src, double src_tag)
     if (p->dia_epoch == p->assemble_epoch && p->dia_tag == src_tag)
         return FV_OK;
     hipLaunchKernelGGL(dia_fill_kernel, dim3(fv_blocks(p->ndia, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->ndia, p->dia_list.p,
-                       p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, p->dia_vals.p);
+                       p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, (const int32_t *)p->dia_pos.p, p->dia_vals.p);
     FV_LAUNCH_CHECK(ctx);
     p->dia_epoch = p->assemble_epoch;
     p->dia_tag = src_tag;

@@ -13,8 +13,20 @@ fv = load_package()
 ns = [int(sys.argv[1]) if len(sys.argv) > 1 else 464] * 3
 mins, maxs = bench.spacing_box(ns)
 dn, src = bench.box_setup(ns)
-p = fv.Problem.regulargrid(mins, maxs, ns, dn)
-p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
-p.transient_begin(0.1, None, np.full(p.N, 1e3))
-t = [p.bench_spmv(1 / 60.0, 10) for _ in range(5)]
-print("FV_BAND=%s: median %.3f ms min %.3f ms" % (os.environ.get("FV_BAND", "default"), float(np.median(t)), min(t)), flush=True)
+lib = fv.load()
+probs = {}
+for packed in (0, 1):  # the layout is fixed when a problem's DIA copy is built: one problem per layout, same process
+    lib.fv_tune(11, packed)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    p.bench_spmv(1 / 60.0, 2)
+    probs[packed] = p
+res = {}
+for r in range(5):
+    for packed in (0, 1):
+        for march in (1, 0):
+            lib.fv_tune(9, march)
+            res.setdefault((packed, march), []).append(probs[packed].bench_spmv(1 / 60.0, 10))
+for (packed, march), t in sorted(res.items()):
+    print("FV_BAND=%s values %s, %s: median %.3f ms min %.3f ms" % (os.environ.get("FV_BAND", "default"), "packed" if packed else "padded to 8 blocks", "plane-marching" if march else "slice by slice", float(np.median(t)), min(t)), flush=True)
