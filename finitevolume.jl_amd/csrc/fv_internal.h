@@ -115,6 +115,7 @@ struct fv_dist {
     // interior / boundary groups split by storage form (built at the first distributed SpMV)
     DevBuf<int32_t> int_dia, int_csr, bnd_dia, bnd_csr;
     int64_t n_int_dia = 0, n_int_csr = 0, n_bnd_dia = 0, n_bnd_csr = 0;
+    int64_t int_lo = 0, int_hi = 0; // the interior groups as a slice range [lo, hi) when they are contiguous (else empty)
     bool split_built = false;
 };
 

@@ -718,10 +718,12 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
 // short-lived it is in L2 (a 4 MiB L2 turns over in ~6 us at this rate, far less than the time between planes in any
 // slice-by-slice traversal).  Work items are (pencil, segment of `seglen` plane steps); XCD k owns the segments
 // [k m, (k+1) m) and its resident waves march through neighbouring pencils of one segment together, so the in-plane
-// arms (+-1, +-line) are shared through L2 as before.
+// arms (+-1, +-line) are shared through L2 as before.  Only slices inside [win_lo, win_hi) are computed (a row block's
+// interior pass); the others are merely walked through.
 template <bool DOT, bool NT>
 __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int shift, int64_t stride,
-                                                                   int seglen, int segs_per_xcd, const int32_t *__restrict__ dia_pos,
+                                                                   int seglen, int segs_per_xcd, int64_t win_lo, int64_t win_hi,
+                                                                   const int32_t *__restrict__ dia_pos,
                                                                    const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                    const double *__restrict__ sval, const double *__restrict__ x,
                                                                    double *__restrict__ y, const double *__restrict__ dshift, double sigma,
@@ -771,7 +773,7 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                     nx_pos = dia_pos[nsl];
                 }
             }
-            if (noff > 0) {
+            if (noff > 0 && sl >= win_lo && sl < win_hi) { // the window: all slices, or the interior ones of a row block
                 const double *sv = sval + pos * 64 + lane;
                 double sum = 0.0;
 #pragma unroll
@@ -1000,6 +1002,8 @@ struct GroupSubset {
     int64_t ndia = 0;
     const int32_t *csr = nullptr; // its CSR groups
     int64_t ncsr = 0;
+    // when the subset's groups are exactly the slices [win_lo, win_hi): lets the plane-marching kernel do its DIA part
+    int64_t win_lo = 0, win_hi = 0;
 };
 
 static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const double *vals_override, int mode, double *partials,
@@ -1045,7 +1049,7 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
     hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, dcount, dlist, p->dia_pos.p, p->sl_noff.p, \
                        p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, partials, scal, epi)
         // structured grids: plane-marching form over the whole DIA part (not for subsets or the fused set-up)
-        const bool march = g_march && !subset && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0;
+        const bool march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         int GM = 0;
         if (march) {
             const int64_t ns = (p->n + 63) >> 6;
@@ -1081,7 +1085,7 @@ static int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, c
             GM = (int)g;
 #define FV_MARCH(D_, N_)                                                                                                                      \
     hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
-                       seglen, segs_per_xcd, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
+                       seglen, segs_per_xcd, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
                        (const double *)p->dia_vals.p, x, y, shift, sigma, partials, scal)
             if (mode == SPMV_DOT) {
                 if (g_nt)
@@ -1931,6 +1935,17 @@ static int dist_build_split(fv_problem *p)
         FV_TRY(build_dia(p));
     FV_TRY(split_list(p, d->groups_int.p, d->n_int, d->int_dia, &d->n_int_dia, d->int_csr, &d->n_int_csr));
     FV_TRY(split_list(p, d->groups_bnd.p, d->n_bnd, d->bnd_dia, &d->n_bnd_dia, d->bnd_csr, &d->n_bnd_csr));
+    // x-slab partitions of a structured grid: the interior groups are one contiguous run of slices
+    d->int_lo = d->int_hi = 0;
+    if (d->n_int > 0) {
+        int32_t first = 0, last = 0;
+        FV_HIP(p->ctx, hipMemcpy(&first, d->groups_int.p, sizeof first, hipMemcpyDeviceToHost));
+        FV_HIP(p->ctx, hipMemcpy(&last, d->groups_int.p + (d->n_int - 1), sizeof last, hipMemcpyDeviceToHost));
+        if ((int64_t)last - first + 1 == d->n_int) {
+            d->int_lo = first;
+            d->int_hi = (int64_t)last + 1;
+        }
+    }
     d->split_built = true;
     return FV_OK;
 }
@@ -1950,6 +1965,8 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     interior.ndia = d->n_int_dia;
     interior.csr = d->int_csr.p;
     interior.ncsr = d->n_int_csr;
+    interior.win_lo = d->int_lo;
+    interior.win_hi = d->int_hi;
     boundary.dia = d->bnd_dia.p;
     boundary.ndia = d->n_bnd_dia;
     boundary.csr = d->bnd_csr.p;

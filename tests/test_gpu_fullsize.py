@@ -163,13 +163,13 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
     kernel and the CSR wave-stream form against a float64 CSR product on the host; the p.q epilogue against numpy."""
     import scipy.sparse as sp
 
-    ns = [120, 100, 100]
+    ns = [40, 200, 200]  # planes of 198 x 200 = 39 600 rows (>= 32 768: the operator counts as plane-structured), 38 of them
     mins, maxs = bench.spacing_box(ns)
     dn, src = bench.box_setup(ns)
     p = fv.Problem.regulargrid(mins, maxs, ns, dn)
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
     p.transient_begin(0.1, None, np.full(p.N, 1e3))
-    assert p.n >= 1 << 20
+    assert p.n >= 1 << 20 and p.n == 38 * 39600
     A = p.csc()
     As = sp.csc_matrix((A.nzval, A.rowval - 1, A.colptr - 1), shape=(p.n, p.n)).tocsr()
     _, _, _, vol = fv.regulargrid(mins, maxs, ns)
@@ -204,3 +204,43 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
         lib.fv_tune(9, 1)
         lib.fv_tune(6, 1)
         lib.fv_tune(10, 0)
+
+
+def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv):
+    """Row blocks with >= 2^20 rows take the plane-marching kernel for their interior slices (a window of the
+    pencils) and the slice kernel for the boundary ones: virtual ranks on one GPU against the global product, and the
+    one-rank distributed driver (RCCL communicator of one rank) against the plain fixed-dt loop."""
+    from fvamd import dist
+
+    ns = [64, 200, 200]  # planes of 39 600 rows; two ranks get 31 planes (1.23e6 rows) each
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    rng = np.random.default_rng(5)
+    K = 1e-5 * np.exp(0.5 * rng.standard_normal(p.F))
+    p.assemble(K, src, np.full(len(dn), 1e3))
+    u0 = np.full(p.N, 1e3) + rng.standard_normal(p.N)
+    st = p.transient_begin(0.1, None, u0)
+    x = rng.standard_normal(p.n)
+    for sigma in (0.0, 1 / 60.0):
+        y_global = p.spmv(x, sigma)
+        for nranks in (2, 3):
+            for rank in range(nranks):
+                blk = dist.RowBlock(p, nranks, rank)
+                if nranks == 2:
+                    assert blk.nloc >= 1 << 20
+                plan = blk.plan()
+                y = blk.spmv_halo(x[blk.lo : blk.hi], x[plan["halo_cols"]], sigma)
+                assert np.abs(y - y_global[blk.lo : blk.hi]).max() <= 1e-13 * np.abs(y_global).max(), (nranks, rank, sigma)
+                blk.close()
+    ctx = p.ctx
+    dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
+    try:
+        blk = dist.RowBlock(p, 1, 0)
+        it_d, info_d, _ = blk.run_fixed(600.0, 6, 1e-12)
+        it_s, info_s, _ = p.run_fixed(st, 600.0, 6, 1e-12)
+        assert info_d.converged and info_s.converged and np.array_equal(it_d, it_s)
+        assert np.abs(blk.state() - st.free_values()).max() <= 1e-9
+        blk.close()
+    finally:
+        fv.load().fv_comm_destroy(ctx.handle)
