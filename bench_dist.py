@@ -6,6 +6,7 @@ torch.distributed (gloo) is only the control plane here: rendezvous, broadcast o
 the RCCL unique id, barriers and the max-over-ranks of the timed region."""
 import json
 import os
+import sys
 import time
 
 import numpy as np
@@ -23,10 +24,19 @@ def run_distributed(fv, args, world, rank):
         local_rank = int(os.environ["FV_BENCH_DEVICE"])
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")  # only reached without the launcher (one-rank rehearsal)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    ctx = fv.Context(local_rank)
-    name, cus, mem = ctx.device_info()
-    fvdist.comm_init_from_torch(ctx)
+    # gloo and RCCL print banners on stdout while they initialise; the driver wants exactly one JSON line there
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ctx = fv.Context(local_rank)
+        name, cus, mem = ctx.device_info()
+        fvdist.comm_init_from_torch(ctx)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
 
     ns = [args.ns] * 3
     mins, maxs = bench.spacing_box(ns)

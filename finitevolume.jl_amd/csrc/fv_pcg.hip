@@ -1986,9 +1986,23 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     return FV_OK;
 }
 
-// x_next / carry_prev: the ping-pong state and the residual carry-over of PcgSystem, same meaning.
+// up to five partial-sum arrays reduced by one launch (block k sums array k into out[k])
+struct SumSet {
+    const double *a[5];
+};
+__global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, int nparts, double *__restrict__ out)
+{
+    __shared__ double smem[4];
+    const double t = reduce_partials(set.a[blockIdx.x], nparts, smem);
+    if (threadIdx.x == 0)
+        out[blockIdx.x] = t;
+}
+
+// x_next / carry_prev / speculate / use_spec: the ping-pong state, the residual carry-over and the speculative set-up
+// of PcgSystem, same meaning.  All-reduce buffer: red[0] p.q; red[1..2] r.M^-1 r, r.r; red[3] rhs.rhs of a regular
+// set-up, or red[3..5] the next step's r.M^-1 r, r.r, rhs.rhs left by pcg_update_spec_kernel.
 static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info, double *x_next = nullptr,
-                     const double *carry_prev = nullptr)
+                     const double *carry_prev = nullptr, bool speculate_in = false, bool use_spec_in = false)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
@@ -2003,26 +2017,42 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     double *red = d->red.p;
-    if (carry_prev && !compute_minv) {
-        // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
-        hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->D.p, dt,
-                           (const double *)u, carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
-                           p->part_bb.p);
+    const bool use_spec = use_spec_in && p->spec_valid && !compute_minv;
+    p->spec_valid = false;
+    const bool speculate = speculate_in && x_next && !compute_minv && p->last_iters == 1 && maxiter > 0;
+    if (speculate && !p->pnext.p)
+        FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+    if (use_spec) {
+        // r, p' and the all-reduced set-up scalars (red[3..5]) were left by the previous step's K2S
+        std::swap(p->pvec.p, p->pnext.p);
+        std::swap(p->pvec.n, p->pnext.n);
+        hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3), (const double *)(red + 4),
+                           (const double *)(red + 5), 1, rtol, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
     } else {
-        // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
-        FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
-        hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
-                           p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
-                           p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+        if (carry_prev && !compute_minv) {
+            // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
+            hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->D.p,
+                               dt, (const double *)u, carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
+                               p->part_bb.p);
+        } else {
+            // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
+            FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
+            hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
+                               p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
+                               p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
+        }
+        SumSet init{};
+        init.a[0] = p->part_rz.p;
+        init.a[1] = p->part_rr.p;
+        init.a[2] = p->part_bb.p;
+        hipLaunchKernelGGL(final_sum_multi_kernel, dim3(3), dim3(FV_BLOCK), 0, ctx->stream, init, Gv, red + 1);
+        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 3, ctx->stream));
+        hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 1), (const double *)(red + 2),
+                           (const double *)(red + 3), 1, rtol, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_bb.p, Gv, red + 3);
-    FV_LAUNCH_CHECK(ctx);
-    FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 3, ctx->stream));
-    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 1), (const double *)(red + 2),
-                       (const double *)(red + 3), 1, rtol, p->scal.p);
-    FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
     int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
@@ -2032,22 +2062,39 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
+            const bool spec = iter == 0 && speculate;
             FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
             FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
-            if (iter == 0 && x_next)
+            SumSet sums{};
+            sums.a[0] = p->part_rz.p;
+            sums.a[1] = p->part_rr.p;
+            if (spec) {
+                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
+                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
+                                   (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p, p->pnext.p,
+                                   p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS, p->part_bb.p + FV_MAX_PARTIALS);
+                sums.a[2] = p->part_rz.p + FV_MAX_PARTIALS;
+                sums.a[3] = p->part_rr.p + FV_MAX_PARTIALS;
+                sums.a[4] = p->part_bb.p + FV_MAX_PARTIALS;
+            } else if (iter == 0 && x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)u, x_next, p->r.p,
                                    p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
             else
                 hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)nullptr,
                                    x_next ? x_next : u, p->r.p, p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p);
-            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
-            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
+            const int nsums = spec ? 5 : 2;
+            hipLaunchKernelGGL(final_sum_multi_kernel, dim3(nsums), dim3(FV_BLOCK), 0, ctx->stream, sums, Gv, red + 1);
             FV_LAUNCH_CHECK(ctx);
-            FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 2, ctx->stream));
-            hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
-                               p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
-                               (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0.0);
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, nsums, ctx->stream));
+            if (spec)
+                hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
+                                   (const double *)u, (const double *)x_next, (const double *)p->D.p, dt);
+            else
+                hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
+                                   (const double *)nullptr, (const double *)nullptr, (const double *)nullptr, 0.0);
             FV_LAUNCH_CHECK(ctx);
         }
         it += m;
@@ -2063,6 +2110,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
+    p->spec_valid = speculate && hs->done == 1 && hs->iters == 1;
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
@@ -2102,7 +2150,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     const double *prev = nullptr;
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         const bool carry = prev != nullptr && (s % refresh) != 0;
-        rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr);
+        rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr, pingpong && g_carry_speculate && s + 1 < nsteps, carry);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
         if (pingpong && rc == FV_OK) {

@@ -312,6 +312,16 @@ def test_single_rank_rccl_path_matches_plain_run(fv):
     assert info_d.converged and info_s.converged
     assert np.array_equal(it_d, it_s)
     assert relerr(blk.state(), st.free_values()) < 1e-12
+    # one-iteration regime (tiny dt): both drivers prepare step k+1 inside step k's vector update; then a large step,
+    # where that speculation misses
+    for dt, nsteps in ((2.0**-10, 40), (3600.0, 3)):
+        it_d, info_d, _ = blk.run_fixed(dt, nsteps, 1e-12)
+        it_s, info_s, _ = p.run_fixed(st, dt, nsteps, 1e-12)
+        assert info_d.converged and info_s.converged
+        assert np.array_equal(it_d, it_s), (dt, it_d, it_s)
+        assert relerr(blk.state(), st.free_values()) < 1e-12
+        if dt < 1:
+            assert (it_s == 1).all()
     fv.load().fv_comm_destroy(ctx.handle)
 
 
