@@ -88,6 +88,7 @@ SIGNATURES = {
     "fv_state_norm2_diff": (C.c_int, [c_prob, C.c_int32, C.c_int32, P(C.c_double)]),
     "fv_transient_step": (C.c_int, [c_prob, C.c_int32, C.c_int32, C.c_double, _f64p, C.c_int, C.c_double, C.c_int64, P(SolveInfo)]),
     "fv_transient_run_fixed": (C.c_int, [c_prob, C.c_int32, C.c_double, C.c_int64, C.c_double, C.c_int64, C.c_void_p, P(SolveInfo), P(C.c_double)]),
+    "fv_transient_run_adaptive": (C.c_int, [c_prob, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, _f64p, P(C.c_int64), P(C.c_int64), P(SolveInfo)]),
     "fv_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
     "fv_bench_spmv": (C.c_int, [c_prob, C.c_double, C.c_int32, P(C.c_double)]),
     "fv_dot": (C.c_int, [c_prob, _f64p, _f64p, P(C.c_double)]),

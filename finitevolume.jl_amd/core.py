@@ -305,6 +305,15 @@ class Problem:
         self.check(load().fv_transient_run_fixed(self.handle, state.slot, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
         return iters[: int(nsteps)], info, ms.value
 
+    def run_adaptive(self, state, t0, tfinal, dt0=1.0, atol=1e-4, rtol=SQRT_EPS, maxiter=1000, max_outer=1 << 20):
+        """The default stepper of backwardeulerintegrate (step doubling, transient.jl:78-121,136-154) with constant b,
+        entirely on the device: the state is advanced to tfinal.  Returns (ts, nsolves, info), ts as the reference's."""
+        ts = np.empty(int(max_outer) + 1, np.float64)
+        nout, nsol = C.c_int64(), C.c_int64()
+        info = SolveInfo()
+        self.check(load().fv_transient_run_adaptive(self.handle, state.slot, float(t0), float(tfinal), float(dt0), float(atol), float(rtol), int(maxiter), int(max_outer), ptr(ts), C.byref(nout), C.byref(nsol), C.byref(info)))
+        return ts[: nout.value + 1].copy(), nsol.value, info
+
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             load().fv_problem_destroy(self.handle)

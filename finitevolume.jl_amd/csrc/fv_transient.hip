@@ -412,6 +412,145 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     return rc;
 }
 
+// ------------------------------------------------------------------ the adaptive stepper on the device
+// transient.jl:78-121,136-154 with constant b: step-doubling error control (one step of dt against two of dt/2, grow
+// x2 when the difference is below atol/4, halve on failure and re-use the half step as the next trial's full step,
+// sub-step without overshoot), everything resident; the host only sees scalars.  The state in `slot` is advanced to
+// tfinal; ts_out receives the outer step times (ts[0] = t0), as the reference's `ts`.
+namespace {
+struct TwoStep {
+    double *result; // twostep (accepted) or twostep1 (rejected)
+    double last;    // dt taken: dt or dt/2
+    bool increase;
+};
+} // namespace
+
+static int adaptive_twostep(fv_problem *p, double *uk, double dt, double *onestep, bool have_onestep, double *two1, double *two, double atol,
+                            double rtol, int64_t maxiter, fv_solve_info *inf, int64_t *nsolves, TwoStep *out)
+{
+    if (!have_onestep) {
+        FV_TRY(step_impl(p, uk, onestep, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
+        ++*nsolves;
+    }
+    FV_TRY(step_impl(p, uk, two1, 0.5 * dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
+    FV_TRY(step_impl(p, two1, two, 0.5 * dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
+    *nsolves += 2;
+    double err = 0.0;
+    FV_TRY(fv_norm2_diff_device(p, onestep, two, &err)); // norm(onestep - twostep), transient.jl:81
+    if (err < atol) {
+        out->result = two;
+        out->last = dt;
+        out->increase = err < atol / 4;
+    } else {
+        out->result = two1;
+        out->last = 0.5 * dt;
+        out->increase = false;
+    }
+    return FV_OK;
+}
+
+extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, double atol, double rtol,
+                                         int64_t maxiter, int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves,
+                                         fv_solve_info *last_info)
+{
+    if (!p || !(tfinal >= t0) || max_outer < 0 || (max_outer > 0 && !ts_out))
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_transient(p, "fv_transient_run_adaptive"));
+    if (!(dt0 > 0)) {
+        fv_set_error(ctx, "time step must be positive");
+        return FV_ERR_DT;
+    }
+    int32_t scratch[4] = {-1, -1, -1, -1};
+    int rc = FV_OK;
+    for (int i = 0; i < 4 && rc == FV_OK; i++)
+        rc = fv_slot_new(p, &scratch[i]);
+    double *U = nullptr;
+    if (rc == FV_OK)
+        rc = slot_ptr(p, slot, &U); // after the allocations: the slot table may have moved
+    fv_solve_info inf = {};
+    int64_t nout = 0, nsolves = 0;
+    if (rc == FV_OK) {
+        double *E = p->slots[(size_t)scratch[0]], *S1 = p->slots[(size_t)scratch[1]], *S2 = p->slots[(size_t)scratch[2]],
+               *S3 = p->slots[(size_t)scratch[3]];
+        const size_t bytes = (size_t)p->n * sizeof(double);
+        double t = t0;
+        double dt = dt0 < tfinal - t0 ? dt0 : tfinal - t0;
+        if (ts_out && max_outer > 0)
+            ts_out[0] = t0;
+        while (rc == FV_OK && t < tfinal && nout < max_outer) {
+            TwoStep ts{};
+            rc = adaptive_twostep(p, U, dt, S1, false, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
+            if (rc != FV_OK)
+                break;
+            const double *unew = ts.result;
+            if (ts.last < dt) { // rejected: sub-step to t + dt, transient.jl:93-120
+                bool failed = true;
+                double elapsed = 0.0, target = ts.last;
+                if (hipMemcpyAsync(E, U, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                    rc = FV_ERR_HIP;
+                    break;
+                }
+                std::swap(S1, S2); // the half step just computed is the next trial's full step
+                while (rc == FV_OK && elapsed < dt) {
+                    rc = adaptive_twostep(p, E, target, S1, failed, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
+                    if (rc != FV_OK)
+                        break;
+                    if (ts.last == target) {
+                        elapsed += ts.last;
+                        if (hipMemcpyAsync(E, ts.result, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                            rc = FV_ERR_HIP;
+                            break;
+                        }
+                        if (ts.increase)
+                            target = 2 * ts.last;
+                        failed = false;
+                    } else if (ts.last < target) {
+                        target = ts.last;
+                        failed = true;
+                        std::swap(S1, S2);
+                    } else {
+                        fv_set_error(ctx, "Code is broken -- laststeptime should never be greater than targetdt"); // transient.jl:115
+                        rc = FV_ERR_STATE;
+                        break;
+                    }
+                    if (dt - elapsed < target)
+                        target = dt - elapsed;
+                }
+                unew = E;
+            }
+            if (rc != FV_OK)
+                break;
+            if (hipMemcpyAsync(U, unew, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                rc = FV_ERR_HIP;
+                break;
+            }
+            t += dt;
+            nout++;
+            if (ts_out)
+                ts_out[nout] = t;
+            const double remaining = tfinal - t;
+            const double want = ts.increase ? 2 * ts.last : ts.last;
+            dt = remaining < want ? remaining : want;
+        }
+        if (rc == FV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = FV_ERR_HIP;
+        if (rc == FV_ERR_HIP)
+            fv_set_error(ctx, "fv_transient_run_adaptive: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    }
+    for (int i = 0; i < 4; i++)
+        if (scratch[i] >= 0)
+            p->slot_used[(size_t)scratch[i]] = 0;
+    if (n_outer)
+        *n_outer = nout;
+    if (n_solves)
+        *n_solves = nsolves;
+    if (last_info)
+        *last_info = inf;
+    return rc;
+}
+
 // ------------------------------------------------------------------ kernel-level entry points
 extern "C" int fv_spmv(fv_problem *p, const double *x_free, double sigma, double *y_free)
 {

@@ -309,4 +309,19 @@ function backwardeulerintegrate(u0, tspan, getb::Function, Ss::Number, volumes::
 	return result, ts
 end
 
+# The same integration (default stepper, constant b) entirely on the device: only u(tfinal) comes back, with the
+# reference's `ts`.  For grids where the reference's per-step history (`us`) would not fit the host.
+function backwardeulerintegrate_last(u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, atol=1e-4, rtol=sqrt(eps(Float64)), maxiter=1000, maxsteps=1 << 20)
+	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
+	assemble!(p, conductivities, sources, dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
+	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], Float64[u0...]))
+	ts = Array{Float64}(undef, maxsteps + 1)
+	nouter = Ref{Int64}(0)
+	nsolves = Ref{Int64}(0)
+	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
+	check(p.ctx, ccall((:fv_transient_run_adaptive, libfvhip), Cint, (Ptr{Cvoid}, Int32, Float64, Float64, Float64, Float64, Float64, Int64, Int64, Ptr{Float64}, Ref{Int64}, Ref{Int64}, Ref{SolveInfo}),
+		p.handle, Int32(0), tspan[1], tspan[2], dt0, atol, rtol, maxiter, maxsteps, ts, nouter, nsolves, info))
+	return nodevalues(DeviceVector(p, Int32(0))), ts[1:nouter[] + 1]
+end
+
 end # module

@@ -227,7 +227,9 @@ def backwardeulerintegrate(u0, *args, **kwargs):
       backwardeulerintegrate(u0, tspan, getb::Function, Ss, volumes, neighbors, ... same ...)
 
     Extra keywords of this build: rtol/maxiter configure the device PCG when
-    `linearsolver` is left at its default."""
+    `linearsolver` is left at its default; keep="last" (high-level methods with constant b) runs the whole
+    adaptive integration on the device (fv_transient_run_adaptive) and returns ([u0, u(tfinal)], ts) instead
+    of every intermediate state."""
     if "stepper_" in kwargs:
         kwargs["stepper"] = kwargs.pop("stepper_")
     rtol = kwargs.pop("rtol", None)
@@ -244,10 +246,24 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     metaindex = rest[8] if len(rest) > 8 else None
     logt = rest[9] if len(rest) > 9 else False
     dt0 = kwargs.pop("dt0", 1.0)
+    keep = kwargs.pop("keep", "all")
     u0 = af64(u0)
     # assembleA + assembleb + scalebyvolume! (transient.jl:157-169) — one device problem
     p = _assembled_problem(neighbors, aol, K, sources, dnodes, dheads, metaindex, logt)
     first = p.transient_begin(Ss, volumes, u0)  # u0[freenodes], transient.jl:170
+    if keep == "last":
+        # the reference stores every outer step on the host (us); at 10^7-10^8 cells that is the cost of the run.
+        # keep="last": the default stepper and solver, constant b, entirely on the device -> ([u0, u(tfinal)], ts)
+        if getb is not None or any(k in kwargs for k in ("stepper", "linearsolver", "callback")):
+            raise ValueError('keep="last" runs the default adaptive stepper with the device PCG and a constant b')
+        if rtol is not None or maxiter is not None:
+            kwargs.pop("linearsolver", None)
+        ts, _, info = p.run_adaptive(first, tspan[0], tspan[1], dt0=dt0, atol=kwargs.pop("atol", 1e-4), rtol=rtol if rtol is not None else SQRT_EPS, maxiter=maxiter if maxiter is not None else 1000)
+        if kwargs:
+            raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
+        return [u0.copy(), first.node_values()], [float(t) for t in ts]
+    if keep != "all":
+        raise ValueError('keep must be "all" or "last"')
     op = DeviceOperator(p)
     # constant-b method: the assembled b stays on the device (bhat = None); getb method: host closure per step
     us, ts = _integrate_generic(first, op, getb if getb is not None else None, dt0, tspan[0], tspan[1], _history="device", **kwargs)

@@ -169,6 +169,15 @@ int fv_transient_step(fv_problem *p, int32_t src, int32_t dst, double dt, const 
  * device: slot is advanced in place; iters_per_step (nsteps, may be NULL). */
 int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, int64_t nsteps, double rtol, int64_t maxiter,
                            int32_t *iters_per_step, fv_solve_info *last_info, double *total_ms);
+/* backwardeulerintegrate with the default stepper adaptivebackwardeulerstep! (transient.jl:78-121,136-154) and a
+ * constant b, without leaving the device: step doubling (one step of dt against two of dt/2, accept below atol, grow
+ * x2 below atol/4, on failure halve and sub-step to the requested time without overshoot), final step clipped to
+ * tfinal.  The slot is advanced from t0 to tfinal (or by max_outer outer steps, whichever comes first); ts_out
+ * (max_outer + 1 entries) receives the reference's `ts`: t0 and the time after every outer step; *n_outer their
+ * count - 1, *n_solves the number of linear solves. */
+int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, double atol, double rtol,
+                              int64_t maxiter, int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves,
+                              fv_solve_info *last_info);
 
 /* ---------------------------------------------------------------- kernel-level entry points (parity tests, roofline) */
 /* y = (A + sigma*D) x on n free unknowns */

@@ -247,6 +247,15 @@ def test_theis_and_thiem(fv, oracle):
     assert len(ts) == len(ots) and np.allclose(ts, ots, rtol=0, atol=0)
     assert relerr(us[-1], ous[-1]) < HEAD_RTOL
     assert solver.solves > 3000
+    # the same adaptive run without leaving the device (fv_transient_run_adaptive): same outer time grid, same heads
+    p = fv.Problem.create(nb, c["aol"], len(c["volumes"]), c["dnodes"]).assemble(c["K"], c["sources"], c["dheads"])
+    st = p.transient_begin(c["Ss"], c["volumes"], c["u0"])
+    ts_d, nsolves, info = p.run_adaptive(st, c["tspan"][0], c["tspan"][1], dt0=c["dt0"], atol=c["atol"], rtol=1e-12, maxiter=2000)
+    assert info.converged and len(ts_d) == len(ts) and np.array_equal(ts_d, np.array(ts))
+    assert nsolves == solver.solves
+    assert relerr(st.node_values(), us[-1]) < 1e-10
+    us2, ts2 = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], atol=c["atol"], dt0=c["dt0"], rtol=1e-12, maxiter=2000, keep="last")
+    assert len(us2) == 2 and ts2 == ts and np.array_equal(us2[0], c["u0"]) and relerr(us2[1], us[-1]) < 1e-10
     # the steady solve with the AMG V-cycle in the preconditioner's seat, as the reference runs it (maxiter = 400)
     usteady_a, ch_a, *_ = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], preconditioner="amg")
     assert ch_a.isconverged and ch_a.iters < ch.iters and ch_a.iters <= 60
