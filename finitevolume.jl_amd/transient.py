@@ -234,7 +234,8 @@ def backwardeulerintegrate(u0, *args, **kwargs):
         kwargs["stepper"] = kwargs.pop("stepper_")
     rtol = kwargs.pop("rtol", None)
     maxiter = kwargs.pop("maxiter", None)
-    if (rtol is not None or maxiter is not None) and "linearsolver" not in kwargs:
+    auto_solver = (rtol is not None or maxiter is not None) and "linearsolver" not in kwargs
+    if auto_solver:
         kwargs["linearsolver"] = DevicePCG(rtol if rtol is not None else SQRT_EPS, maxiter if maxiter is not None else 1000)
     if not _is_tspan(args[0]):
         A, b_or_getb, dt0, t0, tfinal = args
@@ -254,10 +255,10 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     if keep == "last":
         # the reference stores every outer step on the host (us); at 10^7-10^8 cells that is the cost of the run.
         # keep="last": the default stepper and solver, constant b, entirely on the device -> ([u0, u(tfinal)], ts)
+        if auto_solver:
+            kwargs.pop("linearsolver")
         if getb is not None or any(k in kwargs for k in ("stepper", "linearsolver", "callback")):
             raise ValueError('keep="last" runs the default adaptive stepper with the device PCG and a constant b')
-        if rtol is not None or maxiter is not None:
-            kwargs.pop("linearsolver", None)
         ts, _, info = p.run_adaptive(first, tspan[0], tspan[1], dt0=dt0, atol=kwargs.pop("atol", 1e-4), rtol=rtol if rtol is not None else SQRT_EPS, maxiter=maxiter if maxiter is not None else 1000)
         if kwargs:
             raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
