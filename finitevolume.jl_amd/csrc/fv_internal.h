@@ -185,6 +185,9 @@ struct fv_problem {
     DevBuf<double> r, pvec, q, minv, rhs, tmp;
     DevBuf<double> pnext;    // p' of a speculatively prepared next step (swapped with pvec when used)
     bool spec_valid = false; // r, pnext and the upper halves of part_rz/rr/bb hold the next step's set-up
+    int spec_extra_bb = 0;   // extra rhs.rhs partials behind the speculative half (sparse-b gather)
+    DevBuf<int32_t> bnz_idx; // rows where the assembled b is non-zero
+    int64_t bnz_count = 0, bnz_epoch = -1;
     DevBuf<double> part_pq, part_rz, part_rr, part_bb;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;

@@ -20,6 +20,7 @@
 #include "fv_spmv.h"
 
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
+int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
 
 // ------------------------------------------------------------------ PCG vector kernels
 
@@ -135,12 +136,12 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, con
 __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const double *__restrict__ part_rz,
                                                                       const double *__restrict__ part_rr,
                                                                       const double *__restrict__ part_bb, int nparts, double rtol,
-                                                                      PcgScalars *__restrict__ scal)
+                                                                      PcgScalars *__restrict__ scal, int nparts_bb = -1)
 {
     __shared__ double smem[4];
     const double rz = reduce_partials(part_rz, nparts, smem);
     const double rr = reduce_partials(part_rr, nparts, smem);
-    const double bb = reduce_partials(part_bb, nparts, smem);
+    const double bb = reduce_partials(part_bb, nparts_bb >= 0 ? nparts_bb : nparts, smem); // rhs.rhs may come in more pieces (sparse b part)
     if (threadIdx.x == 0) {
         scal->rz[0] = rz;
         scal->rz[1] = 0.0;
@@ -302,6 +303,51 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     }
 }
 
+// rhs.rhs of the next step when K2S was run without b': rhs = b' + h with h = D x/dt, and K2S summed h.h only.  b' is
+// sparse (rows next to a Dirichlet cell or with a source), so the rest, sum over its support of b'(2 h + b'), is a
+// gather over a short list: the 8 B/row stream of b' leaves the vector pass.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_rhs_sparse_kernel(int64_t m, const int32_t *__restrict__ idx, const double *__restrict__ bprime,
+                                                                   const double *__restrict__ D, const double *__restrict__ x, double dt,
+                                                                   const PcgScalars *__restrict__ scal, double *__restrict__ part)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    double acc = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; k < m; k += vec_stride()) {
+        const int32_t i = idx[k];
+        const double bi = bprime[i];
+        acc += bi * (2.0 * (D[i] * (x[i] / dt)) + bi);
+    }
+    const double t = block_sum(acc, smem);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void nonzero_flag_kernel(int64_t n, const double *__restrict__ v, int32_t *__restrict__ flag)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        flag[i] = v[i] != 0.0;
+}
+
+// support of the assembled b (rebuilt after every fv_assemble); *count < 0: b is not sparse enough to bother
+static int ensure_b_support(fv_problem *p, int64_t *count)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->bnz_epoch != p->assemble_epoch) {
+        DevBuf<int32_t> flag;
+        FV_TRY(flag.alloc(ctx, (size_t)p->n));
+        hipLaunchKernelGGL(nonzero_flag_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->b.p, flag.p);
+        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(p->bnz_idx.alloc(ctx, (size_t)p->n));
+        FV_TRY(fv_compact_flags(ctx, flag.p, p->n, p->bnz_idx.p, &p->bnz_count));
+        p->bnz_epoch = p->assemble_epoch;
+    }
+    *count = (p->bnz_count * 8 <= p->n) ? p->bnz_count : -1;
+    return FV_OK;
+}
+
 // K3.  UNSPEC: the K2 before it was pcg_update_spec_kernel and the step did not converge there: r carries the next
 // step's D (x_out - x_in)/dt term, which is taken out again here (same expression, same operands).
 template <bool UNSPEC>
@@ -375,7 +421,7 @@ int fv_pcg_prepare(fv_problem *p)
     FV_TRY(p->part_pq.alloc(ctx, 4 * FV_MAX_PARTIALS)); // distributed: interior + boundary pass, each DIA + CSR
     FV_TRY(p->part_rz.alloc(ctx, 2 * FV_MAX_PARTIALS));
     FV_TRY(p->part_rr.alloc(ctx, 2 * FV_MAX_PARTIALS));
-    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_MAX_PARTIALS));
+    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_MAX_PARTIALS + 64)); // + the pieces of pcg_rhs_sparse_kernel behind the speculative half
     FV_TRY(p->scal.alloc(ctx, 1));
     FV_TRY(p->scal.zero(ctx));
     FV_TRY(p->pvec.zero(ctx));
@@ -419,8 +465,15 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->precond == FV_PRECOND_JACOBI && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+    // K2S without the b' stream when b' (the assembled b) is sparse: its share of rhs.rhs comes from a gather over its support
+    int64_t bsupport = -1;
+    if (speculate && g_sparse_b && sys.rhs == p->b.p)
+        FV_TRY(ensure_b_support(p, &bsupport));
+    const int Gs = bsupport > 0 ? (int)((bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) < 64 ? (bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) : 64) : 0;
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
+    int in_nbb = -1;
     if (use_spec) {
+        in_nbb = Gv + p->spec_extra_bb;
         std::swap(p->pvec.p, p->pnext.p);
         std::swap(p->pvec.n, p->pnext.n);
         in_rz += FV_MAX_PARTIALS;
@@ -468,7 +521,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p);
+    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p, in_nbb);
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = 0;
@@ -510,11 +563,18 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_PROF(1);
             FV_PROF(2);
             const bool spec = iter == 0 && speculate;
-            if (spec)
+            if (spec) {
                 hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
-                                   sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p, p->pnext.p,
-                                   p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS, p->part_bb.p + FV_MAX_PARTIALS);
+                                   bsupport >= 0 ? (const double *)nullptr : sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p,
+                                   p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS,
+                                   p->part_bb.p + FV_MAX_PARTIALS);
+                if (Gs > 0)
+                    hipLaunchKernelGGL(pcg_rhs_sparse_kernel, dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, bsupport, (const int32_t *)p->bnz_idx.p,
+                                       (const double *)p->b.p, (const double *)p->D.p, (const double *)sys.x_next, sys.dt,
+                                       (const PcgScalars *)p->scal.p, p->part_bb.p + FV_MAX_PARTIALS + Gv);
+                p->spec_extra_bb = Gs;
+            }
             else if (iter == 0 && sys.x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)x, sys.x_next,
                                    p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);

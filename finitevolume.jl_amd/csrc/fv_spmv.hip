@@ -266,6 +266,7 @@ static int g_march = 1;      // plane-marching sliced-DIA kernel on structured g
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
+extern int g_sparse_b;                         // fv_pcg.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -293,6 +294,8 @@ extern "C" int fv_tune(int key, int value)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))
         g_dia_packed = value;
+    else if (key == 12 && (value == 0 || value == 1))
+        g_sparse_b = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
