@@ -40,3 +40,4 @@ from .transient import (  # noqa: F401
     fixedbackwardeulerstep,
     scalebyvolume,
 )
+from . import meshio  # noqa: F401,E402

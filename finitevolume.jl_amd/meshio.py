@@ -1,0 +1,57 @@
+"""Mesh ingestion for the reference's DFN workflow (host-side glue, as in the reference:
+/root/reference/examples/fractures/setupmesh.jl:3-47).  PFLOTRAN "unstructured explicit" grids (.uge):
+
+    CELLS <n>
+    <id> <x> <y> <z> <volume>            (n lines)
+    CONNECTIONS <m>
+    <id1> <id2> <x> <y> <z> <area>       (m lines; x y z = face centre)
+
+give everything the solver wants: neighbours, areas/lengths (length = distance between the two cell centres,
+setupmesh.jl:42-43) and — unlike the mesh.jld the reference saves — the cell volumes the transient path needs."""
+import numpy as np
+
+
+def read_uge(path):
+    """-> dict(xs, ys, zs, volumes, node1, node2, areas, areasoverlengths); node indices 1-based int64."""
+    with open(path) as f:
+        head = f.readline().split()
+        if len(head) < 2 or head[0].upper() != "CELLS":
+            raise ValueError("%s: expected 'CELLS <n>' on the first line" % path)
+        ncells = int(head[1])
+        cells = np.loadtxt(f, dtype=np.float64, max_rows=ncells, ndmin=2)
+        if cells.shape != (ncells, 5):
+            raise ValueError("%s: expected %d cell lines of 5 columns, got %s" % (path, ncells, cells.shape))
+        head = f.readline().split()
+        if len(head) < 2 or head[0].upper() != "CONNECTIONS":
+            raise ValueError("%s: expected 'CONNECTIONS <m>' after the cells" % path)
+        nconn = int(head[1])
+        conn = np.loadtxt(f, dtype=np.float64, max_rows=nconn, ndmin=2)
+        if conn.shape[0] != nconn or conn.shape[1] < 6:
+            raise ValueError("%s: expected %d connection lines of 6 columns, got %s" % (path, nconn, conn.shape))
+    ids = cells[:, 0].astype(np.int64)
+    if not np.array_equal(ids, np.arange(1, ncells + 1)):
+        raise ValueError("%s: cell ids must run 1..n in order" % path)
+    xs, ys, zs, volumes = cells[:, 1].copy(), cells[:, 2].copy(), cells[:, 3].copy(), cells[:, 4].copy()
+    node1, node2 = conn[:, 0].astype(np.int64), conn[:, 1].astype(np.int64)
+    if nconn and (min(node1.min(), node2.min()) < 1 or max(node1.max(), node2.max()) > ncells):
+        raise ValueError("%s: connection refers to a cell outside 1..%d" % (path, ncells))
+    areas = conn[:, -1].copy()  # connectiondata[:, end], setupmesh.jl:41
+    a, b = node1 - 1, node2 - 1
+    lengths = np.sqrt((xs[a] - xs[b]) ** 2 + (ys[a] - ys[b]) ** 2 + (zs[a] - zs[b]) ** 2)
+    return dict(xs=xs, ys=ys, zs=zs, volumes=volumes, node1=node1, node2=node2, areas=areas, areasoverlengths=areas / lengths)
+
+
+def fracture_conductivities(node1, node2, fractureconductivities, fractureindices):
+    """Per-connection conductivity = geometric mean of the two cells' fracture conductivities (setupmesh.jl:36-39).
+    fractureindices: 1-based fracture id per cell; fractureconductivities: one value per fracture."""
+    k = np.asarray(fractureconductivities, dtype=np.float64)
+    fi = np.asarray(fractureindices, dtype=np.int64)
+    n1, n2 = np.asarray(node1, dtype=np.int64), np.asarray(node2, dtype=np.int64)
+    return np.sqrt(k[fi[n1 - 1] - 1] * k[fi[n2 - 1] - 1])
+
+
+def dirichlet_from_predicate(xs, ys, zs, isdirichletnode, dirichlethead):
+    """dirichletnodes (1-based) and heads from the two closures setupmesh.jl:45-46 takes."""
+    nodes = np.array([i + 1 for i in range(len(xs)) if isdirichletnode(xs[i], ys[i], zs[i])], dtype=np.int64)
+    heads = np.array([dirichlethead(xs[i - 1], ys[i - 1], zs[i - 1]) for i in nodes], dtype=np.float64)
+    return nodes, heads

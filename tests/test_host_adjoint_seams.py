@@ -73,3 +73,36 @@ def test_integratedfdplambda_rejects_plain_conductivity(fv):
 
     with pytest.raises(Exception, match="not supported"):
         fv.integratedfdplambda(lambda t: np.zeros(2), np.zeros(4), [np.zeros(1)] * 2, [0.0, 1.0], (0.0, 1.0), 1.0, np.ones(2), np.array([[1, 2]]), np.ones(1), np.ones(1), np.zeros(2), np.array([1]), np.zeros(1), None, False)
+
+
+def test_uge_mesh_reader_roundtrip(fv, tmp_path):
+    """examples/fractures/setupmesh.jl:3-47: CELLS / CONNECTIONS of a .uge file -> neighbours, areas / centre distances,
+    volumes; conductivities as the geometric mean of the two cells' fracture values."""
+    xs = np.array([0.0, 1.0, 1.0, 3.0])
+    ys = np.array([0.0, 0.0, 2.0, 2.0])
+    zs = np.array([0.0, 0.0, 0.0, 1.0])
+    vol = np.array([0.5, 0.25, 2.0, 1.0])
+    conn = [(1, 2, 0.5, 0.0, 0.0, 0.3), (2, 3, 1.0, 1.0, 0.0, 0.7), (3, 4, 2.0, 2.0, 0.5, 1.1)]
+    path = tmp_path / "full_mesh_vol_area.uge"
+    with open(path, "w") as f:
+        f.write("CELLS 4\n")
+        for i in range(4):
+            f.write("%d %.17g %.17g %.17g %.17g\n" % (i + 1, xs[i], ys[i], zs[i], vol[i]))
+        f.write("CONNECTIONS 3\n")
+        for c in conn:
+            f.write("%d %d %.17g %.17g %.17g %.17g\n" % c)
+    m = fv.meshio.read_uge(str(path))
+    assert m["node1"].tolist() == [1, 2, 3] and m["node2"].tolist() == [2, 3, 4]
+    assert np.array_equal(m["volumes"], vol) and np.array_equal(m["xs"], xs)
+    want = np.array([0.3 / 1.0, 0.7 / 2.0, 1.1 / np.sqrt(4.0 + 0.0 + 1.0)])
+    assert np.allclose(m["areasoverlengths"], want, rtol=1e-15)
+    k = fv.meshio.fracture_conductivities(m["node1"], m["node2"], [1e-12, 4e-12], [1, 1, 2, 2])
+    assert np.allclose(k, [1e-12, 2e-12, 4e-12], rtol=1e-15)
+    dn, dh = fv.meshio.dirichlet_from_predicate(xs, ys, zs, lambda x, y, z: x == 0.0 or x == 3.0, lambda x, y, z: 2e6 if x < 1 else 1e6)
+    assert dn.tolist() == [1, 4] and dh.tolist() == [2e6, 1e6]
+    import pytest
+
+    with open(path, "w") as f:
+        f.write("CELLS 1\n1 0 0 0 1\nCONNECTIONS 1\n1 2 0 0 0 1\n")
+    with pytest.raises(ValueError, match="outside"):
+        fv.meshio.read_uge(str(path))
