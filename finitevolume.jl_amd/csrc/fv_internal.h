@@ -98,7 +98,9 @@ struct PcgScalars {
     double bnorm2; // ||b||^2
     double pq;     // last p.Ap (diagnostic)
     int32_t iters;
-    int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN)
+    int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN), 3 a chain of unpolled one-iteration steps broke here
+    int32_t chain_step; // done == 3: index (within the burst) of the step that needs more than its one iteration
+    int32_t pad_;
 };
 
 // Plan and buffers of a row block in a distributed run (built by fv_dist_setup).
@@ -255,9 +257,15 @@ struct PcgSystem {
     // speculate: the first K2 of this step may also prepare the next step's set-up (pcg_update_spec_kernel) when the
     // previous solve took one iteration; use_spec: start from such a prepared set-up if the previous solve left one.
     bool speculate = false, use_spec = false;
+    // Bursts of one-iteration steps (fixed-dt runs): chain_index >= 0 enqueues this step (speculative set-up, K1, K2S, K3)
+    // WITHOUT polling the device; a step whose one iteration does not converge sets done = 3 and everything enqueued
+    // behind it turns into no-ops.  resume_it > 0 continues such a step from its iteration resume_it (no set-up).
+    int chain_index = -1;
+    int resume_it = 0;
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
+int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
                    int *npartials = nullptr);

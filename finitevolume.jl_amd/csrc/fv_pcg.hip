@@ -21,6 +21,7 @@
 
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
+int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index is treated as not converged, once
 
 // ------------------------------------------------------------------ PCG vector kernels
 
@@ -136,9 +137,11 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, con
 __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const double *__restrict__ part_rz,
                                                                       const double *__restrict__ part_rr,
                                                                       const double *__restrict__ part_bb, int nparts, double rtol,
-                                                                      PcgScalars *__restrict__ scal, int nparts_bb = -1)
+                                                                      PcgScalars *__restrict__ scal, int nparts_bb = -1, int chained = 0)
 {
     __shared__ double smem[4];
+    if (chained && scal->done != 1)
+        return; // the step before this one (not polled by the host) did not converge in its one iteration: the chain stops
     const double rz = reduce_partials(part_rz, nparts, smem);
     const double rr = reduce_partials(part_rr, nparts, smem);
     const double bb = reduce_partials(part_bb, nparts_bb >= 0 ? nparts_bb : nparts, smem); // rhs.rhs may come in more pieces (sparse b part)
@@ -355,7 +358,8 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
                                                                 double *__restrict__ pv, const double *__restrict__ part_rz,
                                                                 const double *__restrict__ part_rr, int nparts, PcgScalars *__restrict__ scal,
                                                                 double *__restrict__ hist, int64_t hist_cap, const double *__restrict__ xin,
-                                                                const double *__restrict__ xout, const double *__restrict__ D, double dt)
+                                                                const double *__restrict__ xout, const double *__restrict__ D, double dt,
+                                                                int chain_index = -1, int force_unconverged = 0)
 {
     __shared__ double smem[4];
     if (scal->done)
@@ -363,7 +367,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     const double rzn = reduce_partials(part_rz, nparts, smem);
     const double rrn = reduce_partials(part_rr, nparts, smem);
     const double beta = rzn / scal->rz[it & 1];
-    const bool converged = rrn <= scal->tol2; // same value in every block: the search direction is not needed any more
+    // same value in every block: the search direction is not needed any more (force_unconverged: fault injection for the
+    // chained-step tests, fv_tune key 14 — constant forcing never makes a later step need MORE iterations by itself)
+    const bool converged = rrn <= scal->tol2 && !force_unconverged;
     const int64_t n2 = converged ? 0 : (n >> 1);
     double2 *r2 = reinterpret_cast<double2 *>(r);
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
@@ -402,6 +408,10 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
             hist[it] = sqrt(rrn);
         if (converged)
             scal->done = 1;
+        else if (chain_index >= 0) { // unpolled chain: stop here; the host resumes this step at iteration it + 1
+            scal->done = 3;
+            scal->chain_step = chain_index;
+        }
     }
 }
 
@@ -457,11 +467,17 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     int Ginit = Gv; // number of per-block partials the set-up produced
+    const bool chained = sys.chain_index >= 0; // caller guarantees: spec_valid, speculation on, Jacobi, one-iteration regime
+    const bool resume = sys.resume_it > 0;
     // speculative set-up left behind by the previous step's K2S (pcg_update_spec_kernel): r, p' and the partials are ready
-    const bool use_spec = sys.use_spec && p->spec_valid && sys.implicit_step && !compute_minv;
+    const bool use_spec = !resume && sys.use_spec && p->spec_valid && sys.implicit_step && !compute_minv;
     p->spec_valid = false;
+    if (chained && !use_spec) {
+        fv_set_error(ctx, "internal: chained step without a prepared set-up");
+        return FV_ERR_STATE;
+    }
     // ... and whether this step's first K2 should prepare the next step the same way
-    const bool speculate = sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
+    const bool speculate = !resume && sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
                            p->precond == FV_PRECOND_JACOBI && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
@@ -472,7 +488,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     const int Gs = bsupport > 0 ? (int)((bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) < 64 ? (bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) : 64) : 0;
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
-    if (use_spec) {
+    if (resume) {
+        // nothing to set up: r, p and the scalars are those of the interrupted solve
+    } else if (use_spec) {
         in_nbb = Gv + p->spec_extra_bb;
         std::swap(p->pvec.p, p->pnext.p);
         std::swap(p->pvec.n, p->pnext.n);
@@ -521,10 +539,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p, in_nbb);
+    if (!resume)
+        hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p, in_nbb,
+                           chained && sys.chain_index > 0 ? 1 : 0);
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
-    int64_t it = 0;
+    int64_t it = resume ? sys.resume_it : 0;
     constexpr int64_t MAX_CHUNK = 32;
     bool polled = false;
     if (p->precond == FV_PRECOND_AMG) {
@@ -542,6 +562,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
     if (chunk > MAX_CHUNK)
         chunk = MAX_CHUNK;
+    if (chained) {
+        chunk = 1;
+        maxiter = 1;
+    }
+    const int64_t kprof = chained ? sys.chain_index : 0; // profiling slots of this launch set
     if (p->profile && p->prof_ev.empty()) {
         p->prof_ev.resize((size_t)(6 * MAX_CHUNK));
         for (hipEvent_t &e : p->prof_ev)
@@ -549,7 +574,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
 #define FV_PROF(idx)                                                                                            \
     if (p->profile)                                                                                             \
-    FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * k + (idx))], ctx->stream))
+    FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         int32_t iters_before = 0;
@@ -587,7 +612,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
-                                   (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt);
+                                   (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt, sys.chain_index,
+                                   (chained && sys.chain_index == g_chain_test_break) ? 1 : 0);
             else
                 hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
@@ -596,6 +622,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         }
         FV_LAUNCH_CHECK(ctx);
         it += m;
+        if (chained) { // the caller polls once per burst (fv_pcg_chain_poll)
+            p->last_iters = 1;
+            p->spec_valid = true;
+            return FV_OK;
+        }
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         polled = true;
@@ -640,6 +671,45 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (hs->done == 2) {
         fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs->pq);
     }
+    return FV_OK;
+}
+
+// After a burst of `nsteps` chained steps: one poll.  *completed = steps that converged in their one iteration; when it is
+// < nsteps, step *completed is interrupted after its first iteration (done flag cleared here so that it can be resumed).
+int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info)
+{
+    fv_ctx *ctx = p->ctx;
+    PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
+    FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int ndone = hs->done == 3 ? hs->chain_step : nsteps;
+    if (p->profile)
+        for (int k = 0; k < nsteps && k <= ndone && k < 32; k++)
+            for (int c = 0; c < 3; c++) {
+                if (c == 2 && k == ndone)
+                    continue; // the p-update of an interrupted step did real work; it is counted when the step resumes
+                float ms = 0.f;
+                FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k + 2 * c)], p->prof_ev[(size_t)(6 * k + 2 * c + 1)]));
+                p->prof_ms[c] += ms;
+                p->prof_launches[c]++;
+            }
+    *completed = ndone;
+    g_chain_test_break = -1;
+    if (hs->done == 3) {
+        p->spec_valid = false;
+        p->last_iters = 2; // at least
+        const int32_t zero = 0;
+        FV_HIP(ctx, hipMemcpyAsync(&p->scal.p->done, &zero, sizeof zero, hipMemcpyHostToDevice, ctx->stream));
+    } else if (info) {
+        info->converged = hs->done == 1;
+        info->iters = hs->iters;
+        info->bnorm = sqrt(hs->bnorm2);
+        info->relres = hs->bnorm2 > 0 ? sqrt(hs->rr / hs->bnorm2) : sqrt(hs->rr);
+        info->solve_ms = 0.0;
+        info->resnorm_len = 0;
+    }
+    if (hs->done == 2)
+        fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs->pq);
     return FV_OK;
 }
 

@@ -266,7 +266,8 @@ static int g_march = 1;      // plane-marching sliced-DIA kernel on structured g
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
-extern int g_sparse_b;                         // fv_pcg.hip
+extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
+extern int g_chain_steps;                      // fv_transient.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -296,6 +297,10 @@ extern "C" int fv_tune(int key, int value)
         g_dia_packed = value;
     else if (key == 12 && (value == 0 || value == 1))
         g_sparse_b = value;
+    else if (key == 13 && value >= 0 && value <= 32)
+        g_chain_steps = value;
+    else if (key == 14 && value >= -1 && value < 32)
+        g_chain_test_break = value;
     else
         return FV_ERR_ARG;
     return FV_OK;

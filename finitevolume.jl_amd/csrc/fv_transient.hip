@@ -278,17 +278,18 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
 
 int g_carry_refresh = 32; // fv_tune key 7: 0 = every step computes its residual with an SpMV
 int g_carry_speculate = 1; // fv_tune key 8: the first K2 of a step also prepares the next step (pcg_update_spec_kernel)
+int g_chain_steps = 8;     // fv_tune key 13: one-iteration steps enqueued per device poll (< 2: poll every step)
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
                      int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
-                     const double *carry_prev = nullptr, bool speculate = false)
+                     const double *carry_prev = nullptr, bool speculate = false, int chain_index = -1, int resume_it = 0)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
         fv_set_error(ctx, "time step must be positive"); // transient.jl:68-70
         return FV_ERR_DT;
     }
-    if (usrc != udst)
+    if (usrc != udst && resume_it == 0)
         FV_HIP(ctx, hipMemcpyAsync(udst, usrc, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     PcgSystem sys;
     sys.sigma = 1.0 / dt;
@@ -299,6 +300,8 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.carry_prev = carry_prev;
     sys.speculate = speculate;              // prepare the next step inside this step's first K2 ...
     sys.use_spec = carry_prev != nullptr;   // ... and start from such a set-up when the residual may be carried
+    sys.chain_index = chain_index;
+    sys.resume_it = resume_it;
     if (mode == FV_STEP_FORWARD) {
         sys.rhs = bhat_dev ? bhat_dev : p->b.p;
         sys.b_times_D = bhat_dev != nullptr;
@@ -372,6 +375,48 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     }
     const double *prev = nullptr; // state the last solve started from, while p->r holds that solve's final residual
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
+        // One-iteration regime: a burst of steps is enqueued without polling the device in between (each step is the
+        // prepared set-up + K1 + K2S + K3; a step that does not converge in its iteration stops the chain on the device).
+        if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
+            int L = 0;
+            while (L < g_chain_steps && L < 32 && s + L + 1 < nsteps && ((s + L) % refresh) != 0)
+                L++;
+            if (L >= 2) {
+                double *snap_u[32], *snap_alt[32];
+                for (int j = 0; j < L && rc == FV_OK; j++) {
+                    snap_u[j] = u;
+                    snap_alt[j] = alt;
+                    rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, true, alt, prev, true, j);
+                    prev = u;
+                    std::swap(u, alt);
+                }
+                int completed = 0;
+                if (rc == FV_OK)
+                    rc = fv_pcg_chain_poll(p, L, &completed, &inf);
+                if (rc != FV_OK)
+                    break;
+                for (int j = 0; j < completed && j < L; j++)
+                    if (iters_per_step)
+                        iters_per_step[s + j] = 1;
+                if (completed < L) { // step `completed` needs more iterations: back to its pointers, resume at iteration 1
+                    u = snap_u[completed];
+                    alt = snap_alt[completed];
+                    if ((L - 1 - completed) & 1) { // direction vectors: undo the swaps of the no-op steps behind it
+                        std::swap(p->pvec.p, p->pnext.p);
+                        std::swap(p->pvec.n, p->pnext.n);
+                    }
+                    rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, true, alt, nullptr, false, -1, 1);
+                    if (iters_per_step)
+                        iters_per_step[s + completed] = inf.iters;
+                    prev = u;
+                    if (rc == FV_OK && inf.iters > 0)
+                        std::swap(u, alt);
+                    s += completed; // + 1 by the loop
+                } else
+                    s += L - 1;
+                continue;
+            }
+        }
         const bool carry = prev != nullptr && (s % refresh) != 0;
         rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,
                        pingpong && g_carry_speculate && s + 1 < nsteps);

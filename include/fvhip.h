@@ -218,7 +218,10 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *   9: plane-marching sliced-DIA SpMV on operators with a plane stride (structured grids) [1]
  *  10: segments per XCD of that kernel, 0 = chosen per operator [0]
  *  11: sliced-DIA values packed (1) or padded to 8 blocks per slice (0); read when the DIA copy is built [1]
- *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support [1] */
+ *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support [1]
+ *  13: one-iteration steps of a fixed-dt run enqueued per device poll (a step that needs more iterations stops the
+ *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
+ *  14: fault injection for the tests of key 13: the chained step with this index is treated as not converged, once [-1] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);

@@ -588,6 +588,26 @@ def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle,
     for key in ((32, 1), (32, 0), (5, 1)):
         assert relerr(heads[key], heads[(0, 0)]) < 1e-11
         assert np.abs(its[key] - base).max() <= 1
+    if schedule == "one_iteration":
+        # bursts of unpolled steps (fv_tune key 13): off, short, long; and a chain broken on the device (fault
+        # injection, key 14: the 4th step of the first burst is treated as not converged and resumed by the host)
+        try:
+            for chain, brk in ((0, -1), (3, -1), (16, -1), (8, 3), (8, 0), (8, 7)):
+                assert lib.fv_tune(13, chain) == 0 and lib.fv_tune(14, brk) == 0
+                p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+                st = p.transient_begin(0.1, vol, u0)
+                a, info, _ = p.run_fixed(st, dts[0], 30, rtol=rtol)
+                b, info, _ = p.run_fixed(st, dts[1], 40, rtol=rtol)
+                assert info.converged and relerr(st.node_values(), ous2[-1]) < HEAD_RTOL, (chain, brk)
+                assert relerr(st.node_values(), heads[(0, 0)]) < 1e-11
+                it = np.r_[a, b]
+                if brk < 0:
+                    assert (it == 1).all()
+                else:
+                    assert (it == 2).sum() == 1 and (it == 1).sum() == 69, (chain, brk, it)
+        finally:
+            lib.fv_tune(13, 8)
+            lib.fv_tune(14, -1)
 
 
 def test_run_fixed_at_steady_state_takes_zero_iterations(fv):
