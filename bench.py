@@ -172,7 +172,8 @@ def main():
         tune = dict(kv.split("=") for kv in os.environ.get("FV_TUNE", "").split(",") if "=" in kv)
         fused = tune.get("7", "32") != "0" and tune.get("8", "1") != "0" and float(np.mean(iters)) == 1.0
         # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel): 7 streams in, 3 out
-        for k, bytes_ in (("update", (80 if fused else 56) * p.n), ("pupdate", 32 * p.n)):
+        fused_bytes = 72 if tune.get("12", "1") != "0" else 80  # the sparse b's share of |rhs|^2 comes from a gather (fv_tune key 12)
+        for k, bytes_ in (("update", (fused_bytes if fused else 56) * p.n), ("pupdate", 32 * p.n)):
             kms, kc = prof[k]
             if kc:
                 kern[k] = {"avg_ms": kms / kc, "launches": kc}
