@@ -368,10 +368,10 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     if (pingpong) {
         if (p->pingpong_slot < 0)
             rc = fv_slot_new(p, &p->pingpong_slot);
-        if (rc == FV_OK) {
-            FV_TRY(slot_ptr(p, slot, &u)); // slot_new may have reallocated the table
+        if (rc == FV_OK)
+            rc = slot_ptr(p, slot, &u); // slot_new may have reallocated the table
+        if (rc == FV_OK)
             alt = p->slots[(size_t)p->pingpong_slot];
-        }
     }
     const double *prev = nullptr; // state the last solve started from, while p->r holds that solve's final residual
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
