@@ -34,13 +34,13 @@ __device__ inline double reduce_partials(const double *__restrict__ part, int co
 
 __device__ inline int64_t vec_stride() { return (int64_t)gridDim.x * FV_BLOCK; }
 
-// grid of the double2 vector kernels: at most FV_MAX_PARTIALS blocks, one partial sum per block
+// grid of the double2 vector kernels: at most FV_VEC_PARTIALS blocks, one partial sum per block
 static inline int vec_grid(int64_t n)
 {
     int64_t g = (n / 2 + FV_BLOCK - 1) / FV_BLOCK;
     if (g < 1)
         g = 1;
-    if (g > FV_MAX_PARTIALS)
-        g = FV_MAX_PARTIALS;
+    if (g > FV_VEC_PARTIALS)
+        g = FV_VEC_PARTIALS;
     return (int)g;
 }

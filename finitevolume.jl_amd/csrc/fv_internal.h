@@ -12,7 +12,11 @@
 #include "fvhip.h"
 
 constexpr int FV_BLOCK = 256;        // 4 waves of 64
-constexpr int FV_MAX_PARTIALS = 2048; // 8 blocks/CU x 256 CUs: one partial per block
+constexpr int FV_MAX_PARTIALS = 2048; // 8 blocks/CU x 256 CUs: one partial per block (SpMV kernels: all blocks resident)
+#ifndef FV_VEC_MAX_BLOCKS
+#define FV_VEC_MAX_BLOCKS 2048
+#endif
+constexpr int FV_VEC_PARTIALS = FV_VEC_MAX_BLOCKS; // blocks (= partial sums) of the streaming vector kernels
 constexpr int FV_VEC_PAD = 32;        // slack behind every vector (double2 tails read past n)
 
 struct fv_ctx {

@@ -429,9 +429,9 @@ int fv_pcg_prepare(fv_problem *p)
     FV_TRY(p->tmp.alloc(ctx, n));
     // two launches (sliced-DIA part + CSR part) may each leave up to FV_MAX_PARTIALS partials
     FV_TRY(p->part_pq.alloc(ctx, 4 * FV_MAX_PARTIALS)); // distributed: interior + boundary pass, each DIA + CSR
-    FV_TRY(p->part_rz.alloc(ctx, 2 * FV_MAX_PARTIALS));
-    FV_TRY(p->part_rr.alloc(ctx, 2 * FV_MAX_PARTIALS));
-    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_MAX_PARTIALS + 64)); // + the pieces of pcg_rhs_sparse_kernel behind the speculative half
+    FV_TRY(p->part_rz.alloc(ctx, 2 * FV_VEC_PARTIALS));
+    FV_TRY(p->part_rr.alloc(ctx, 2 * FV_VEC_PARTIALS));
+    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_VEC_PARTIALS + 64)); // + the pieces of pcg_rhs_sparse_kernel behind the speculative half
     FV_TRY(p->scal.alloc(ctx, 1));
     FV_TRY(p->scal.zero(ctx));
     FV_TRY(p->pvec.zero(ctx));
@@ -494,9 +494,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         in_nbb = Gv + p->spec_extra_bb;
         std::swap(p->pvec.p, p->pnext.p);
         std::swap(p->pvec.n, p->pnext.n);
-        in_rz += FV_MAX_PARTIALS;
-        in_rr += FV_MAX_PARTIALS;
-        in_bb += FV_MAX_PARTIALS;
+        in_rz += FV_VEC_PARTIALS;
+        in_rr += FV_VEC_PARTIALS;
+        in_bb += FV_VEC_PARTIALS;
     } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
         hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
                            (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
@@ -592,12 +592,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    bsupport >= 0 ? (const double *)nullptr : sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p,
-                                   p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS,
-                                   p->part_bb.p + FV_MAX_PARTIALS);
+                                   p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
+                                   p->part_bb.p + FV_VEC_PARTIALS);
                 if (Gs > 0)
                     hipLaunchKernelGGL(pcg_rhs_sparse_kernel, dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, bsupport, (const int32_t *)p->bnz_idx.p,
                                        (const double *)p->b.p, (const double *)p->D.p, (const double *)sys.x_next, sys.dt,
-                                       (const PcgScalars *)p->scal.p, p->part_bb.p + FV_MAX_PARTIALS + Gv);
+                                       (const PcgScalars *)p->scal.p, p->part_bb.p + FV_VEC_PARTIALS + Gv);
                 p->spec_extra_bb = Gs;
             }
             else if (iter == 0 && sys.x_next)
@@ -751,10 +751,10 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_kernel(const double *__res
 static int reduce_to_host(fv_problem *p, int G, double *out_host)
 {
     fv_ctx *ctx = p->ctx;
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, p->part_bb.p, G, p->part_bb.p + (FV_MAX_PARTIALS - 1));
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, p->part_bb.p, G, p->part_bb.p + (FV_VEC_PARTIALS - 1));
     FV_LAUNCH_CHECK(ctx);
     double *h = reinterpret_cast<double *>(ctx->pinned);
-    FV_HIP(ctx, hipMemcpyAsync(h, p->part_bb.p + (FV_MAX_PARTIALS - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipMemcpyAsync(h, p->part_bb.p + (FV_VEC_PARTIALS - 1), sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out_host = *h;
     return FV_OK;
@@ -764,8 +764,8 @@ int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_h
 {
     FV_TRY(fv_pcg_prepare(p));
     int G = vec_grid(p->n);
-    if (G > FV_MAX_PARTIALS - 1)
-        G = FV_MAX_PARTIALS - 1;
+    if (G > FV_VEC_PARTIALS - 1)
+        G = FV_VEC_PARTIALS - 1;
     hipLaunchKernelGGL(dot_kernel, dim3(G), dim3(FV_BLOCK), 0, p->ctx->stream, p->n, a, b, p->part_bb.p);
     FV_LAUNCH_CHECK(p->ctx);
     return reduce_to_host(p, G, out_host);
@@ -775,8 +775,8 @@ int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double
 {
     FV_TRY(fv_pcg_prepare(p));
     int G = vec_grid(p->n);
-    if (G > FV_MAX_PARTIALS - 1)
-        G = FV_MAX_PARTIALS - 1;
+    if (G > FV_VEC_PARTIALS - 1)
+        G = FV_VEC_PARTIALS - 1;
     hipLaunchKernelGGL(diff2_kernel, dim3(G), dim3(FV_BLOCK), 0, p->ctx->stream, p->n, a, b, p->part_bb.p);
     FV_LAUNCH_CHECK(p->ctx);
     double s = 0.0;
@@ -1023,10 +1023,10 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p, p->pnext.p,
-                                   p->part_rz.p + FV_MAX_PARTIALS, p->part_rr.p + FV_MAX_PARTIALS, p->part_bb.p + FV_MAX_PARTIALS);
-                sums.a[2] = p->part_rz.p + FV_MAX_PARTIALS;
-                sums.a[3] = p->part_rr.p + FV_MAX_PARTIALS;
-                sums.a[4] = p->part_bb.p + FV_MAX_PARTIALS;
+                                   p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS, p->part_bb.p + FV_VEC_PARTIALS);
+                sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
+                sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
+                sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;
             } else if (iter == 0 && x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)u, x_next, p->r.p,
                                    p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
