@@ -102,6 +102,7 @@ SIGNATURES = {
     "fv_comm_unique_id": (C.c_int, [C.c_char_p]),
     "fv_comm_init": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p]),
     "fv_comm_destroy": (C.c_int, [c_ctx]),
+    "fv_comm_init_local": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
     "fv_dist_plan_sizes": (C.c_int, [c_prob] + [P(C.c_int64)] * 7),
     "fv_dist_get_plan": (C.c_int, [c_prob] + [_i64p] * 7),

@@ -3,7 +3,11 @@
 // row-partitioned multi-GPU PCG ("Multi-GPU").
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 
 #include "fv_internal.h"
 
@@ -45,6 +49,114 @@ extern "C" int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_
     return FV_OK;
 }
 
+// ------------------------------------------------------------------ loopback transport (one device, several ranks)
+// RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), so a one-GPU box cannot run the multi-rank protocol
+// through it.  For rehearsals and tests, N host threads of ONE process, each with its own context on the same
+// device, can form a local group instead: halos move by device-to-device copies between the ranks' buffers and the
+// scalar reductions are summed on the host in rank order.  Same call sequence, same plan, same kernels as the RCCL
+// path; only the transport differs (and nothing overlaps).  Not meant for production runs.
+namespace {
+struct LocalGroup {
+    int nranks = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    int members = 0;
+    std::vector<const double *> sendbuf;
+    std::vector<const fv_dist *> plan;
+    std::vector<std::vector<double>> red;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t gen = generation;
+        if (++arrived == nranks) {
+            arrived = 0;
+            generation++;
+            cv.notify_all();
+        } else
+            cv.wait(lk, [&] { return generation != gen; });
+    }
+};
+std::mutex g_groups_mutex;
+std::map<int, LocalGroup *> g_groups;
+} // namespace
+
+extern "C" int fv_comm_init_local(fv_ctx *ctx, int nranks, int rank, int group_id)
+{
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks)
+        return FV_ERR_ARG;
+    fv_comm_destroy(ctx);
+    std::lock_guard<std::mutex> lk(g_groups_mutex);
+    LocalGroup *&g = g_groups[group_id];
+    if (!g) {
+        g = new LocalGroup();
+        g->nranks = nranks;
+        g->sendbuf.assign((size_t)nranks, nullptr);
+        g->plan.assign((size_t)nranks, nullptr);
+        g->red.assign((size_t)nranks, std::vector<double>(8, 0.0));
+    }
+    if (g->nranks != nranks) {
+        fv_set_error(ctx, "local group %d was created for %d ranks, not %d", group_id, g->nranks, nranks);
+        return FV_ERR_ARG;
+    }
+    g->members++;
+    ctx->local_group = g;
+    ctx->local_group_id = group_id;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return FV_OK;
+}
+
+static int local_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream)
+{
+    LocalGroup *g = static_cast<LocalGroup *>(ctx->local_group);
+    FV_HIP(ctx, hipStreamSynchronize(stream)); // my packed values are in place
+    g->sendbuf[(size_t)d->rank] = sendbuf;
+    g->plan[(size_t)d->rank] = d;
+    g->barrier();
+    int64_t roff = 0;
+    for (int q = 0; q < d->nranks; q++) {
+        const int64_t rcnt = d->recv_counts[(size_t)q];
+        if (q != d->rank && rcnt > 0) {
+            const fv_dist *dq = g->plan[(size_t)q];
+            int64_t off = 0; // where rank q keeps what it sends to me: its send list is grouped by destination
+            for (int t = 0; t < d->rank; t++)
+                off += dq->send_counts[(size_t)t];
+            if (dq->send_counts[(size_t)d->rank] != rcnt) {
+                fv_set_error(ctx, "loopback halo exchange: rank %d sends %lld values to rank %d, which expects %lld", q,
+                             (long long)dq->send_counts[(size_t)d->rank], d->rank, (long long)rcnt);
+                g->barrier();
+                return FV_ERR_COMM;
+            }
+            FV_HIP(ctx, hipMemcpyAsync(recv_base + roff, g->sendbuf[(size_t)q] + off, (size_t)rcnt * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        roff += rcnt;
+    }
+    FV_HIP(ctx, hipStreamSynchronize(stream));
+    g->barrier(); // nobody repacks before everybody has copied
+    return FV_OK;
+}
+
+static int local_allreduce(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream)
+{
+    LocalGroup *g = static_cast<LocalGroup *>(ctx->local_group);
+    if (count > 8)
+        return FV_ERR_ARG;
+    std::vector<double> &mine = g->red[(size_t)d->rank];
+    FV_HIP(ctx, hipMemcpyAsync(mine.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
+    FV_HIP(ctx, hipStreamSynchronize(stream));
+    g->barrier();
+    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < d->nranks; q++) // rank order: every rank gets the same bits
+        for (int k = 0; k < count; k++)
+            sum[k] += g->red[(size_t)q][(size_t)k];
+    g->barrier(); // everybody has read before anybody overwrites its slot in the next reduction
+    FV_HIP(ctx, hipMemcpyAsync(buf, sum, (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
+    FV_HIP(ctx, hipStreamSynchronize(stream)); // `sum` is on this stack frame
+    return FV_OK;
+}
+
 extern "C" int fv_comm_destroy(fv_ctx *ctx)
 {
     if (!ctx)
@@ -52,6 +164,15 @@ extern "C" int fv_comm_destroy(fv_ctx *ctx)
     if (ctx->comm) {
         (void)ncclCommDestroy((ncclComm_t)ctx->comm);
         ctx->comm = nullptr;
+    }
+    if (ctx->local_group) {
+        std::lock_guard<std::mutex> lk(g_groups_mutex);
+        LocalGroup *g = static_cast<LocalGroup *>(ctx->local_group);
+        if (--g->members == 0) {
+            g_groups.erase(ctx->local_group_id);
+            delete g;
+        }
+        ctx->local_group = nullptr;
     }
     ctx->nranks = 1;
     ctx->rank = 0;
@@ -66,6 +187,8 @@ int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, 
 {
     if (d->nranks <= 1)
         return FV_OK;
+    if (ctx->local_group && ctx->nranks == d->nranks && ctx->rank == d->rank)
+        return local_halo_exchange(ctx, d, sendbuf, recv_base, stream);
     if (!ctx->comm || ctx->nranks != d->nranks || ctx->rank != d->rank) {
         fv_set_error(ctx, "distributed problem (%d ranks) without a matching communicator: call fv_comm_init first", d->nranks);
         return FV_ERR_COMM;
@@ -92,6 +215,8 @@ int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count,
 {
     if (d->nranks <= 1)
         return FV_OK;
+    if (ctx->local_group && ctx->nranks == d->nranks)
+        return local_allreduce(ctx, d, buf, count, stream);
     if (!ctx->comm || ctx->nranks != d->nranks) {
         fv_set_error(ctx, "distributed problem (%d ranks) without a matching communicator: call fv_comm_init first", d->nranks);
         return FV_ERR_COMM;

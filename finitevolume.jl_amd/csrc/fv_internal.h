@@ -32,6 +32,8 @@ struct fv_ctx {
     std::string err;
     // RCCL
     void *comm = nullptr;
+    void *local_group = nullptr; // loopback transport for single-device rehearsals (fv_comm_init_local)
+    int local_group_id = 0;
     int nranks = 1, rank = 0;
 };
 

@@ -23,6 +23,11 @@ def comm_init(ctx, nranks, rank, uid):
     ctx.check(load().fv_comm_init(ctx.handle, int(nranks), int(rank), C.create_string_buffer(uid, _lib.FV_COMM_ID_BYTES)))
 
 
+def comm_init_local(ctx, nranks, rank, group_id=0):
+    """Loopback transport: `nranks` threads of this process, one context each on the same device (rehearsals/tests)."""
+    ctx.check(load().fv_comm_init_local(ctx.handle, int(nranks), int(rank), int(group_id)))
+
+
 def comm_init_from_torch(ctx):
     """Rank 0 creates the RCCL id; torch.distributed (any backend) broadcasts it."""
     import torch.distributed as dist

@@ -231,6 +231,11 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
 int fv_comm_unique_id(char id[FV_COMM_ID_BYTES]);
 int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_COMM_ID_BYTES]);
 int fv_comm_destroy(fv_ctx *ctx);
+/* Loopback transport for rehearsals on ONE device (RCCL refuses two ranks on one GPU): nranks host threads of one
+ * process, each with its own context on the same device, join the group `group_id`; halos then move by device-to-device
+ * copies and the reductions are summed on the host in rank order.  Same plan, kernels and call sequence as the RCCL
+ * path.  Every rank's thread must make the same sequence of distributed calls. */
+int fv_comm_init_local(fv_ctx *ctx, int nranks, int rank, int group_id);
 
 /* Row-block partition for one-process-per-GPU runs (no reference counterpart:
  * FiniteVolume.jl is single-process).  Call on a global problem after fv_assemble

@@ -244,3 +244,33 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
         blk.close()
     finally:
         fv.load().fv_comm_destroy(ctx.handle)
+
+
+def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
+    """The row-block driver with several ranks on one GPU (loopback transport, one host thread per rank): two ranks
+    whose blocks (1.23e6 rows) take the plane-marching interior pass, in the bench's one-iteration regime; and the
+    8-way partition the multi-GPU bench uses, on a small box."""
+    from tests.test_gpu_solve import _run_ranks_in_threads, relerr
+
+    for ns, nranks, schedule, gid in (([64, 200, 200], 2, [(60.0, 12), (3600.0, 3)], 201), ([40, 12, 10], 8, [(3600.0, 5), (2.0**-10, 20)], 208)):
+        mins, maxs = bench.spacing_box(ns)
+        dn, src = bench.box_setup(ns)
+
+        def make_problem(ctx):
+            p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+            K = 1e-5 * np.exp(0.3 * np.random.default_rng(0).standard_normal(p.F))
+            p.assemble(K, src, np.full(len(dn), 1e3))
+            p.transient_begin(0.1, None, np.full(p.N, 1e3) + np.random.default_rng(1).standard_normal(p.N))
+            return p
+
+        ref = make_problem(fv.default_context())
+        st = fv.DeviceVector(ref, 0, owned=False)
+        ref_its = np.concatenate([ref.run_fixed(st, dt, k, 1e-12)[0] for dt, k in schedule])
+        want = st.free_values()
+        ref.close()
+        out = _run_ranks_in_threads(fv, nranks, gid, make_problem, schedule, 1e-12)
+        got = np.empty_like(want)
+        for lo, hi, state, its in out:
+            got[lo:hi] = state
+            assert np.abs(its.astype(int) - ref_its.astype(int)).max() <= 1, (its, ref_its)
+        assert relerr(got, want) < 1e-11, (ns, nranks)

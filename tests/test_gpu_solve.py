@@ -702,3 +702,73 @@ def test_amg_in_implicit_steps_matches_jacobi_steps(fv):
         out[kind] = (st.node_values(), iters)
     assert relerr(out["amg"][0], out["jacobi"][0]) < 1e-9
     assert out["amg"][1].sum() * 3 < out["jacobi"][1].sum()
+
+
+# ------------------------------------------------------------------ multi-rank protocol on one GPU (loopback transport)
+def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol):
+    """One host thread per rank, each with its own context on device 0 and the loopback transport (fv_comm_init_local):
+    the complete row-block driver — plan, pack, halo exchange, interior/boundary passes, reductions, carry-over,
+    speculation — with real kernels; only the wire differs from RCCL."""
+    import threading
+
+    from fvamd import dist
+
+    out, errors = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = fv.Context(0)
+            dist.comm_init_local(ctx, nranks, rank, group_id)
+            p = make_problem(ctx)
+            blk = dist.RowBlock(p, nranks, rank)
+            p.close()
+            its = []
+            for dt, nsteps in schedule:
+                it, info, _ = blk.run_fixed(dt, nsteps, rtol)
+                assert info.converged
+                its.append(it.copy())
+            out[rank] = (blk.lo, blk.hi, blk.state(), np.concatenate(its))
+            blk.close()
+            fv.load().fv_comm_destroy(ctx.handle)
+        except BaseException as e:  # noqa: BLE001  (a failing rank would leave the others waiting at a barrier)
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank did not finish (deadlock in the protocol?)"
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
+    import bench
+
+    ns = [14, 9, 7]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+
+    def make_problem(ctx):
+        p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+        K = 1e-5 * np.exp(np.random.default_rng(0).standard_normal(p.F))
+        p.assemble(K, src, np.full(len(dn), 1e3))
+        u0 = np.full(p.N, 1e3) + np.random.default_rng(1).standard_normal(p.N)
+        p.transient_begin(0.1, None, u0)
+        return p
+
+    # several iterations per step, then the one-iteration regime (speculative set-up, 5-scalar reduction), then a
+    # large step again (the speculation misses)
+    schedule = [(3600.0, 6), (2.0**-10, 40), (3600.0, 3)]
+    ref = make_problem(fv.default_context())
+    st = fv.DeviceVector(ref, 0, owned=False)
+    ref_its = np.concatenate([ref.run_fixed(st, dt, k, 1e-12)[0] for dt, k in schedule])
+    want = st.free_values()
+    out = _run_ranks_in_threads(fv, nranks, 100 + nranks, make_problem, schedule, 1e-12)
+    got = np.empty_like(want)
+    for lo, hi, state, its in out:
+        got[lo:hi] = state
+        assert np.array_equal(its, ref_its), (its, ref_its)  # reductions differ in order only: same iteration counts
+    assert relerr(got, want) < 1e-12
