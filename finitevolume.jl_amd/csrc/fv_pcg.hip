@@ -58,7 +58,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const dou
         double mi;
         if (compute_minv) {
             const double d = D ? diagA[i] + sigma * D[i] : diagA[i];
-            mi = 1.0 / d;
+            mi = d > 0.0 ? 1.0 / d : 0.0; // a free cell without any face has an empty row: leave it where it is (0 * x = b must hold)
             minv[i] = mi;
         } else
             mi = minv[i];

@@ -212,7 +212,10 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
                 bi = rhsv;
                 double mi;
                 if (epi.compute_minv) {
-                    mi = 1.0 / (epi.diagA[row] + epi.sigma * di);
+                    {
+                        const double dd = epi.diagA[row] + epi.sigma * di;
+                        mi = dd > 0.0 ? 1.0 / dd : 0.0;
+                    }
                     epi.minv[row] = mi;
                 } else
                     mi = epi.minv[row];
@@ -660,7 +663,10 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
                 const double ri = epi.q_shifted ? rhs - sum : bi - sum;
                 double mi;
                 if (epi.compute_minv) {
-                    mi = 1.0 / (epi.diagA[row] + epi.sigma * di);
+                    {
+                        const double dd = epi.diagA[row] + epi.sigma * di;
+                        mi = dd > 0.0 ? 1.0 / dd : 0.0;
+                    }
                     epi.minv[row] = mi;
                 } else
                     mi = epi.minv[row];

@@ -772,3 +772,51 @@ def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
         got[lo:hi] = state
         assert np.array_equal(its, ref_its), (its, ref_its)  # reductions differ in order only: same iteration counts
     assert relerr(got, want) < 1e-12
+
+
+def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
+    """AMG set-up on an irregular operator: repeated faces, self-loops (zero contribution), rows of very different
+    length, free nodes whose only neighbours are Dirichlet (no couplings: the smoother alone must solve them), a
+    few thousand rows so that real coarsening happens."""
+    rng = np.random.default_rng(21)
+    N, F = 6000, 26000
+    n1 = rng.integers(1, N - 30, F)  # the last 30 nodes have no face at all
+    n2 = rng.integers(1, N - 30, F)
+    n2[::40] = n1[::40]
+    aol = np.exp(rng.uniform(-3, 3, F))
+    K = np.exp(rng.normal(0.0, 1.0, F))
+    dn = rng.choice(N - 30, 300, replace=False) + 1
+    dh = rng.uniform(0.0, 2.0, 300)
+    src = 1e-2 * rng.standard_normal(N)
+    src[dn - 1] = 0
+    src[N - 30 :] = 0  # the isolated nodes: 0 * x = 0 stays solvable for CG
+    nb = np.stack([n1, n2], 1)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+    A, b = p.csc().toscipy().tocsr(), p.b()
+    deg = np.diff(A.indptr)
+    assert deg.max() > 3 * max(deg[deg > 0].min(), 1)
+    p.set_preconditioner("amg")
+    rows, nnz = p.amg_info()
+    assert len(rows) >= 2 and rows[-1] <= 2048
+    head, res, ch = p.solve_steady(None, 1e-12, 400)
+    assert ch.isconverged
+    live = A.diagonal() > 0
+    r = A @ res - b
+    assert np.linalg.norm(r[live]) <= 1e-10 * np.linalg.norm(b)
+    p.set_preconditioner("jacobi")
+    head_j, res_j, ch_j = p.solve_steady(None, 1e-12, 20000)
+    assert ch_j.isconverged and ch.iters < ch_j.iters
+    assert relerr(res[live], res_j[live]) < 1e-8
+
+
+def test_run_adaptive_degenerate_spans(fv):
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (6, 5, 4), sigma=0.5)
+    N = len(vol)
+    p = fv.Problem.create(nb, aol, N, dn).assemble(K, np.zeros(N), dh)
+    st = p.transient_begin(0.1, vol, np.full(N, 0.25))
+    ts, nsolves, info = p.run_adaptive(st, 3.0, 3.0, dt0=1.0)  # empty span: no step, state untouched
+    assert ts.tolist() == [3.0] and nsolves == 0 and np.array_equal(st.node_values()[~np.isin(np.arange(1, N + 1), dn)], np.full(N - len(dn), 0.25))
+    ts, nsolves, info = p.run_adaptive(st, 0.0, 1e-3, dt0=5.0, atol=1e-4, rtol=1e-12)  # dt0 clipped to the span
+    assert ts[0] == 0.0 and ts[-1] == 1e-3 and nsolves >= 3 and info.converged
+    with pytest.raises(fv.FVError):
+        p.run_adaptive(st, 0.0, 1.0, dt0=0.0)
