@@ -1101,7 +1101,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     const double *prev = nullptr;
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         const bool carry = prev != nullptr && (s % refresh) != 0;
-        rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr, pingpong && g_carry_speculate && s + 1 < nsteps, carry);
+        rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr, pingpong && g_carry_speculate, carry);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
         if (pingpong && rc == FV_OK) {

@@ -379,7 +379,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
         // prepared set-up + K1 + K2S + K3; a step that does not converge in its iteration stops the chain on the device).
         if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
             int L = 0;
-            while (L < g_chain_steps && L < 32 && s + L + 1 < nsteps && ((s + L) % refresh) != 0)
+            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s + L) % refresh) != 0)
                 L++;
             if (L >= 2) {
                 double *snap_u[32], *snap_alt[32];
@@ -419,7 +419,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
         }
         const bool carry = prev != nullptr && (s % refresh) != 0;
         rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,
-                       pingpong && g_carry_speculate && s + 1 < nsteps);
+                       pingpong && g_carry_speculate); // also on the last step: a 2-step warm-up then runs every kernel of the loop
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
         if (pingpong && rc == FV_OK) {
