@@ -743,7 +743,7 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol):
     return out
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 16])  # 16: blocks thinner than a grid plane, i.e. more than two peers per rank
 def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
     import bench
 
