@@ -227,7 +227,7 @@ class Problem:
         ch = ConvergenceHistory(info, hist[: info.resnorm_len].copy() if hist is not None else None)
         return head, res, ch
 
-    PRECONDITIONERS = {"jacobi": 0, "amg": 1}
+    PRECONDITIONERS = {"jacobi": 0, "amg": 1, "auto": 2}
 
     def set_preconditioner(self, kind):
         """"jacobi" (default) or "amg": the aggregation-AMG V-cycle that stands where the reference uses
@@ -415,14 +415,15 @@ def freenodes2nodes(result, sources, dirichletnodes, dirichletheads, ctx=None):
     return head, freenode, n2f
 
 
-def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None, preconditioner="jacobi"):
+def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None, preconditioner="auto"):
     """FiniteVolume.jl:157-165 -> head, ch, A, b, freenode.
 
-    The reference preconditions CG with Ruge-Stuben AMG.  Here the default is the Jacobi-PCG of
-    BASELINE.json's north_star (`maxiter` then counts Jacobi-PCG iterations); preconditioner="amg"
-    selects the aggregation-AMG V-cycle (fv_precond_set), which is what high-contrast or anisotropic
-    steady problems want.  As in the reference, non-convergence is reported through ch.isconverged,
-    not raised."""
+    The reference preconditions CG with Ruge-Stuben AMG.  preconditioner="jacobi": the Jacobi-PCG of
+    BASELINE.json's north_star (`maxiter` counts its iterations); "amg": the aggregation-AMG V-cycle
+    (fv_precond_set); "auto" (default): Jacobi-PCG for min(maxiter/4, 100) iterations — easy problems never
+    pay for a hierarchy — then AMG-PCG from that iterate, the shape of the reference's defaultlinearsolver
+    (transient.jl:50-58), so that the reference's maxiter = 400 keeps converging on high-contrast or anisotropic
+    problems.  As in the reference, non-convergence is reported through ch.isconverged, not raised."""
     p = _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, None, False, ctx)
     if preconditioner != "jacobi":
         p.set_preconditioner(preconditioner)

@@ -932,9 +932,9 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
 // ------------------------------------------------------------------ C ABI
 extern "C" int fv_precond_set(fv_problem *p, int kind)
 {
-    if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG))
+    if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG && kind != FV_PRECOND_AUTO))
         return FV_ERR_ARG;
-    if (kind == FV_PRECOND_AMG && (p->dist || p->nhalo)) {
+    if (kind != FV_PRECOND_JACOBI && (p->dist || p->nhalo)) {
         fv_set_error(p->ctx, "the AMG preconditioner is not available for row blocks of a distributed operator");
         return FV_ERR_STATE;
     }

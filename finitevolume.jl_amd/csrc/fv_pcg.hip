@@ -478,7 +478,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     // ... and whether this step's first K2 should prepare the next step the same way
     const bool speculate = !resume && sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
-                           p->precond == FV_PRECOND_JACOBI && p->last_iters == 1 && maxiter > 0;
+                           p->precond != FV_PRECOND_AMG && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
     // K2S without the b' stream when b' (the assembled b) is sparse: its share of rhs.rhs comes from a gather over its support

@@ -79,7 +79,35 @@ extern "C" int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol
     PcgSystem sys;
     sys.rhs = p->b.p;
     sys.x0_zero = x0_free == nullptr;
-    const int rc = fv_pcg_solve(p, x, sys, rtol, maxiter, &local, true);
+    // FV_PRECOND_AUTO: like the reference's defaultlinearsolver (transient.jl:50-58: plain CG first, the AMG-preconditioned
+    // one from the current iterate if that did not converge) — a quarter of the budget (at most 100 iterations) of
+    // Jacobi-PCG, which settles easy problems without any set-up, then the V-cycle for the rest.
+    const int kind = p->precond;
+    int64_t first_budget = maxiter;
+    if (kind == FV_PRECOND_AUTO) {
+        p->precond = FV_PRECOND_JACOBI;
+        first_budget = maxiter / 4 < 100 ? maxiter / 4 : 100;
+    }
+    int rc = FV_OK;
+    local = fv_solve_info{};
+    if (kind != FV_PRECOND_AUTO || first_budget > 0)
+        rc = fv_pcg_solve(p, x, sys, rtol, first_budget, &local, true);
+    const bool exhausted = local.iters >= first_budget; // stopped by the budget, not by a breakdown
+    if (rc == FV_OK && kind == FV_PRECOND_AUTO && !local.converged && exhausted && maxiter > first_budget) {
+        p->precond = FV_PRECOND_AMG;
+        if (p->hist.p) { // the history continues behind the first phase
+            p->hist.p += local.iters;
+            p->hist_cap -= local.iters;
+        }
+        if (first_budget > 0)
+            sys.x0_zero = false;
+        fv_solve_info second = {};
+        rc = fv_pcg_solve(p, x, sys, rtol, maxiter - first_budget, &second, true);
+        second.iters += local.iters;
+        second.solve_ms += local.solve_ms;
+        local = second;
+    }
+    p->precond = kind;
     p->hist.p = saved_hist;
     p->hist_cap = saved_cap;
     FV_TRY(rc);
@@ -363,7 +391,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     // readable at no extra traffic; every g_carry_refresh steps the residual is recomputed from scratch (b' - A u), which
     // bounds the drift between the carried recurrence residual and the true one.
     const int64_t refresh = g_carry_refresh;
-    const bool pingpong = refresh > 0 && nsteps >= 2 && p->precond == FV_PRECOND_JACOBI;
+    const bool pingpong = refresh > 0 && nsteps >= 2 && p->precond != FV_PRECOND_AMG; // FV_PRECOND_AUTO steps like Jacobi
     double *alt = nullptr;
     if (pingpong) {
         if (p->pingpong_slot < 0)

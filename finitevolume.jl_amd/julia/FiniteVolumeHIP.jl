@@ -185,12 +185,13 @@ end
 
 # solvediffusion, FiniteVolume.jl:157-165.  Jacobi-PCG on the GPU replaces RS-AMG-PCG;
 # `maxiter` therefore counts Jacobi-PCG iterations.  Non-convergence is reported in ch, as in the reference.
-function solvediffusion(neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector; maxiter=400, rtol=sqrt(eps(Float64)), preconditioner=:jacobi)
+function solvediffusion(neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector; maxiter=400, rtol=sqrt(eps(Float64)), preconditioner=:auto)
 	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
 	assemble!(p, conductivities, sources, dirichletheads, nothing, false)
 	# :amg = the aggregation-AMG V-cycle in the seat of AlgebraicMultigrid.ruge_stuben (FiniteVolume.jl:159-161)
-	preconditioner in (:jacobi, :amg) || error("preconditioner must be :jacobi or :amg")
-	check(p.ctx, ccall((:fv_precond_set, libfvhip), Cint, (Ptr{Cvoid}, Cint), p.handle, preconditioner == :amg ? 1 : 0))
+	# :auto = Jacobi-PCG first, then AMG-PCG from that iterate (the shape of defaultlinearsolver, transient.jl:50-58)
+	preconditioner in (:jacobi, :amg, :auto) || error("preconditioner must be :jacobi, :amg or :auto")
+	check(p.ctx, ccall((:fv_precond_set, libfvhip), Cint, (Ptr{Cvoid}, Cint), p.handle, preconditioner == :amg ? 1 : (preconditioner == :auto ? 2 : 0)))
 	head = Array{Float64}(undef, p.N)
 	resnorm = Array{Float64}(undef, max(maxiter, 1))
 	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))

@@ -197,6 +197,9 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * Not available for row blocks of a distributed run. */
 #define FV_PRECOND_JACOBI 0
 #define FV_PRECOND_AMG 1
+/* steady solves: Jacobi-PCG for min(maxiter/4, 100) iterations, then AMG-PCG from that iterate for the rest — the
+ * shape of the reference's defaultlinearsolver (transient.jl:50-58); implicit steps: Jacobi. */
+#define FV_PRECOND_AUTO 2
 int fv_precond_set(fv_problem *p, int kind);
 /* theta: strength threshold of the matching (0.25); omega: Jacobi damping of the smoother (2/3); passes: pairwise
  * passes per level (3 -> aggregates of ~8-10); rounds: handshake rounds per pass (6).  Process-wide. */

@@ -104,7 +104,7 @@ def test_box_steady_heads_vs_direct(fv, oracle, ns, sigma):
 
 def test_steady_maxiter_reports_nonconvergence(fv):
     coords, nb, aol, vol, K, dn, dh = _box(fv, (12, 12, 12), sigma=3.0)
-    head, ch, *_ = fv.solvediffusion(nb, aol, K, np.zeros(len(vol)), dn, dh, maxiter=3, rtol=1e-14)
+    head, ch, *_ = fv.solvediffusion(nb, aol, K, np.zeros(len(vol)), dn, dh, maxiter=3, rtol=1e-14, preconditioner="jacobi")
     assert not ch.isconverged and ch.iters == 3
 
 
@@ -112,7 +112,7 @@ def test_fourfractures_steady_vs_direct_and_pflotran(fv, oracle):
     d = np.load(os.path.join(GOLDEN, "fourfractures.npz"))
     nb = np.stack([d["node1"], d["node2"]], 1)
     src = np.zeros(2106)
-    head, ch, A, b, fn = fv.solvediffusion(nb, d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], maxiter=20000, rtol=1e-13)
+    head, ch, A, b, fn = fv.solvediffusion(nb, d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], maxiter=20000, rtol=1e-13, preconditioner="jacobi")
     assert ch.isconverged
     ohead = oracle.solvediffusion(d["node1"], d["node2"], d["areasoverlengths"], d["conductivities"], src, d["dirichletnodes"], d["dirichletheads"], solver="direct")[0]
     assert relerr(head, ohead) < HEAD_RTOL
@@ -234,7 +234,7 @@ def test_theis_and_thiem(fv, oracle):
     grid = lambda a, b, n: (lambda r: (r[0], r[1][:, 0], r[1][:, 1], r[2], r[3]))(fv.regulargrid(a, b, n))  # noqa: E731
     c = refcases.theis(grid)
     nb = np.stack([c["node1"], c["node2"]], 1)
-    usteady, ch, A, b, freenode = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], maxiter=20000)
+    usteady, ch, A, b, freenode = fv.solvediffusion(nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], maxiter=20000, preconditioner="jacobi")
     solver = fv.DevicePCG(rtol=1e-12, maxiter=2000)
     us, ts = fv.backwardeulerintegrate(c["u0"], c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], atol=c["atol"], dt0=c["dt0"], linearsolver=solver)
     assert ts[-1] == c["tspan"][1]
@@ -658,9 +658,16 @@ def test_amg_preconditioned_solve_matches_direct_and_beats_jacobi(fv, oracle):
     p2 = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh, None, True).set_preconditioner("amg")
     head_b, res_b, ch_b = p2.solve_steady(None, 1e-10, 400)
     assert np.array_equal(res_a, res_b) and np.array_equal(hist, ch_b.data["resnorm"])
-    # the public wrapper
+    # the public wrapper: "amg", and the default "auto" (100 Jacobi iterations, then the V-cycle from that iterate:
+    # one residual history, converged inside the reference's maxiter = 400)
     head_w, ch_w, *_ = fv.solvediffusion(nb, aol, np.exp(K), src, dn, dh, maxiter=400, rtol=1e-10, preconditioner="amg")
     assert ch_w.isconverged and relerr(head_w, ohead) < HEAD_RTOL
+    head_d, ch_d, *_ = fv.solvediffusion(nb, aol, np.exp(K), src, dn, dh, maxiter=400, rtol=1e-10)
+    assert ch_d.isconverged and 100 < ch_d.iters < 400 and relerr(head_d, ohead) < HEAD_RTOL
+    assert len(ch_d.data["resnorm"]) == ch_d.iters and np.isfinite(ch_d.data["resnorm"]).all()
+    assert ch_d.data["resnorm"][-1] <= 1e-10 * np.linalg.norm(p.b()) * 1.0000001
+    _, ch_j400, *_ = fv.solvediffusion(nb, aol, np.exp(K), src, dn, dh, maxiter=400, rtol=1e-10, preconditioner="jacobi")
+    assert not ch_j400.isconverged
 
 
 def test_amg_cycle_is_symmetric_positive_definite(fv):
