@@ -19,9 +19,9 @@
 #include "fv_device.h"
 #include "fv_spmv.h"
 
-extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
+extern int g_carry_refresh, g_carry_speculate, g_chain_steps; // fv_transient.hip
 int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
-int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index is treated as not converged, once
+int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index of every burst is treated as not converged
 
 // ------------------------------------------------------------------ PCG vector kernels
 
@@ -683,7 +683,7 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
     FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int ndone = hs->done == 3 ? hs->chain_step : nsteps;
-    if (p->profile)
+    if (p->profile && !p->prof_ev.empty() && !p->dist)
         for (int k = 0; k < nsteps && k <= ndone && k < 32; k++)
             for (int c = 0; c < 3; c++) {
                 if (c == 2 && k == ndone)
@@ -694,7 +694,6 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
                 p->prof_launches[c]++;
             }
     *completed = ndone;
-    g_chain_test_break = -1;
     if (hs->done == 3) {
         p->spec_valid = false;
         p->last_iters = 2; // at least
@@ -940,11 +939,12 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
 // up to five partial-sum arrays reduced by one launch (block k sums array k into out[k])
 struct SumSet {
     const double *a[5];
+    int extra[5]; // partials beyond the common count (the sparse-b pieces of rhs.rhs)
 };
 __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, int nparts, double *__restrict__ out)
 {
     __shared__ double smem[4];
-    const double t = reduce_partials(set.a[blockIdx.x], nparts, smem);
+    const double t = reduce_partials(set.a[blockIdx.x], nparts + set.extra[blockIdx.x], smem);
     if (threadIdx.x == 0)
         out[blockIdx.x] = t;
 }
@@ -953,7 +953,8 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, i
 // of PcgSystem, same meaning.  All-reduce buffer: red[0] p.q; red[1..2] r.M^-1 r, r.r; red[3] rhs.rhs of a regular
 // set-up, or red[3..5] the next step's r.M^-1 r, r.r, rhs.rhs left by pcg_update_spec_kernel.
 static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info, double *x_next = nullptr,
-                     const double *carry_prev = nullptr, bool speculate_in = false, bool use_spec_in = false)
+                     const double *carry_prev = nullptr, bool speculate_in = false, bool use_spec_in = false, int chain_index = -1,
+                     int resume_it = 0)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
@@ -968,17 +969,28 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     p->minv_sigma = sigma;
     p->minv_epoch = p->assemble_epoch;
     double *red = d->red.p;
-    const bool use_spec = use_spec_in && p->spec_valid && !compute_minv;
+    const bool chained = chain_index >= 0, resume = resume_it > 0; // bursts of unpolled steps, as in fv_pcg_solve
+    const bool use_spec = !resume && use_spec_in && p->spec_valid && !compute_minv;
     p->spec_valid = false;
-    const bool speculate = speculate_in && x_next && !compute_minv && p->last_iters == 1 && maxiter > 0;
+    if (chained && !use_spec) {
+        fv_set_error(ctx, "internal: chained step without a prepared set-up");
+        return FV_ERR_STATE;
+    }
+    const bool speculate = !resume && speculate_in && x_next && !compute_minv && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
-    if (use_spec) {
+    int64_t bsupport = -1; // the block's b is as sparse as the global one: its share of rhs.rhs by a gather (pcg_rhs_sparse_kernel)
+    if (speculate && g_sparse_b)
+        FV_TRY(ensure_b_support(p, &bsupport));
+    const int Gs = bsupport > 0 ? (int)((bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) < 64 ? (bsupport + 4 * FV_BLOCK - 1) / (4 * FV_BLOCK) : 64) : 0;
+    if (resume) {
+        // r, p and the scalars are those of the interrupted solve
+    } else if (use_spec) {
         // r, p' and the all-reduced set-up scalars (red[3..5]) were left by the previous step's K2S
         std::swap(p->pvec.p, p->pnext.p);
         std::swap(p->pvec.n, p->pnext.n);
         hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3), (const double *)(red + 4),
-                           (const double *)(red + 5), 1, rtol, p->scal.p);
+                           (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
         FV_LAUNCH_CHECK(ctx);
     } else {
         if (carry_prev && !compute_minv) {
@@ -1005,10 +1017,14 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         FV_LAUNCH_CHECK(ctx);
     }
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
-    int64_t it = 0;
+    int64_t it = resume ? resume_it : 0;
     int64_t chunk = p->last_iters > 0 ? p->last_iters : 1;
     if (chunk > 32)
         chunk = 32;
+    if (chained) {
+        chunk = 1;
+        maxiter = 1;
+    }
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         for (int64_t k = 0; k < m; k++) {
@@ -1022,11 +1038,17 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             if (spec) {
                 hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
-                                   (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p, p->pnext.p,
-                                   p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS, p->part_bb.p + FV_VEC_PARTIALS);
+                                   bsupport >= 0 ? (const double *)nullptr : (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p,
+                                   p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
+                                   p->part_bb.p + FV_VEC_PARTIALS);
+                if (Gs > 0)
+                    hipLaunchKernelGGL(pcg_rhs_sparse_kernel, dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, bsupport, (const int32_t *)p->bnz_idx.p,
+                                       (const double *)p->b.p, (const double *)p->D.p, (const double *)x_next, dt, (const PcgScalars *)p->scal.p,
+                                       p->part_bb.p + FV_VEC_PARTIALS + Gv);
                 sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
                 sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
                 sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;
+                sums.extra[4] = Gs;
             } else if (iter == 0 && x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)u, x_next, p->r.p,
                                    p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
@@ -1041,7 +1063,8 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
-                                   (const double *)u, (const double *)x_next, (const double *)p->D.p, dt);
+                                   (const double *)u, (const double *)x_next, (const double *)p->D.p, dt, chain_index,
+                                   (chained && chain_index == g_chain_test_break) ? 1 : 0);
             else
                 hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
@@ -1049,6 +1072,11 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             FV_LAUNCH_CHECK(ctx);
         }
         it += m;
+        if (chained) { // polled once per burst by the caller
+            p->last_iters = 1;
+            p->spec_valid = true;
+            return FV_OK;
+        }
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done)
@@ -1100,6 +1128,48 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     double *alt = (pingpong && rc == FV_OK) ? p->slots[(size_t)p->pingpong_slot] : nullptr;
     const double *prev = nullptr;
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
+        // bursts of unpolled one-iteration steps, as in fv_transient_run_fixed: with collectives in every step the host
+        // needs tens of microseconds to enqueue one, which the device would otherwise spend idle after every poll
+        if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
+            int L = 0;
+            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s + L) % refresh) != 0)
+                L++;
+            if (L >= 2) {
+                double *snap_u[32], *snap_alt[32];
+                for (int j = 0; j < L && rc == FV_OK; j++) {
+                    snap_u[j] = u;
+                    snap_alt[j] = alt;
+                    rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, prev, true, true, j);
+                    prev = u;
+                    std::swap(u, alt);
+                }
+                int completed = 0;
+                if (rc == FV_OK)
+                    rc = fv_pcg_chain_poll(p, L, &completed, &inf);
+                if (rc != FV_OK)
+                    break;
+                for (int j = 0; j < completed && j < L; j++)
+                    if (iters_per_step)
+                        iters_per_step[s + j] = 1;
+                if (completed < L) {
+                    u = snap_u[completed];
+                    alt = snap_alt[completed];
+                    if ((L - 1 - completed) & 1) {
+                        std::swap(p->pvec.p, p->pnext.p);
+                        std::swap(p->pvec.n, p->pnext.n);
+                    }
+                    rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, nullptr, false, false, -1, 1);
+                    if (iters_per_step)
+                        iters_per_step[s + completed] = inf.iters;
+                    prev = u;
+                    if (rc == FV_OK && inf.iters > 0)
+                        std::swap(u, alt);
+                    s += completed;
+                } else
+                    s += L - 1;
+                continue;
+            }
+        }
         const bool carry = prev != nullptr && (s % refresh) != 0;
         rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr, pingpong && g_carry_speculate, carry);
         if (iters_per_step)

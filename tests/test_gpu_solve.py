@@ -603,8 +603,8 @@ def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle,
                 it = np.r_[a, b]
                 if brk < 0:
                     assert (it == 1).all()
-                else:
-                    assert (it == 2).sum() == 1 and (it == 1).sum() == 69, (chain, brk, it)
+                else:  # every burst breaks at that index: some steps take a second iteration, nothing else changes
+                    assert set(np.unique(it)) == {1, 2} and 2 <= (it == 2).sum() <= 35, (chain, brk, it)
         finally:
             lib.fv_tune(13, 8)
             lib.fv_tune(14, -1)
@@ -778,6 +778,17 @@ def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
     for lo, hi, state, its in out:
         got[lo:hi] = state
         assert np.array_equal(its, ref_its), (its, ref_its)  # reductions differ in order only: same iteration counts
+    assert relerr(got, want) < 1e-12
+    # the bursts of unpolled steps break (fault injection) at the same place on every rank and are resumed
+    lib = fv.load()
+    try:
+        lib.fv_tune(14, 2)
+        out = _run_ranks_in_threads(fv, nranks, 300 + nranks, make_problem, schedule, 1e-12)
+    finally:
+        lib.fv_tune(14, -1)
+    for lo, hi, state, its in out:
+        got[lo:hi] = state
+        assert np.array_equal(its, out[0][3]) and (its[6:46] == 2).sum() >= 2 and set(np.unique(its[6:46])) == {1, 2}
     assert relerr(got, want) < 1e-12
 
 
