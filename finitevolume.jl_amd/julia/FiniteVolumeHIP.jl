@@ -183,8 +183,9 @@ function freenodes2nodes(result, sources, dirichletnodes, dirichletheads)
 	return head, freenode, nodei2freenodei
 end
 
-# solvediffusion, FiniteVolume.jl:157-165.  Jacobi-PCG on the GPU replaces RS-AMG-PCG;
-# `maxiter` therefore counts Jacobi-PCG iterations.  Non-convergence is reported in ch, as in the reference.
+# solvediffusion, FiniteVolume.jl:157-165.  The reference's RS-AMG-PCG becomes, by default, Jacobi-PCG for up to 100
+# iterations followed by PCG with an aggregation-AMG V-cycle from that iterate (`maxiter` counts both phases).
+# Non-convergence is reported in ch, as in the reference.
 function solvediffusion(neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector; maxiter=400, rtol=sqrt(eps(Float64)), preconditioner=:auto)
 	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
 	assemble!(p, conductivities, sources, dirichletheads, nothing, false)
