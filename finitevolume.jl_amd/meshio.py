@@ -55,3 +55,45 @@ def dirichlet_from_predicate(xs, ys, zs, isdirichletnode, dirichlethead):
     nodes = np.array([i + 1 for i in range(len(xs)) if isdirichletnode(xs[i], ys[i], zs[i])], dtype=np.int64)
     heads = np.array([dirichlethead(xs[i - 1], ys[i - 1], zs[i - 1]) for i in nodes], dtype=np.float64)
     return nodes, heads
+
+
+def locality_order(node1, node2, N):
+    """A node order that puts connected cells next to each other (reverse Cuthill-McKee of the connectivity graph).
+    DFN meshes often number the cells of a fracture in an order unrelated to their position; every x element the SpMV
+    gathers is then its own cache line and the kernel runs at a third of its rate on a well-ordered mesh.  The solver
+    keeps whatever order it is given (its exports are checked index for index against the reference), so re-ordering
+    is a pre-processing step, like the rest of this module: returns `order` (new position -> old node, 1-based) and
+    `rank` (old node -> new position, 1-based)."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    a = np.asarray(node1, dtype=np.int64) - 1
+    b = np.asarray(node2, dtype=np.int64) - 1
+    keep = a != b
+    g = sp.coo_matrix((np.ones(int(keep.sum()), np.int8), (a[keep], b[keep])), shape=(N, N)).tocsr()
+    g = (g + g.T).tocsr()
+    order0 = np.asarray(reverse_cuthill_mckee(g, symmetric_mode=True), dtype=np.int64)
+    rank0 = np.empty(N, np.int64)
+    rank0[order0] = np.arange(N)
+    return order0 + 1, rank0 + 1
+
+
+def reorder_mesh(mesh, rank):
+    """The mesh dict of read_uge (or any dict with node1/node2 and per-node arrays) renumbered by `rank` (old -> new,
+    1-based).  Faces keep their order (so per-face arrays stay valid) but are re-oriented to first < second, as the
+    reference's meshes list them; per-node arrays (length N) are permuted; `dirichletnodes` are renamed."""
+    rank = np.asarray(rank, dtype=np.int64)
+    N = len(rank)
+    out = dict(mesh)
+    n1, n2 = rank[np.asarray(mesh["node1"], dtype=np.int64) - 1], rank[np.asarray(mesh["node2"], dtype=np.int64) - 1]
+    out["node1"], out["node2"] = np.minimum(n1, n2), np.maximum(n1, n2)
+    order = np.empty(N, np.int64)
+    order[rank - 1] = np.arange(N)
+    for k, v in mesh.items():
+        if k in ("node1", "node2"):
+            continue
+        if k in ("dirichletnodes", "dnodes"):
+            out[k] = rank[np.asarray(v, dtype=np.int64) - 1]
+        elif isinstance(v, np.ndarray) and v.ndim == 1 and len(v) == N:
+            out[k] = v[order]
+    return out

@@ -838,3 +838,17 @@ def test_run_adaptive_degenerate_spans(fv):
     assert ts[0] == 0.0 and ts[-1] == 1e-3 and nsolves >= 3 and info.converged
     with pytest.raises(fv.FVError):
         p.run_adaptive(st, 0.0, 1.0, dt0=0.0)
+
+
+def test_reordered_mesh_gives_the_same_heads(fv):
+    """meshio.locality_order is a renaming of the cells: heads of the re-ordered problem, mapped back, are the heads."""
+    from tests import workloads
+
+    w = workloads.fractures_like(4, 50, seed=2)
+    order, rank = fv.meshio.locality_order(w["node1"], w["node2"], w["N"])
+    m = fv.meshio.reorder_mesh(dict(node1=w["node1"], node2=w["node2"], aol=w["aol"], volumes=w["volumes"], dnodes=w["dnodes"], dheads=w["dheads"]), rank)
+    src = np.zeros(w["N"])
+    h0, ch0, *_ = fv.solvediffusion(np.stack([w["node1"], w["node2"]], 1), w["aol"], w["K"], src, w["dnodes"], w["dheads"], maxiter=20000, rtol=1e-13, preconditioner="jacobi")
+    h1, ch1, *_ = fv.solvediffusion(np.stack([m["node1"], m["node2"]], 1), m["aol"], w["K"], src, m["dnodes"], m["dheads"], maxiter=20000, rtol=1e-13, preconditioner="jacobi")
+    assert ch0.isconverged and ch1.isconverged
+    assert relerr(h1[rank - 1], h0) < 1e-9

@@ -106,3 +106,20 @@ def test_uge_mesh_reader_roundtrip(fv, tmp_path):
         f.write("CELLS 1\n1 0 0 0 1\nCONNECTIONS 1\n1 2 0 0 0 1\n")
     with pytest.raises(ValueError, match="outside"):
         fv.meshio.read_uge(str(path))
+
+
+def test_locality_order_and_reorder_mesh(fv):
+    """meshio.locality_order / reorder_mesh: a permutation (RCM) that brings connected cells together, faces kept in
+    order and re-oriented first < second, per-node arrays permuted, Dirichlet nodes renamed."""
+    from tests import workloads
+
+    w = workloads.fractures_like(3, 40, seed=1)
+    order, rank = fv.meshio.locality_order(w["node1"], w["node2"], w["N"])
+    assert sorted(order.tolist()) == list(range(1, w["N"] + 1)) and np.array_equal(rank[order - 1], np.arange(1, w["N"] + 1))
+    m = fv.meshio.reorder_mesh(dict(node1=w["node1"], node2=w["node2"], aol=w["aol"], volumes=w["volumes"], dnodes=w["dnodes"], dheads=w["dheads"]), rank)
+    assert (m["node1"] < m["node2"]).all() and np.array_equal(m["aol"], w["aol"]) and np.array_equal(m["dheads"], w["dheads"])
+    assert np.array_equal(m["dnodes"], rank[w["dnodes"] - 1])
+    assert np.array_equal(m["volumes"][rank - 1], w["volumes"])  # new position of old node i holds its volume
+    assert np.array_equal(np.sort(np.stack([m["node1"], m["node2"]], 1), 1), np.sort(np.stack([rank[w["node1"] - 1], rank[w["node2"] - 1]], 1), 1))
+    spread = lambda a, b: np.abs(a - b).mean()  # noqa: E731
+    assert spread(m["node1"], m["node2"]) < 0.25 * spread(w["node1"], w["node2"])
