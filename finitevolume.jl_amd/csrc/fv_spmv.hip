@@ -272,6 +272,16 @@ extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
 extern int g_chain_steps;                      // fv_transient.hip
 
+// blocks that are all resident at 8 waves per SIMD: 8 per CU (2048 on the 256-CU MI355X; fewer on a partitioned device)
+static int g_resident_blocks = FV_MAX_PARTIALS;
+static void set_resident_blocks(const fv_ctx *ctx)
+{
+    int64_t b = (int64_t)ctx->num_cus * 8 / 8 * 8;
+    if (b < 8)
+        b = 8;
+    g_resident_blocks = b > FV_MAX_PARTIALS ? FV_MAX_PARTIALS : (int)b;
+}
+
 extern "C" int fv_tune(int key, int value)
 {
     if (key == 0 && (value == 1 || value == 2))
@@ -438,6 +448,7 @@ static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double si
                             int64_t npos_override = -1, int *grid_out = nullptr)
 {
     fv_ctx *ctx = p->ctx;
+    set_resident_blocks(ctx);
     if (!p->order_built)
         FV_TRY(build_group_order(p));
     int G = fv_spmv_grid(p);
@@ -946,8 +957,8 @@ static int stream_grid(int64_t npos)
     int64_t g = ((npos + 3) / 4 + 7) / 8 * 8; // 4 groups per block and pass, multiple of 8 (XCD shares)
     if (g < 8)
         g = 8;
-    if (g > FV_MAX_PARTIALS)
-        g = FV_MAX_PARTIALS;
+    if (g > g_resident_blocks)
+        g = g_resident_blocks;
     return (int)g;
 }
 
@@ -997,6 +1008,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
                const StepInitEpilogue *epi_in, bool use_done, int *nparts, const GroupSubset *subset)
 {
     fv_ctx *ctx = p->ctx;
+    set_resident_blocks(ctx);
     if (!p->order_built)
         FV_TRY(build_group_order(p));
     if (!p->dia_built)
@@ -1052,8 +1064,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
                 for (int m = 1; m <= 8; m++) {
                     const int64_t items = (int64_t)m * step;
                     int64_t gg = ((items + 3) / 4) * 8;
-                    if (gg > FV_MAX_PARTIALS)
-                        gg = FV_MAX_PARTIALS;
+                    if (gg > g_resident_blocks)
+                        gg = g_resident_blocks;
                     const int64_t waves = gg / 8 * 4;
                     const double eff = (double)items / (double)(((items + waves - 1) / waves) * waves);
                     if (eff > best) {
@@ -1067,8 +1079,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             const int seglen = (int)((nk + 8 * segs_per_xcd - 1) / (8 * segs_per_xcd));
             const int64_t per_xcd = (int64_t)segs_per_xcd * step;
             int64_t g = ((per_xcd + 3) / 4) * 8;
-            if (g > FV_MAX_PARTIALS)
-                g = FV_MAX_PARTIALS;
+            if (g > g_resident_blocks)
+                g = g_resident_blocks;
             GM = (int)g;
 #define FV_MARCH(D_, N_)                                                                                                                      \
     hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
