@@ -939,6 +939,7 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
         return FV_ERR_STATE;
     }
     p->precond = kind;
+    p->auto_steps_amg = false;
     return FV_OK;
 }
 

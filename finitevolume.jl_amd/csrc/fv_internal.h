@@ -96,6 +96,8 @@ inline unsigned fv_blocks(int64_t n, int per_block = FV_BLOCK)
     return (unsigned)(b < 1 ? 1 : b);
 }
 
+constexpr int FV_AUTO_SWITCH_ITERS = 50;
+
 // Device-side PCG scalars (one instance per problem).
 struct PcgScalars {
     double rz[2];  // r.M^-1.r, indexed by iteration parity
@@ -187,6 +189,9 @@ struct fv_problem {
 
     // preconditioner of the PCG: FV_PRECOND_JACOBI (fused into the vector kernels) or FV_PRECOND_AMG (fv_amg.hip)
     int precond = 0;
+    // FV_PRECOND_AUTO in implicit steps: Jacobi until a step needs more than FV_AUTO_SWITCH_ITERS iterations, the AMG
+    // V-cycle from then on (one V-cycle iteration costs ~3 Jacobi-PCG iterations, measured); reset by fv_precond_set.
+    bool auto_steps_amg = false;
     fv_amg *amg = nullptr;
 
     // PCG workspace
@@ -278,6 +283,14 @@ int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, doub
 int fv_spmv_grid(fv_problem *p);
 int fv_dot_device(fv_problem *p, const double *a, const double *b, double *out_host);
 int fv_norm2_diff_device(fv_problem *p, const double *a, const double *b, double *out_host);
+
+// the preconditioner an implicit step / a solve of this problem actually runs with
+inline int fv_step_precond(const fv_problem *p)
+{
+    if (p->precond == FV_PRECOND_AUTO)
+        return p->auto_steps_amg ? FV_PRECOND_AMG : FV_PRECOND_JACOBI;
+    return p->precond;
+}
 
 // ---- fv_amg.hip
 int fv_amg_prepare(fv_problem *p, double sigma);

@@ -478,7 +478,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     // ... and whether this step's first K2 should prepare the next step the same way
     const bool speculate = !resume && sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
-                           p->precond != FV_PRECOND_AMG && p->last_iters == 1 && maxiter > 0;
+                           fv_step_precond(p) != FV_PRECOND_AMG && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
     // K2S without the b' stream when b' (the assembled b) is sparse: its share of rhs.rhs comes from a gather over its support
@@ -547,7 +547,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     int64_t it = resume ? sys.resume_it : 0;
     constexpr int64_t MAX_CHUNK = 32;
     bool polled = false;
-    if (p->precond == FV_PRECOND_AMG) {
+    if ((sys.implicit_step ? fv_step_precond(p) : p->precond) == FV_PRECOND_AMG) {
         if (sys.x_next) {
             fv_set_error(ctx, "fv_pcg_solve: the ping-pong state is a Jacobi-path feature");
             return FV_ERR_STATE;

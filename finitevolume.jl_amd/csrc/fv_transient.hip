@@ -338,7 +338,14 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
         hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 1);
         FV_LAUNCH_CHECK(ctx);
     }
+    if (fv_step_precond(p) == FV_PRECOND_AMG) { // the V-cycle path steps in place: no ping-pong, no carried residual
+        sys.x_next = nullptr;
+        sys.carry_prev = nullptr;
+        sys.speculate = sys.use_spec = false;
+    }
     FV_TRY(fv_pcg_solve(p, udst, sys, rtol, maxiter, info, time_it));
+    if (p->precond == FV_PRECOND_AUTO && !p->auto_steps_amg && info && chain_index < 0 && info->iters > FV_AUTO_SWITCH_ITERS && !p->dist)
+        p->auto_steps_amg = true; // this operator wants the V-cycle (it pays from ~30-50 Jacobi iterations per step)
     if (mode == FV_STEP_ADJOINT) {
         hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 0);
         FV_LAUNCH_CHECK(ctx);
@@ -391,7 +398,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     // readable at no extra traffic; every g_carry_refresh steps the residual is recomputed from scratch (b' - A u), which
     // bounds the drift between the carried recurrence residual and the true one.
     const int64_t refresh = g_carry_refresh;
-    const bool pingpong = refresh > 0 && nsteps >= 2 && p->precond != FV_PRECOND_AMG; // FV_PRECOND_AUTO steps like Jacobi
+    const bool pingpong = refresh > 0 && nsteps >= 2 && fv_step_precond(p) != FV_PRECOND_AMG;
     double *alt = nullptr;
     if (pingpong) {
         if (p->pingpong_slot < 0)
@@ -444,6 +451,13 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                     s += L - 1;
                 continue;
             }
+        }
+        if (fv_step_precond(p) == FV_PRECOND_AMG) { // FV_PRECOND_AUTO switched over (or AMG was chosen): plain in-place steps
+            rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2);
+            if (iters_per_step)
+                iters_per_step[s] = inf.iters;
+            prev = nullptr;
+            continue;
         }
         const bool carry = prev != nullptr && (s % refresh) != 0;
         rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,

@@ -198,7 +198,8 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
 #define FV_PRECOND_JACOBI 0
 #define FV_PRECOND_AMG 1
 /* steady solves: Jacobi-PCG for min(maxiter/4, 100) iterations, then AMG-PCG from that iterate for the rest — the
- * shape of the reference's defaultlinearsolver (transient.jl:50-58); implicit steps: Jacobi. */
+ * shape of the reference's defaultlinearsolver (transient.jl:50-58); implicit steps: Jacobi until one step needs more
+ * than 50 iterations, the V-cycle from the next step on (large time steps). */
 #define FV_PRECOND_AUTO 2
 int fv_precond_set(fv_problem *p, int kind);
 /* theta: strength threshold of the matching (0.25); omega: Jacobi damping of the smoother (2/3); passes: pairwise

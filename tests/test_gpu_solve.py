@@ -701,7 +701,7 @@ def test_amg_in_implicit_steps_matches_jacobi_steps(fv):
     N = len(vol)
     src = np.zeros(N)
     out = {}
-    for kind in ("jacobi", "amg"):
+    for kind in ("jacobi", "amg", "auto"):
         p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh, None, True).set_preconditioner(kind)
         st = p.transient_begin(0.1, vol, np.zeros(N))
         iters, info, _ = p.run_fixed(st, 3.0e4, 6, rtol=1e-12, maxiter=20000)
@@ -709,6 +709,9 @@ def test_amg_in_implicit_steps_matches_jacobi_steps(fv):
         out[kind] = (st.node_values(), iters)
     assert relerr(out["amg"][0], out["jacobi"][0]) < 1e-9
     assert out["amg"][1].sum() * 3 < out["jacobi"][1].sum()
+    # "auto": the first step runs Jacobi-PCG, needs more than 50 iterations, and the V-cycle takes over from the second
+    assert relerr(out["auto"][0], out["jacobi"][0]) < 1e-9
+    assert out["auto"][1][0] == out["jacobi"][1][0] > 50 and (out["auto"][1][1:] <= out["amg"][1][1:] + 1).all()
 
 
 # ------------------------------------------------------------------ multi-rank protocol on one GPU (loopback transport)
