@@ -229,7 +229,8 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     Extra keywords of this build: rtol/maxiter configure the device PCG when
     `linearsolver` is left at its default; keep="last" (high-level methods with constant b) runs the whole
     adaptive integration on the device (fv_transient_run_adaptive) and returns ([u0, u(tfinal)], ts) instead
-    of every intermediate state."""
+    of every intermediate state; preconditioner="jacobi" | "amg" | "auto" (default: Jacobi-PCG until a step needs more
+    than 50 iterations, then PCG with the AMG V-cycle — large time steps)."""
     if "stepper_" in kwargs:
         kwargs["stepper"] = kwargs.pop("stepper_")
     rtol = kwargs.pop("rtol", None)
@@ -248,10 +249,13 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     logt = rest[9] if len(rest) > 9 else False
     dt0 = kwargs.pop("dt0", 1.0)
     keep = kwargs.pop("keep", "all")
+    preconditioner = kwargs.pop("preconditioner", "auto")  # Jacobi-PCG; the AMG V-cycle once a step needs > 50 iterations
     u0 = af64(u0)
     # assembleA + assembleb + scalebyvolume! (transient.jl:157-169) — one device problem
     p = _assembled_problem(neighbors, aol, K, sources, dnodes, dheads, metaindex, logt)
     first = p.transient_begin(Ss, volumes, u0)  # u0[freenodes], transient.jl:170
+    if preconditioner != "jacobi":
+        p.set_preconditioner(preconditioner)
     if keep == "last":
         # the reference stores every outer step on the host (us); at 10^7-10^8 cells that is the cost of the run.
         # keep="last": the default stepper and solver, constant b, entirely on the device -> ([u0, u(tfinal)], ts)
