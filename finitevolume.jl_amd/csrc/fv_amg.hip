@@ -358,6 +358,24 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_smooth_kernel(int64_t n, const d
         x[i] += omega * dinv[i] * (b[i] - t[i]);
 }
 
+// the last smoothing pass of the top level, with the PCG's r.z folded in (b is r, x is z): one partial per block
+__global__ __launch_bounds__(FV_BLOCK) void amg_smooth_dot_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ b,
+                                                                   const double *__restrict__ t, double omega, double *__restrict__ x,
+                                                                   double *__restrict__ part)
+{
+    __shared__ double smem[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
+        const double bi = b[i];
+        const double xi = x[i] + omega * dinv[i] * (bi - t[i]);
+        x[i] = xi;
+        acc += bi * xi;
+    }
+    const double s = block_sum(acc, smem);
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = s;
+}
+
 // b_c[I] = sum over the members of (b - t): 8 lanes per aggregate (aggregates of a high-conductivity region can have
 // thousands of members), fixed lane partition + shuffle tree, so the sum order is fixed
 __global__ __launch_bounds__(FV_BLOCK) void amg_restrict_kernel(int64_t nc, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
@@ -747,7 +765,8 @@ int fv_amg_prepare(fv_problem *p, double sigma)
 }
 
 // x_l = V(b_l) on level l (x, b: the level's vectors; level 0: the caller's)
-static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma)
+// dot_part (top level only): per-block partials of b.x, i.e. the PCG's r.z, written by the last smoothing pass
+static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     fv_amg *a = p->amg;
@@ -788,7 +807,11 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
         FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
     else
         FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
-    hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
+    if (dot_part)
+        hipLaunchKernelGGL(amg_smooth_dot_kernel, dim3(vec_grid(L->n)), blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b,
+                           (const double *)L->t.p, g_omega, x, dot_part);
+    else
+        hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
@@ -902,8 +925,10 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (hs->done || maxiter <= 0)
         return FV_OK;
-    FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma));
-    hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p, p->part_rz.p);
+    const bool fused_dot = a->lev.size() > 1; // a single-level "hierarchy" (tiny problem) ends in the dense solve, not in a smoothing pass
+    FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
+    if (!fused_dot)
+        hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p, p->part_rz.p);
     hipLaunchKernelGGL(amg_pcg_start_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)a->z.p, p->pvec.p,
                        (const double *)p->part_rz.p, Gv, p->scal.p);
     FV_LAUNCH_CHECK(ctx);
@@ -919,9 +944,10 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done)
             break;
-        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma));
-        hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p,
-                           p->part_rz.p);
+        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
+        if (!fused_dot)
+            hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p,
+                               p->part_rz.p);
         hipLaunchKernelGGL(amg_pcg_direction_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, (const double *)a->z.p, p->pvec.p,
                            (const double *)p->part_rz.p, Gv, p->scal.p);
         FV_LAUNCH_CHECK(ctx);
