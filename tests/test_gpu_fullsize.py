@@ -252,7 +252,10 @@ def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
     8-way partition the multi-GPU bench uses, on a small box."""
     from tests.test_gpu_solve import _run_ranks_in_threads, relerr
 
-    for ns, nranks, schedule, gid in (([64, 200, 200], 2, [(60.0, 12), (3600.0, 3)], 201), ([40, 12, 10], 8, [(3600.0, 5), (2.0**-10, 20)], 208)):
+    # ... and the multi-GPU bench's own decomposition at an eighth of its size per dimension pair: 232^3 over 8 ranks
+    # (1.5e6-row blocks on the marching kernel, bursts of unpolled steps, 5-scalar reductions)
+    for ns, nranks, schedule, gid in (([64, 200, 200], 2, [(60.0, 12), (3600.0, 3)], 201), ([40, 12, 10], 8, [(3600.0, 5), (2.0**-10, 20)], 208),
+                                      ([232, 232, 232], 8, [(60.0, 24)], 209)):
         mins, maxs = bench.spacing_box(ns)
         dn, src = bench.box_setup(ns)
 
