@@ -383,6 +383,40 @@ class DeviceMatrix(SparseMatrixCSC):
         self.problem = problem
 
 
+def renumbered_inputs(neighbors, N, dirichletnodes):
+    """(order, rank, neighbors', dirichletnodes') for meshio.locality_order: faces keep their order and orientation."""
+    from . import meshio
+
+    n1, n2 = _split_neighbors(neighbors)
+    order, rank = meshio.locality_order(n1, n2, N)
+    return order, rank, (rank[n1 - 1], rank[n2 - 1]), rank[ai64(dirichletnodes) - 1]
+
+
+def free_permutation(problem, rank):
+    """freenode in the caller's numbering, and for every free cell in the caller's (reference) free order the 0-based
+    free index the renumbered device problem gave it."""
+    freenode_int, n2f_int = problem.free_maps()
+    freenode = freenode_int[rank - 1]
+    return freenode, n2f_int[rank[np.nonzero(freenode)[0]] - 1] - 1
+
+
+def _solvediffusion_reordered(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter, rtol, ctx, preconditioner):
+    import scipy.sparse as sp
+
+    src = af64(sources)
+    order, rank, nb2, dn2 = renumbered_inputs(neighbors, len(src), dirichletnodes)
+    p = _assembled_problem(nb2, areasoverlengths, conductivities, src[order - 1], dn2, dirichletheads, None, False, ctx)
+    if preconditioner != "jacobi":
+        p.set_preconditioner(preconditioner)
+    head2, _, ch = p.solve_steady(None, rtol, maxiter)
+    freenode, pf = free_permutation(p, rank)
+    A2 = p.csc().toscipy().tocsr()
+    A = sp.csc_matrix(A2[pf][:, pf])
+    A.sort_indices()
+    Acsc = SparseMatrixCSC(A.shape[0], A.shape[1], A.indptr.astype(np.int64) + 1, A.indices.astype(np.int64) + 1, A.data.copy())
+    return head2[rank - 1], ch, DeviceMatrix(p, Acsc), p.b()[pf], freenode
+
+
 def _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity, ctx=None):
     p = Problem.create(neighbors, areasoverlengths, len(sources), dirichletnodes, ctx)
     p.assemble(conductivities, sources, dirichletheads, metaindex, logtransformconductivity)
@@ -415,7 +449,7 @@ def freenodes2nodes(result, sources, dirichletnodes, dirichletheads, ctx=None):
     return head, freenode, n2f
 
 
-def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None, preconditioner="auto"):
+def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter=400, rtol=SQRT_EPS, ctx=None, preconditioner="auto", reorder=False):
     """FiniteVolume.jl:157-165 -> head, ch, A, b, freenode.
 
     The reference preconditions CG with Ruge-Stuben AMG.  preconditioner="jacobi": the Jacobi-PCG of
@@ -423,7 +457,12 @@ def solvediffusion(neighbors, areasoverlengths, conductivities, sources, dirichl
     (fv_precond_set); "auto" (default): Jacobi-PCG for min(maxiter/4, 100) iterations — easy problems never
     pay for a hierarchy — then AMG-PCG from that iterate, the shape of the reference's defaultlinearsolver
     (transient.jl:50-58), so that the reference's maxiter = 400 keeps converging on high-contrast or anisotropic
-    problems.  As in the reference, non-convergence is reported through ch.isconverged, not raised."""
+    problems.  As in the reference, non-convergence is reported through ch.isconverged, not raised.
+    reorder=True: the device works on the mesh renumbered by meshio.locality_order (worth a factor ~2 in SpMV rate on
+    meshes whose cells are numbered without regard to position); head, A, b and freenode still come back in the
+    caller's numbering (A and b are the same numbers, permuted back on the host)."""
+    if reorder:
+        return _solvediffusion_reordered(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, maxiter, rtol, ctx, preconditioner)
     p = _assembled_problem(neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, None, False, ctx)
     if preconditioner != "jacobi":
         p.set_preconditioner(preconditioner)

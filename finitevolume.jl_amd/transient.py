@@ -230,7 +230,8 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     `linearsolver` is left at its default; keep="last" (high-level methods with constant b) runs the whole
     adaptive integration on the device (fv_transient_run_adaptive) and returns ([u0, u(tfinal)], ts) instead
     of every intermediate state; preconditioner="jacobi" | "amg" | "auto" (default: Jacobi-PCG until a step needs more
-    than 50 iterations, then PCG with the AMG V-cycle — large time steps)."""
+    than 50 iterations, then PCG with the AMG V-cycle — large time steps); reorder=True renumbers the mesh for
+    locality on the way in (meshio.locality_order) and the states back on the way out."""
     if "stepper_" in kwargs:
         kwargs["stepper"] = kwargs.pop("stepper_")
     rtol = kwargs.pop("rtol", None)
@@ -247,6 +248,15 @@ def backwardeulerintegrate(u0, *args, **kwargs):
     Ss, volumes, neighbors, aol, K, sources, dnodes, dheads = rest[:8]
     metaindex = rest[8] if len(rest) > 8 else None
     logt = rest[9] if len(rest) > 9 else False
+    if kwargs.pop("reorder", False):
+        # the device works on the mesh renumbered by meshio.locality_order; states come back in the caller's numbering
+        from .core import renumbered_inputs
+
+        if getb is not None:
+            raise ValueError("reorder=True is for the constant-b method (a getb(t) returns vectors in the caller's free order)")
+        order, rank, nb2, dn2 = renumbered_inputs(neighbors, len(sources), dnodes)
+        us2, ts2 = backwardeulerintegrate(af64(u0)[order - 1], tspan, Ss, af64(volumes)[order - 1], nb2, aol, K, af64(sources)[order - 1], dn2, dheads, metaindex, logt, **kwargs)
+        return [u[rank - 1] for u in us2], ts2
     dt0 = kwargs.pop("dt0", 1.0)
     keep = kwargs.pop("keep", "all")
     preconditioner = kwargs.pop("preconditioner", "auto")  # Jacobi-PCG; the AMG V-cycle once a step needs > 50 iterations

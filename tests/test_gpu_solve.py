@@ -855,3 +855,15 @@ def test_reordered_mesh_gives_the_same_heads(fv):
     h1, ch1, *_ = fv.solvediffusion(np.stack([m["node1"], m["node2"]], 1), m["aol"], w["K"], src, m["dnodes"], m["dheads"], maxiter=20000, rtol=1e-13, preconditioner="jacobi")
     assert ch0.isconverged and ch1.isconverged
     assert relerr(h1[rank - 1], h0) < 1e-9
+    # the same through reorder=True: head, A, b, freenode in the caller's numbering; A and b bit for bit what the
+    # un-reordered assembly gives (per-entry sums run in face order whatever the cells are called)
+    nb = np.stack([w["node1"], w["node2"]], 1)
+    h2, ch2, A2, b2, fn2 = fv.solvediffusion(nb, w["aol"], w["K"], src, w["dnodes"], w["dheads"], maxiter=20000, rtol=1e-13, preconditioner="jacobi", reorder=True)
+    _, _, A0, b0, fn0 = fv.solvediffusion(nb, w["aol"], w["K"], src, w["dnodes"], w["dheads"], maxiter=5, preconditioner="jacobi")
+    assert ch2.isconverged and relerr(h2, h0) < 1e-9
+    assert np.array_equal(fn2, fn0) and np.array_equal(b2, b0)
+    assert np.array_equal(A2.colptr, A0.colptr) and np.array_equal(A2.rowval, A0.rowval) and np.array_equal(A2.nzval, A0.nzval)
+    u0 = np.full(w["N"], 1.5e6)
+    us_a, ts_a = fv.backwardeulerintegrate(u0, (0.0, 3.0), 1e-9, w["volumes"], nb, w["aol"], w["K"], src, w["dnodes"], w["dheads"], stepper=fv.fixedbackwardeulerstep, dt0=1.0, rtol=1e-13)
+    us_b, ts_b = fv.backwardeulerintegrate(u0, (0.0, 3.0), 1e-9, w["volumes"], nb, w["aol"], w["K"], src, w["dnodes"], w["dheads"], stepper=fv.fixedbackwardeulerstep, dt0=1.0, rtol=1e-13, reorder=True)
+    assert ts_a == ts_b and all(relerr(a, b) < 1e-10 for a, b in zip(us_a, us_b))
