@@ -265,6 +265,7 @@ static int g_nt = 1;
 int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 int g_use_dia = 1;
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
+static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
@@ -310,6 +311,8 @@ extern "C" int fv_tune(int key, int value)
         g_dia_packed = value;
     else if (key == 12 && (value == 0 || value == 1))
         g_sparse_b = value;
+    else if (key == 17 && value >= 0 && value <= 3)
+        g_march_dbg = value;
     else if (key == 13 && value >= 0 && value <= 32)
         g_chain_steps = value;
     else if (key == 14 && value >= -1 && value < 32)
@@ -729,7 +732,7 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
 // interior pass); the others are merely walked through.
 template <bool DOT, bool NT>
 __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int shift, int64_t stride,
-                                                                   int seglen, int segs_per_xcd, int64_t win_lo, int64_t win_hi,
+                                                                   int seglen, int segs_per_xcd, int dbg, int64_t win_lo, int64_t win_hi,
                                                                    const int32_t *__restrict__ dia_pos,
                                                                    const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                    const double *__restrict__ sval, const double *__restrict__ x,
@@ -792,23 +795,29 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                         if (off == 0)
                             xv = curc;
                         else if (off == -st32 && have_prev) {
-                            xv = __shfl(prevc, (lane - shift) & 63, 64);
-                            if (lane < shift) {
-                                int32_t c = row - st32;
-                                c = c < 0 ? 0 : c;
-                                xv = x[c];
-                            }
+                            // lanes >= shift: the previous slice's centre, `shift` lanes down; the first `shift` lanes: loaded.
+                            // Every lane issues the load (the others re-read the slice's first row) so that there is no
+                            // divergent branch — a masked load inside one costs 6 % of the kernel (exec-mask bookkeeping
+                            // serialises the loads in flight)
+                            const double sh = __shfl(prevc, (lane - shift) & 63, 64);
+                            int32_t c = lane < shift ? row - st32 : row - lane;
+                            c = c < 0 ? 0 : c;
+                            const double ld = (dbg & 2) ? 0.0 : x[c];
+                            xv = lane < shift ? ld : sh;
                         } else if (off == st32 && have_next) {
-                            xv = __shfl(nextc, (lane + shift) & 63, 64);
-                            if (lane + shift >= 64) {
-                                int32_t c = row + st32;
-                                c = c >= nc32 ? nc32 - 1 : c;
+                            const double sh = __shfl(nextc, (lane + shift) & 63, 64);
+                            int32_t c = lane + shift >= 64 ? row + st32 : row - lane + 63;
+                            c = c >= nc32 ? nc32 - 1 : c;
+                            const double ld = (dbg & 2) ? 0.0 : x[c];
+                            xv = lane + shift >= 64 ? ld : sh;
+                        } else {
+                            if (dbg & 1) // diagnosis only (wrong results): what the in-plane arm loads cost
+                                xv = curc;
+                            else {
+                                int32_t c = row + off; // |off| <= stride < n/4: no overflow
+                                c = c < 0 ? 0 : (c >= nc32 ? nc32 - 1 : c);
                                 xv = x[c];
                             }
-                        } else {
-                            int32_t c = row + off; // |off| <= stride < n/4: no overflow
-                            c = c < 0 ? 0 : (c >= nc32 ? nc32 - 1 : c);
-                            xv = x[c];
                         }
                         sum += v * xv;
                     }
@@ -1084,7 +1093,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             GM = (int)g;
 #define FV_MARCH(D_, N_)                                                                                                                      \
     hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
-                       seglen, segs_per_xcd, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
+                       seglen, segs_per_xcd, g_march_dbg, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
                        (const double *)p->dia_vals.p, x, y, shift, sigma, partials, scal)
             if (mode == SPMV_DOT) {
                 if (g_nt)
