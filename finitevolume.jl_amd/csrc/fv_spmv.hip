@@ -266,6 +266,7 @@ int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up k
 int g_use_dia = 1;
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
+static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
@@ -313,6 +314,8 @@ extern "C" int fv_tune(int key, int value)
         g_sparse_b = value;
     else if (key == 17 && value >= 0 && value <= 3)
         g_march_dbg = value;
+    else if (key == 18 && (value == 0 || value == 1))
+        g_march_wide = value;
     else if (key == 13 && value >= 0 && value <= 32)
         g_chain_steps = value;
     else if (key == 14 && value >= -1 && value < 32)
@@ -730,7 +733,24 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
 // [k m, (k+1) m) and its resident waves march through neighbouring pencils of one segment together, so the in-plane
 // arms (+-1, +-line) are shared through L2 as before.  Only slices inside [win_lo, win_hi) are computed (a row block's
 // interior pass); the others are merely walked through.
-template <bool DOT, bool NT>
+// One 16-byte access per lane covering the 128 x elements [64 slice - 32, 64 slice + 96): lane l holds elements 2l, 2l+1 of
+// that window.  Lanes whose elements would fall outside [0, ncols) are clamped: they hold misplaced but finite values that
+// only ever meet absent (zero) matrix entries.
+__device__ inline double2 march_window(const double *__restrict__ x, int64_t slice, int lane, int32_t ncols)
+{
+    int32_t i = (int32_t)(slice << 6) - 32 + 2 * lane;
+    const int32_t hi = (ncols - 2) & ~1;
+    i = i < 0 ? 0 : (i > hi ? hi : i);
+    return *reinterpret_cast<const double2 *>(x + i);
+}
+// element j (0..127, per lane) of such a window
+__device__ inline double march_window_elem(double2 w, int j)
+{
+    const double a = __shfl(w.x, j >> 1, 64), b = __shfl(w.y, j >> 1, 64);
+    return (j & 1) ? b : a;
+}
+
+template <bool DOT, bool NT, bool WIDE>
 __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int shift, int64_t stride,
                                                                    int seglen, int segs_per_xcd, int dbg, int64_t win_lo, int64_t win_hi,
                                                                    const int32_t *__restrict__ dia_pos,
@@ -757,7 +777,21 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
         // rows and columns fit int32 (device indices are int32): keeps the address arithmetic in one register
         const int32_t nc32 = (int32_t)ncols, st32 = (int32_t)stride;
         double prevc = 0.0, curc, nextc;
-        {
+        // WIDE (0 < shift <= 32): one window access per step brings the next centre AND the `shift` elements on either side
+        // of it that the plane arms need beyond the register shuffle: m0 / m1 = the -plane arm of this / the next slice
+        // (taken from the windows of the slices before them), parm = the +plane arm of this slice (from the next window)
+        double m0 = 0.0, m1 = 0.0, parm = 0.0;
+        bool have_m0 = false;
+        if (WIDE) {
+            const double2 w0 = march_window(x, sl, lane, nc32);
+            curc = march_window_elem(w0, 32 + lane);
+            m1 = march_window_elem(w0, 32 - shift + lane);
+            if (sl - step >= 0) {
+                const double2 wp = march_window(x, sl - step, lane, nc32);
+                m0 = march_window_elem(wp, 32 - shift + lane);
+                have_m0 = true;
+            }
+        } else {
             const int32_t r0 = (int32_t)(sl << 6) + lane;
             curc = r0 < nc32 ? x[r0] : 0.0;
         }
@@ -774,9 +808,20 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
             const int noff = __builtin_amdgcn_readfirstlane(nx_noff);
             const int32_t offs = nx_offs;
             const int64_t pos = __builtin_amdgcn_readfirstlane(nx_pos);
+            double mnew = 0.0;
             {
-                const int32_t rn = (int32_t)(nsl << 6) + lane;
-                nextc = (have_next && rn < nc32) ? x[rn] : 0.0;
+                if (WIDE) {
+                    nextc = 0.0;
+                    if (have_next) {
+                        const double2 w = march_window(x, nsl, lane, nc32);
+                        nextc = march_window_elem(w, 32 + lane);
+                        parm = march_window_elem(w, 32 + shift + lane);
+                        mnew = march_window_elem(w, 32 - shift + lane);
+                    }
+                } else {
+                    const int32_t rn = (int32_t)(nsl << 6) + lane;
+                    nextc = (have_next && rn < nc32) ? x[rn] : 0.0;
+                }
                 if (have_next && k + 1 < seglen) {
                     nx_noff = (int)sl_noff[nsl];
                     nx_offs = (lane < DIA_K) ? sl_off[nsl * DIA_K + lane] : 0;
@@ -794,7 +839,11 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                         double xv;
                         if (off == 0)
                             xv = curc;
-                        else if (off == -st32 && have_prev) {
+                        else if (WIDE && off == -st32 && have_m0)
+                            xv = m0;
+                        else if (WIDE && off == st32 && have_next)
+                            xv = parm;
+                        else if (!WIDE && off == -st32 && have_prev) {
                             // lanes >= shift: the previous slice's centre, `shift` lanes down; the first `shift` lanes: loaded.
                             // Every lane issues the load (the others re-read the slice's first row) so that there is no
                             // divergent branch — a masked load inside one costs 6 % of the kernel (exec-mask bookkeeping
@@ -804,7 +853,7 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                             c = c < 0 ? 0 : c;
                             const double ld = (dbg & 2) ? 0.0 : x[c];
                             xv = lane < shift ? ld : sh;
-                        } else if (off == st32 && have_next) {
+                        } else if (!WIDE && off == st32 && have_next) {
                             const double sh = __shfl(nextc, (lane + shift) & 63, 64);
                             int32_t c = lane + shift >= 64 ? row + st32 : row - lane + 63;
                             c = c >= nc32 ? nc32 - 1 : c;
@@ -836,6 +885,11 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
             prevc = curc;
             curc = nextc;
             have_prev = true;
+            if (WIDE) {
+                m0 = m1;
+                m1 = mnew;
+                have_m0 = true;
+            }
         }
     }
     if (DOT) {
@@ -1091,10 +1145,17 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             if (g > g_resident_blocks)
                 g = g_resident_blocks;
             GM = (int)g;
-#define FV_MARCH(D_, N_)                                                                                                                      \
-    hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
+#define FV_MARCH_W(D_, N_, W_)                                                                                                                 \
+    hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_, W_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
                        seglen, segs_per_xcd, g_march_dbg, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
                        (const double *)p->dia_vals.p, x, y, shift, sigma, partials, scal)
+#define FV_MARCH(D_, N_)                                                                                                                      \
+    do {                                                                                                                                      \
+        if (g_march_wide && sh > 0 && sh <= 32)                                                                                               \
+            FV_MARCH_W(D_, N_, true);                                                                                                         \
+        else                                                                                                                                  \
+            FV_MARCH_W(D_, N_, false);                                                                                                        \
+    } while (0)
             if (mode == SPMV_DOT) {
                 if (g_nt)
                     FV_MARCH(true, true);
@@ -1106,6 +1167,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
                 else
                     FV_MARCH(false, false);
             }
+#undef FV_MARCH_W
 #undef FV_MARCH
         }
         if (dcount > 0 && !march) {

@@ -225,6 +225,7 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support [1]
  *  13: one-iteration steps of a fixed-dt run enqueued per device poll (a step that needs more iterations stops the
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
+ *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
  *  17: diagnosis switches of the marching kernel (bit 0: no in-plane arm loads, bit 1: no plane-arm edge loads);
  *      results are wrong when set [0]
  *  14: fault injection for the tests of key 13: the chained step with this index of every burst is treated as not

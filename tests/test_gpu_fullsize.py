@@ -158,18 +158,19 @@ def test_synthetic_464_cubed_operator_identities(fv):
     assert abs(float(y @ ax) - float(x @ ay)) / (np.linalg.norm(x) * np.linalg.norm(ay)) < 1e-13  # symmetry
 
 
-def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
+@pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192]])  # plane strides 39 600 (= 48 mod 64: centre + edge loads), 36 100 (= 4 mod 64: 16-byte windows), 36 864 (= 0 mod 64)
+def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
     """>= 2^20 unknowns with a plane stride: the plane-marching sliced-DIA kernel (default), the slice-by-slice DIA
     kernel and the CSR wave-stream form against a float64 CSR product on the host; the p.q epilogue against numpy."""
     import scipy.sparse as sp
 
-    ns = [40, 200, 200]  # planes of 198 x 200 = 39 600 rows (>= 32 768: the operator counts as plane-structured), 38 of them
+    # planes of (n2 - 2) x n3 rows (>= 32 768: the operator counts as plane-structured), 38 of them
     mins, maxs = bench.spacing_box(ns)
     dn, src = bench.box_setup(ns)
     p = fv.Problem.regulargrid(mins, maxs, ns, dn)
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
     p.transient_begin(0.1, None, np.full(p.N, 1e3))
-    assert p.n >= 1 << 20 and p.n == 38 * 39600
+    assert p.n >= 1 << 20 and p.n == 38 * (ns[1] - 2) * ns[2]
     A = p.csc()
     As = sp.csc_matrix((A.nzval, A.rowval - 1, A.colptr - 1), shape=(p.n, p.n)).tocsr()
     _, _, _, vol = fv.regulargrid(mins, maxs, ns)
@@ -182,7 +183,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
     scale = np.abs(ref).max()
     lib = fv.load()
     try:
-        for name, knobs in (("march", {9: 1, 6: 1}), ("march m=1", {9: 1, 10: 1}), ("march m=5", {9: 1, 10: 5}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
+        for name, knobs in (("march", {9: 1, 6: 1, 18: 1}), ("march m=1", {9: 1, 10: 1}), ("march m=5", {9: 1, 10: 5}), ("march, no windows", {9: 1, 18: 0}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
                 assert lib.fv_tune(k, v) == 0
             y = p.spmv(x, sigma)
@@ -204,6 +205,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv):
         lib.fv_tune(9, 1)
         lib.fv_tune(6, 1)
         lib.fv_tune(10, 0)
+        lib.fv_tune(18, 1)
 
 
 def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv):
@@ -254,7 +256,7 @@ def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
 
     # ... and the multi-GPU bench's own decomposition at an eighth of its size per dimension pair: 232^3 over 8 ranks
     # (1.5e6-row blocks on the marching kernel, bursts of unpolled steps, 5-scalar reductions)
-    for ns, nranks, schedule, gid in (([64, 200, 200], 2, [(60.0, 12), (3600.0, 3)], 201), ([40, 12, 10], 8, [(3600.0, 5), (2.0**-10, 20)], 208),
+    for ns, nranks, schedule, gid in (([64, 192, 190], 2, [(60.0, 12), (3600.0, 3)], 201), ([40, 12, 10], 8, [(3600.0, 5), (2.0**-10, 20)], 208),
                                       ([232, 232, 232], 8, [(60.0, 24)], 209)):
         mins, maxs = bench.spacing_box(ns)
         dn, src = bench.box_setup(ns)

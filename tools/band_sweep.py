@@ -25,13 +25,15 @@ for packed in (0, 1):  # the layout is fixed when a problem's DIA copy is built:
 res = {}
 for r in range(5):
     for packed in (0, 1):
-        for march in (1, 0):
-            lib.fv_tune(9, march)
+        for march in (1, 4, 0):  # 4: marching with separate centre + edge loads instead of the 16-byte window
+            lib.fv_tune(9, 1 if march else 0)
+            lib.fv_tune(18, 0 if march == 4 else 1)
             res.setdefault((packed, march), []).append(probs[packed].bench_spmv(1 / 60.0, 10))
+        lib.fv_tune(18, 1)
     for dbg in (1, 2, 3):  # diagnosis (wrong results): marching kernel without in-plane arm loads / masked edge loads / both
         lib.fv_tune(9, 1)
         lib.fv_tune(17, dbg)
         res.setdefault((1, 10 + dbg), []).append(probs[1].bench_spmv(1 / 60.0, 10))
         lib.fv_tune(17, 0)
 for (packed, march), t in sorted(res.items()):
-    print("FV_BAND=%s values %s, %s: median %.3f ms min %.3f ms" % (os.environ.get("FV_BAND", "default"), "packed" if packed else "padded to 8 blocks", {1: "plane-marching", 0: "slice by slice", 11: "marching WITHOUT in-plane arm loads (diagnosis)", 12: "marching WITHOUT masked edge loads (diagnosis)", 13: "marching without both (diagnosis)"}[march], float(np.median(t)), min(t)), flush=True)
+    print("FV_BAND=%s values %s, %s: median %.3f ms min %.3f ms" % (os.environ.get("FV_BAND", "default"), "packed" if packed else "padded to 8 blocks", {1: "plane-marching", 4: "plane-marching, centre + edge loads (no window)", 0: "slice by slice", 11: "marching WITHOUT in-plane arm loads (diagnosis)", 12: "marching WITHOUT masked edge loads (diagnosis)", 13: "marching without both (diagnosis)"}[march], float(np.median(t)), min(t)), flush=True)
