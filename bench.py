@@ -162,7 +162,7 @@ def main():
     # run folds D/dt into the stored diagonal, so the "+8 n if the shift vector is read separately" does not apply.
     spmv_bytes = 12 * p.nnz + 20 * p.n
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": "K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true> (plane-marching sliced-DIA; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)",
+            "kernel": "K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)",
             "algorithmic_bytes_per_launch": spmv_bytes}
     kern = {}
     if prof and prof["spmv_dot"][1] > 0:
