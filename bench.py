@@ -188,7 +188,7 @@ def main():
             pass
 
     out = {
-        "metric": "DoF-updates/s (cells x steps) implicit transient; SpMV HBM GB/s vs peak",
+        "metric": "DoF-updates/s (cells\u00d7steps) implicit transient; SpMV HBM GB/s vs peak",
         "value": value,
         "unit": "DoF-updates/s",
         "n_gpus": 1,

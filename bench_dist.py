@@ -76,7 +76,7 @@ def run_distributed(fv, args, world, rank):
     dist.all_gather_object(gathered, dict(rank=rank, rows=blk.nloc, nnz=blk.nnz, halo=blk.nhalo, send=blk.nsend, spmv_ms=ms, spmv_gbs=ach, device_ms=dev_ms))
     if rank == 0:
         out = {
-            "metric": "DoF-updates/s (cells x steps) implicit transient; SpMV HBM GB/s vs peak",
+            "metric": "DoF-updates/s (cells\u00d7steps) implicit transient; SpMV HBM GB/s vs peak",
             "value": N * args.steps / sec,
             "unit": "DoF-updates/s",
             "n_gpus": world,
