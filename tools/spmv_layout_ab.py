@@ -1,4 +1,4 @@
-"""time the PCG SpMV (sliced-DIA) of the bench operator for the FV_BAND given in the environment"""
+"""Same-process A/B of the sliced-DIA value layout (packed / padded) x SpMV kernel (plane-marching with and without the 16-byte windows, slice by slice) on the bench operator, plus the elimination diagnosis of the marching kernel (fv_tune 17)."""
 import os
 import sys
 
