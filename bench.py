@@ -131,6 +131,7 @@ def main():
 
     ctx = fv.default_context()
     name, cus, mem = ctx.device_info()
+    free0, _ = ctx.mem_info()
     ns = [args.ns] * 3
     mins, maxs = spacing_box(ns)
     dn, src = box_setup(ns)
@@ -208,6 +209,7 @@ def main():
             "device": name, "compute_units": cus,
             "setup_s": {"grid+symbolic": t_symbolic, "assemble": t_assemble, "total": t_setup},
             "device_ms_total": dev_ms,
+            "hbm_in_use_gb": (free0 - ctx.mem_info()[0]) / 1e9,
             "other_kernels": kern,
         },
         "roofline": roof,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fv_bench_spmv": (C.c_int, [c_prob, C.c_double, C.c_int32, P(C.c_double)]),
     "fv_dot": (C.c_int, [c_prob, _f64p, _f64p, P(C.c_double)]),
     "fv_tune": (C.c_int, [C.c_int, C.c_int]),
+    "fv_device_mem_info": (C.c_int, [c_ctx, P(C.c_int64), P(C.c_int64)]),
     "fv_precond_set": (C.c_int, [c_prob, C.c_int]),
     "fv_amg_configure": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_int]),
     "fv_amg_info": (C.c_int, [c_prob, P(C.c_int32), _i64p, _i64p, C.c_int32]),
@@ -175,6 +176,12 @@ class Context:
 
     def synchronize(self):
         self.check(load().fv_ctx_synchronize(self.handle))
+
+    def mem_info(self):
+        """(free, total) bytes of the device."""
+        f, t = C.c_int64(), C.c_int64()
+        self.check(load().fv_device_mem_info(self.handle, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def device_info(self):
         name = C.create_string_buffer(256)

@@ -98,6 +98,20 @@ extern "C" int fv_device_info(fv_ctx *ctx, char *name, int name_cap, int *comput
     return FV_OK;
 }
 
+extern "C" int fv_device_mem_info(fv_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    if (!ctx)
+        return FV_ERR_ARG;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    FV_HIP(ctx, hipMemGetInfo(&f, &t));
+    if (free_bytes)
+        *free_bytes = (int64_t)f;
+    if (total_bytes)
+        *total_bytes = (int64_t)t;
+    return FV_OK;
+}
+
 // ------------------------------------------------------------------ exclusive scan
 // Three-phase hierarchical scan: tiles of 2048 int32 (256 threads x 8), tile
 // totals scanned recursively in int64, then added back.  Deterministic.

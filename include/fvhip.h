@@ -70,6 +70,8 @@ int fv_abi_version(void);
 int fv_ctx_create(int device, fv_ctx **out);
 void fv_ctx_destroy(fv_ctx *ctx);
 int fv_ctx_synchronize(fv_ctx *ctx);
+/* hipMemGetInfo of the context's device: how much of the 288 GB a problem occupies. */
+int fv_device_mem_info(fv_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* ctx may be NULL: last error of the calling thread outside any context. */
 const char *fv_last_error(fv_ctx *ctx);
 int fv_device_info(fv_ctx *ctx, char *name, int name_cap, int *compute_units, int64_t *total_mem_bytes);
