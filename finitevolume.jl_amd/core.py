@@ -174,6 +174,22 @@ class Problem:
         return cls(h, ctx)
 
     @classmethod
+    def regulargrid_slab(cls, mins, maxs, ns, dirichletnodes, i1_lo, i1_hi, ctx=None):
+        """One slab of the grid (planes [i1_lo, i1_hi) along the first axis): global node arrays, local faces only.
+        For row-block runs whose ranks never hold the global operator (fv_problem_create_regulargrid_slab)."""
+        ctx = ctx or default_context()
+        mins_, maxs_, ns_, d = af64(mins), af64(maxs), ai64(ns), ai64(dirichletnodes)
+        h = _lib.c_prob()
+        ctx.check(load().fv_problem_create_regulargrid_slab(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), len(d), ptr(d), int(i1_lo), int(i1_hi), C.byref(h)))
+        return cls(h, ctx)
+
+    def free_rows_before(self, node0):
+        """Number of free cells whose 0-based node index is below node0."""
+        rows = C.c_int64()
+        self.check(load().fv_problem_free_rows_before(self.handle, int(node0), C.byref(rows)))
+        return rows.value
+
+    @classmethod
     def from_csc(cls, A, ctx=None):
         ctx = ctx or default_context()
         colptr, rowval, nzval = ai64(A.colptr), ai64(A.rowval), af64(A.nzval)

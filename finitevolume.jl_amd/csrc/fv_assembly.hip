@@ -617,6 +617,74 @@ extern "C" int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], 
     return FV_OK;
 }
 
+// The problem of ONE slab of a structured grid, for row-block runs that never hold the global operator: node arrays
+// (maps, volumes) are global, but only the faces emitted by the cells of the planes [i1_lo - 1, i1_hi) exist — every face
+// incident to a cell of the planes [i1_lo, i1_hi), in the order of the global face list.  After fv_assemble the free rows of
+// those planes are complete (bit for bit the rows of the global operator); the others are empty or partial and must not
+// be used: hand the problem to fv_dist_setup_bounds with bounds that follow the same planes.
+extern "C" int fv_problem_create_regulargrid_slab(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3],
+                                                  int64_t ndir, const int64_t *dirichletnodes, int64_t i1_lo, int64_t i1_hi,
+                                                  fv_problem **out)
+{
+    if (!ctx || !out || !mins || !maxs || !ns || ndir < 0 || (ndir > 0 && !dirichletnodes))
+        return FV_ERR_ARG;
+    *out = nullptr;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    int64_t N, F;
+    FV_TRY(fv_regulargrid_sizes(ns, &N, &F));
+    if (i1_lo < 0 || i1_hi > ns[0] || i1_lo >= i1_hi) {
+        fv_set_error(ctx, "slab planes [%lld, %lld) outside the grid's %lld", (long long)i1_lo, (long long)i1_hi, (long long)ns[0]);
+        return FV_ERR_ARG;
+    }
+    const int64_t gen_lo = i1_lo > 0 ? i1_lo - 1 : 0; // the x-faces into plane i1_lo are emitted by the cells of the plane before it
+    const int64_t Fl = fv_grid_face_offset(ns, i1_hi) - fv_grid_face_offset(ns, gen_lo);
+    if (Fl > 0x7fffffffLL) {
+        fv_set_error(ctx, "F=%lld exceeds the int32 device index range", (long long)Fl);
+        return FV_ERR_TOO_LARGE;
+    }
+    fv_problem *p = new fv_problem();
+    p->ctx = ctx;
+    p->N = N;
+    p->F = Fl;
+    p->ndir = ndir;
+    p->from_grid = true;
+    p->slab_lo = i1_lo;
+    p->slab_hi = i1_hi;
+    for (int d = 0; d < 3; d++)
+        p->ns[d] = ns[d];
+    int rc;
+    if ((rc = p->node1.alloc(ctx, (size_t)Fl)) || (rc = p->node2.alloc(ctx, (size_t)Fl)) || (rc = p->aol.alloc(ctx, (size_t)Fl)) ||
+        (rc = p->gridvol.alloc(ctx, (size_t)N)) ||
+        (rc = fv_grid_generate_device(ctx, mins, maxs, ns, p->node1.p, p->node2.p, p->aol.p, p->gridvol.p, nullptr, gen_lo, i1_hi)) ||
+        (rc = finish_problem(p, dirichletnodes))) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return FV_OK;
+}
+
+// number of free cells with a (0-based) node index below `node`: the first free row of the plane that starts there
+extern "C" int fv_problem_free_rows_before(fv_problem *p, int64_t node, int64_t *rows)
+{
+    if (!p || !rows || node < 0 || node > p->N)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int32_t> chunk(4096);
+    for (int64_t at = node; at < p->N; at += (int64_t)chunk.size()) {
+        const int64_t m = p->N - at < (int64_t)chunk.size() ? p->N - at : (int64_t)chunk.size();
+        FV_HIP(ctx, hipMemcpy(chunk.data(), p->nodemap.p + at, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < m; k++)
+            if (chunk[(size_t)k] >= 0) { // the first free cell at or after `node`: its free index is the answer
+                *rows = chunk[(size_t)k];
+                return FV_OK;
+            }
+    }
+    *rows = p->n;
+    return FV_OK;
+}
+
 extern "C" void fv_problem_destroy(fv_problem *p)
 {
     if (!p)

@@ -118,7 +118,24 @@ static int copy_slice(fv_ctx *ctx, DevBuf<double> &dst, const double *src, int64
     return FV_OK;
 }
 
+static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *bounds, fv_problem **out);
+
 extern "C" int fv_dist_setup(fv_problem *pg, int nranks, int rank, fv_problem **out)
+{
+    return dist_setup_impl(pg, nranks, rank, nullptr, out);
+}
+
+// The same with the caller's row ranges: rank r owns the free rows [bounds[r], bounds[r+1]) (bounds[0] = 0,
+// bounds[nranks] = n, non-decreasing; every rank must pass the same array).  With a slab problem
+// (fv_problem_create_regulargrid_slab) the rank's range must lie inside the slab's planes.
+extern "C" int fv_dist_setup_bounds(fv_problem *pg, int nranks, int rank, const int64_t *bounds, fv_problem **out)
+{
+    if (!bounds)
+        return FV_ERR_ARG;
+    return dist_setup_impl(pg, nranks, rank, bounds, out);
+}
+
+static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *bounds, fv_problem **out)
 {
     if (!pg || !out || nranks < 1 || rank < 0 || rank >= nranks)
         return FV_ERR_ARG;
@@ -139,7 +156,28 @@ extern "C" int fv_dist_setup(fv_problem *pg, int nranks, int rank, fv_problem **
     d->rank = rank;
     d->bounds.resize((size_t)nranks + 1);
     for (int r = 0; r <= nranks; r++)
-        d->bounds[(size_t)r] = ((int64_t)r * n) / nranks; // partition.row_ranges
+        d->bounds[(size_t)r] = bounds ? bounds[r] : ((int64_t)r * n) / nranks; // default: partition.row_ranges
+    bool bounds_ok = d->bounds[0] == 0 && d->bounds[(size_t)nranks] == n;
+    for (int r = 0; r < nranks; r++)
+        bounds_ok = bounds_ok && d->bounds[(size_t)r] <= d->bounds[(size_t)r + 1];
+    if (!bounds_ok) {
+        fv_set_error(ctx, "fv_dist_setup_bounds: bounds must run from 0 to n = %lld without decreasing", (long long)n);
+        delete d;
+        return FV_ERR_ARG;
+    }
+    if (pg->slab_lo >= 0) { // a slab problem only has the rows of its planes
+        int64_t first = 0, last = 0;
+        const int64_t plane = pg->ns[1] * pg->ns[2];
+        int rc0 = fv_problem_free_rows_before(pg, pg->slab_lo * plane, &first);
+        if (rc0 == FV_OK)
+            rc0 = fv_problem_free_rows_before(pg, pg->slab_hi * plane, &last);
+        if (rc0 != FV_OK || d->bounds[(size_t)rank] < first || d->bounds[(size_t)rank + 1] > last) {
+            fv_set_error(ctx, "fv_dist_setup_bounds: rank %d's rows [%lld, %lld) are not inside the slab's rows [%lld, %lld)", rank,
+                         (long long)d->bounds[(size_t)rank], (long long)d->bounds[(size_t)rank + 1], (long long)first, (long long)last);
+            delete d;
+            return rc0 != FV_OK ? rc0 : FV_ERR_ARG;
+        }
+    }
     const int64_t lo = d->bounds[(size_t)rank], hi = d->bounds[(size_t)rank + 1];
     const int64_t nloc = hi - lo;
     d->lo = lo;

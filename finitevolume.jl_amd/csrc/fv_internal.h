@@ -139,6 +139,7 @@ struct fv_problem {
     fv_dist *dist = nullptr;       // plan + buffers of the distributed run (fv_dist.hip)
     bool from_grid = false, from_csc = false, assembled = false, transient_ready = false;
     int64_t ns[3] = {0, 0, 0};
+    int64_t slab_lo = -1, slab_hi = -1; // fv_problem_create_regulargrid_slab: the planes whose rows are complete
 
     // mesh (0-based int32 on device)
     DevBuf<int32_t> node1, node2;
@@ -233,7 +234,8 @@ int fv_exclusive_scan_i32(fv_ctx *ctx, const int32_t *in, int32_t *out, int64_t 
 // ---- fv_grid.hip
 int fv_grid_axes(const double mins[3], const double maxs[3], const int64_t ns[3], std::vector<double> ax[3]);
 int fv_grid_generate_device(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3], int32_t *node1,
-                            int32_t *node2, double *aol, double *volumes, double *coords);
+                            int32_t *node2, double *aol, double *volumes, double *coords, int64_t i1_lo = -1, int64_t i1_hi = -1);
+int64_t fv_grid_face_offset(const int64_t ns[3], int64_t i1);
 
 // ---- fv_assembly.hip
 int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes_host_or_dev);

@@ -10,6 +10,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import SolveInfo, load, ptr
+from .core import ai64
 from .core import Problem
 
 
@@ -39,12 +40,46 @@ def comm_init_from_torch(ctx):
     return rank, world
 
 
+def slab_planes(n1, nranks):
+    """Plane ranges of an x-slab decomposition: rank r gets the planes [planes[r], planes[r+1])."""
+    return [(r * int(n1)) // int(nranks) for r in range(int(nranks) + 1)]
+
+
+def slab_face_range(ns, i1_lo, i1_hi):
+    """The slab's faces as a range [f0, f1) of the global face list (regulargrid's order): what to cut out of per-face
+    conductivities before handing them to the slab problem's assemble."""
+    n1, n2, n3 = (int(v) for v in ns)
+
+    def offset(i1):
+        return min(i1, n1 - 1) * n2 * n3 + i1 * (n2 - 1) * n3 + i1 * n2 * (n3 - 1)
+
+    return offset(max(int(i1_lo) - 1, 0)), offset(int(i1_hi))
+
+
+def slab_problem(mins, maxs, ns, dirichletnodes, nranks, rank, ctx=None):
+    """The rank's slab problem and the row bounds of all ranks (identical on every rank): assemble it / begin the
+    transient with the GLOBAL sources, heads and u0, then RowBlock(problem, nranks, rank, bounds)."""
+    planes = slab_planes(ns[0], nranks)
+    if planes[rank] == planes[rank + 1]:
+        raise ValueError("more ranks than planes")
+    p = Problem.regulargrid_slab(mins, maxs, ns, dirichletnodes, planes[rank], planes[rank + 1], ctx)
+    plane = int(ns[1]) * int(ns[2])
+    bounds = [p.free_rows_before(q * plane) for q in planes]
+    return p, bounds
+
+
 class RowBlock:
     """A rank's contiguous range of free rows (fv_dist_setup)."""
 
-    def __init__(self, global_problem, nranks, rank):
+    def __init__(self, global_problem, nranks, rank, bounds=None):
         h = _lib.c_prob()
-        global_problem.check(load().fv_dist_setup(global_problem.handle, int(nranks), int(rank), C.byref(h)))
+        if bounds is None:
+            global_problem.check(load().fv_dist_setup(global_problem.handle, int(nranks), int(rank), C.byref(h)))
+        else:
+            b = ai64(bounds)
+            if len(b) != int(nranks) + 1:
+                raise ValueError("bounds needs nranks + 1 entries")
+            global_problem.check(load().fv_dist_setup_bounds(global_problem.handle, int(nranks), int(rank), ptr(b), C.byref(h)))
         self.handle, self.ctx = h, global_problem.ctx
         self.nranks, self.rank = int(nranks), int(rank)
         v = [C.c_int64() for _ in range(7)]

@@ -254,6 +254,19 @@ int fv_comm_init_local(fv_ctx *ctx, int nranks, int rank, int group_id);
  * [local | halo]; the global problem can be destroyed afterwards.  State slot 0 of
  * the block is the rank's slice of the global slot 0. */
 int fv_dist_setup(fv_problem *global, int nranks, int rank, fv_problem **block);
+/* Row ranges chosen by the caller: rank r owns the free rows [bounds[r], bounds[r+1]) (bounds[0] = 0, bounds[nranks] = n,
+ * the same array on every rank). */
+int fv_dist_setup_bounds(fv_problem *global_problem, int nranks, int rank, const int64_t *bounds, fv_problem **block);
+/* Row-block runs WITHOUT the global operator on every GPU: the problem of one slab of a structured grid — global node
+ * arrays, but only the faces of the cells in the planes [i1_lo, i1_hi) (and the x-faces into plane i1_lo).  After
+ * fv_assemble / fv_transient_begin (called with the global sources, heads, u0) its free rows of those planes are bit
+ * for bit the global operator's; pass it to fv_dist_setup_bounds with bounds on plane boundaries, which
+ * fv_problem_free_rows_before(problem, i1 * ns[1] * ns[2], &rows) converts into row numbers.  Per-face conductivities are
+ * indexed by the slab's own faces (a contiguous range of the global face list); a single value or a metaindex work as
+ * before. */
+int fv_problem_create_regulargrid_slab(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3], int64_t ndir,
+                                       const int64_t *dirichletnodes, int64_t i1_lo, int64_t i1_hi, fv_problem **out);
+int fv_problem_free_rows_before(fv_problem *p, int64_t node0, int64_t *rows);
 int fv_dist_plan_sizes(fv_problem *block, int64_t *lo, int64_t *hi, int64_t *nnz_loc, int64_t *nhalo, int64_t *nsend,
                        int64_t *n_interior_groups, int64_t *n_boundary_groups);
 /* The plan, 0-based (device convention): local CSR, global column of every halo slot,

@@ -279,3 +279,25 @@ def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
             got[lo:hi] = state
             assert np.abs(its.astype(int) - ref_its.astype(int)).max() <= 1, (its, ref_its)
         assert relerr(got, want) < 1e-11, (ns, nranks)
+        if nranks != 8:
+            continue
+        # the same with every rank assembling only its own planes (what bench.py --gpus N does)
+        from fvamd import dist
+
+        Kg = 1e-5 * np.exp(0.3 * np.random.default_rng(0).standard_normal(3 * ns[0] * ns[1] * ns[2] - ns[0] * ns[1] - ns[0] * ns[2] - ns[1] * ns[2]))
+        u0 = np.full(ns[0] * ns[1] * ns[2], 1e3) + np.random.default_rng(1).standard_normal(ns[0] * ns[1] * ns[2])
+        planes = dist.slab_planes(ns[0], nranks)
+
+        def make_slab(ctx, rank):
+            p, bounds = dist.slab_problem(mins, maxs, ns, dn, nranks, rank, ctx)
+            f0, f1 = dist.slab_face_range(ns, planes[rank], planes[rank + 1])
+            p.assemble(Kg[f0:f1], src, np.full(len(dn), 1e3))
+            p.transient_begin(0.1, None, u0)
+            return p, bounds
+
+        out = _run_ranks_in_threads(fv, nranks, gid + 20, make_slab, schedule, 1e-12, by_rank=True)
+        assert [o[0] for o in out] + [out[-1][1]] == [max(q - 1, 0) * (ns[1] - 2) * ns[2] if q < ns[0] else len(want) for q in planes]
+        for lo, hi, state, its in out:
+            got[lo:hi] = state
+            assert np.abs(its.astype(int) - ref_its.astype(int)).max() <= 1, (its, ref_its)
+        assert relerr(got, want) < 1e-11, (ns, nranks, "slabs")

@@ -715,7 +715,7 @@ def test_amg_in_implicit_steps_matches_jacobi_steps(fv):
 
 
 # ------------------------------------------------------------------ multi-rank protocol on one GPU (loopback transport)
-def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol):
+def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol, by_rank=False):
     """One host thread per rank, each with its own context on device 0 and the loopback transport (fv_comm_init_local):
     the complete row-block driver — plan, pack, halo exchange, interior/boundary passes, reductions, carry-over,
     speculation — with real kernels; only the wire differs from RCCL."""
@@ -729,8 +729,9 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol):
         try:
             ctx = fv.Context(0)
             dist.comm_init_local(ctx, nranks, rank, group_id)
-            p = make_problem(ctx)
-            blk = dist.RowBlock(p, nranks, rank)
+            p = make_problem(ctx) if not by_rank else make_problem(ctx, rank)
+            p, bounds = p if isinstance(p, tuple) else (p, None)
+            blk = dist.RowBlock(p, nranks, rank, bounds)
             p.close()
             its = []
             for dt, nsteps in schedule:
@@ -793,6 +794,71 @@ def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
         got[lo:hi] = state
         assert np.array_equal(its, out[0][3]) and (its[6:46] == 2).sum() >= 2 and set(np.unique(its[6:46])) == {1, 2}
     assert relerr(got, want) < 1e-12
+
+
+@pytest.mark.parametrize("nranks", [2, 5])
+def test_slab_assembled_row_blocks_equal_the_globally_assembled_ones(fv, nranks):
+    """Each rank assembles only the faces of its own planes (fv_problem_create_regulargrid_slab) and takes its rows with
+    fv_dist_setup_bounds: same plan, same matrix rows, bit-identical run as blocks cut from the global operator."""
+    import bench
+    from fvamd import dist
+
+    ns = [11, 6, 5]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    dn = np.union1d(dn, [1 + 3 * 30 + 7, 1 + 4 * 30, 1 + 4 * 30 + 1])  # Dirichlet cells inside, two at the start of a plane
+    dh = np.full(len(dn), 1e3)
+    ref = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    Kg = 1e-5 * np.exp(np.random.default_rng(0).standard_normal(ref.F))
+    u0 = np.full(ref.N, 1e3) + np.random.default_rng(1).standard_normal(ref.N)
+    planes = dist.slab_planes(ns[0], nranks)
+    bounds_ref = [ref.free_rows_before(q * 30) for q in planes]
+    free, n2f = ref.free_maps()
+    assert bounds_ref == [int(free[: q * 30].sum()) for q in planes] and bounds_ref[-1] == ref.n
+
+    def global_blocks(ctx, rank):
+        p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+        p.assemble(Kg, src, dh)
+        p.transient_begin(0.1, None, u0)
+        return p, bounds_ref
+
+    plans = {}
+
+    def slab_blocks(ctx, rank):
+        p, bounds = dist.slab_problem(mins, maxs, ns, dn, nranks, rank, ctx)
+        assert bounds == bounds_ref
+        f0, f1 = dist.slab_face_range(ns, planes[rank], planes[rank + 1])
+        assert p.F == f1 - f0 and p.N == ref.N and p.n == ref.n
+        p.assemble(Kg[f0:f1], src, dh)
+        p.transient_begin(0.1, None, u0)
+        blk = dist.RowBlock(p, nranks, rank, bounds)  # a second one, for the plan only (no communication)
+        rng = np.random.default_rng(rank)
+        plans[rank] = (blk.plan(), blk.spmv_halo(rng.standard_normal(blk.nloc), rng.standard_normal(blk.nhalo), 0.5))
+        blk.close()
+        return p, bounds
+
+    schedule = [(3600.0, 4), (2.0**-10, 20)]
+    a = _run_ranks_in_threads(fv, nranks, 500 + nranks, global_blocks, schedule, 1e-12, by_rank=True)
+    b = _run_ranks_in_threads(fv, nranks, 520 + nranks, slab_blocks, schedule, 1e-12, by_rank=True)
+    ref.assemble(Kg, src, dh)
+    ref.transient_begin(0.1, None, u0)
+    for rank, (x, y) in enumerate(zip(a, b)):
+        assert x[:2] == y[:2] == (bounds_ref[rank], bounds_ref[rank + 1])
+        assert np.array_equal(x[2], y[2]) and np.array_equal(x[3], y[3])
+        want = dist.RowBlock(ref, nranks, rank, bounds_ref)
+        for u, v in zip(want.plan(), plans[rank][0]):
+            assert np.array_equal(u, v)
+        rng = np.random.default_rng(rank)
+        assert np.array_equal(want.spmv_halo(rng.standard_normal(want.nloc), rng.standard_normal(want.nhalo), 0.5), plans[rank][1])
+        want.close()
+    # a rank whose rows are not inside its slab is refused
+    p, bounds = dist.slab_problem(mins, maxs, ns, dn, nranks, 0)
+    p.assemble(1e-5, src, dh)
+    p.transient_begin(0.1, None, u0)
+    with pytest.raises(fv.FVError, match="not inside the slab"):
+        dist.RowBlock(p, nranks, 1, bounds)
+    with pytest.raises(fv.FVError, match="bounds must run"):
+        dist.RowBlock(p, nranks, 0, [0] + bounds[1:-1] + [bounds[-1] - 1])
 
 
 def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
