@@ -267,7 +267,8 @@ int g_use_dia = 1;
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
 static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
-static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9)
+static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9): 0 never, 1 when x outgrows the last-level cache, 2 always
+static int g_march_min_mb = 320; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache; measured crossover ~4e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
@@ -304,8 +305,10 @@ extern "C" int fv_tune(int key, int value)
         g_carry_refresh = value;
     else if (key == 8 && (value == 0 || value == 1))
         g_carry_speculate = value;
-    else if (key == 9 && (value == 0 || value == 1))
+    else if (key == 9 && value >= 0 && value <= 2)
         g_march = value;
+    else if (key == 19 && value >= 0)
+        g_march_min_mb = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))
@@ -1111,7 +1114,12 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
     hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, I_>), dim3(GA), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, dcount, dlist, p->dia_pos.p, p->sl_noff.p, \
                        p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, partials, scal, epi)
         // structured grids: plane-marching form over the whole DIA part (not for subsets or the fused set-up)
-        const bool march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
+        // ... when it pays: while x (8 bytes per column) stays in the 256 MB last-level cache the -plane / +plane arms of the
+        // slice-by-slice kernel come from there and the marching kernel's static partition only costs (short pencils, uneven
+        // XCD shares): 177 vs 216 us on 1.2e7 rows, 352 vs 364 on 2.5e7, 505 vs 539 on 3.4e7, 777 vs 758 on 5e7, ~2000 vs 1600 on 1e8
+        // (tools/march_vs_dia.py, profiles/r01_march_vs_dia.log)
+        const bool march_pays = g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
+        const bool march = g_march && march_pays && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         int GM = 0;
         if (march) {
             const int64_t ns = (p->n + 63) >> 6;

@@ -221,12 +221,15 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      0 = every step computes its initial residual with an SpMV
  *   8: in such runs, after a one-iteration step, the first vector update of a step also prepares the next step's
  *      set-up, so a step is SpMV + one fused vector pass [1]
- *   9: plane-marching sliced-DIA SpMV on operators with a plane stride (structured grids) [1]
+ *   9: plane-marching sliced-DIA SpMV on operators with a plane stride (structured grids): 0 never, 1 when the x
+ *      vector outgrows the last-level cache (key 19), 2 always [1]
  *  10: segments per XCD of that kernel, 0 = chosen per operator [0]
  *  11: sliced-DIA values packed (1) or padded to 8 blocks per slice (0); read when the DIA copy is built [1]
  *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support [1]
  *  13: one-iteration steps of a fixed-dt run enqueued per device poll (a step that needs more iterations stops the
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
+ *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
+ *      slice-by-slice kernel is faster; measured crossover 3.4e7-5e7 rows) [320]
  *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
  *  17: diagnosis switches of the marching kernel (bit 0: no in-plane arm loads, bit 1: no plane-arm edge loads);
  *      results are wrong when set [0]

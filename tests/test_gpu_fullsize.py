@@ -183,7 +183,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
     scale = np.abs(ref).max()
     lib = fv.load()
     try:
-        for name, knobs in (("march", {9: 1, 6: 1, 18: 1}), ("march m=1", {9: 1, 10: 1}), ("march m=5", {9: 1, 10: 5}), ("march, no windows", {9: 1, 18: 0}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
+        for name, knobs in (("march", {9: 2, 6: 1, 18: 1}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
                 assert lib.fv_tune(k, v) == 0
             y = p.spmv(x, sigma)
@@ -192,7 +192,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
             lib.fv_tune(10, 0)
         # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
         heads = {}
-        for name, knobs in (("march", {9: 1, 6: 1}), ("slices", {9: 0, 6: 1})):
+        for name, knobs in (("march", {9: 2, 6: 1}), ("slices", {9: 0, 6: 1})):
             for k, v in knobs.items():
                 lib.fv_tune(k, v)
             st = p.new_state()
@@ -224,7 +224,9 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     u0 = np.full(p.N, 1e3) + rng.standard_normal(p.N)
     st = p.transient_begin(0.1, None, u0)
     x = rng.standard_normal(p.n)
-    for sigma in (0.0, 1 / 60.0):
+    lib = fv.load()
+    for sigma, forced in ((0.0, 2), (1 / 60.0, 2), (1 / 60.0, 1)):  # 2: marching at any size; 1: the library's choice (slices at this size)
+        lib.fv_tune(9, forced)
         y_global = p.spmv(x, sigma)
         for nranks in (2, 3):
             for rank in range(nranks):
@@ -238,6 +240,7 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     ctx = p.ctx
     dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
     try:
+        lib.fv_tune(9, 2)
         blk = dist.RowBlock(p, 1, 0)
         it_d, info_d, _ = blk.run_fixed(600.0, 6, 1e-12)
         it_s, info_s, _ = p.run_fixed(st, 600.0, 6, 1e-12)
@@ -245,6 +248,7 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
         assert np.abs(blk.state() - st.free_values()).max() <= 1e-9
         blk.close()
     finally:
+        lib.fv_tune(9, 1)
         fv.load().fv_comm_destroy(ctx.handle)
 
 
@@ -273,7 +277,11 @@ def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
         ref_its = np.concatenate([ref.run_fixed(st, dt, k, 1e-12)[0] for dt, k in schedule])
         want = st.free_values()
         ref.close()
-        out = _run_ranks_in_threads(fv, nranks, gid, make_problem, schedule, 1e-12)
+        fv.load().fv_tune(9, 2)  # blocks this small would take the slice kernel (x fits the last-level cache): force the marching pass
+        try:
+            out = _run_ranks_in_threads(fv, nranks, gid, make_problem, schedule, 1e-12)
+        finally:
+            fv.load().fv_tune(9, 1)
         got = np.empty_like(want)
         for lo, hi, state, its in out:
             got[lo:hi] = state

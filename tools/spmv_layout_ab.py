@@ -26,7 +26,7 @@ res = {}
 for r in range(5):
     for packed in (0, 1):
         for march in (1, 4, 0):  # 4: marching with separate centre + edge loads instead of the 16-byte window
-            lib.fv_tune(9, 1 if march else 0)
+            lib.fv_tune(9, 2 if march else 0)
             lib.fv_tune(18, 0 if march == 4 else 1)
             res.setdefault((packed, march), []).append(probs[packed].bench_spmv(1 / 60.0, 10))
         lib.fv_tune(18, 1)

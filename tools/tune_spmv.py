@@ -34,7 +34,7 @@ def select(form, order, fold, nt, dia, march):
     lib.fv_tune(3, fold)
     lib.fv_tune(4, nt)
     lib.fv_tune(6, dia)
-    lib.fv_tune(9, 1 if march else 0)
+    lib.fv_tune(9, 2 if march else 0)
     if march:
         lib.fv_tune(10, max(march, 0))  # -1: let the library choose the segment count
 
