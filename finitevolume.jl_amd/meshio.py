@@ -7,8 +7,30 @@
     <id1> <id2> <x> <y> <z> <area>       (m lines; x y z = face centre)
 
 give everything the solver wants: neighbours, areas/lengths (length = distance between the two cell centres,
-setupmesh.jl:42-43) and — unlike the mesh.jld the reference saves — the cell volumes the transient path needs."""
+setupmesh.jl:42-43) and — unlike the mesh.jld the reference saves — the cell volumes the transient path needs.
+The saved meshes themselves (`mesh.jld`, setupmesh.jl:46; read back at examples/fractures/ex.jl:9) are read by
+`read_mesh_jld` through the HDF5-subset reader in jldio.py."""
 import numpy as np
+
+from .jldio import JLDFormatError, load_jld  # noqa: F401  (re-exported)
+
+_MESH_JLD_FIELDS = ("xs", "ys", "zs", "neighbors", "areasoverlengths", "fractureindices", "dirichletnodes", "dirichletheads", "conductivities")
+
+
+def read_mesh_jld(path):
+    """The variables examples/fractures/ex.jl:9 loads from a mesh.jld, as a dict: xs, ys, zs, neighbors ((m, 2) int64,
+    1-based), node1/node2 (its columns), areasoverlengths, fractureindices, dirichletnodes (1-based), dirichletheads,
+    conductivities, and metaindex — the 1-based fracture of each connection's first node (ex.jl:11-13)."""
+    mesh = dict(zip(_MESH_JLD_FIELDS, load_jld(path, *_MESH_JLD_FIELDS)))
+    nb = mesh["neighbors"]
+    if nb.ndim != 2 or nb.shape[1] != 2:
+        raise JLDFormatError("%s: neighbors is not a list of pairs" % path)
+    N = len(mesh["xs"])
+    if len(nb) and (nb.min() < 1 or nb.max() > N):
+        raise ValueError("%s: connection refers to a cell outside 1..%d" % (path, N))
+    mesh["node1"], mesh["node2"] = nb[:, 0].copy(), nb[:, 1].copy()
+    mesh["metaindex"] = mesh["fractureindices"][mesh["node1"] - 1]
+    return mesh
 
 
 def read_uge(path):

@@ -123,6 +123,24 @@ def test_fourfractures_steady_vs_direct_and_pflotran(fv, oracle):
     assert relerr(head_a, ohead) < HEAD_RTOL
 
 
+def test_fractures_example_from_the_saved_mesh_file(fv, oracle):
+    """examples/fractures/ex.jl:9-14 as written: JLD.load of mesh.jld, per-fracture conductivities through a
+    metaindex, solvediffusion — from the reference's own data file (tests/golden/fourfractures/mesh.jld)."""
+    m = fv.meshio.read_mesh_jld(os.path.join(GOLDEN, "fourfractures", "mesh.jld"))
+    N = len(m["xs"])
+    src = np.zeros(N)
+    kf = np.array([1e-12, 3e-12, 5e-13, 2e-12])  # one conductivity per fracture
+    head, ch, A, b, fn = fv.solvediffusion(m["neighbors"], m["areasoverlengths"], kf, src, m["dirichletnodes"], m["dirichletheads"],
+                                           metaindex=m["metaindex"], maxiter=400, rtol=1e-13)
+    assert ch.isconverged
+    ohead = oracle.solvediffusion(m["node1"], m["node2"], m["areasoverlengths"], kf[m["metaindex"] - 1], src, m["dirichletnodes"], m["dirichletheads"], solver="direct")[0]
+    assert relerr(head, ohead) < HEAD_RTOL
+    # the file's own per-connection conductivities: the run of ex.jl itself
+    head, ch, *_ = fv.solvediffusion(m["neighbors"], m["areasoverlengths"], m["conductivities"], src, m["dirichletnodes"], m["dirichletheads"], maxiter=400, rtol=1e-13)
+    h = fv.meshio.load_jld(os.path.join(GOLDEN, "fourfractures", "pflotran_solution.jld"), "h")
+    assert ch.isconverged and relerr(head, h) < 1.1e-2
+
+
 def test_fixed_steps_vs_oracle_direct(fv, oracle):
     coords, nb, aol, vol, K, dn, dh = _box(fv, (14, 12, 10), sigma=1.0)
     N = len(vol)

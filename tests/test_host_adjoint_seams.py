@@ -123,3 +123,34 @@ def test_locality_order_and_reorder_mesh(fv):
     assert np.array_equal(np.sort(np.stack([m["node1"], m["node2"]], 1), 1), np.sort(np.stack([rank[w["node1"] - 1], rank[w["node2"] - 1]], 1), 1))
     spread = lambda a, b: np.abs(a - b).mean()  # noqa: E731
     assert spread(m["node1"], m["node2"]) < 0.25 * spread(w["node1"], w["node2"])
+
+
+def test_mesh_jld_reader_on_the_reference_data_files(fv, tmp_path):
+    """read_mesh_jld / load_jld (HDF5-subset reader, no HDF5 library) on the two data files of
+    examples/fractures/fourfractures, against the same data extracted with h5dump (tests/golden/fourfractures.npz,
+    make_fourfractures.py): every array bit for bit."""
+    import os
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    want = np.load(os.path.join(golden, "fourfractures.npz"))
+    mesh = fv.meshio.read_mesh_jld(os.path.join(golden, "fourfractures", "mesh.jld"))
+    for name in ("xs", "ys", "zs", "areasoverlengths", "conductivities", "dirichletnodes", "dirichletheads", "fractureindices", "node1", "node2"):
+        assert mesh[name].dtype == want[name].dtype and np.array_equal(mesh[name], want[name]), name
+    assert mesh["neighbors"].shape == (6314, 2) and np.array_equal(mesh["metaindex"], want["fractureindices"][want["node1"] - 1])
+    h = fv.meshio.load_jld(os.path.join(golden, "fourfractures", "pflotran_solution.jld"), "h")
+    assert np.array_equal(h, want["pflotran_h"])
+    everything = fv.meshio.load_jld(os.path.join(golden, "fourfractures", "mesh.jld"))
+    assert sorted(everything) == sorted(["xs", "ys", "zs", "neighbors", "areasoverlengths", "fractureindices", "dirichletnodes", "dirichletheads", "conductivities"])
+    # errors: a missing variable, a file that is not HDF5, a truncated file
+    import pytest
+
+    with pytest.raises(KeyError, match="no variable volumes"):
+        fv.meshio.load_jld(os.path.join(golden, "fourfractures", "mesh.jld"), "volumes")
+    bad = tmp_path / "bad.jld"
+    bad.write_bytes(b"Julia data file (HDF5), version 0.1.1" + b"\0" * 2000)
+    with pytest.raises(fv.meshio.JLDFormatError, match="no HDF5 signature"):
+        fv.meshio.load_jld(str(bad))
+    data = open(os.path.join(golden, "fourfractures", "mesh.jld"), "rb").read()
+    bad.write_bytes(data[:60000])
+    with pytest.raises(fv.meshio.JLDFormatError):
+        fv.meshio.load_jld(str(bad))
