@@ -27,7 +27,7 @@ from .core import (  # noqa: F401
     regulargrid,
     solvediffusion,
 )
-from .adjoint import adjointintegrate, getadjointfunctions, getcontinuoussolution, gradientintegrate, integratedfdplambda, transpose  # noqa: F401
+from .adjoint import adjointintegrate, devicegradientintegral, getadjointfunctions, getcontinuoussolution, gradientintegrate, integratedfdplambda, transpose  # noqa: F401
 from .transient import (  # noqa: F401
     DeviceOperator,
     DevicePCG,

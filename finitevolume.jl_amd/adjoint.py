@@ -221,6 +221,58 @@ def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neigh
     return g, dgdu, dfdp, dgdp, du0dp, G
 
 
+def devicegradientintegral(uc, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, scale="reference", ctx=None):
+    """The integral over tspan of dfdp(uc, t, p) * lambda(t) — what gradientintegrate(lambdac, du0dp, dgdp, dfdp, tspan)
+    adds to the gradient (transient.jl:208-219 with the dfdp of transientadjointutils.jl:23-30) — computed by
+    fv_param_gradient_integral: one thread per face walks the merged knots of uc (a LinearInterpolant of node vectors)
+    and lambda (free-indexed, piecewise linear over ts_lambda); exact, no quadrature.
+
+    scale: "reference" divides lambda_f by (Ss*volumes)[f] with the FREE index f, as the reference's scalebyvolume!
+    call does (see getadjointfunctions); "storage" by the volume of the node behind f; None not at all."""
+    from .core import Problem, _metaindex_array, _split_neighbors, getfreenodes, getnodei2dirichleti
+
+    if not isinstance(uc, LinearInterpolant):
+        raise TypeError("devicegradientintegral needs the piecewise-linear solution object (getcontinuoussolution)")
+    K, dh = af64(conductivities), af64(dirichletheads)
+    nK, N, ndir = len(K), len(sources), len(dh)
+    n1, n2 = _split_neighbors(neighbors)
+    F = len(n1)
+    freenode, n2f = getfreenodes(N, dirichletnodes)
+    nfree = int(freenode.sum())
+    lam = LinearInterpolant(lambdas, ts_lambda)
+    lo, hi = float(tspan[0]), float(tspan[1])
+    knots = np.unique(np.concatenate([lam.ts, uc.ts, [lo, hi]]))
+    knots = knots[(knots >= lo) & (knots <= hi)]
+    if len(knots) < 2:
+        return np.zeros(nK + N + ndir)
+    U = uc.at(knots)[:, freenode]
+    L = lam.at(knots)
+    vols = Ss * af64(volumes)
+    if scale == "reference":
+        L = L / vols[:nfree]
+    elif scale == "storage":
+        L = L / vols[freenode]
+    elif scale is not None:
+        raise ValueError("scale must be 'reference', 'storage' or None")
+    # (the Jacobian does not depend on the source values: none are handed over, so none can sit on a Dirichlet node)
+    p = Problem.create(neighbors, areasoverlengths, N, dirichletnodes, ctx).assemble(K, np.zeros(N), dh, metaindex, logtransformconductivity)
+    try:
+        face_k, face_dir, row_src = p.param_gradient_integral(knots, U, L, False, logtransformconductivity)
+    finally:
+        p.close()
+    mi = _metaindex_array(metaindex, F)
+    m = (mi - 1) if mi is not None else np.arange(F)
+    out = np.zeros(nK + N + ndir)
+    out[:nK] = np.bincount(m, weights=face_k, minlength=nK)
+    out[nK + np.nonzero(freenode)[0]] = row_src
+    n2d = getnodei2dirichleti(np.zeros(N), dirichletnodes)
+    a, b = n1 - 1, n2 - 1
+    for fr, di in ((a, b), (b, a)):  # faces with exactly one free end: their term goes to the head of the other end
+        sel = freenode[fr] & ~freenode[di]
+        out[nK + N :] += np.bincount(n2d[di[sel]] - 1, weights=face_dir[sel], minlength=ndir)
+    return out
+
+
 class FVErrorNotSupported(Exception):
     """error("not supported"), FiniteVolume.jl:363"""
 
@@ -255,7 +307,7 @@ def _product_integrals(lam, u2, nodes, freeidx, tspan):
     return np.array([sum(quad(lambda t: lam(t)[f] * u2(n + 1, t), a, b)[0] for a, b in zip(knots[:-1], knots[1:])) for n, f in zip(nodes, freeidx)])
 
 
-def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, complete=False):
+def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, complete=False, device=True):
     """transientadjointutils.jl:57-63 -> FiniteVolume.jl:271-377 (integrateb_pmA_pxlambda): the integral over tspan of
     dfdp(t) * lambda(t) with lambda piecewise linear over ts_lambda and u2 = getcontinuoussolution(us, ts, 2).
 
@@ -265,9 +317,10 @@ def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors
         into the Dirichlet head, plus  + c * integral(lambda_f * u_node) / (Ss*volumes[f])   into K   (:339-360)
         with volumes indexed by the FREE index f there, and the u term entering with a plus sign;
       * no free|free face terms; logtransformconductivity=false raises "not supported"       (:362-363).
-    complete=True instead integrates the full Jacobian (b_p - A_px, every face, the D^-1 scaling of dfdp in
-    getadjointfunctions) by Gauss-Kronrod between lambda's knots — the quantity gradientintegrate(lambdac, ..., dfdp)
-    integrates."""
+    complete=True instead integrates the full Jacobian (b_p - A_px, every face, scaled by D^-1 = 1 / (Ss * volume of
+    the node behind each free unknown)) — the quantity gradientintegrate(lambdac, ..., dfdp) integrates: on the device, exactly, when
+    u2 is the piecewise-linear solution object (devicegradientintegral); device=False or an opaque u2(i, t) falls back
+    to Gauss-Kronrod between lambda's knots with the Jacobian rebuilt on the host at every evaluation."""
     from .core import _metaindex_array, _split_neighbors, getfreenodes, getnodei2dirichleti
 
     if not logtransformconductivity:
@@ -278,6 +331,9 @@ def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors
     vols = Ss * af64(volumes)
     freenode, n2f = getfreenodes(N, dirichletnodes)
     lam = LinearInterpolant(lambdas, ts_lambda)
+    if complete and device and isinstance(u2, LinearInterpolant):
+        # both factors piecewise linear: the device kernel integrates every face exactly (fv_param_gradient_integral)
+        return devicegradientintegral(u2, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, True, scale="storage")
     if complete:
         import inspect
 
@@ -293,7 +349,7 @@ def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors
 
         def integrand(t):
             M, _, _ = _parameter_jacobians(np.asarray(uc(t))[freenode], neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, True)
-            return (M @ sp.diags(1.0 / vols[: M.shape[1]])) @ lam(t)
+            return (M @ sp.diags(1.0 / vols[freenode])) @ lam(t)
 
         total = np.zeros(nK + N + ndir)
         knots = sorted(set(float(t) for t in ts_lambda if tspan[0] <= t <= tspan[1]) | {float(tspan[0]), float(tspan[1])})

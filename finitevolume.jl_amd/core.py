@@ -303,6 +303,20 @@ class Problem:
         self.check(load().fv_transient_begin(self.handle, float(Ss), ptr(v), ptr(u)))
         return DeviceVector(self, 0, owned=False)
 
+    def param_gradient_integral(self, ts, x_knots, lam_knots, scale_by_storage=False, logtransformconductivity=False):
+        """fv_param_gradient_integral: exact time integral of (b_p - A_p u)' w for piecewise-linear u, w given at the
+        common knots ts (rows of x_knots / lam_knots, free-indexed).  -> per-face K terms, per-face Dirichlet-head
+        terms, per-free-row source terms."""
+        t = af64(ts)
+        X = np.ascontiguousarray(x_knots, dtype=np.float64)
+        L = np.ascontiguousarray(lam_knots, dtype=np.float64)
+        if X.shape != (len(t), self.n) or L.shape != X.shape:
+            raise FVError(_lib.FV_ERR_ARG, "x_knots and lam_knots must be (len(ts), n) arrays")
+        fk, fd, rs = np.empty(self.F), np.empty(self.F), np.empty(self.n)
+        self.check(load().fv_param_gradient_integral(self.handle, len(t), ptr(t), ptr(X), ptr(L), int(bool(scale_by_storage)),
+                                                     int(bool(logtransformconductivity)), ptr(fk), ptr(fd), ptr(rs)))
+        return fk, fd, rs
+
     def new_state(self):
         s = C.c_int32()
         self.check(load().fv_state_alloc(self.handle, C.byref(s)))

@@ -285,6 +285,8 @@ static void set_resident_blocks(const fv_ctx *ctx)
     g_resident_blocks = b > FV_MAX_PARTIALS ? FV_MAX_PARTIALS : (int)b;
 }
 
+extern int g_gradient_knots_per_pass; // fv_gradient.hip
+
 extern "C" int fv_tune(int key, int value)
 {
     if (key == 0 && (value == 1 || value == 2))
@@ -309,6 +311,8 @@ extern "C" int fv_tune(int key, int value)
         g_march = value;
     else if (key == 19 && value >= 0)
         g_march_min_mb = value;
+    else if (key == 20 && (value == 0 || value >= 2))
+        g_gradient_knots_per_pass = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))

@@ -181,6 +181,21 @@ int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfi
                               int64_t maxiter, int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves,
                               fv_solve_info *last_info);
 
+/* ---------------------------------------------------------------- parameter gradients (adjoint workflow)
+ * The time integral of dfdp(t)' * lambda(t) over [ts[0], ts[nt-1]] with dfdp = (b_p - A_p u), optionally scaled by
+ * D^-1 = 1 / (Ss volumes) as transientadjointutils.jl:23-30 does — the quantity gradientintegrate integrates
+ * (transient.jl:208-219) and FiniteVolume.jl:271-377 (integrateb_pmA_pxlambda) unrolls by hand.  u (x_knots) and lambda
+ * (lam_knots) are given at nt common knots, free-indexed, knot after knot (nt * n doubles each, host memory), and taken
+ * as linear in between, so the result is exact.  Returned per face / per free row; the caller sums them into
+ * p = [conductivities; sources; dirichletheads]:
+ *   face_k[i]    -> conductivities[metaindex(i)]   (includes dc/dK: areasoverlengths, or the conductance itself when
+ *                                                   logtransform != 0)
+ *   face_dir[i]  -> dirichletheads[position of face i's Dirichlet end]   (0 for faces without exactly one)
+ *   row_src[f]   -> sources[node of free row f]
+ * Uses the conductances and heads of the last fv_assemble; scale_by_storage needs fv_transient_begin. */
+int fv_param_gradient_integral(fv_problem *p, int64_t nt, const double *ts, const double *x_knots, const double *lam_knots,
+                               int scale_by_storage, int logtransform, double *face_k, double *face_dir, double *row_src);
+
 /* ---------------------------------------------------------------- kernel-level entry points (parity tests, roofline) */
 /* y = (A + sigma*D) x on n free unknowns */
 int fv_spmv(fv_problem *p, const double *x_free, double sigma, double *y_free);
@@ -230,6 +245,7 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
  *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
  *      slice-by-slice kernel is faster; measured crossover 3.4e7-5e7 rows) [320]
+ *  20: knots per device pass of fv_param_gradient_integral, 0 = as many as fit 2 GiB [0]
  *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
  *  17: diagnosis switches of the marching kernel (bit 0: no in-plane arm loads, bit 1: no plane-arm edge loads);
  *      results are wrong when set [0]

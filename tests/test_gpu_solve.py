@@ -124,17 +124,18 @@ def test_fourfractures_steady_vs_direct_and_pflotran(fv, oracle):
 
 
 def test_fractures_example_from_the_saved_mesh_file(fv, oracle):
-    """examples/fractures/ex.jl:9-14 as written: JLD.load of mesh.jld, per-fracture conductivities through a
-    metaindex, solvediffusion — from the reference's own data file (tests/golden/fourfractures/mesh.jld)."""
+    """examples/fractures/ex.jl:9-14 as written: JLD.load of mesh.jld, per-fracture conductivities, solvediffusion — from the reference's own data file (tests/golden/fourfractures/mesh.jld)."""
     m = fv.meshio.read_mesh_jld(os.path.join(GOLDEN, "fourfractures", "mesh.jld"))
     N = len(m["xs"])
     src = np.zeros(N)
     kf = np.array([1e-12, 3e-12, 5e-13, 2e-12])  # one conductivity per fracture
-    head, ch, A, b, fn = fv.solvediffusion(m["neighbors"], m["areasoverlengths"], kf, src, m["dirichletnodes"], m["dirichletheads"],
-                                           metaindex=m["metaindex"], maxiter=400, rtol=1e-13)
+    head, ch, A, b, fn = fv.solvediffusion(m["neighbors"], m["areasoverlengths"], kf[m["metaindex"] - 1], src, m["dirichletnodes"], m["dirichletheads"], maxiter=400, rtol=1e-13)
     assert ch.isconverged
     ohead = oracle.solvediffusion(m["node1"], m["node2"], m["areasoverlengths"], kf[m["metaindex"] - 1], src, m["dirichletnodes"], m["dirichletheads"], solver="direct")[0]
     assert relerr(head, ohead) < HEAD_RTOL
+    # the same through the metaindex of the assembly (assembleA / assembleb take it: FiniteVolume.jl:75, 106)
+    p = fv.Problem.create(m["neighbors"], m["areasoverlengths"], N, m["dirichletnodes"]).assemble(kf, src, m["dirichletheads"], m["metaindex"])
+    assert np.array_equal(p.csc().nzval, A.nzval) and np.array_equal(p.b(), b)
     # the file's own per-connection conductivities: the run of ex.jl itself
     head, ch, *_ = fv.solvediffusion(m["neighbors"], m["areasoverlengths"], m["conductivities"], src, m["dirichletnodes"], m["dirichletheads"], maxiter=400, rtol=1e-13)
     h = fv.meshio.load_jld(os.path.join(GOLDEN, "fourfractures", "pflotran_solution.jld"), "h")
@@ -449,6 +450,9 @@ def test_onenode_adjoint_gradient_vs_finite_differences(fv):
     uc_init2 = fv.getcontinuoussolution(us_i, ts_i, 2)
     idl = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, complete=True)
     dGdp2 = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc_init, t, p0), idl, c["tspan"])
+    # (complete=True ran on the device — fv_param_gradient_integral; the host quadrature of the same integral agrees)
+    idl_host = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True, complete=True, device=False)
+    assert np.allclose(idl, idl_host, rtol=1e-8, atol=1e-12 * np.abs(idl_host).max())
     idl_ref = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, c["tspan"], c["Ss"], c["volumes"], nb, c["aol"], c["K"], c["sources"], c["dnodes"], c["dheads"], None, True)
     assert np.allclose(idl_ref[[2, 3]], idl[[2, 3]], rtol=1e-6, atol=0)
     # ... and carry the u term of the conductivity entry with the opposite sign (dhead = 0 here: that is the whole entry)
@@ -461,6 +465,78 @@ def test_onenode_adjoint_gradient_vs_finite_differences(fv):
         fd = (G(pp) - G(pm)) / (2 * deltap)
         assert abs(fd - dGdp[i]) <= 1e-2 * max(abs(fd), abs(dGdp[i])), (i, fd, dGdp[i])
         assert abs(dGdp2[i] - dGdp[i]) <= 1e-3 * abs(dGdp[i]) + 1e-14
+
+
+@pytest.mark.parametrize("logk", [True, False])
+def test_device_gradient_integral_vs_host_simpson_of_the_jacobians(fv, logk):
+    """fv_param_gradient_integral (one thread per face walking the knots) against Simpson's rule — exact for the
+    piecewise-quadratic integrand — over the host-built Jacobians b_p - A_px: box with a log-normal field, a
+    metaindex sharing parameters between faces, interior Dirichlet cells, a repeated Dirichlet node, a self-loop face,
+    unevenly spaced knots that differ between u and lambda, a tspan cutting through intervals."""
+    from fvamd import adjoint
+
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (9, 7, 6), sigma=1.0)
+    N, F = len(vol), len(aol)
+    rng = np.random.default_rng(3)
+    nb = np.vstack([nb, [[5, 5]]])  # a face from a node to itself: no contribution
+    aol = np.r_[aol, 1.0]
+    F += 1
+    dn = np.r_[dn, [N // 2, N // 2 + 1, dn[0]]]  # interior Dirichlet cells; dn[0] repeated: the last head wins
+    dh = np.r_[dh, [0.3, -0.2, 7.0]]
+    nK = 11
+    mi = rng.integers(1, nK + 1, F)
+    Kp = rng.standard_normal(nK) * 0.5 + (np.log(1e-3) if logk else 0.0)
+    if not logk:
+        Kp = np.exp(Kp) * 1e-3
+    src = rng.standard_normal(N) * 1e-4
+    Ss = 0.2
+    freenode, n2f = fv.getfreenodes(N, dn)
+    src[~freenode] = 0.0
+    nfree = int(freenode.sum())
+    ts_u = np.cumsum(np.r_[0.0, rng.uniform(0.5, 2.0, 7)])
+    ts_l = np.cumsum(np.r_[0.0, rng.uniform(0.3, 3.0, 5)])
+    ts_l *= ts_u[-1] / ts_l[-1]
+    us = [rng.standard_normal(N) for _ in ts_u]
+    lambdas = [rng.standard_normal(nfree) for _ in ts_l]
+    uc = fv.getcontinuoussolution(us, ts_u)
+    lam = adjoint.LinearInterpolant(lambdas, ts_l)
+    tspan = (0.37, 0.93 * ts_u[-1])
+    for scale, w in (("reference", 1.0 / (Ss * vol[:nfree])), ("storage", 1.0 / (Ss * vol[freenode])), (None, np.ones(nfree))):
+        got = fv.devicegradientintegral(uc, lambdas, ts_l, tspan, Ss, vol, nb, aol, Kp, src, dn, dh, mi, logk, scale=scale)
+
+        def f(t):
+            M, _, _ = adjoint._parameter_jacobians(uc(t)[freenode], nb, aol, Kp, src, dn, dh, mi, logk)
+            return M @ (lam(t) * w)
+
+        knots = np.unique(np.r_[ts_u, ts_l, tspan])
+        knots = knots[(knots >= tspan[0]) & (knots <= tspan[1])]
+        want = sum((b - a) / 6.0 * (f(a) + 4.0 * f(0.5 * (a + b)) + f(b)) for a, b in zip(knots[:-1], knots[1:]))
+        assert got.shape == want.shape == (nK + N + len(dh),)
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), scale
+        assert np.count_nonzero(got[:nK]) == nK and np.count_nonzero(got[nK + N :]) > 0
+    # many knots: several passes over the time series inside the library (chunks share a knot), same answer
+    p = fv.Problem.create(nb, aol, N, dn).assemble(Kp, src, dh, mi, logk)
+    kn = np.linspace(0.0, 5.0, 41)
+    X, L = rng.standard_normal((41, nfree)), rng.standard_normal((41, nfree))
+    whole = p.param_gradient_integral(kn, X, L, False, logk)
+    parts = [p.param_gradient_integral(kn[a : b + 1], X[a : b + 1], L[a : b + 1], False, logk) for a, b in ((0, 13), (13, 14), (14, 40))]
+    fv.load().fv_tune(20, 5)  # ... and with the library itself taking 5 knots per pass (10 passes)
+    try:
+        passes = p.param_gradient_integral(kn, X, L, False, logk)
+    finally:
+        fv.load().fv_tune(20, 0)
+    for k in range(3):
+        assert np.allclose(whole[k], sum(part[k] for part in parts), rtol=1e-12, atol=1e-14 * np.abs(whole[k]).max())
+        assert np.allclose(whole[k], passes[k], rtol=1e-12, atol=1e-14 * np.abs(whole[k]).max())
+    with pytest.raises(fv.FVError, match="needs fv_transient_begin"):
+        p.param_gradient_integral(kn, X, L, True, logk)
+    with pytest.raises(fv.FVError, match="knots must not decrease"):
+        p.param_gradient_integral(kn[::-1].copy(), X, L, False, logk)
+    p.transient_begin(Ss, vol, np.zeros(N))
+    scaled = p.param_gradient_integral(kn, X, L, True, logk)
+    direct = p.param_gradient_integral(kn, X, L / (Ss * vol[freenode]), False, logk)
+    for k in range(3):
+        assert np.allclose(scaled[k], direct[k], rtol=1e-12, atol=1e-14 * np.abs(direct[k]).max())
 
 
 def test_parameter_jacobians_vs_finite_differences_of_the_oracle_assembly(fv, oracle):
@@ -558,6 +634,21 @@ def test_theisadjoint_gradient_vs_finite_differences(fv):
         pm[i] -= deltap
         x1 = (G(pp) - G(pm)) / (2 * deltap)
         assert abs(x1 - dGdp[i]) <= 1e-3 * max(abs(x1), abs(dGdp[i])), (int(i), x1, dGdp[i])
+    # the whole Jacobian integrated on the device (fv_param_gradient_integral): the same source and head entries, and
+    # conductivity entries that hold up against finite differences too (the hand-unrolled routine above, followed term
+    # by term from the reference, has no free|free face terms, so its conductivity entries do not)
+    idl_dev = fv.integratedfdplambda(uc_init2, p0, lambdas, ts_l, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, complete=True)
+    dGdp_dev = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc_init, t, p0), idl_dev, tspan)
+    assert np.allclose(dGdp_dev[F : F + N], dGdp[F : F + N], rtol=1e-9, atol=1e-12 * np.abs(dGdp).max())
+    for i in np.r_[np.argsort(-np.abs(dGdp_dev[:F]), kind="stable")[:4], F + N + np.argsort(-np.abs(dGdp_dev[F + N :]), kind="stable")[:2]]:
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += deltap
+        pm[i] -= deltap
+        x1 = (G(pp) - G(pm)) / (2 * deltap)
+        print("conductivity / head entry", int(i), "FD", x1, "device integral", dGdp_dev[i], "hand-unrolled", dGdp[i])
+        # measured: conductivities 1.7e-4 apart; the head entry 2.4 % (a head change is a step at t = 0, resolved to the
+        # stepper's atol), where the hand-unrolled value is a factor 2 off (volumes taken by free index)
+        assert abs(x1 - dGdp_dev[i]) <= (2e-3 if i < F else 5e-2) * max(abs(x1), abs(dGdp_dev[i])), (int(i), x1, dGdp_dev[i])
 
 
 @pytest.mark.parametrize("schedule", ["several_iterations", "one_iteration", "one_then_several"])
