@@ -326,4 +326,43 @@ function backwardeulerintegrate_last(u0, tspan, Ss::Number, volumes::Vector, nei
 	return nodevalues(DeviceVector(p, Int32(0))), ts[1:nouter[] + 1]
 end
 
+# ---------------------------------------------------------------- gradients, transientadjointutils.jl:57-63
+# integratedfdplambda with the reference's argument list (u2: the getcontinuoussolution(us, ts, 2) object is replaced by
+# the stored states themselves, `us`/`ts_u`): the integral over tspan of dfdp(t)' * lambda(t) with the COMPLETE Jacobian
+# b_p - A_p u (every face; D^-1 by node volume), exact for the piecewise-linear u and lambda (fv_param_gradient_integral).
+function lininterp(vs::Vector, ts::Vector, t)
+	k = clamp(searchsortedlast(ts, t), 1, length(ts) - 1)
+	w = (t - ts[k]) / (ts[k + 1] - ts[k])
+	return (1 - w) * vs[k] + w * vs[k + 1]
+end
+
+function integratedfdplambda(us::Vector, ts_u::Vector, p::Vector, lambdas::Vector, ts_lambda::Vector, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity::Bool=false)
+	nK, N, nd = length(conductivities), length(sources), length(dirichletheads)
+	pK, pd = p[1:nK], p[nK + N + 1:nK + N + nd]
+	prob = createproblem(neighbors, areasoverlengths, N, dirichletnodes)
+	assemble!(prob, pK, zeros(N), pd, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
+	check(prob.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), prob.handle, Ss, Float64[volumes...], zeros(N)))
+	freenodes, nodei2freenodei = getfreenodes(N, dirichletnodes)
+	knots = sort(unique(filter(t->tspan[1] <= t <= tspan[2], vcat(ts_u, ts_lambda, [tspan[1], tspan[2]]))))
+	X = hcat([lininterp(us, ts_u, t)[freenodes] for t in knots]...)      # n x nt, column-major = knot after knot
+	L = hcat([lininterp(lambdas, ts_lambda, t) for t in knots]...)
+	facek = Array{Float64}(undef, prob.F); facedir = Array{Float64}(undef, prob.F); rowsrc = Array{Float64}(undef, prob.n)
+	check(prob.ctx, ccall((:fv_param_gradient_integral, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+		prob.handle, length(knots), knots, X, L, 1, logtransformconductivity ? 1 : 0, facek, facedir, rowsrc))
+	result = zeros(nK + N + nd)
+	nodei2dirichleti = getnodei2dirichleti(sources, dirichletnodes)
+	for (i, (node1, node2)) in enumerate(neighbors)
+		result[metaindex === nothing ? i : metaindex(i)] += facek[i]
+		if freenodes[node1] != freenodes[node2]
+			result[nK + N + nodei2dirichleti[freenodes[node1] ? node2 : node1]] += facedir[i]
+		end
+	end
+	for node = 1:N
+		if freenodes[node]
+			result[nK + node] = rowsrc[nodei2freenodei[node]]
+		end
+	end
+	return result
+end
+
 end # module
