@@ -33,6 +33,8 @@ def run_distributed(fv, args, world, rank):
         ctx = fv.Context(local_rank)
         name, cus, mem = ctx.device_info()
         fvdist.comm_init_from_torch(ctx)
+        if not fvdist.comm_selftest(ctx):  # ring send/recv + all-reduce over the new communicator, before anything depends on it
+            raise RuntimeError("RCCL self-test failed on rank %d: data did not arrive intact" % rank)
     finally:
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
@@ -101,7 +103,7 @@ def run_distributed(fv, args, world, rank):
                 "device": name, "setup_s": t_setup, "per_rank": gathered,
             },
             "roofline": {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / bench.HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "spmv_dia_march_kernel (interior window) + spmv_dia_kernel / spmv_wstream_kernel (boundary groups) on rank 0's row block, per GPU", "algorithmic_bytes_per_launch": spmv_bytes,
+                         "traffic": None, "kernel": "sliced-DIA SpMV of rank 0's row block, interior + boundary passes (spmv_dia_kernel while the block's x fits the last-level cache, spmv_dia_march_kernel on the interior window above 4e7 rows; spmv_wstream_kernel on non-grid-like slices), per GPU", "algorithmic_bytes_per_launch": spmv_bytes,
                          "avg_launch_ms": ms},
         }
         print(json.dumps(out))

@@ -211,9 +211,54 @@ int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, 
     return FV_OK;
 }
 
+// Health check of the transport: every rank sends `count` doubles to the next rank and receives from the previous one
+// (to itself in a one-rank communicator) in one ncclSend/ncclRecv group on the halo stream — the call pattern of
+// fv_comm_halo_exchange — and all ranks sum a vector with ncclAllReduce; *ok = 1 when both arrive as expected.
+extern "C" int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok)
+{
+    if (!ctx || !ok || count < 1)
+        return FV_ERR_ARG;
+    *ok = 0;
+    if (!ctx->comm) {
+        fv_set_error(ctx, "fv_comm_selftest: no RCCL communicator (fv_comm_init)");
+        return FV_ERR_COMM;
+    }
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<double> host((size_t)count);
+    for (int64_t i = 0; i < count; i++)
+        host[(size_t)i] = 1000.0 * ctx->rank + (double)(i % 997);
+    DevBuf<double> a, b;
+    FV_TRY(a.alloc(ctx, (size_t)count));
+    FV_TRY(b.alloc(ctx, (size_t)count));
+    FV_HIP(ctx, hipMemcpy(a.p, host.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    FV_HIP(ctx, hipMemset(b.p, 0, (size_t)count * sizeof(double)));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    const int next = (ctx->rank + 1) % ctx->nranks, prev = (ctx->rank + ctx->nranks - 1) % ctx->nranks;
+    FV_NCCL(ctx, ncclGroupStart());
+    FV_NCCL(ctx, ncclSend(a.p, (size_t)count, ncclDouble, next, comm, ctx->stream2));
+    FV_NCCL(ctx, ncclRecv(b.p, (size_t)count, ncclDouble, prev, comm, ctx->stream2));
+    FV_NCCL(ctx, ncclGroupEnd());
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
+    std::vector<double> got((size_t)count);
+    FV_HIP(ctx, hipMemcpy(got.data(), b.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    bool good = true;
+    for (int64_t i = 0; i < count; i++)
+        good = good && got[(size_t)i] == 1000.0 * prev + (double)(i % 997);
+    FV_NCCL(ctx, ncclAllReduce(a.p, a.p, (size_t)count, ncclDouble, ncclSum, comm, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FV_HIP(ctx, hipMemcpy(got.data(), a.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    const double ranks = (double)ctx->nranks;
+    for (int64_t i = 0; i < count; i++)
+        good = good && got[(size_t)i] == 1000.0 * (ranks * (ranks - 1.0) / 2.0) + ranks * (double)(i % 997);
+    *ok = good ? 1 : 0;
+    return FV_OK;
+}
+
+int g_comm_single_rank_collectives = 0; // fv_tune key 21: issue the all-reduces of a one-rank run too (tests: the RCCL call path on one GPU)
+
 int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream)
 {
-    if (d->nranks <= 1)
+    if (d->nranks <= 1 && !(g_comm_single_rank_collectives && ctx->comm && ctx->nranks == 1))
         return FV_OK;
     if (ctx->local_group && ctx->nranks == d->nranks)
         return local_allreduce(ctx, d, buf, count, stream);

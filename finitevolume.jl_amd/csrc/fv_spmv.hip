@@ -286,6 +286,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 }
 
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
+extern int g_comm_single_rank_collectives; // fv_comm.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -313,6 +314,8 @@ extern "C" int fv_tune(int key, int value)
         g_march_min_mb = value;
     else if (key == 20 && (value == 0 || value >= 2))
         g_gradient_knots_per_pass = value;
+    else if (key == 21 && (value == 0 || value == 1))
+        g_comm_single_rank_collectives = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))

@@ -24,6 +24,13 @@ def comm_init(ctx, nranks, rank, uid):
     ctx.check(load().fv_comm_init(ctx.handle, int(nranks), int(rank), C.create_string_buffer(uid, _lib.FV_COMM_ID_BYTES)))
 
 
+def comm_selftest(ctx, count=1 << 16):
+    """fv_comm_selftest: ring send/recv + all-reduce over the RCCL communicator; True when the data arrived intact."""
+    ok = C.c_int(0)
+    ctx.check(load().fv_comm_selftest(ctx.handle, int(count), C.byref(ok)))
+    return bool(ok.value)
+
+
 def comm_init_local(ctx, nranks, rank, group_id=0):
     """Loopback transport: `nranks` threads of this process, one context each on the same device (rehearsals/tests)."""
     ctx.check(load().fv_comm_init_local(ctx.handle, int(nranks), int(rank), int(group_id)))

@@ -245,6 +245,7 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
  *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
  *      slice-by-slice kernel is faster; measured crossover 3.4e7-5e7 rows) [320]
+ *  21: a one-rank row-block run issues its all-reduces through RCCL anyway (tests of the call path on one GPU) [0]
  *  20: knots per device pass of fv_param_gradient_integral, 0 = as many as fit 2 GiB [0]
  *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
  *  17: diagnosis switches of the marching kernel (bit 0: no in-plane arm loads, bit 1: no plane-arm edge loads);
@@ -260,6 +261,9 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
 int fv_comm_unique_id(char id[FV_COMM_ID_BYTES]);
 int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_COMM_ID_BYTES]);
 int fv_comm_destroy(fv_ctx *ctx);
+/* Health check of the RCCL transport, to run once after fv_comm_init on every rank: a ring of ncclSend/ncclRecv (the halo
+ * exchange's call pattern, on the halo stream) and an ncclAllReduce of `count` doubles; *ok = 1 when the data arrived. */
+int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok);
 /* Loopback transport for rehearsals on ONE device (RCCL refuses two ranks on one GPU): nranks host threads of one
  * process, each with its own context on the same device, join the group `group_id`; halos then move by device-to-device
  * copies and the reductions are summed on the host in rank order.  Same plan, kernels and call sequence as the RCCL

@@ -240,6 +240,7 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     ctx = p.ctx
     dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
     try:
+        assert dist.comm_selftest(ctx, 100000)  # ncclSend/ncclRecv group on the halo stream + ncclAllReduce really move data
         lib.fv_tune(9, 2)
         blk = dist.RowBlock(p, 1, 0)
         it_d, info_d, _ = blk.run_fixed(600.0, 6, 1e-12)
@@ -247,8 +248,22 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
         assert info_d.converged and info_s.converged and np.array_equal(it_d, it_s)
         assert np.abs(blk.state() - st.free_values()).max() <= 1e-9
         blk.close()
+        # once more with every all-reduce of the driver (p.q; r.z with r.r; the 5-scalar set of the one-iteration regime)
+        # going through ncclAllReduce on the one-rank communicator: same iterations, bit-identical state
+        states = {}
+        for collectives in (1, 0):
+            lib.fv_tune(21, collectives)
+            p.transient_begin(0.1, None, u0)
+            blk = dist.RowBlock(p, 1, 0)
+            it_a, info_a, _ = blk.run_fixed(600.0, 6, 1e-12)
+            it_b, info_b, _ = blk.run_fixed(2.0**-10, 12, 1e-12)  # speculation + bursts of unpolled steps
+            assert info_a.converged and info_b.converged and np.array_equal(it_a, it_d) and (it_b == 1).all()
+            states[collectives] = blk.state()
+            blk.close()
+        assert np.array_equal(states[0], states[1])
     finally:
         lib.fv_tune(9, 1)
+        lib.fv_tune(21, 0)
         fv.load().fv_comm_destroy(ctx.handle)
 
 
