@@ -97,7 +97,7 @@ def run_distributed(fv, args, world, rank):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic %d^3 box (%.3g cells), transient, fixed dt=%gs, Jacobi-PCG rtol %.0e, contiguous row blocks (x-slabs) over %d GPUs, RCCL halo + 2 all-reduces per iteration" % (args.ns, N, args.dt, args.rtol, world),
+                "workload": "synthetic %d^3 box (%.3g cells), transient, fixed dt=%gs, Jacobi-PCG rtol %.0e, contiguous row blocks (x-slabs) over %d GPUs, RCCL halo exchange + one merged 6-double all-reduce per one-iteration step (two per PCG iteration otherwise)" % (args.ns, N, args.dt, args.rtol, world),
                 "cells": N, "unknowns": n_total, "nnz": int(sum(g["nnz"] for g in gathered)), "assembly": assembly,
                 "pcg_iters_per_step": float(np.mean(iters)), "last_relres": info.relres, "converged": bool(info.converged),
                 "device": name, "setup_s": t_setup, "per_rank": gathered,

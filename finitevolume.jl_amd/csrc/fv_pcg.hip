@@ -947,6 +947,8 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     return FV_OK;
 }
 
+int g_defer_reduce = 1; // fv_tune key 22: chained steps of a row-block run merge their two all-reduces (see dist_step)
+
 // up to five partial-sum arrays reduced by one launch (block k sums array k into out[k])
 struct SumSet {
     const double *a[5];
@@ -963,9 +965,17 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, i
 // x_next / carry_prev / speculate / use_spec: the ping-pong state, the residual carry-over and the speculative set-up
 // of PcgSystem, same meaning.  All-reduce buffer: red[0] p.q; red[1..2] r.M^-1 r, r.r; red[3] rhs.rhs of a regular
 // set-up, or red[3..5] the next step's r.M^-1 r, r.r, rhs.rhs left by pcg_update_spec_kernel.
+//
+// Bursts of chained steps (chain_index >= 0) with g_defer_reduce: a step's five sums (its own r.M^-1 r, r.r and the next
+// step's set-up scalars) are NOT all-reduced at its end but together with the next step's p.q — one 6-double collective
+// per step instead of a 1- and a 5-double one.  The next step's K1 only needs p' (left by K2S), so it runs before the
+// previous step's convergence is known; that verdict (pcg_pupdate_kernel<true> of the PREVIOUS step, with that step's
+// vectors) and the new step's scalars follow the merged all-reduce.  A step that did not converge stops the chain there
+// as before: K1 of the step after it has run for nothing, everything later is skipped by the done flag.  The last step
+// of a burst reduces its sums itself, so the host poll sees a finished state.
 static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info, double *x_next = nullptr,
                      const double *carry_prev = nullptr, bool speculate_in = false, bool use_spec_in = false, int chain_index = -1,
-                     int resume_it = 0)
+                     int resume_it = 0, bool last_in_burst = true)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
@@ -994,15 +1004,19 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     if (speculate && g_sparse_b)
         FV_TRY(ensure_b_support(p, &bsupport));
     const int Gs = sparse_b_grid(bsupport);
+    const bool defer_in = chained && chain_index > 0 && g_defer_reduce && speculate && carry_prev;   // red[1..5]: the previous step's local sums
+    const bool defer_out = chained && !last_in_burst && g_defer_reduce && speculate; // leave this step's sums to the next one
     if (resume) {
         // r, p and the scalars are those of the interrupted solve
     } else if (use_spec) {
         // r, p' and the all-reduced set-up scalars (red[3..5]) were left by the previous step's K2S
         std::swap(p->pvec.p, p->pnext.p);
         std::swap(p->pvec.n, p->pnext.n);
-        hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3), (const double *)(red + 4),
-                           (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
-        FV_LAUNCH_CHECK(ctx);
+        if (!defer_in) {
+            hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
+                               (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
+            FV_LAUNCH_CHECK(ctx);
+        }
     } else {
         if (carry_prev && !compute_minv) {
             // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
@@ -1042,7 +1056,19 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             const int iter = (int)(it + k);
             const bool spec = iter == 0 && speculate;
             FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
-            FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
+            if (defer_in && iter == 0) {
+                // p.q of this step with the five sums the previous step left un-reduced; then that step's verdict (on its
+                // own vectors: its p is this step's pnext, its iterate went from carry_prev to u) and this step's scalars
+                FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 6, ctx->stream));
+                hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, 0, p->r.p, (const double *)p->minv.p,
+                                   p->pnext.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
+                                   carry_prev, (const double *)u, (const double *)p->D.p, dt, chain_index - 1,
+                                   (chain_index - 1 == g_chain_test_break) ? 1 : 0);
+                hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
+                                   (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, 1);
+                FV_LAUNCH_CHECK(ctx);
+            } else
+                FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
             SumSet sums{};
             sums.a[0] = p->part_rz.p;
             sums.a[1] = p->part_rr.p;
@@ -1070,6 +1096,8 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             const int nsums = spec ? 5 : 2;
             hipLaunchKernelGGL(final_sum_multi_kernel, dim3(nsums), dim3(FV_BLOCK), 0, ctx->stream, sums, Gv, red + 1);
             FV_LAUNCH_CHECK(ctx);
+            if (defer_out && spec)
+                continue; // reduced with the next step's p.q, judged there
             FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, nsums, ctx->stream));
             if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
@@ -1150,7 +1178,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
                 for (int j = 0; j < L && rc == FV_OK; j++) {
                     snap_u[j] = u;
                     snap_alt[j] = alt;
-                    rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, prev, true, true, j);
+                    rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, prev, true, true, j, 0, j == L - 1);
                     prev = u;
                     std::swap(u, alt);
                 }

@@ -287,6 +287,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
+extern int g_defer_reduce;                  // fv_pcg.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -316,6 +317,8 @@ extern "C" int fv_tune(int key, int value)
         g_gradient_knots_per_pass = value;
     else if (key == 21 && (value == 0 || value == 1))
         g_comm_single_rank_collectives = value;
+    else if (key == 22 && (value == 0 || value == 1))
+        g_defer_reduce = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))

@@ -892,17 +892,34 @@ def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
         got[lo:hi] = state
         assert np.array_equal(its, ref_its), (its, ref_its)  # reductions differ in order only: same iteration counts
     assert relerr(got, want) < 1e-12
-    # the bursts of unpolled steps break (fault injection) at the same place on every rank and are resumed
+    # the bursts of unpolled steps break (fault injection) at the same place on every rank and are resumed: at the first
+    # step of a burst, in the middle, at the last one (which reduces its own sums) — with a step's five sums all-reduced
+    # together with the next step's p.q (fv_tune 22, the default) and separately: same bits either way
     lib = fv.load()
+    baseline = [o[2].copy() for o in out]
+    for brk in (2, 0, 7):
+        states = {}
+        for merged in (1, 0):
+            try:
+                lib.fv_tune(14, brk)
+                lib.fv_tune(22, merged)
+                res = _run_ranks_in_threads(fv, nranks, 300 + 10 * brk + merged + 100 * nranks, make_problem, schedule, 1e-12)
+            finally:
+                lib.fv_tune(14, -1)
+                lib.fv_tune(22, 1)
+            for lo, hi, state, its in res:
+                got[lo:hi] = state
+                assert np.array_equal(its, res[0][3]) and (its[6:46] == 2).sum() >= 2 and set(np.unique(its[6:46])) == {1, 2}
+            assert relerr(got, want) < 1e-12
+            states[merged] = [r[2] for r in res]
+        assert all(np.array_equal(a, b) for a, b in zip(states[0], states[1])), brk
+    # ... and without injected breaks the merged reduction changes no bit either
+    lib.fv_tune(22, 0)
     try:
-        lib.fv_tune(14, 2)
-        out = _run_ranks_in_threads(fv, nranks, 300 + nranks, make_problem, schedule, 1e-12)
+        res = _run_ranks_in_threads(fv, nranks, 900 + nranks, make_problem, schedule, 1e-12)
     finally:
-        lib.fv_tune(14, -1)
-    for lo, hi, state, its in out:
-        got[lo:hi] = state
-        assert np.array_equal(its, out[0][3]) and (its[6:46] == 2).sum() >= 2 and set(np.unique(its[6:46])) == {1, 2}
-    assert relerr(got, want) < 1e-12
+        lib.fv_tune(22, 1)
+    assert all(np.array_equal(a, r[2]) for a, r in zip(baseline, res))
 
 
 @pytest.mark.parametrize("nranks", [2, 5])

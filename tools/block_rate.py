@@ -15,6 +15,9 @@ from __graft_entry__ import load_package  # noqa: E402
 fv = load_package()
 from fvamd import dist as fvdist  # noqa: E402
 
+for kv in os.environ.get("FV_TUNE", "").split(","):  # e.g. FV_TUNE=21=1: the one-rank run issues its all-reduces through RCCL
+    if "=" in kv:
+        fv.load().fv_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 planes = int(sys.argv[1]) if len(sys.argv) > 1 else 58
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 ns = [planes + 2, 464, 464]  # + the two Dirichlet planes
