@@ -326,6 +326,65 @@ function backwardeulerintegrate_last(u0, tspan, Ss::Number, volumes::Vector, nei
 	return nodevalues(DeviceVector(p, Int32(0))), ts[1:nouter[] + 1]
 end
 
+# ---------------------------------------------------------------- adjoint hooks, transient.jl:176-216
+# getcontinuoussolution: the piecewise-linear-in-time interpolants (Interpolations.jl in the reference; written out here)
+function getcontinuoussolution(us::Vector{T}, ts::Vector) where {T <: AbstractArray}
+	return t->begin
+		(t < ts[1] || t > ts[end]) && throw(BoundsError(ts, t))
+		lininterp(us, ts, t)
+	end
+end
+
+function getcontinuoussolution(us::Vector{T}, ts::Vector, ::Type{Val{2}}) where {T <: AbstractArray}
+	return (i, t)->begin
+		(t < ts[1] || t > ts[end]) && throw(BoundsError(ts, t))
+		lininterp(us, ts, t)[i]
+	end
+end
+
+function freevalues(v::DeviceVector)
+	out = Array{Float64}(undef, v.problem.n)
+	check(v.problem.ctx, ccall((:fv_state_get_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), v.problem.handle, v.slot, out))
+	return out
+end
+
+# adjointintegrate(getdgdu, tspan, Ss, volumes, ...) — transient.jl:188-205.  gamma(t) = lambda(T - t) obeys
+# dgamma/dt = transpose(D^-1 A) gamma + dgdu(T - t); with w = D^-1 gamma every implicit step is the same SPD solve as a
+# forward step, which is what FV_STEP_ADJOINT (mode = 1) of fv_transient_step does.  The steppers above are reused as
+# they are; states stay on the device, lambda comes back free-indexed and reversed in time like the reference's.
+function adjointintegrate(getdgdu::Function, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, stepper! =adaptivebackwardeulerstep!, atol=1e-4, callback=(t, dt)->nothing, rtol=sqrt(eps(Float64)), maxiter=1000)
+	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
+	assemble!(p, conductivities, zeros(length(sources)), dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
+	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], Ptr{Float64}(C_NULL)))
+	check(p.ctx, ccall((:fv_state_set_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, Int32(0), zeros(p.n)))   # gamma0 = 0
+	T = tspan[2]
+	getb = t->getdgdu(T - t)
+	gammas = DeviceVector[DeviceVector(p, Int32(0))]
+	tsgamma = [tspan[1]]
+	dt = min(dt0, tspan[2] - tspan[1])
+	while tsgamma[end] < tspan[2]
+		solution, laststeptime, increasestepsize = stepper!(p, getb, gammas[end], tsgamma[end], dt, atol, callback; rtol=rtol, maxiter=maxiter, mode=1)
+		push!(gammas, solution)
+		push!(tsgamma, tsgamma[end] + dt)
+		dt = increasestepsize ? min(tspan[2] - tsgamma[end], 2 * laststeptime) : min(tspan[2] - tsgamma[end], laststeptime)
+	end
+	result = map(freevalues, gammas)
+	foreach(freestate, gammas)
+	return reverse(result), reverse(T .- tsgamma)
+end
+
+# gradientintegrate(lambda0, du0dp, dgdp, integrateddfdplambda, tspan) — transient.jl:213-216; the integral of dgdp by
+# the composite Simpson rule over 64 panels (QuadGK in the reference; dgdp is identically zero in its workflows)
+function gradientintegrate(lambda0::Vector, du0dp, dgdp, integrateddfdplambda::Vector, tspan; kwargs...)
+	m = 64
+	h = (tspan[2] - tspan[1]) / m
+	I1 = (dgdp(tspan[1]) + dgdp(tspan[2])) * (h / 3)
+	for k = 1:m - 1
+		I1 += dgdp(tspan[1] + k * h) * ((isodd(k) ? 4 : 2) * h / 3)
+	end
+	return du0dp * lambda0 + I1 + integrateddfdplambda
+end
+
 # ---------------------------------------------------------------- gradients, transientadjointutils.jl:57-63
 # integratedfdplambda with the reference's argument list (u2: the getcontinuoussolution(us, ts, 2) object is replaced by
 # the stored states themselves, `us`/`ts_u`): the integral over tspan of dfdp(t)' * lambda(t) with the COMPLETE Jacobian
