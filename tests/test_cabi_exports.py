@@ -51,3 +51,21 @@ def test_no_device_fails_loudly(fv):
         pytest.skip("a GPU is visible here")
     with pytest.raises(fv.FVError, match="no CPU fallback"):
         fv.Context(0)
+
+
+def test_julia_shim_calls_only_declared_symbols_with_matching_arity():
+    """The Julia binding was written without a Julia runtime: at least every `ccall((:name, libfvhip), ...)` must name a
+    symbol of include/fvhip.h, with as many argument types as the C declaration has parameters."""
+    hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    arity = {}
+    for name, params in re.findall(r"\b(fv_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        params = params.strip()
+        arity[name] = 0 if params in ("", "void") else params.count(",") + 1
+    src = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(\w+),\s*libfvhip\),\s*\w+(?:\{[^}]*\})?,\s*\(([^)]*)\)", src)
+    assert len(calls) >= 20
+    for name, types in calls:
+        assert name in arity, "the shim calls %s, which include/fvhip.h does not declare" % name
+        ntypes = len([t for t in re.split(r",(?![^{]*\})", types) if t.strip()])
+        assert ntypes == arity[name], "%s: %d argument types in the shim, %d parameters in the header" % (name, ntypes, arity[name])
