@@ -98,6 +98,65 @@ def cpu_baseline(dt, rtol):
     }
 
 
+def other_baseline_configs(fv, ctx):
+    """The other single-GPU configurations of BASELINE.json (SURVEY 8d inputs), one short measurement each, reported inside
+    `config` — the headline `value` stays the 10^8-cell run.  The same code as tools/config_rates.py."""
+    from tests import workloads
+
+    rows = []
+
+    def row(name, cells, steps, sec, **extra):
+        rows.append(dict(config=name, cells=int(cells), steps=int(steps), seconds=sec, dof_updates_per_s=cells * steps / sec, **extra))
+
+    # configs[1]: box_model 256^3, one steady solve, sigma = 3 log-conductivity field; PCG with the aggregation-AMG V-cycle
+    ns = [256, 256, 256]
+    dn, dh = workloads.box_model_dirichlet(ns)
+    p = fv.Problem.regulargrid([-50.0, -50.0, 0.0], [50.0, 50.0, 10.0], ns, dn, ctx)
+    logk = np.log(1e-5) + 3.0 * workloads.smooth_gaussian_field(ns, seed=0)
+    n1, n2 = np.empty(p.F, np.int64), np.empty(p.F, np.int64)
+    p.check(fv.load().fv_problem_get_grid(p.handle, n1.ctypes.data, n2.ctypes.data, None, None))
+    Kf = fv.nodehycos2neighborhycos((n1, n2), logk, True)
+    del n1, n2
+    p.assemble(Kf, np.zeros(p.N), dh, None, True)
+    p.set_preconditioner("amg")
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    levels = p.amg_info()
+    head, res, ch = p.solve_steady(None, 1e-8, 400, want_head=False, want_resnorm=False)
+    ctx.synchronize()
+    row("box_model 256^3 steady, sigma=3 field, AMG-PCG rtol 1e-8 (hierarchy set-up included)", p.N, 1, time.perf_counter() - t0,
+        pcg_iters=int(ch.iters), converged=bool(ch.isconverged), amg_levels=int(len(levels[0])))
+    p.close()
+    # configs[2]: watertable-like 10 M cells, 100 implicit steps
+    ns = [216, 216, 216]
+    dn, src = box_setup(ns)
+    p = fv.Problem.regulargrid([0.0, 0.0, 0.0], [1000.0, 1000.0, 100.0], ns, dn, ctx)
+    p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    p.run_fixed(st, 60.0, 3, 1e-10)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iters, info, _ = p.run_fixed(st, 60.0, 100, 1e-10)
+    ctx.synchronize()
+    row("watertable-like 216^3 transient, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, time.perf_counter() - t0,
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged))
+    p.close()
+    # configs[3]: fractures-like 5 M cells, irregular CSR (cells numbered at random inside each fracture), 100 implicit steps
+    w = workloads.fractures_like(20, 500, seed=0)
+    p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], w["N"], w["dnodes"], ctx)
+    p.assemble(w["K"], np.zeros(w["N"]), w["dheads"])
+    st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
+    p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iters, info, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
+    ctx.synchronize()
+    row("fractures-like 5M cells (irregular CSR, as numbered), transient, 100 steps, dt=1s, Jacobi-PCG rtol 1e-10", p.N, 100, time.perf_counter() - t0,
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged))
+    p.close()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +167,7 @@ def main():
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--maxiter", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json's other single-GPU configurations")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     args = ap.parse_args()
 
@@ -163,7 +223,9 @@ def main():
     # run folds D/dt into the stored diagonal, so the "+8 n if the shift vector is read separately" does not apply.
     spmv_bytes = 12 * p.nnz + 20 * p.n
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": "K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)",
+            "kernel": ("K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)"
+                       if 8 * p.n > 320 * 2**20 else
+                       "K1 q=(A+D/dt)p with p.q: spmv_dia_kernel<true,true,false> (slice-by-slice sliced-DIA: x fits the last-level cache at this size)"),
             "algorithmic_bytes_per_launch": spmv_bytes}
     kern = {}
     if prof and prof["spmv_dot"][1] > 0:
@@ -216,6 +278,12 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
+    if not args.no_other_configs:
+        p.close()  # 45 GB back before the next problems
+        try:
+            out["config"]["other_baseline_configs"] = other_baseline_configs(fv, ctx)
+        except Exception as e:  # never lose the headline line to a side measurement
+            out["config"]["other_baseline_configs"] = "failed: %r" % (e,)
     print(json.dumps(out))
 
 
