@@ -109,6 +109,7 @@ struct PcgScalars {
     int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN), 3 a chain of unpolled one-iteration steps broke here
     int32_t chain_step; // done == 3: index (within the burst) of the step that needs more than its one iteration
     int32_t pad_;
+    double tol2x[2]; // tol2 of the chained steps by parity of their index (row-block bursts: a step's verdict is taken while the next step's scalars are written)
 };
 
 // Plan and buffers of a row block in a distributed run (built by fv_dist_setup).

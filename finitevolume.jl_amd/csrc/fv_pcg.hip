@@ -151,6 +151,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const doubl
         scal->rr = rr;
         scal->bnorm2 = bb;
         scal->tol2 = rtol * rtol * bb; // stop when ||r|| <= rtol*||b||  (IterativeSolvers' reltol)
+        scal->tol2x[0] = scal->tol2x[1] = scal->tol2;
         scal->pq = 0.0;
         scal->iters = 0;
         scal->done = (rr <= scal->tol2) ? 1 : 0;
@@ -422,6 +423,73 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
         else if (chain_index >= 0) { // unpolled chain: stop here; the host resumes this step at iteration it + 1
             scal->done = 3;
             scal->chain_step = chain_index;
+        }
+    }
+}
+
+// Row-block bursts with merged collectives: the verdict on the PREVIOUS chained step (pcg_pupdate_kernel<true> on that
+// step's vectors) and the scalars of the step that has just done its K1 (pcg_init_finalize_kernel) in one launch, after
+// the 6-double all-reduce: red[1..2] the previous step's r.M^-1 r and r.r, red[3..5] this step's r.M^-1 r, r.r, rhs.rhs.
+// Every block takes the same verdict from values no block of this launch writes (red, the previous step's tol2 by index
+// parity); block 0 then either closes the chain (done = 3) or writes the new step's scalars, which the other blocks never
+// read on that path.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n, double *__restrict__ r, const double *__restrict__ minv,
+                                                                       double *__restrict__ pv, const double *__restrict__ red, double rtol,
+                                                                       PcgScalars *scal, const double *__restrict__ xin,
+                                                                       const double *__restrict__ xout, const double *__restrict__ D, double dt,
+                                                                       int prev_index, int force_unconverged)
+{
+    if (scal->done)
+        return;
+    const double rzn = red[1], rrn = red[2];
+    const bool converged = rrn <= scal->tol2x[prev_index & 1] && !force_unconverged;
+    if (!converged) { // as pcg_pupdate_kernel<true>: take the next step's D (x_out - x_in)/dt out of r again, p = z + beta p
+        const double beta = rzn / scal->rz[0];
+        const int64_t n2 = n >> 1;
+        double2 *r2 = reinterpret_cast<double2 *>(r);
+        const double2 *m2 = reinterpret_cast<const double2 *>(minv);
+        double2 *p2 = reinterpret_cast<double2 *>(pv);
+        const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
+        const double2 *xo2 = reinterpret_cast<const double2 *>(xout);
+        const double2 *D2 = reinterpret_cast<const double2 *>(D);
+        for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+            double2 rv = r2[i];
+            const double2 mv = m2[i];
+            const double2 a = xi2[i], b = xo2[i], dv = D2[i];
+            rv.x -= dv.x * ((b.x - a.x) / dt);
+            rv.y -= dv.y * ((b.y - a.y) / dt);
+            r2[i] = rv;
+            double2 pvv = p2[i];
+            pvv.x = mv.x * rv.x + beta * pvv.x;
+            pvv.y = mv.y * rv.y + beta * pvv.y;
+            p2[i] = pvv;
+        }
+        if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t i = n - 1;
+            double ri = r[i];
+            ri -= D[i] * ((xout[i] - xin[i]) / dt);
+            r[i] = ri;
+            pv[i] = minv[i] * ri + beta * pv[i];
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!converged) {
+            scal->rz[1] = rzn;
+            scal->rr = rrn;
+            scal->iters = 1;
+            scal->done = 3;
+            scal->chain_step = prev_index;
+        } else {
+            const double bb = red[5], tol2 = rtol * rtol * bb;
+            scal->rz[0] = red[3];
+            scal->rz[1] = 0.0;
+            scal->rr = red[4];
+            scal->bnorm2 = bb;
+            scal->tol2 = tol2;
+            scal->tol2x[(prev_index + 1) & 1] = tol2;
+            scal->pq = 0.0;
+            scal->iters = 0;
+            scal->done = (red[4] <= tol2) ? 1 : 0;
         }
     }
 }
@@ -1057,15 +1125,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             const bool spec = iter == 0 && speculate;
             FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
             if (defer_in && iter == 0) {
-                // p.q of this step with the five sums the previous step left un-reduced; then that step's verdict (on its
-                // own vectors: its p is this step's pnext, its iterate went from carry_prev to u) and this step's scalars
+                // p.q of this step with the five sums the previous step left un-reduced; then, in one launch, that step's
+                // verdict (on its own vectors: its p is this step's pnext, its iterate went from carry_prev to u) and this
+                // step's scalars
                 FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 6, ctx->stream));
-                hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, 0, p->r.p, (const double *)p->minv.p,
-                                   p->pnext.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
-                                   carry_prev, (const double *)u, (const double *)p->D.p, dt, chain_index - 1,
-                                   (chain_index - 1 == g_chain_test_break) ? 1 : 0);
-                hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
-                                   (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, 1);
+                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
+                                   p->pnext.p, (const double *)red, rtol, p->scal.p, carry_prev, (const double *)u, (const double *)p->D.p, dt,
+                                   chain_index - 1, (chain_index - 1 == g_chain_test_break) ? 1 : 0);
                 FV_LAUNCH_CHECK(ctx);
             } else
                 FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));

@@ -57,4 +57,15 @@ for rep in range(3):
     ctx.synchronize()
     t = time.perf_counter() - t
     print("row-block driver rows %d  %.3f ms/step (device %.3f)  %.2f it/step" % (blk.nloc, t / steps * 1e3, ms / steps, it.mean()), flush=True)
+if os.environ.get("FV_BLOCK_RATE_AB"):  # in-process A/B of a tune key, e.g. FV_BLOCK_RATE_AB=22 (process-to-process noise is ~10 us)
+    key = int(os.environ["FV_BLOCK_RATE_AB"])
+    for rep in range(4):
+        for val in (1, 0):
+            fv.load().fv_tune(key, val)
+            blk.run_fixed(60.0, 16, 1e-10)
+            ctx.synchronize()
+            t = time.perf_counter()
+            it, info, ms = blk.run_fixed(60.0, steps, 1e-10)
+            ctx.synchronize()
+            print("row-block driver, fv_tune(%d, %d): %.4f ms/step" % (key, val, (time.perf_counter() - t) / steps * 1e3), flush=True)
 blk.close()
