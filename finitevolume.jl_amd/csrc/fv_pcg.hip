@@ -981,8 +981,9 @@ static int dist_build_split(fv_problem *p)
 
 // y = (A + sigma D) x on the row block; with want_dot the local x.y lands in red[0] (not yet all-reduced).
 // skip_exchange: the halo slots of xext were filled by the caller (single-GPU rehearsal of the boundary pass).
+// npq_out: leave the partial sums of x.y in part_pq (their count goes to *npq_out) instead of reducing them into red[0].
 static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const double *folded, bool want_dot, bool use_done,
-                     bool skip_exchange = false)
+                     bool skip_exchange = false, int *npq_out = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
@@ -1008,7 +1009,9 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
         FV_TRY(dist_exchange_wait(p));
     if (d->n_bnd > 0)
         FV_TRY(spmv_apply(p, xext, y, sigma, folded, mode, want_dot ? p->part_pq.p + na : nullptr, nullptr, use_done, &nb, &boundary));
-    if (want_dot) {
+    if (want_dot && npq_out)
+        *npq_out = na + nb;
+    else if (want_dot) {
         hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_pq.p, na + nb, d->red.p);
         FV_LAUNCH_CHECK(ctx);
     }
@@ -1019,8 +1022,8 @@ int g_defer_reduce = 1; // fv_tune key 22: chained steps of a row-block run merg
 
 // up to five partial-sum arrays reduced by one launch (block k sums array k into out[k])
 struct SumSet {
-    const double *a[5];
-    int extra[5]; // partials beyond the common count (the sparse-b pieces of rhs.rhs)
+    const double *a[6];
+    int extra[6]; // partials beyond (or, negative, short of) the common count: the sparse-b pieces of rhs.rhs; p.q's own count
 };
 __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, int nparts, double *__restrict__ out)
 {
@@ -1123,8 +1126,22 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
             const bool spec = iter == 0 && speculate;
-            FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
+            int npq = 0;
+            FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true, false, (defer_in && iter == 0) ? &npq : nullptr));
             if (defer_in && iter == 0) {
+                // one reduction launch for the six sums of the merged collective: this step's p.q and the five the previous
+                // step's K2S left in its partial arrays (nothing has written them since)
+                SumSet six{};
+                six.a[0] = p->part_pq.p;
+                six.extra[0] = npq - Gv;
+                six.a[1] = p->part_rz.p;
+                six.a[2] = p->part_rr.p;
+                six.a[3] = p->part_rz.p + FV_VEC_PARTIALS;
+                six.a[4] = p->part_rr.p + FV_VEC_PARTIALS;
+                six.a[5] = p->part_bb.p + FV_VEC_PARTIALS;
+                six.extra[5] = Gs;
+                hipLaunchKernelGGL(final_sum_multi_kernel, dim3(6), dim3(FV_BLOCK), 0, ctx->stream, six, Gv, red);
+                FV_LAUNCH_CHECK(ctx);
                 // p.q of this step with the five sums the previous step left un-reduced; then, in one launch, that step's
                 // verdict (on its own vectors: its p is this step's pnext, its iterate went from carry_prev to u) and this
                 // step's scalars
@@ -1159,11 +1176,11 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)nullptr,
                                    x_next ? x_next : u, p->r.p, p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p);
+            if (defer_out && spec)
+                continue; // summed and all-reduced with the next step's p.q, judged there
             const int nsums = spec ? 5 : 2;
             hipLaunchKernelGGL(final_sum_multi_kernel, dim3(nsums), dim3(FV_BLOCK), 0, ctx->stream, sums, Gv, red + 1);
             FV_LAUNCH_CHECK(ctx);
-            if (defer_out && spec)
-                continue; // reduced with the next step's p.q, judged there
             FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, nsums, ctx->stream));
             if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
