@@ -217,6 +217,17 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it,
     }
 }
 
+// the sparse assembled b of K2S: its support (rows next to a Dirichlet cell or with a source) and where the gather
+// blocks leave their partial sums; nblocks = 0: b' is streamed by the vector blocks (or there is none)
+struct SparseRhs {
+    int64_t m = 0;
+    const int32_t *idx = nullptr;
+    const double *b = nullptr;
+    double *part = nullptr;
+    int nblocks = 0;     // extra blocks at the end of the launch that do the gather, or
+    int in_vector = 0;   // every vector block gathers its share of the support after its stream (partials: one per block)
+};
+
 // K2S — the first K2 of a fixed-dt step that is expected to converge in this iteration (the previous step did):
 // besides alpha, x_out = x_in + alpha p, r -= alpha q and the partials of the convergence test, it prepares the NEXT
 // step the way pcg_carry_init_kernel would: r0' = r + D (x_out - x_in)/dt is what it leaves in r, p' = M^-1 r0' goes to
@@ -230,7 +241,8 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
                                                                     const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
                                                                     double *__restrict__ part_rz, double *__restrict__ part_rr,
                                                                     double *__restrict__ pnext, double *__restrict__ spec_rz,
-                                                                    double *__restrict__ spec_rr, double *__restrict__ spec_bb)
+                                                                    double *__restrict__ spec_rr, double *__restrict__ spec_bb,
+                                                                    SparseRhs sb)
 {
     __shared__ double smem[4];
     if (scal->done)
@@ -244,6 +256,24 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
         return;
     }
     const double alpha = scal->rz[0] / pq;
+    const int gmain = (int)gridDim.x - sb.nblocks; // the last sb.nblocks blocks of the launch do the sparse-b gather instead
+    if ((int)blockIdx.x >= gmain) {
+        // rhs'.rhs' = h.h + sum over b's support of b'(2 h + b') with h = D x_out/dt: x_out of these few rows is formed
+        // here from x_in and p (the vector blocks of this launch write it, in no particular order)
+        const int gb = (int)blockIdx.x - gmain;
+        double acc = 0.0;
+        for (int64_t k = (int64_t)gb * FV_BLOCK + threadIdx.x; k < sb.m; k += (int64_t)sb.nblocks * FV_BLOCK) {
+            const int32_t i = sb.idx[k];
+            const double bi = sb.b[i];
+            const double xn = xin[i] + alpha * pv[i];
+            acc += bi * (2.0 * (D[i] * (xn / dt)) + bi);
+        }
+        const double t = block_sum(acc, smem);
+        if (threadIdx.x == 0)
+            sb.part[gb] = t;
+        return;
+    }
+    const int64_t stride = (int64_t)gmain * FV_BLOCK;
     double arz = 0.0, arr = 0.0, srz = 0.0, srr = 0.0, sbb = 0.0;
     const int64_t n2 = n >> 1;
     const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
@@ -255,7 +285,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     const double2 *D2 = reinterpret_cast<const double2 *>(D);
     const double2 *b2 = reinterpret_cast<const double2 *>(bprime);
     double2 *pn2 = reinterpret_cast<double2 *>(pnext);
-    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += stride) {
         const double2 xv = xi2[i], pvv = p2[i], qv = q2[i], mv = m2[i], dv = D2[i];
         const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
         double2 rv = r2[i];
@@ -291,41 +321,31 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
         srr += c * c;
         sbb += h * h;
     }
+    double sgather = 0.0;
+    if (sb.in_vector)
+        for (int64_t k = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; k < sb.m; k += stride) {
+            const int32_t i = sb.idx[k];
+            const double bi = sb.b[i];
+            const double xn = xin[i] + alpha * pv[i];
+            sgather += bi * (2.0 * (D[i] * (xn / dt)) + bi);
+        }
     const double t0 = block_sum(arz, smem);
     const double t1 = block_sum(arr, smem);
     const double t2 = block_sum(srz, smem);
     const double t3 = block_sum(srr, smem);
     const double t4 = block_sum(sbb, smem);
+    const double t5 = sb.in_vector ? block_sum(sgather, smem) : 0.0;
     if (threadIdx.x == 0) {
         part_rz[blockIdx.x] = t0;
         part_rr[blockIdx.x] = t1;
         spec_rz[blockIdx.x] = t2;
         spec_rr[blockIdx.x] = t3;
         spec_bb[blockIdx.x] = t4;
+        if (sb.in_vector)
+            sb.part[blockIdx.x] = t5;
         if (blockIdx.x == 0)
             scal->pq = pq;
     }
-}
-
-// rhs.rhs of the next step when K2S was run without b': rhs = b' + h with h = D x/dt, and K2S summed h.h only.  b' is
-// sparse (rows next to a Dirichlet cell or with a source), so the rest, sum over its support of b'(2 h + b'), is a
-// gather over a short list: the 8 B/row stream of b' leaves the vector pass.
-__global__ __launch_bounds__(FV_BLOCK) void pcg_rhs_sparse_kernel(int64_t m, const int32_t *__restrict__ idx, const double *__restrict__ bprime,
-                                                                   const double *__restrict__ D, const double *__restrict__ x, double dt,
-                                                                   const PcgScalars *__restrict__ scal, double *__restrict__ part)
-{
-    __shared__ double smem[4];
-    if (scal->done)
-        return;
-    double acc = 0.0;
-    for (int64_t k = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; k < m; k += vec_stride()) {
-        const int32_t i = idx[k];
-        const double bi = bprime[i];
-        acc += bi * (2.0 * (D[i] * (x[i] / dt)) + bi);
-    }
-    const double t = block_sum(acc, smem);
-    if (threadIdx.x == 0)
-        part[blockIdx.x] = t;
 }
 
 // a gather of three scattered doubles per entry is latency-bound: enough blocks to keep every CU busy (64 blocks took 53 us
@@ -337,6 +357,28 @@ static int sparse_b_grid(int64_t support)
         return 0;
     const int64_t g = (support + FV_BLOCK - 1) / FV_BLOCK;
     return (int)(g < FV_SPARSE_B_BLOCKS ? g : FV_SPARSE_B_BLOCKS);
+}
+
+// the sparse-b argument of K2S and the number of extra partials it leaves behind the vector blocks' (g_sparse_b: 1 = extra
+// gather blocks, 2 = inside the vector blocks)
+static SparseRhs sparse_b_arg(fv_problem *p, int64_t support, int Gv, int *extra_blocks, int *extra_partials)
+{
+    SparseRhs sb;
+    *extra_blocks = *extra_partials = 0;
+    if (support <= 0)
+        return sb;
+    sb.m = support;
+    sb.idx = p->bnz_idx.p;
+    sb.b = p->b.p;
+    sb.part = p->part_bb.p + FV_VEC_PARTIALS + Gv;
+    if (g_sparse_b == 2) {
+        sb.in_vector = 1;
+        *extra_partials = Gv;
+    } else {
+        sb.nblocks = sparse_b_grid(support);
+        *extra_blocks = *extra_partials = sb.nblocks;
+    }
+    return sb;
 }
 
 __global__ __launch_bounds__(FV_BLOCK) void nonzero_flag_kernel(int64_t n, const double *__restrict__ v, int32_t *__restrict__ flag)
@@ -510,7 +552,7 @@ int fv_pcg_prepare(fv_problem *p)
     FV_TRY(p->part_pq.alloc(ctx, 4 * FV_MAX_PARTIALS)); // distributed: interior + boundary pass, each DIA + CSR
     FV_TRY(p->part_rz.alloc(ctx, 2 * FV_VEC_PARTIALS));
     FV_TRY(p->part_rr.alloc(ctx, 2 * FV_VEC_PARTIALS));
-    FV_TRY(p->part_bb.alloc(ctx, 2 * FV_VEC_PARTIALS + FV_SPARSE_B_BLOCKS)); // + the pieces of pcg_rhs_sparse_kernel behind the speculative half
+    FV_TRY(p->part_bb.alloc(ctx, 3 * FV_VEC_PARTIALS)); // + the pieces of K2S's sparse-b gather blocks behind the speculative half
     FV_TRY(p->scal.alloc(ctx, 1));
     FV_TRY(p->scal.zero(ctx));
     FV_TRY(p->pvec.zero(ctx));
@@ -564,7 +606,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     int64_t bsupport = -1;
     if (speculate && g_sparse_b && sys.rhs == p->b.p)
         FV_TRY(ensure_b_support(p, &bsupport));
-    const int Gs = sparse_b_grid(bsupport);
+    int Gx = 0, Gs = 0; // extra blocks of the K2S launch, extra rhs.rhs partials it leaves
+    const SparseRhs sbarg = sparse_b_arg(p, bsupport, Gv, &Gx, &Gs);
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
     if (resume) {
@@ -668,15 +711,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_PROF(2);
             const bool spec = iter == 0 && speculate;
             if (spec) {
-                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
+                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    bsupport >= 0 ? (const double *)nullptr : sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
-                                   p->part_bb.p + FV_VEC_PARTIALS);
-                if (Gs > 0)
-                    hipLaunchKernelGGL(pcg_rhs_sparse_kernel, dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, bsupport, (const int32_t *)p->bnz_idx.p,
-                                       (const double *)p->b.p, (const double *)p->D.p, (const double *)sys.x_next, sys.dt,
-                                       (const PcgScalars *)p->scal.p, p->part_bb.p + FV_VEC_PARTIALS + Gv);
+                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg);
                 p->spec_extra_bb = Gs;
             }
             else if (iter == 0 && sys.x_next)
@@ -1071,10 +1110,11 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     const bool speculate = !resume && speculate_in && x_next && !compute_minv && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
         FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
-    int64_t bsupport = -1; // the block's b is as sparse as the global one: its share of rhs.rhs by a gather (pcg_rhs_sparse_kernel)
+    int64_t bsupport = -1; // the block's b is as sparse as the global one: its share of rhs.rhs by the gather blocks of K2S
     if (speculate && g_sparse_b)
         FV_TRY(ensure_b_support(p, &bsupport));
-    const int Gs = sparse_b_grid(bsupport);
+    int Gx = 0, Gs = 0; // extra blocks of the K2S launch, extra rhs.rhs partials it leaves
+    const SparseRhs sbarg = sparse_b_arg(p, bsupport, Gv, &Gx, &Gs);
     const bool defer_in = chained && chain_index > 0 && g_defer_reduce && speculate && carry_prev;   // red[1..5]: the previous step's local sums
     const bool defer_out = chained && !last_in_burst && g_defer_reduce && speculate; // leave this step's sums to the next one
     if (resume) {
@@ -1156,15 +1196,11 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             sums.a[0] = p->part_rz.p;
             sums.a[1] = p->part_rr.p;
             if (spec) {
-                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
+                hipLaunchKernelGGL(pcg_update_spec_kernel, dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    bsupport >= 0 ? (const double *)nullptr : (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
-                                   p->part_bb.p + FV_VEC_PARTIALS);
-                if (Gs > 0)
-                    hipLaunchKernelGGL(pcg_rhs_sparse_kernel, dim3(Gs), dim3(FV_BLOCK), 0, ctx->stream, bsupport, (const int32_t *)p->bnz_idx.p,
-                                       (const double *)p->b.p, (const double *)p->D.p, (const double *)x_next, dt, (const PcgScalars *)p->scal.p,
-                                       p->part_bb.p + FV_VEC_PARTIALS + Gv);
+                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg);
                 sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
                 sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
                 sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;

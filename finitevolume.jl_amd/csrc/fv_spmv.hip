@@ -323,7 +323,7 @@ extern "C" int fv_tune(int key, int value)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))
         g_dia_packed = value;
-    else if (key == 12 && (value == 0 || value == 1))
+    else if (key == 12 && value >= 0 && value <= 2)
         g_sparse_b = value;
     else if (key == 17 && value >= 0 && value <= 3)
         g_march_dbg = value;

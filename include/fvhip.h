@@ -240,7 +240,8 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      vector outgrows the last-level cache (key 19), 2 always [1]
  *  10: segments per XCD of that kernel, 0 = chosen per operator [0]
  *  11: sliced-DIA values packed (1) or padded to 8 blocks per slice (0); read when the DIA copy is built [1]
- *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support [1]
+ *  12: the fused vector pass of key 8 takes the sparse b's share of |rhs|^2 from a gather over b's support: 1 = by extra
+ *      blocks of the same launch, 2 = inside the vector blocks, 0 = b is streamed like the other vectors [1]
  *  13: one-iteration steps of a fixed-dt run enqueued per device poll (a step that needs more iterations stops the
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
  *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
