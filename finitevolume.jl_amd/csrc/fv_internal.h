@@ -276,6 +276,9 @@ struct PcgSystem {
     // behind it turns into no-ops.  resume_it > 0 continues such a step from its iteration resume_it (no set-up).
     int chain_index = -1;
     int resume_it = 0;
+    // chain_more: another chained step follows in the same burst — this step's verdict and that step's scalars then come
+    // from one launch (pcg_chain_boundary_kernel) and the next step skips its own set-up kernel
+    bool chain_more = false;
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);

@@ -20,6 +20,7 @@
 #include "fv_spmv.h"
 
 extern int g_carry_refresh, g_carry_speculate, g_chain_steps; // fv_transient.hip
+int g_defer_reduce = 1; // fv_tune key 22: bursts of chained steps take a step's verdict and the next step's scalars in one launch; row-block runs also merge their two all-reduces (see dist_step)
 int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
 int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index of every burst is treated as not converged
 
@@ -475,15 +476,21 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
 // Every block takes the same verdict from values no block of this launch writes (red, the previous step's tol2 by index
 // parity); block 0 then either closes the chain (done = 3) or writes the new step's scalars, which the other blocks never
 // read on that path.
+struct BoundarySums { // the previous step's r.M^-1 r, r.r (nprev pieces each) and the new step's r.M^-1 r, r.r (nnext), rhs.rhs (nnext_bb)
+    const double *prev_rz, *prev_rr, *next_rz, *next_rr, *next_bb;
+    int nprev, nnext, nnext_bb;
+};
 __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n, double *__restrict__ r, const double *__restrict__ minv,
-                                                                       double *__restrict__ pv, const double *__restrict__ red, double rtol,
+                                                                       double *__restrict__ pv, BoundarySums sums, double rtol,
                                                                        PcgScalars *scal, const double *__restrict__ xin,
                                                                        const double *__restrict__ xout, const double *__restrict__ D, double dt,
                                                                        int prev_index, int force_unconverged)
 {
+    __shared__ double smem[4];
     if (scal->done)
         return;
-    const double rzn = red[1], rrn = red[2];
+    const double rzn = reduce_partials(sums.prev_rz, sums.nprev, smem);
+    const double rrn = reduce_partials(sums.prev_rr, sums.nprev, smem);
     const bool converged = rrn <= scal->tol2x[prev_index & 1] && !force_unconverged;
     if (!converged) { // as pcg_pupdate_kernel<true>: take the next step's D (x_out - x_in)/dt out of r again, p = z + beta p
         const double beta = rzn / scal->rz[0];
@@ -514,25 +521,32 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
             pv[i] = minv[i] * ri + beta * pv[i];
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (!converged) {
+    if (blockIdx.x != 0)
+        return;
+    if (!converged) {
+        if (threadIdx.x == 0) {
             scal->rz[1] = rzn;
             scal->rr = rrn;
             scal->iters = 1;
             scal->done = 3;
             scal->chain_step = prev_index;
-        } else {
-            const double bb = red[5], tol2 = rtol * rtol * bb;
-            scal->rz[0] = red[3];
-            scal->rz[1] = 0.0;
-            scal->rr = red[4];
-            scal->bnorm2 = bb;
-            scal->tol2 = tol2;
-            scal->tol2x[(prev_index + 1) & 1] = tol2;
-            scal->pq = 0.0;
-            scal->iters = 0;
-            scal->done = (red[4] <= tol2) ? 1 : 0;
         }
+        return;
+    }
+    const double rz0 = reduce_partials(sums.next_rz, sums.nnext, smem);
+    const double rr0 = reduce_partials(sums.next_rr, sums.nnext, smem);
+    const double bb = reduce_partials(sums.next_bb, sums.nnext_bb, smem);
+    if (threadIdx.x == 0) {
+        const double tol2 = rtol * rtol * bb;
+        scal->rz[0] = rz0;
+        scal->rz[1] = 0.0;
+        scal->rr = rr0;
+        scal->bnorm2 = bb;
+        scal->tol2 = tol2;
+        scal->tol2x[(prev_index + 1) & 1] = tol2;
+        scal->pq = 0.0;
+        scal->iters = 0;
+        scal->done = (rr0 <= tol2) ? 1 : 0;
     }
 }
 
@@ -662,8 +676,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     FV_LAUNCH_CHECK(ctx);
     if (!resume)
-        hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p, in_nbb,
-                           chained && sys.chain_index > 0 ? 1 : 0);
+        if (!(chained && sys.chain_index > 0 && g_defer_reduce)) // ... unless the previous chained step's boundary launch wrote them
+            hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p,
+                               in_nbb, chained && sys.chain_index > 0 ? 1 : 0);
     FV_LAUNCH_CHECK(ctx);
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
     int64_t it = resume ? sys.resume_it : 0;
@@ -727,7 +742,14 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                                    p->part_rz.p, p->part_rr.p);
             FV_PROF(3);
             FV_PROF(4);
-            if (spec)
+            if (spec && chained && sys.chain_more && g_defer_reduce) {
+                // this step's verdict and, if it converged, the next chained step's scalars from the set-up K2S left
+                const BoundarySums bs{p->part_rz.p, p->part_rr.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
+                                      p->part_bb.p + FV_VEC_PARTIALS, Gv, Gv, Gv + Gs};
+                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, bs, rtol, p->scal.p, (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt,
+                                   sys.chain_index, (sys.chain_index == g_chain_test_break) ? 1 : 0);
+            } else if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
                                    (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt, sys.chain_index,
@@ -1057,7 +1079,6 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     return FV_OK;
 }
 
-int g_defer_reduce = 1; // fv_tune key 22: chained steps of a row-block run merge their two all-reduces (see dist_step)
 
 // up to five partial-sum arrays reduced by one launch (block k sums array k into out[k])
 struct SumSet {
@@ -1186,8 +1207,9 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 // verdict (on its own vectors: its p is this step's pnext, its iterate went from carry_prev to u) and this
                 // step's scalars
                 FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 6, ctx->stream));
+                const BoundarySums bs{red + 1, red + 2, red + 3, red + 4, red + 5, 1, 1, 1};
                 hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
-                                   p->pnext.p, (const double *)red, rtol, p->scal.p, carry_prev, (const double *)u, (const double *)p->D.p, dt,
+                                   p->pnext.p, bs, rtol, p->scal.p, carry_prev, (const double *)u, (const double *)p->D.p, dt,
                                    chain_index - 1, (chain_index - 1 == g_chain_test_break) ? 1 : 0);
                 FV_LAUNCH_CHECK(ctx);
             } else

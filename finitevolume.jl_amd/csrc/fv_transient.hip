@@ -310,7 +310,8 @@ int g_chain_steps = 8;     // fv_tune key 13: one-iteration steps enqueued per d
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
                      int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
-                     const double *carry_prev = nullptr, bool speculate = false, int chain_index = -1, int resume_it = 0)
+                     const double *carry_prev = nullptr, bool speculate = false, int chain_index = -1, int resume_it = 0,
+                     bool chain_more = false)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
@@ -329,6 +330,7 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.speculate = speculate;              // prepare the next step inside this step's first K2 ...
     sys.use_spec = carry_prev != nullptr;   // ... and start from such a set-up when the residual may be carried
     sys.chain_index = chain_index;
+    sys.chain_more = chain_more;
     sys.resume_it = resume_it;
     if (mode == FV_STEP_FORWARD) {
         sys.rhs = bhat_dev ? bhat_dev : p->b.p;
@@ -421,7 +423,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                 for (int j = 0; j < L && rc == FV_OK; j++) {
                     snap_u[j] = u;
                     snap_alt[j] = alt;
-                    rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, true, alt, prev, true, j);
+                    rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, true, alt, prev, true, j, 0, j + 1 < L);
                     prev = u;
                     std::swap(u, alt);
                 }

@@ -246,8 +246,8 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
  *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
  *      slice-by-slice kernel is faster; measured crossover 3.4e7-5e7 rows) [320]
- *  22: bursts of unpolled steps of a row-block run all-reduce a step's five sums together with the next step's p.q
- *      (one 6-double collective per step instead of two) [1]
+ *  22: bursts of unpolled steps take a step's verdict and the next step's scalars in one launch; a row-block run also
+ *      all-reduces a step's five sums together with the next step's p.q (one 6-double collective per step, not two) [1]
  *  21: a one-rank row-block run issues its all-reduces through RCCL anyway (tests of the call path on one GPU) [0]
  *  20: knots per device pass of fv_param_gradient_integral, 0 = as many as fit 2 GiB [0]
  *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
