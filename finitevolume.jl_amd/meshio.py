@@ -119,3 +119,108 @@ def reorder_mesh(mesh, rank):
         elif isinstance(v, np.ndarray) and v.ndim == 1 and len(v) == N:
             out[k] = v[order]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FEHM / LaGriT files of examples/watertable/setupmodel.jl:7-16 (FEHM.parsegrid, FEHM.parsestor, FEHM.parsezone).
+# FEHM.jl is a dependency outside the reference tree and no .fehmn/.stor/.zone file ships with it, so these readers
+# follow the published file formats (LaGriT "stor" sparse-matrix file, FEHM `coor`/`zone` macros) and are UNPINNED:
+# tested against files written by the tests from the same descriptions, not against FEHM.jl's output.
+def _tokens(f):
+    for line in f:
+        for tok in line.split():
+            yield tok
+
+
+def read_fehm_grid(path):
+    """FEHM.parsegrid: the `coor` block of a .fehmn grid file -> coords (3, N), as setupmodel.jl:7-10 slices it."""
+    with open(path) as f:
+        for line in f:
+            if line.strip().lower().startswith("coor"):
+                break
+        else:
+            raise ValueError("%s: no 'coor' block" % path)
+        n = int(f.readline().split()[0])
+        rows = np.loadtxt(f, dtype=np.float64, max_rows=n, ndmin=2)
+    if rows.shape[0] != n or rows.shape[1] < 4:
+        raise ValueError("%s: expected %d coordinate lines 'id x y z', got %s" % (path, n, rows.shape))
+    if not np.array_equal(rows[:, 0].astype(np.int64), np.arange(1, n + 1)):
+        raise ValueError("%s: node ids must run 1..n in order" % path)
+    return np.ascontiguousarray(rows[:, 1:4].T)
+
+
+def read_fehm_zones(path):
+    """FEHM.parsezone: a `zone` file with `nnum` node lists -> (zonenums, nodesinzones): zone numbers and one int64
+    array of 1-based nodes per zone (setupmodel.jl:15-19)."""
+    zonenums, nodes = [], []
+    with open(path) as f:
+        lines = [ln.strip() for ln in f]
+    i = 0
+    while i < len(lines) and not lines[i].lower().startswith("zone"):
+        i += 1
+    if i == len(lines):
+        raise ValueError("%s: no 'zone' macro" % path)
+    i += 1
+    while i < len(lines):
+        if not lines[i]:
+            i += 1
+            continue
+        if lines[i].lower().startswith("stop"):
+            break
+        zonenums.append(int(lines[i].split()[0]))
+        i += 1
+        if i >= len(lines) or not lines[i].lower().startswith("nnum"):
+            raise ValueError("%s: zone %d is not given as an 'nnum' node list" % (path, zonenums[-1]))
+        i += 1
+        count = int(lines[i].split()[0])
+        vals = [int(t) for t in lines[i].split()[1:]]
+        i += 1
+        while len(vals) < count:
+            vals.extend(int(t) for t in lines[i].split())
+            i += 1
+        if len(vals) != count:
+            raise ValueError("%s: zone %d lists %d nodes, announced %d" % (path, zonenums[-1], len(vals), count))
+        nodes.append(np.array(vals, dtype=np.int64))
+    return zonenums, nodes
+
+
+def read_stor(path):
+    """FEHM.parsestor: a LaGriT ASCII .stor file -> (volumes, areasoverlengths, neighbors) with one entry per stored
+    matrix entry (both directions of every connection and the diagonal, as in the file; setupmodel.jl:12-14 keeps
+    those with node1 < node2).  neighbors is (m, 2) int64, 1-based; areasoverlengths = |A_ij / d_ij|.
+
+    Layout (LaGriT manual, "stor file format"): title; date; `NWRITTEN NEQ NCOEF+NEQ+1 NUM_AREA_COEF [NCON_MAX]`;
+    NEQ Voronoi volumes; NEQ+1 row pointers (offset by NEQ+1) followed by the NCOEF column indices; NCOEF indices into
+    the written coefficients followed by NEQ+1 zeros; NEQ diagonal pointers; NWRITTEN x NUM_AREA_COEF coefficients (the
+    scalar A_ij/d_ij, negative, is the last — or only — component)."""
+    with open(path) as f:
+        title = f.readline()
+        if "stor" not in title.lower():
+            raise ValueError("%s: not a LaGriT stor file (title line %r)" % (path, title.strip()))
+        if "asc" not in title.lower():
+            raise ValueError("%s: only the ASCII form of the stor file is read" % path)
+        f.readline()
+        head = f.readline().split()
+        nwritten, neq, ncoef_tot, nareacoef = (int(t) for t in head[:4])
+        ncoef = ncoef_tot - neq - 1
+        if min(nwritten, neq, ncoef) < 0 or nareacoef not in (1, 3, 4):
+            raise ValueError("%s: implausible matrix parameters %s" % (path, head))
+        tok = _tokens(f)
+        try:
+            volumes = np.array([float(next(tok)) for _ in range(neq)])
+            rowptr = np.array([int(next(tok)) for _ in range(neq + 1)], dtype=np.int64)
+            cols = np.array([int(next(tok)) for _ in range(ncoef)], dtype=np.int64)
+            coefidx = np.array([int(next(tok)) for _ in range(ncoef)], dtype=np.int64)
+            for _ in range(neq + 1 + neq):  # the zero padding and the diagonal pointers
+                next(tok)
+            coefs = np.array([float(next(tok)) for _ in range(nwritten * nareacoef)]).reshape(nareacoef, nwritten)
+        except StopIteration:
+            raise ValueError("%s: file ends before the announced arrays do" % path) from None
+    start = rowptr - (neq + 1)  # 0-based start of every row in `cols`
+    if start[0] != 0 or start[-1] != ncoef or np.any(np.diff(start) < 0):
+        raise ValueError("%s: row pointers do not describe %d entries in %d rows" % (path, ncoef, neq))
+    if ncoef and (cols.min() < 1 or cols.max() > neq or coefidx.min() < 1 or coefidx.max() > nwritten):
+        raise ValueError("%s: column or coefficient index out of range" % path)
+    rows = np.repeat(np.arange(1, neq + 1, dtype=np.int64), np.diff(start))
+    aol = np.abs(coefs[-1][coefidx - 1])
+    return volumes, aol, np.stack([rows, cols], axis=1)

@@ -154,3 +154,78 @@ def test_mesh_jld_reader_on_the_reference_data_files(fv, tmp_path):
     bad.write_bytes(data[:60000])
     with pytest.raises(fv.meshio.JLDFormatError):
         fv.meshio.load_jld(str(bad))
+
+
+def test_fehm_grid_zone_and_stor_readers_on_files_written_from_the_format_descriptions(fv, oracle, tmp_path):
+    """examples/watertable/setupmodel.jl:7-19 needs FEHM.parsegrid / parsestor / parsezone (FEHM.jl: outside the tree, no
+    sample files): the readers against files laid out as the LaGriT / FEHM manuals describe, from a regulargrid whose
+    connections, coefficients and volumes are known; then the solver's own inputs rebuilt from them."""
+    import pytest
+
+    mins, maxs, ns = [0.0, 0.0, 0.0], [4.0, 3.0, 2.0], [5, 4, 3]
+    coords, n1, n2, aol, vol = oracle.regulargrid(mins, maxs, ns)  # (the device grid generator needs a GPU)
+    nb = np.stack([n1, n2], axis=1)
+    N = coords.shape[1]
+    # .fehmn
+    grid = tmp_path / "g.fehmn"
+    with open(grid, "w") as f:
+        f.write("coor\n%10d\n" % N)
+        for i in range(N):
+            f.write("%10d %20.12e %20.12e %20.12e\n" % (i + 1, coords[0, i], coords[1, i], coords[2, i]))
+        f.write("%10d\nelem\n 8 0\n\nstop\n" % 0)
+    assert np.array_equal(fv.meshio.read_fehm_grid(str(grid)), coords)
+    # .zone
+    top = np.nonzero(coords[2] == maxs[2])[0] + 1
+    west = np.nonzero(coords[0] == mins[0])[0] + 1
+    zone = tmp_path / "g_outside.zone"
+    with open(zone, "w") as f:
+        f.write("zone\n00001  top\nnnum\n%10d\n" % len(top))
+        for k in range(0, len(top), 10):
+            f.write(" ".join("%10d" % v for v in top[k : k + 10]) + "\n")
+        f.write("\n00003  left_w\nnnum\n%10d\n" % len(west))
+        f.write(" ".join("%10d" % v for v in west) + "\n\nstop\n")
+    zonenums, nodes = fv.meshio.read_fehm_zones(str(zone))
+    assert zonenums == [1, 3] and np.array_equal(nodes[0], top) and np.array_equal(nodes[1], west)
+    # .stor: full symmetric pattern with diagonal, coefficients -A/d compressed to their distinct values
+    import scipy.sparse as sp
+
+    a, b = nb[:, 0] - 1, nb[:, 1] - 1
+    S = sp.coo_matrix((np.r_[-aol, -aol, np.zeros(N)], (np.r_[a, b, np.arange(N)], np.r_[b, a, np.arange(N)])), shape=(N, N)).tocsr()
+    S.sort_indices()
+    rowsum = np.asarray(-S.sum(axis=1)).ravel()
+    data = S.data.copy()
+    diag_pos = np.empty(N, np.int64)
+    for i in range(N):
+        lo, hi = S.indptr[i], S.indptr[i + 1]
+        k = lo + np.searchsorted(S.indices[lo:hi], i)
+        data[k] = rowsum[i]
+        diag_pos[i] = k
+    distinct, inverse = np.unique(data, return_inverse=True)
+    ncoef = len(data)
+    stor = tmp_path / "g.stor"
+
+    def block(f, values, fmt, per_line=5):
+        for k in range(0, len(values), per_line):
+            f.write("".join(fmt % v for v in values[k : k + per_line]) + "\n")
+
+    with open(stor, "w") as f:
+        f.write("fehmstor ascir8i4 LaGriT Sparse Matrix Voronoi Coefficients\n")
+        f.write(" Sun Oct  4 00:00:00 2026 3-D Linear Diffusion Model (matbld3d_astor)\n")
+        f.write("%10d%10d%10d%10d%10d\n" % (len(distinct), N, ncoef + N + 1, 1, 7))
+        block(f, vol, "%20.12E")
+        block(f, np.r_[S.indptr + N + 1, S.indices + 1], "%10d")
+        block(f, np.r_[inverse + 1, np.zeros(N + 1, np.int64), diag_pos + N + 2], "%10d")
+        block(f, distinct, "%20.12E")
+    volumes, aols, neighbors = fv.meshio.read_stor(str(stor))
+    assert np.allclose(volumes, vol, rtol=1e-12) and neighbors.shape == (ncoef, 2)
+    good = neighbors[:, 0] < neighbors[:, 1]  # setupmodel.jl:13-15
+    order = np.lexsort((nb[:, 1], nb[:, 0]))
+    assert np.array_equal(neighbors[good], nb[order]) and np.allclose(aols[good], aol[order], rtol=1e-12)
+    # malformed files
+    bad = tmp_path / "bad.stor"
+    bad.write_text(open(stor).read()[:600])
+    with pytest.raises(ValueError, match="ends before"):
+        fv.meshio.read_stor(str(bad))
+    bad.write_text("not a matrix\n\n1 2 3 1\n")
+    with pytest.raises(ValueError, match="not a LaGriT stor file"):
+        fv.meshio.read_stor(str(bad))
