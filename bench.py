@@ -224,7 +224,7 @@ def main():
     spmv_bytes = 12 * p.nnz + 20 * p.n
     roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "kernel": ("K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)"
-                       if 8 * p.n > 320 * 2**20 else
+                       if 8 * p.n > 160 * 2**20 else
                        "K1 q=(A+D/dt)p with p.q: spmv_dia_kernel<true,true,false> (slice-by-slice sliced-DIA: x fits the last-level cache at this size)"),
             "algorithmic_bytes_per_launch": spmv_bytes}
     kern = {}

@@ -103,7 +103,7 @@ def run_distributed(fv, args, world, rank):
                 "device": name, "setup_s": t_setup, "per_rank": gathered,
             },
             "roofline": {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / bench.HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sliced-DIA SpMV of rank 0's row block, interior + boundary passes (spmv_dia_kernel while the block's x fits the last-level cache, spmv_dia_march_kernel on the interior window above 4e7 rows; spmv_wstream_kernel on non-grid-like slices), per GPU", "algorithmic_bytes_per_launch": spmv_bytes,
+                         "traffic": None, "kernel": "sliced-DIA SpMV of rank 0's row block, interior + boundary passes (spmv_dia_kernel while the block's x fits the last-level cache, spmv_dia_march_kernel on the interior window above 2.1e7 rows; spmv_wstream_kernel on non-grid-like slices), per GPU", "algorithmic_bytes_per_launch": spmv_bytes,
                          "avg_launch_ms": ms,
                          "note": "10 back-to-back launches after the timed region on resident vectors (a block's x may stay in the last-level cache between them); the in-loop figure of the single-GPU run is bench.py --gpus 1"},
         }

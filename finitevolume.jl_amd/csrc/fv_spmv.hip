@@ -268,7 +268,7 @@ static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per sli
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
 static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9): 0 never, 1 when x outgrows the last-level cache, 2 always
-static int g_march_min_mb = 320; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache; measured crossover ~4e7 rows)
+static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
@@ -1126,8 +1126,10 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         // structured grids: plane-marching form over the whole DIA part (not for subsets or the fused set-up)
         // ... when it pays: while x (8 bytes per column) stays in the 256 MB last-level cache the -plane / +plane arms of the
         // slice-by-slice kernel come from there and the marching kernel's static partition only costs (short pencils, uneven
-        // XCD shares): 177 vs 216 us on 1.2e7 rows, 352 vs 364 on 2.5e7, 505 vs 539 on 3.4e7, 777 vs 758 on 5e7, ~2000 vs 1600 on 1e8
-        // (tools/march_vs_dia.py, profiles/r01_march_vs_dia.log)
+        // XCD shares): back-to-back launches, 177 vs 216 us on 1.2e7 rows, 352 vs 364 on 2.5e7, 505 vs 539 on 3.4e7, 777 vs 758 on
+        // 5e7, ~2000 vs 1600 on 1e8 (tools/march_vs_dia.py, profiles/r01_march_vs_dia.log); inside the stepping loop, where the
+        // vector pass between two SpMVs evicts x, ms per step slices vs marching: 216^3 0.306 / 0.330, 256^3 0.509 / 0.517,
+        // 280^3 0.710 / 0.705, 320^3 1.067 / 1.056, 380^3 1.785 / 1.738 (tools/step_ab.py 9 0 2, profiles/r01_step_ab_march.log)
         const bool march_pays = g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
         const bool march = g_march && march_pays && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         int GM = 0;
