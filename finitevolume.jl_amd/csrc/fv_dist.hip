@@ -196,7 +196,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
     pl->N = pl->n = nloc;
     pl->nnz = nnz_loc;
     pl->from_csc = true;
-    pl->order_built = true; // distributed passes use the interior / boundary lists instead
+    // (the traversal order stays the interior / boundary lists; build_group_order only looks for the plane stride of a row block)
     int rc = FV_OK;
     do {
         // ---- halo: sorted remote columns referenced by my rows

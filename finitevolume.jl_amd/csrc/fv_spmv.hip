@@ -267,6 +267,7 @@ int g_use_dia = 1;
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
 static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
+static int g_trace_spmv = getenv("FV_TRACE_SPMV") ? atoi(getenv("FV_TRACE_SPMV")) : 0;
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9): 0 never, 1 when x outgrows the last-level cache, 2 always
 static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
@@ -319,6 +320,8 @@ extern "C" int fv_tune(int key, int value)
         g_comm_single_rank_collectives = value;
     else if (key == 22 && (value == 0 || value == 1))
         g_defer_reduce = value;
+    else if (key == 25 && value >= 0)
+        g_trace_spmv = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))
@@ -390,6 +393,10 @@ static int build_group_order(fv_problem *p)
     FV_TRY(fv_count_far_stride(p, stride, &agree));
     if (agree < (n - stride) * 8 / 10)
         return FV_OK;
+    if (p->dist) { // a row block is traversed by its interior / boundary lists; the stride lets its interior window march
+        p->order_stride = stride;
+        return FV_OK;
+    }
     int64_t BAND = 8192; // rows per band: ~18 grid lines of the 464^3 box; FV_BAND overrides (experiments)
     if (const char *e = getenv("FV_BAND"))
         BAND = atoll(e) > 0 ? (atoll(e) + 63) / 64 * 64 : BAND;
@@ -1133,6 +1140,13 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         const bool march_pays = g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
         const bool march = g_march && march_pays && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         int GM = 0;
+        if (g_trace_spmv > 0) { // fv_tune key 25 / FV_TRACE_SPMV: the next N kernel choices to stderr
+            g_trace_spmv--;
+            fprintf(stderr, "[fvhip] sliced-DIA SpMV: %s kernel, n %lld (+%lld halo), %lld slices%s, plane stride %lld, window [%lld, %lld)\n",
+                    march ? "plane-marching" : "slice-by-slice", (long long)p->n, (long long)p->nhalo, (long long)dcount,
+                    subset ? " (subset)" : "", (long long)p->order_stride, subset ? (long long)subset->win_lo : 0LL,
+                    subset ? (long long)subset->win_hi : 0LL);
+        }
         if (march) {
             const int64_t ns = (p->n + 63) >> 6;
             const int sh = (int)(p->order_stride % 64);

@@ -159,7 +159,7 @@ def test_synthetic_464_cubed_operator_identities(fv):
 
 
 @pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192]])  # plane strides 39 600 (= 48 mod 64: centre + edge loads), 36 100 (= 4 mod 64: 16-byte windows), 36 864 (= 0 mod 64)
-def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
+def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd):
     """>= 2^20 unknowns with a plane stride: the plane-marching sliced-DIA kernel (default), the slice-by-slice DIA
     kernel and the CSR wave-stream form against a float64 CSR product on the host; the p.q epilogue against numpy."""
     import scipy.sparse as sp
@@ -186,7 +186,10 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
         for name, knobs in (("march", {9: 2, 6: 1, 18: 1}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
                 assert lib.fv_tune(k, v) == 0
+            lib.fv_tune(25, 1)
             y = p.spmv(x, sigma)
+            trace = capfd.readouterr().err
+            assert ("plane-marching kernel" in trace) == name.startswith("march") and ("slice-by-slice kernel" in trace) == (name == "slices"), (name, trace)
             assert np.abs(y - ref).max() <= 1e-13 * scale, name
             assert abs(p.dot(x, y) - x @ y) <= 1e-12 * abs(x @ y)
             lib.fv_tune(10, 0)
@@ -208,7 +211,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns):
         lib.fv_tune(18, 1)
 
 
-def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv):
+def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv, capfd):
     """Row blocks with >= 2^20 rows take the plane-marching kernel for their interior slices (a window of the
     pencils) and the slice kernel for the boundary ones: virtual ranks on one GPU against the global product, and the
     one-rank distributed driver (RCCL communicator of one rank) against the plain fixed-dt loop."""
@@ -225,6 +228,7 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     st = p.transient_begin(0.1, None, u0)
     x = rng.standard_normal(p.n)
     lib = fv.load()
+    lib.fv_tune(25, 64)  # the kernel choices of the first block products go to stderr: the marching kernel must really run on a block's window
     for sigma, forced in ((0.0, 2), (1 / 60.0, 2), (1 / 60.0, 1)):  # 2: marching at any size; 1: the library's choice (slices at this size)
         lib.fv_tune(9, forced)
         y_global = p.spmv(x, sigma)
@@ -237,6 +241,10 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
                 y = blk.spmv_halo(x[blk.lo : blk.hi], x[plan["halo_cols"]], sigma)
                 assert np.abs(y - y_global[blk.lo : blk.hi]).max() <= 1e-13 * np.abs(y_global).max(), (nranks, rank, sigma)
                 blk.close()
+    lib.fv_tune(25, 0)
+    trace = capfd.readouterr().err
+    assert "plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
+    assert "slice-by-slice kernel, n 1227600 (+39600 halo), 620 slices (subset)" in trace  # the boundary pass of the same block
     ctx = p.ctx
     dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
     try:
