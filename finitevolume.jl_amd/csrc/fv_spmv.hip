@@ -288,7 +288,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
-extern int g_defer_reduce;                  // fv_pcg.hip
+extern int g_defer_reduce, g_k2s_nt;        // fv_pcg.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -322,6 +322,8 @@ extern "C" int fv_tune(int key, int value)
         g_defer_reduce = value;
     else if (key == 25 && value >= 0)
         g_trace_spmv = value;
+    else if (key == 26 && ((value >= 0 && value <= 3) || value == 7))
+        g_k2s_nt = value;
     else if (key == 10 && value >= 0 && value <= 16)
         g_march_segs = value;
     else if (key == 11 && (value == 0 || value == 1))

@@ -246,6 +246,8 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
  *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
  *      slice-by-slice kernel is faster; inside the stepping loop the crossover is at ~2e7 rows) [160]
+ *  26: streaming hints of the fused vector pass of key 8: bit 0 = its read-once inputs bypass the caches, bit 1 = its
+ *      x and r outputs too (the next SpMV's input stays cacheable), 7 = the search direction as well [3]
  *  25: print the next N choices between the two sliced-DIA kernels to stderr (also FV_TRACE_SPMV=N in the environment) [0]
  *  22: bursts of unpolled steps take a step's verdict and the next step's scalars in one launch; a row-block run also
  *      all-reduces a step's five sums together with the next step's p.q (one 6-double collective per step, not two) [1]
