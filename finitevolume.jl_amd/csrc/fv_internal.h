@@ -108,7 +108,7 @@ struct PcgScalars {
     int32_t iters;
     int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN), 3 a chain of unpolled one-iteration steps broke here
     int32_t chain_step; // done == 3: index (within the burst) of the step that needs more than its one iteration
-    int32_t pad_;
+    uint32_t zero_mask; // bursts of chained steps: bit j set = step j of the burst was already converged at its set-up (0 iterations)
     double tol2x[2]; // tol2 of the chained steps by parity of their index (row-block bursts: a step's verdict is taken while the next step's scalars are written)
 };
 
@@ -282,7 +282,7 @@ struct PcgSystem {
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
-int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info);
+int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info, uint32_t *zero_mask = nullptr);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
                    int *npartials = nullptr);

@@ -153,6 +153,8 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const doubl
         scal->bnorm2 = bb;
         scal->tol2 = rtol * rtol * bb; // stop when ||r|| <= rtol*||b||  (IterativeSolvers' reltol)
         scal->tol2x[0] = scal->tol2x[1] = scal->tol2;
+        if (!chained)
+            scal->zero_mask = 0u; // a burst starts with a step set up here without the chained flag
         scal->pq = 0.0;
         scal->iters = 0;
         scal->done = (rr <= scal->tol2) ? 1 : 0;
@@ -256,11 +258,30 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
                                                                     double *__restrict__ part_rz, double *__restrict__ part_rr,
                                                                     double *__restrict__ pnext, double *__restrict__ spec_rz,
                                                                     double *__restrict__ spec_rr, double *__restrict__ spec_bb,
-                                                                    SparseRhs sb)
+                                                                    SparseRhs sb, int chain_index)
 {
     __shared__ double smem[4];
-    if (scal->done)
+    if (scal->done) {
+        // A chained step that was already converged at its set-up (the carried residual is within the tolerance): the host
+        // flips the two state vectors after every chained step without looking, so the iterate is handed over unchanged.
+        // r, p' and the set-up sums stay as they are — they describe exactly this state — and the step counts 0 iterations.
+        if (scal->done == 1 && chain_index >= 0 && scal->iters == 0) {
+            const int gmain0 = (int)gridDim.x - sb.nblocks;
+            if ((int)blockIdx.x < gmain0) {
+                const int64_t n2c = n >> 1;
+                const double2 *xi2c = reinterpret_cast<const double2 *>(xin);
+                double2 *xo2c = reinterpret_cast<double2 *>(xout);
+                for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2c; i += (int64_t)gmain0 * FV_BLOCK)
+                    xo2c[i] = xi2c[i];
+                if (blockIdx.x == 0 && threadIdx.x == 0) {
+                    if (n & 1)
+                        xout[n - 1] = xin[n - 1];
+                    scal->zero_mask |= 1u << chain_index;
+                }
+            }
+        }
         return;
+    }
     const double pq = reduce_partials(part_pq, npq, smem);
     if (!(pq > 0.0)) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -779,7 +800,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    bsupport >= 0 ? (const double *)nullptr : sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
-                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg);
+                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg, chained ? sys.chain_index : -1);
                 p->spec_extra_bb = Gs;
             }
             else if (iter == 0 && sys.x_next)
@@ -865,7 +886,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
 
 // After a burst of `nsteps` chained steps: one poll.  *completed = steps that converged in their one iteration; when it is
 // < nsteps, step *completed is interrupted after its first iteration (done flag cleared here so that it can be resumed).
-int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info)
+int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info, uint32_t *zero_mask)
 {
     fv_ctx *ctx = p->ctx;
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
@@ -883,6 +904,8 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
                 p->prof_launches[c]++;
             }
     *completed = ndone;
+    if (zero_mask)
+        *zero_mask = hs->zero_mask;
     if (hs->done == 3) {
         p->spec_valid = false;
         p->last_iters = 2; // at least
@@ -1271,7 +1294,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
                                    bsupport >= 0 ? (const double *)nullptr : (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
-                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg);
+                                   p->part_bb.p + FV_VEC_PARTIALS, sbarg, chained ? chain_index : -1);
                 sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
                 sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
                 sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;
@@ -1373,13 +1396,14 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
                     std::swap(u, alt);
                 }
                 int completed = 0;
+                uint32_t zero_mask = 0;
                 if (rc == FV_OK)
-                    rc = fv_pcg_chain_poll(p, L, &completed, &inf);
+                    rc = fv_pcg_chain_poll(p, L, &completed, &inf, &zero_mask);
                 if (rc != FV_OK)
                     break;
                 for (int j = 0; j < completed && j < L; j++)
                     if (iters_per_step)
-                        iters_per_step[s + j] = 1;
+                        iters_per_step[s + j] = ((zero_mask >> j) & 1u) ? 0 : 1;
                 if (completed < L) {
                     u = snap_u[completed];
                     alt = snap_alt[completed];

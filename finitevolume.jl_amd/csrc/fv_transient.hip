@@ -428,13 +428,14 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                     std::swap(u, alt);
                 }
                 int completed = 0;
+                uint32_t zero_mask = 0; // steps of the burst that were already converged at their set-up
                 if (rc == FV_OK)
-                    rc = fv_pcg_chain_poll(p, L, &completed, &inf);
+                    rc = fv_pcg_chain_poll(p, L, &completed, &inf, &zero_mask);
                 if (rc != FV_OK)
                     break;
                 for (int j = 0; j < completed && j < L; j++)
                     if (iters_per_step)
-                        iters_per_step[s + j] = 1;
+                        iters_per_step[s + j] = ((zero_mask >> j) & 1u) ? 0 : 1;
                 if (completed < L) { // step `completed` needs more iterations: back to its pointers, resume at iteration 1
                     u = snap_u[completed];
                     alt = snap_alt[completed];
