@@ -1086,6 +1086,19 @@ def test_bursts_with_steps_already_converged_at_their_set_up(fv, dt, rtol):
     assert relerr(got, out[8][0]) < 50 * rtol
 
 
+@pytest.mark.parametrize("tight", [False, True])
+def test_bursts_against_step_by_step_polling_on_random_schedules(fv, tight):
+    """tools/burst_fuzz.py: random boxes and random schedules of (dt, steps, rtol) — 0-, 1- and many-iteration steps mixed —
+    run with a poll after every step, with bursts of 8 and of 3 unpolled steps, and with the bursts' merged launches off:
+    states and iteration counts must agree bit for bit."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("burst_fuzz", os.path.join(os.path.dirname(os.path.dirname(GOLDEN)), "tools", "burst_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(fv, 8, tight, verbose=False) == 0
+
+
 def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
     """AMG set-up on an irregular operator: repeated faces, self-loops (zero contribution), rows of very different
     length, free nodes whose only neighbours are Dirichlet (no couplings: the smoother alone must solve them), a
