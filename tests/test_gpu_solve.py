@@ -1099,6 +1099,49 @@ def test_bursts_against_step_by_step_polling_on_random_schedules(fv, tight):
     assert mod.run(fv, 8, tight, verbose=False) == 0
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_row_block_bursts_against_step_by_step_polling_on_random_schedules(fv, seed):
+    """The same differential check for the row-block driver (2 or 3 ranks over the loopback transport): with the rank count
+    fixed, a poll after every step, bursts with the merged collective and bursts with the two separate collectives must
+    give the same bits and the same iteration counts on every rank."""
+    import bench
+
+    rng = np.random.default_rng(1000 + seed)
+    nranks = 2 + seed % 2
+    ns = [int(rng.integers(12, 30)), int(rng.integers(10, 24)), int(rng.integers(8, 20))]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    if seed % 3 == 0:
+        src[:] = 0.0
+    tight = seed % 2 == 1
+    dts, rtols = ([2.0**-10, 2.0**-8, 1.0, 3600.0], [1e-8, 1e-10, 1e-12]) if tight else ([2.0**-8, 1.0, 20.0, 60.0, 600.0], [1e-3, 1e-5, 3e-5, 1e-8])
+    schedule = [(float(rng.choice(dts)), int(rng.integers(1, 40))) for _ in range(int(rng.integers(3, 7)))]
+    rtol = float(rng.choice(rtols))
+
+    def make_problem(ctx):
+        p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+        K = 1e-5 * np.exp(np.random.default_rng(100 + seed).standard_normal(p.F))
+        p.assemble(K, src, np.full(len(dn), 1e3))
+        p.transient_begin(0.1, None, np.full(p.N, 1e3) + np.random.default_rng(200 + seed).standard_normal(p.N))
+        return p
+
+    lib = fv.load()
+    out = {}
+    try:
+        for k, (chain, merged) in enumerate(((0, 1), (8, 1), (8, 0))):
+            lib.fv_tune(13, chain)
+            lib.fv_tune(22, merged)
+            out[(chain, merged)] = _run_ranks_in_threads(fv, nranks, 2000 + 10 * seed + k, make_problem, schedule, rtol)
+    finally:
+        lib.fv_tune(13, 8)
+        lib.fv_tune(22, 1)
+    ref = out[(0, 1)]
+    for key, res in out.items():
+        for a, b in zip(ref, res):
+            assert np.array_equal(a[3], b[3]), (key, schedule, rtol, a[3], b[3])
+            assert np.array_equal(a[2], b[2]), (key, schedule, rtol)
+
+
 def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
     """AMG set-up on an irregular operator: repeated faces, self-loops (zero contribution), rows of very different
     length, free nodes whose only neighbours are Dirichlet (no couplings: the smoother alone must solve them), a
