@@ -4,6 +4,7 @@
 
 static thread_local std::string g_err;
 
+static thread_local unsigned long long g_err_seq = 0, g_err_noctx_seq = 0; // per host thread, like g_err
 void fv_set_error(fv_ctx *ctx, const char *fmt, ...)
 {
     char buf[1024];
@@ -11,14 +12,20 @@ void fv_set_error(fv_ctx *ctx, const char *fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx)
+    g_err_seq++;
+    if (ctx) {
         ctx->err = buf;
+        ctx->err_seq = g_err_seq;
+    } else
+        g_err_noctx_seq = g_err_seq;
     g_err = buf;
 }
 
 extern "C" int fv_abi_version(void) { return FVHIP_ABI_VERSION; }
 
-extern "C" const char *fv_last_error(fv_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+// the context's own last message, unless a helper without a context (argument checks of the grid functions, ...) has
+// reported something since: then that message is the one the failing call produced
+extern "C" const char *fv_last_error(fv_ctx *ctx) { return (ctx && ctx->err_seq > g_err_noctx_seq) ? ctx->err.c_str() : g_err.c_str(); }
 
 extern "C" int fv_ctx_create(int device, fv_ctx **out)
 {

@@ -27,6 +27,7 @@ struct fv_ctx {
     hipStream_t stream = nullptr;  // compute
     hipStream_t stream2 = nullptr; // halo / collectives
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_halo = nullptr, ev_comp = nullptr;
+    unsigned long long err_seq = 0; // when `err` was set (fv_last_error prefers a later context-free message)
     void *pinned = nullptr; // small pinned scratch for scalar read-back
     size_t pinned_bytes = 0;
     std::string err;
