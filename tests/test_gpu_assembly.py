@@ -159,6 +159,50 @@ def test_random_multigraph_with_repeats_selfloops_metaindex(fv, oracle):
         fv.assembleA(np.stack([n1, n2 + N], 1), aol, K, src, dn, dh, meta)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_multigraph_assembly_bit_exact(fv, oracle, seed):
+    """Differential fuzz of assembleA / assembleb against the oracle: random multigraphs (repeated faces, faces in both
+    orientations, self-loops, isolated nodes), random Dirichlet sets with repeats (the last head wins), with and without a
+    metaindex, plain and log conductivities (plain: every value bit-exact; log: exp() within 8 ulp), random sources on
+    free nodes, node counts from 1 up — structure arrays always bit-exact."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(1, 60)) if seed % 4 else int(rng.integers(200, 3000))
+    F = int(rng.integers(0, 6 * N + 1))
+    n1 = rng.integers(1, N + 1, F)
+    n2 = rng.integers(1, N + 1, F)
+    if F > 4:  # repeat some faces, reversed as well
+        k = rng.integers(0, F, F // 5)
+        n1[k], n2[k] = n1[(k + 1) % F], n2[(k + 1) % F]
+        k = rng.integers(0, F, F // 7)
+        n1[k], n2[k] = n2[(k + 2) % F].copy(), n1[(k + 2) % F].copy()
+    aol = np.exp(rng.standard_normal(F) * 2)
+    ndir = int(rng.integers(0, N + 1)) if seed % 5 else N
+    dn = rng.integers(1, N + 1, ndir + int(rng.integers(0, 3))).astype(np.int64)
+    dh = rng.standard_normal(len(dn)) * 100
+    logk = bool(seed % 2)
+    if seed % 3 == 0:
+        nK = int(rng.integers(1, 9))
+        meta = rng.integers(1, nK + 1, F)
+    else:
+        nK, meta = F, None
+    K = rng.standard_normal(nK) if logk else np.exp(rng.standard_normal(nK))
+    free = np.ones(N, bool)
+    free[dn - 1] = False
+    src = np.where(free, rng.standard_normal(N), 0.0)
+    nb = np.stack([n1, n2], 1).astype(np.int64)
+    A = fv.assembleA(nb, aol, K, src, dn, dh, meta, logk)
+    oA = oracle.assembleA(n1, n2, aol, K, src, dn, dh, meta, logk)
+    b = fv.assembleb(nb, aol, K, src, dn, dh, meta, logk)
+    ob = oracle.assembleb(n1, n2, aol, K, src, dn, dh, meta, logk)
+    assert A.n == oA.n == int(free.sum()) and np.array_equal(A.colptr, oA.colptr) and np.array_equal(A.rowval, oA.rowval)
+    if logk:
+        scale = np.abs(oA.nzval).max() if len(oA.nzval) else 1.0
+        assert np.allclose(A.nzval, oA.nzval, rtol=2e-15 * 8, atol=1e-300) or np.abs(A.nzval - oA.nzval).max() <= 1e-14 * scale
+        assert np.allclose(b, ob, rtol=1e-12, atol=1e-12 * (np.abs(ob).max() if len(ob) else 1.0))
+    else:
+        assert np.array_equal(A.nzval, oA.nzval) and np.array_equal(b, ob)
+
+
 def test_fourfractures_fixture_bit_exact(fv, oracle):
     d = np.load(os.path.join(GOLDEN, "fourfractures.npz"))
     nb = np.stack([d["node1"], d["node2"]], 1)
