@@ -158,6 +158,9 @@ def other_baseline_configs(fv, ctx):
 
 
 def main():
+    # multi-process GPU work on this pool needs dmabuf IPC (RCCL's peer mappings fail with the legacy mode); the launcher
+    # normally exports it already — set before anything touches HIP
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # 0.65 s of stepping: one hiccup of the box no longer decides the number

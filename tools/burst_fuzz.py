@@ -18,6 +18,8 @@ def run(fv, nseeds=12, tight=False, verbose=True):
     for seed in range(nseeds):
         rng = np.random.default_rng(seed)
         ns = [int(rng.integers(12, 34)), int(rng.integers(12, 30)), int(rng.integers(8, 26))]
+        if os.environ.get("FV_FUZZ_BIG"):  # > 2^20 rows with planes of > 4096 rows: sliced-DIA kernels, marching when forced (FV_TUNE 9=2)
+            ns = [int(rng.integers(100, 131)), int(rng.integers(90, 120)), int(rng.integers(90, 120))]
         mins, maxs = bench.spacing_box(ns)
         dn, src = bench.box_setup(ns)
         if seed % 3 == 0:
@@ -54,5 +56,8 @@ def run(fv, nseeds=12, tight=False, verbose=True):
 
 if __name__ == "__main__":
     fv_ = load_package()
+    for kv in os.environ.get("FV_TUNE", "").split(","):
+        if "=" in kv:
+            fv_.load().fv_tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     print("mismatches:", run(fv_, n, len(sys.argv) > 2 and sys.argv[2] == "tight"))
