@@ -75,6 +75,42 @@ def slab_problem(mins, maxs, ns, dirichletnodes, nranks, rank, ctx=None):
     return p, bounds
 
 
+def rank_faces(neighbors, N, dirichletnodes, nranks, rank, bounds=None):
+    """Block-local assembly for face-list (unstructured) meshes: the faces a rank needs, i.e. those with an end among the
+    free rows [bounds[rank], bounds[rank+1]) — in the order of the global list, so that the rank's rows come out bit for
+    bit as in the global operator.  -> (face indices (0-based, ascending), bounds).  bounds=None: equal shares of rows,
+    as fv_dist_setup."""
+    import numpy as _np
+
+    from .core import _split_neighbors
+
+    n1, n2 = _split_neighbors(neighbors)
+    free = _np.ones(int(N), bool)
+    free[ai64(dirichletnodes) - 1] = False
+    n = int(free.sum())
+    if bounds is None:
+        bounds = [(r * n) // int(nranks) for r in range(int(nranks) + 1)]
+    row = _np.cumsum(free) - 1  # free row of every free node
+    lo, hi = bounds[rank], bounds[rank + 1]
+    mine = free & (row >= lo) & (row < hi)
+    sel = _np.nonzero(mine[n1 - 1] | mine[n2 - 1])[0]
+    return sel, [int(b) for b in bounds]
+
+
+def partial_problem(neighbors, areasoverlengths, N, dirichletnodes, nranks, rank, bounds=None, ctx=None):
+    """The rank's problem of a face-list mesh without the global operator: all nodes, only the faces of rank_faces.
+    -> (problem, bounds, faces): assemble with conductivities[faces] (or a metaindex[faces]), the global sources, heads
+    and u0, then RowBlock(problem, nranks, rank, bounds)."""
+    import numpy as _np
+
+    from .core import _split_neighbors
+
+    sel, bounds = rank_faces(neighbors, N, dirichletnodes, nranks, rank, bounds)
+    n1, n2 = _split_neighbors(neighbors)
+    p = Problem.create(_np.stack([n1[sel], n2[sel]], axis=1), _np.asarray(areasoverlengths, dtype=_np.float64)[sel], N, dirichletnodes, ctx)
+    return p, bounds, sel
+
+
 class RowBlock:
     """A rank's contiguous range of free rows (fv_dist_setup)."""
 

@@ -1142,6 +1142,68 @@ def test_row_block_bursts_against_step_by_step_polling_on_random_schedules(fv, s
             assert np.array_equal(a[2], b[2]), (key, schedule, rtol)
 
 
+@pytest.mark.parametrize("case", ["fourfractures", "multigraph"])
+def test_rank_local_assembly_of_a_face_list_mesh(fv, case):
+    """Unstructured meshes without the global operator on every rank: a rank builds its problem from the faces incident to
+    its rows only (dist.partial_problem) — plan, block product and the whole run bit-identical to blocks cut from the
+    globally assembled operator (the real DFN mesh, 3 ranks; a random multigraph with repeated faces, 4 ranks)."""
+    from fvamd import dist
+
+    rng = np.random.default_rng(7)
+    if case == "fourfractures":
+        d = np.load(os.path.join(GOLDEN, "fourfractures.npz"))
+        nb = np.stack([d["node1"], d["node2"]], 1)
+        aol, dn, dh = d["areasoverlengths"], d["dirichletnodes"], d["dirichletheads"]
+        N, nranks = 2106, 3
+        K = d["conductivities"] * np.exp(rng.standard_normal(len(aol)))
+        vol = np.exp(rng.standard_normal(N)) * 1e-3
+        u0 = np.full(N, 1.5e6) + 1e3 * rng.standard_normal(N)
+        Ss, schedule, rtol = 1e-9, [(50.0, 5), (0.5, 12)], 1e-12
+    else:
+        N, F, nranks = 1500, 6000, 4
+        nb = np.stack([rng.integers(1, N + 1, F), rng.integers(1, N + 1, F)], 1)
+        nb[rng.integers(0, F, 500)] = nb[rng.integers(0, F, 500)]  # repeated faces
+        aol = np.exp(rng.standard_normal(F))
+        dn = rng.choice(N, 200, replace=False) + 1
+        dh = rng.standard_normal(200)
+        K = np.exp(rng.standard_normal(F))
+        vol = np.exp(rng.standard_normal(N))
+        u0 = rng.standard_normal(N)
+        Ss, schedule, rtol = 1.0, [(0.5, 4), (0.001, 12)], 1e-12
+    src = np.zeros(N)
+
+    def global_blocks(ctx, rank):
+        p = fv.Problem.create(nb, aol, N, dn, ctx).assemble(K, src, dh)
+        p.transient_begin(Ss, vol, u0)
+        return p
+
+    probes = {}
+
+    def local_blocks(ctx, rank):
+        p, bounds, faces = dist.partial_problem(nb, aol, N, dn, nranks, rank, None, ctx)
+        assert 0 < len(faces) < len(aol) and p.F == len(faces)
+        p.assemble(K[faces], src, dh)
+        p.transient_begin(Ss, vol, u0)
+        blk = dist.RowBlock(p, nranks, rank, bounds)
+        r2 = np.random.default_rng(rank)
+        probes[rank] = (blk.plan(), blk.spmv_halo(r2.standard_normal(blk.nloc), r2.standard_normal(blk.nhalo), 0.3))
+        blk.close()
+        return p, bounds
+
+    a = _run_ranks_in_threads(fv, nranks, 3000 + nranks, global_blocks, schedule, rtol, by_rank=True)
+    b = _run_ranks_in_threads(fv, nranks, 3010 + nranks, local_blocks, schedule, rtol, by_rank=True)
+    ref = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+    ref.transient_begin(Ss, vol, u0)
+    for rank, (x, y) in enumerate(zip(a, b)):
+        assert x[:2] == y[:2] and np.array_equal(x[2], y[2]) and np.array_equal(x[3], y[3])
+        want = dist.RowBlock(ref, nranks, rank)
+        for u, v in zip(want.plan(), probes[rank][0]):
+            assert np.array_equal(u, v)
+        r2 = np.random.default_rng(rank)
+        assert np.array_equal(want.spmv_halo(r2.standard_normal(want.nloc), r2.standard_normal(want.nhalo), 0.3), probes[rank][1])
+        want.close()
+
+
 def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
     """AMG set-up on an irregular operator: repeated faces, self-loops (zero contribution), rows of very different
     length, free nodes whose only neighbours are Dirichlet (no couplings: the smoother alone must solve them), a
