@@ -244,20 +244,20 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      blocks of the same launch, 2 = inside the vector blocks, 0 = b is streamed like the other vectors [1]
  *  13: one-iteration steps of a fixed-dt run enqueued per device poll (a step that needs more iterations stops the
  *      chain on the device and is resumed by the host); < 2 = poll after every step [8]
- *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
- *      slice-by-slice kernel is faster; inside the stepping loop the crossover is at ~2e7 rows) [160]
- *  26: streaming hints of the fused vector pass of key 8: bit 0 = its read-once inputs bypass the caches, bit 1 = its
- *      x and r outputs too (the next SpMV's input stays cacheable), 7 = the search direction as well [3]
- *  25: print the next N choices between the two sliced-DIA kernels to stderr (also FV_TRACE_SPMV=N in the environment) [0]
- *  22: bursts of unpolled steps take a step's verdict and the next step's scalars in one launch; a row-block run also
- *      all-reduces a step's five sums together with the next step's p.q (one 6-double collective per step, not two) [1]
- *  21: a one-rank row-block run issues its all-reduces through RCCL anyway (tests of the call path on one GPU) [0]
- *  20: knots per device pass of fv_param_gradient_integral, 0 = as many as fit 2 GiB [0]
- *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
+ *  14: fault injection for the tests of key 13: the chained step with this index of every burst is treated as not
+ *      converged [-1]
  *  17: diagnosis switches of the marching kernel (bit 0: no in-plane arm loads, bit 1: no plane-arm edge loads);
  *      results are wrong when set [0]
- *  14: fault injection for the tests of key 13: the chained step with this index of every burst is treated as not
- *      converged [-1] */
+ *  18: marching kernel: one 16-byte window access per step instead of centre + two edge loads when stride mod 64 <= 32 [1]
+ *  19: MiB of x above which key 9 = 1 takes the marching kernel (below, x stays in the 256 MB infinity cache and the
+ *      slice-by-slice kernel is faster; inside the stepping loop the crossover is at ~2e7 rows) [160]
+ *  20: knots per device pass of fv_param_gradient_integral, 0 = as many as fit 2 GiB [0]
+ *  21: a one-rank row-block run issues its all-reduces through RCCL anyway (tests of the call path on one GPU) [0]
+ *  22: bursts of unpolled steps take a step's verdict and the next step's scalars in one launch; a row-block run also
+ *      all-reduces a step's five sums together with the next step's p.q (one 6-double collective per step, not two) [1]
+ *  25: print the next N choices between the two sliced-DIA kernels to stderr (also FV_TRACE_SPMV=N in the environment) [0]
+ *  26: streaming hints of the fused vector pass of key 8: bit 0 = its read-once inputs bypass the caches, bit 1 = its
+ *      x and r outputs too (the next SpMV's input stays cacheable), 7 = the search direction as well [3] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
