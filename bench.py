@@ -26,6 +26,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
+K2S_BYTES_PER_ROW = 64  # pcg_update_spec_kernel: x_in, q, M^-1, D, r in; x_out, r, p' out (p = M^-1 r is recomputed, b' gathered)
+KERNEL_NAMES = {  # fv_spmv_form id -> kernel(s) that ran
+    0: "spmv_wstream_kernel<512,true,true> (wave-private CSR stream)",
+    1: "spmv_dia_kernel<true,true,false> (sliced-DIA, slice by slice: x fits the last-level cache at this size)",
+    2: "spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses)",
+    3: "spmv_symdia_march_kernel<true,5,true> (symmetric plane-marching: diagonal + 3 upper diagonals streamed, lower arms from the upper arrays; first/last plane by spmv_dia_kernel)",
+}
 
 
 def box_setup(ns, i1_lo=None, i1_hi=None):
@@ -60,23 +67,28 @@ def cpu_baseline(dt, rtol):
     """The oracle (CPU restatement of the reference: assembleA/b, scalebyvolume!,
     fixedbackwardeulerstep!, IterativeSolvers-style CG) timed on ONE host core on a
     bounded sample of the same workload: same cell size / K / Ss / dt / BCs, 256^3
-    cells, 30 steps (10-20 s of CPU).  Only the stepping loop is timed, as for the GPU."""
+    cells, 30 steps (10-20 s of CPU).  Only the stepping loop is timed, as for the GPU.
+    Beside it the path north_star names — `linearsolver = (A, b, x0) -> A \\ b` (test/ode.jl:36), i.e. a sparse direct
+    solve per step — on 32^3 cells x 3 steps with SciPy's SuperLU standing in for Julia's UMFPACK/CHOLMOD (`direct`)."""
     from oracle import fv_oracle as o
 
-    ns = [256, 256, 256]
-    steps = 30
-    mins, maxs = spacing_box(ns)
-    _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
-    dn, src = box_setup(ns)
-    dh = np.full(len(dn), 1e3)
-    K = np.full(len(aol), 1e-5)
-    Ss = 0.1
-    freenodes, n2f = o.getfreenodes(len(vol), dn)
-    f2n = o.freenodei2nodei(n2f)
-    A = o.assembleA(n1, n2, aol, K, src, dn, dh)
-    b = o.assembleb(n1, n2, aol, K, src, dn, dh)
-    o.scalebyvolume_A(A, Ss * vol, f2n)
-    b = o.scalebyvolume_b(b, Ss * vol, f2n)
+    def problem(ns):
+        mins, maxs = spacing_box(ns)
+        _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
+        dn, src = box_setup(ns)
+        dh = np.full(len(dn), 1e3)
+        K = np.full(len(aol), 1e-5)
+        Ss = 0.1
+        freenodes, n2f = o.getfreenodes(len(vol), dn)
+        f2n = o.freenodei2nodei(n2f)
+        A = o.assembleA(n1, n2, aol, K, src, dn, dh)
+        b = o.assembleb(n1, n2, aol, K, src, dn, dh)
+        o.scalebyvolume_A(A, Ss * vol, f2n)
+        b = o.scalebyvolume_b(b, Ss * vol, f2n)
+        return A, b, len(vol)
+
+    ns, steps = [256, 256, 256], 30
+    A, b, N = problem(ns)
     u0 = np.full(A.n, 1e3)
     iters = []
 
@@ -88,20 +100,32 @@ def cpu_baseline(dt, rtol):
     t0 = time.perf_counter()
     us, ts = o.backwardeulerintegrate_generic(u0, A, b, dt, 0.0, dt * steps, stepper=o.fixedbackwardeulerstep, linearsolver=solver)
     sec = time.perf_counter() - t0
-    N = len(vol)
-    return {
+    out = {
         "value": N * steps / sec,
         "unit": "DoF-updates/s",
         "cores": 1,
+        "cores_available": os.cpu_count(),
         "kind": "port",
         "sample": "oracle (C restatement of the reference path, unpreconditioned CG rtol %.0e) on %dx%dx%d cells x %d steps, same cell size/K/Ss/dt/BCs; %.1f s; %.1f CG iters/step" % (rtol, ns[0], ns[1], ns[2], steps, sec, float(np.mean(iters))),
     }
+    del A, b, us
+    try:  # the backslash path: one sparse LU per step (the reference factorises the shifted matrix anew in every step)
+        nsd, stepsd = [32, 32, 32], 3
+        A, b, Nd = problem(nsd)
+        t0 = time.perf_counter()
+        o.backwardeulerintegrate_generic(np.full(A.n, 1e3), A, b, dt, 0.0, dt * stepsd, stepper=o.fixedbackwardeulerstep, linearsolver=o.directlinearsolver)
+        secd = time.perf_counter() - t0
+        out["direct"] = {"value": Nd * stepsd / secd, "unit": "DoF-updates/s", "cores": 1, "kind": "port-direct",
+                         "sample": "linearsolver = A \\ b (test/ode.jl:36) as scipy.sparse.linalg.splu per step on %dx%dx%d cells x %d steps; %.1f s" % (nsd[0], nsd[1], nsd[2], stepsd, secd)}
+    except Exception as e:
+        out["direct"] = "failed: %r" % (e,)
+    return out
 
 
 def other_baseline_configs(fv, ctx):
     """The other single-GPU configurations of BASELINE.json (SURVEY 8d inputs), one short measurement each, reported inside
     `config` — the headline `value` stays the 10^8-cell run.  The same code as tools/config_rates.py."""
-    from tests import workloads
+    workloads = fv.workloads
 
     rows = []
 
@@ -173,6 +197,76 @@ def other_baseline_configs(fv, ctx):
     return rows
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh child processes of this script, one per GPU, with the
+    torch.distributed.run environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's single JSON
+    line and return non-zero if any rank fails.  The parent never loads libfvhip or touches HIP (a process that has
+    initialised the GPU must not be replaced or forked on this pool), and a failed rank takes the others down with it
+    instead of leaving them waiting in a collective."""
+    import signal
+    import socket
+    import subprocess
+
+    with socket.socket() as s:  # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    rc = 0
+    out0 = b""
+    try:
+        pending = set(range(n))
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        eof0 = False
+        while pending:
+            if not eof0:
+                for key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        out0 += chunk
+                    else:
+                        eof0 = True
+                        sel.unregister(key.fileobj)
+            else:
+                time.sleep(0.2)
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print("bench.py: rank %d exited with code %d; stopping the other ranks" % (r, code), file=sys.stderr)
+                    for q in pending:
+                        try:
+                            os.killpg(procs[q].pid, signal.SIGTERM)
+                        except ProcessLookupError:
+                            pass
+        if not eof0:
+            out0 += procs[0].stdout.read()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.strip().startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print("bench.py: rank 0 printed %d JSON lines instead of one" % len(lines), file=sys.stderr)
+        rc = 3
+    for l in lines:
+        print(l)
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     # multi-process GPU work on this pool needs dmabuf IPC (RCCL's peer mappings fail with the legacy mode); the launcher
     # normally exports it already — set before anything touches HIP
@@ -187,15 +281,18 @@ def main():
     ap.add_argument("--maxiter", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json's other single-GPU configurations")
+    ap.add_argument("--no-multi-iteration", action="store_true", help="skip the second measured block (dt = 1 h, ~10 PCG iterations per step)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process (which has not touched HIP) starts the N ranks itself
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print("bench.py: --gpus %d needs the torch.distributed.run launcher (one process per GPU)" % args.gpus, file=sys.stderr)
-            sys.exit(2)
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch one process per GPU (or let bench.py start them: unset WORLD_SIZE)" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     from __graft_entry__ import load_package
 
     fv = load_package()
@@ -237,37 +334,7 @@ def main():
     p.profile(False)
 
     value = p.N * args.steps / sec
-    # algorithmic bytes of the dominant kernel, the PCG SpMV q = (A + D/dt) p with the p.q epilogue, in
-    # SURVEY.md §8d's CSR accounting: vals 8 + colind 4 per entry; rowptr 4 + x 8 + y 8 per row.  The fixed-dt
-    # run folds D/dt into the stored diagonal, so the "+8 n if the shift vector is read separately" does not apply.
-    spmv_bytes = 12 * p.nnz + 20 * p.n
-    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": ("K1 q=(A+D/dt)p with p.q: spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses; + spmv_wstream_kernel<512,true,true> on non-grid-like slices, none on this grid)"
-                       if 8 * p.n > 160 * 2**20 else
-                       "K1 q=(A+D/dt)p with p.q: spmv_dia_kernel<true,true,false> (slice-by-slice sliced-DIA: x fits the last-level cache at this size)"),
-            "algorithmic_bytes_per_launch": spmv_bytes}
-    kern = {}
-    if prof and prof["spmv_dot"][1] > 0:
-        ms, cnt = prof["spmv_dot"]
-        ach = spmv_bytes / (ms / cnt * 1e-3) / 1e9
-        roof.update(achieved=ach, frac=ach / HBM_PEAK_GBS, avg_launch_ms=ms / cnt, launches=cnt)
-        tune = dict(kv.split("=") for kv in os.environ.get("FV_TUNE", "").split(",") if "=" in kv)
-        fused = tune.get("7", "32") != "0" and tune.get("8", "1") != "0" and float(np.mean(iters)) == 1.0
-        # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel): 7 streams in, 3 out
-        fused_bytes = 72 if tune.get("12", "1") != "0" else 80  # the sparse b's share of |rhs|^2 comes from a gather (fv_tune key 12)
-        for k, bytes_ in (("update", (fused_bytes if fused else 56) * p.n), ("pupdate", 32 * p.n)):
-            kms, kc = prof[k]
-            if kc:
-                kern[k] = {"avg_ms": kms / kc, "launches": kc}
-                if kms / kc > 0.05 * (32 * p.n / 5e12 * 1e3):  # the last p-update of a solve is skipped on convergence: no bandwidth figure for no-ops
-                    kern[k]["GB/s"] = bytes_ / (kms / kc * 1e-3) / 1e9
-    tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
-    if os.path.exists(tfile):
-        try:
-            t = json.load(open(tfile))
-            roof["traffic"] = t.get(str(args.ns))
-        except Exception:
-            pass
+    roof, kern = roofline_block(p, prof, float(np.mean(iters)), args.ns)
 
     out = {
         "metric": "DoF-updates/s (cells\u00d7steps) implicit transient; SpMV HBM GB/s vs peak",
@@ -295,15 +362,99 @@ def main():
         },
         "roofline": roof,
     }
+    if not args.no_multi_iteration:
+        try:
+            out["config"]["multi_iteration"] = multi_iteration_block(p, args)
+        except Exception as e:  # never lose the headline line to a side measurement
+            out["config"]["multi_iteration"] = "failed: %r" % (e,)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
     if not args.no_other_configs:
         p.close()  # 45 GB back before the next problems
         try:
             out["config"]["other_baseline_configs"] = other_baseline_configs(fv, ctx)
-        except Exception as e:  # never lose the headline line to a side measurement
+        except Exception as e:
             out["config"]["other_baseline_configs"] = "failed: %r" % (e,)
     print(json.dumps(out))
+
+
+def roofline_block(p, prof, iters_per_step, ns):
+    """The `roofline` object for K1, the PCG SpMV q = (A + D/dt) p with the p.q epilogue.
+    achieved / frac use the bytes one launch of the storage form that ran has to move with every array touched once
+    (fv_spmv_form: e.g. 32 n of matrix + 16 n of vectors for the symmetric plane-marching form) over the HIP-event average of
+    the live launches inside the timed region — a real HBM rate, never above what the hardware does.  SURVEY 8d's CSR
+    accounting (12 nnz + 20 n, what a general CSR SpMV of this operator would move) is reported next to it as
+    `effective_csr`; it exceeds the real rate by construction for forms that store no column indices / half the matrix.
+    `traffic` is the PMC measurement committed under profiles/ for exactly this kernel and size (null when the committed
+    figure belongs to another kernel)."""
+    form_id, form_name, form_bytes = p.spmv_form()
+    csr_bytes = 12 * p.nnz + 20 * p.n
+    roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "kernel": "K1 q=(A+D/dt)p with p.q: %s" % KERNEL_NAMES.get(form_id, form_name), "form": form_name,
+            "algorithmic_bytes_per_launch": form_bytes,
+            "bytes_model": "bytes the storage form must move, every array once (fv_spmv_form); the CSR accounting of SURVEY 8d is in effective_csr"}
+    kern = {}
+    if prof and prof["spmv_dot"][1] > 0:
+        ms, cnt = prof["spmv_dot"]
+        t = ms / cnt * 1e-3
+        roof.update(achieved=form_bytes / t / 1e9, frac=form_bytes / t / 1e9 / HBM_PEAK_GBS, avg_launch_ms=ms / cnt, launches=cnt)
+        roof["effective_csr"] = {"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / t / 1e9, "frac": csr_bytes / t / 1e9 / HBM_PEAK_GBS}
+        tune = dict(kv.split("=") for kv in os.environ.get("FV_TUNE", "").split(",") if "=" in kv)
+        fused = tune.get("7", "32") != "0" and tune.get("8", "1") != "0" and iters_per_step == 1.0
+        # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel): 5 streams in, 3 out
+        # (p is recomputed as M^-1 r; +8 when the assembled b is dense instead of gathered over its support)
+        fused_bytes = K2S_BYTES_PER_ROW if tune.get("12", "1") != "0" else K2S_BYTES_PER_ROW + 8
+        for k, bytes_ in (("update", (fused_bytes if fused else 56) * p.n), ("pupdate", 32 * p.n)):
+            kms, kc = prof[k]
+            if kc:
+                kern[k] = {"avg_ms": kms / kc, "launches": kc}
+                if kms / kc > 0.05 * (32 * p.n / 5e12 * 1e3):  # the last p-update of a solve is skipped on convergence: no bandwidth figure for no-ops
+                    kern[k]["GB/s"] = bytes_ / (kms / kc * 1e-3) / 1e9
+                    kern[k]["bytes_per_row"] = bytes_ // p.n
+    tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile)).get(str(ns))
+            if t and t.get("form") == form_id:  # measured for the kernel that ran here, not for an earlier one
+                roof["traffic"] = t["bytes"]
+                roof["traffic_source"] = t.get("source")
+                if roof.get("avg_launch_ms"):
+                    roof["frac_traffic"] = t["bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        except Exception:
+            pass
+    return roof, kern
+
+
+def multi_iteration_block(p, args):
+    """A second measured block on the same operator: dt = 1 h, where a step needs ~10 PCG iterations (the headline's dt =
+    60 s converges in one).  Per iteration K1 + K2 + K3 = B_spmv + 88 n bytes (SURVEY 8d's fused floor)."""
+    dt, steps = 3600.0, 6
+    st = p.new_state()
+    st.set_nodes(np.full(p.N, 1e3))
+    p.run_fixed(st, dt, 2, args.rtol, args.maxiter)
+    p.profile(True)
+    p.ctx.synchronize()
+    t0 = time.perf_counter()
+    iters, info, _ = p.run_fixed(st, dt, steps, args.rtol, args.maxiter)
+    p.ctx.synchronize()
+    sec = time.perf_counter() - t0
+    prof = p.profile_get()
+    p.profile(False)
+    del st
+    form_id, form_name, form_bytes = p.spmv_form()
+    nit = int(np.sum(iters))
+    per_it_bytes = form_bytes + 88 * p.n
+    ms_it = sec / max(nit, 1) * 1e3
+    out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
+           "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
+           "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes, "bytes_model": "K1 storage form (%s) + 88 n for K2 + K3" % form_name,
+           "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
+    for k, bytes_ in (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n)):
+        kms, kc = prof[k]
+        if kc:
+            out["kernels"][k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
+    return out
 
 
 if __name__ == "__main__":

@@ -59,8 +59,11 @@ def run_distributed(fv, args, world, rank):
     p.close()
     t_setup = time.perf_counter() - t_setup
 
+    prob = fv.Problem(blk.handle, ctx)  # a view of the block for the profiling entry points; the block owns the handle
     if args.warmup > 0:
         blk.run_fixed(args.dt, args.warmup, args.rtol, args.maxiter)
+    if not args.no_profile:
+        prob.profile(True)
     ctx.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
@@ -68,20 +71,30 @@ def run_distributed(fv, args, world, rank):
     ctx.synchronize()
     dist.barrier()
     sec = time.perf_counter() - t0
+    prof = prob.profile_get() if not args.no_profile else None
+    prob.profile(False)
     tmax = torch.tensor([sec], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     sec = float(tmax[0])
 
-    # roofline of the dominant kernel on this rank's block: the PCG SpMV, timed with HIP events
-    spmv_bytes = 12 * blk.nnz + 20 * blk.nloc  # CSR accounting, shift folded into the diagonal (as bench.py)
-    prob = fv.Problem(blk.handle, ctx)
+    # roofline of the dominant kernel on this rank's block: the PCG SpMV of the block (pack + interior pass + wait for the
+    # halo + boundary pass), HIP events around every live launch set inside the timed region
+    form_id, prob_form, form_bytes = prob.spmv_form()
+    csr_bytes = 12 * blk.nnz + 20 * blk.nloc  # SURVEY 8d's CSR accounting
+    ms_inloop = prof["spmv_dot"][0] / prof["spmv_dot"][1] if prof and prof["spmv_dot"][1] else None
+    ms_k2 = prof["update"][0] / prof["update"][1] if prof and prof["update"][1] else None
     try:
-        ms = prob.bench_spmv(1.0 / args.dt, 10)
+        ms_b2b = prob.bench_spmv(1.0 / args.dt, 10)  # 10 back-to-back launches on resident vectors (cache-warm): a ceiling, not the loop's time
     finally:
-        prob.handle = None  # the block owns the handle
-    ach = spmv_bytes / (ms * 1e-3) / 1e9
+        prob.handle = None
+    ms = ms_inloop if ms_inloop else ms_b2b
+    ach = form_bytes / (ms * 1e-3) / 1e9
     gathered = [None] * world
-    dist.all_gather_object(gathered, dict(rank=rank, rows=blk.nloc, nnz=blk.nnz, halo=blk.nhalo, send=blk.nsend, spmv_ms=ms, spmv_gbs=ach, device_ms=dev_ms))
+    dist.all_gather_object(gathered, dict(rank=rank, rows=blk.nloc, nnz=blk.nnz, halo=blk.nhalo, send=blk.nsend, spmv_ms_in_loop=ms_inloop,
+                                          spmv_ms_back_to_back=ms_b2b, spmv_gbs=ach, update_ms_in_loop=ms_k2, device_ms=dev_ms))
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = bench.cpu_baseline(args.dt, args.rtol)  # the other ranks wait at the barrier below
     if rank == 0:
         out = {
             "metric": "DoF-updates/s (cells\u00d7steps) implicit transient; SpMV HBM GB/s vs peak",
@@ -103,10 +116,14 @@ def run_distributed(fv, args, world, rank):
                 "device": name, "setup_s": t_setup, "per_rank": gathered,
             },
             "roofline": {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / bench.HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "sliced-DIA SpMV of rank 0's row block, interior + boundary passes (spmv_dia_kernel while the block's x fits the last-level cache, spmv_dia_march_kernel on the interior window above 2.1e7 rows; spmv_wstream_kernel on non-grid-like slices), per GPU", "algorithmic_bytes_per_launch": spmv_bytes,
-                         "avg_launch_ms": ms,
-                         "note": "10 back-to-back launches after the timed region on resident vectors (a block's x may stay in the last-level cache between them); the in-loop figure of the single-GPU run is bench.py --gpus 1"},
+                         "traffic": None, "kernel": "PCG SpMV of rank 0's row block: pack + interior pass || halo exchange + boundary pass (%s), per GPU" % prob_form,
+                         "algorithmic_bytes_per_launch": form_bytes, "avg_launch_ms": ms,
+                         "timing": "HIP events around every live launch set inside the timed region (includes the wait for the halo)" if ms_inloop else "back-to-back launches after the timed region",
+                         "effective_csr": {"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / (ms * 1e-3) / 1e9, "frac": csr_bytes / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS,
+                                           "note": "SURVEY 8d CSR accounting 12 nnz + 20 n; the storage form moves fewer bytes, so this can exceed the hardware rate"}},
         }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     dist.barrier()
     blk.close()

@@ -40,4 +40,4 @@ from .transient import (  # noqa: F401
     fixedbackwardeulerstep,
     scalebyvolume,
 )
-from . import meshio  # noqa: F401,E402
+from . import meshio, workloads  # noqa: F401,E402

@@ -284,6 +284,15 @@ class Problem:
         self.check(load().fv_bench_spmv(self.handle, float(sigma), int(reps), C.byref(ms)))
         return ms.value
 
+    SPMV_FORMS = {-1: "none yet", 0: "CSR wave-stream", 1: "sliced-DIA, slice by slice", 2: "sliced-DIA, plane-marching",
+                  3: "symmetric plane-marching (diagonal + 3 upper diagonals)"}
+
+    def spmv_form(self):
+        """(form id, form name, bytes one launch of it must move) of the most recent SpMV (fv_spmv_form)."""
+        form, nbytes = C.c_int32(), C.c_int64()
+        self.check(load().fv_spmv_form(self.handle, C.byref(form), C.byref(nbytes)))
+        return form.value, self.SPMV_FORMS.get(form.value, "?"), nbytes.value
+
     def profile(self, on=True):
         self.check(load().fv_profile_enable(self.handle, int(bool(on))))
 

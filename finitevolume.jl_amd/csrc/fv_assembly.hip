@@ -859,6 +859,49 @@ __global__ __launch_bounds__(FV_BLOCK) void iota_kernel(int32_t *p, int64_t n)
         p[i] = (int32_t)i;
 }
 
+// The CSC arrays of the caller are used as they are as CSR arrays, which is the same operator only for a symmetric matrix,
+// and the PCG needs a symmetric one anyway: every stored (i, j) must have a stored (j, i) with the same value (to
+// rounding: 1e-12 relative).  first_bad: the smallest offending entry index, or 0x7fffffff.
+__global__ __launch_bounds__(FV_BLOCK) void csc_symmetry_kernel(int64_t n, const int32_t *__restrict__ ptr, const int32_t *__restrict__ idx,
+                                                                 const double *__restrict__ vals, int32_t *__restrict__ first_bad)
+{
+    const int64_t c = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (c >= n)
+        return;
+    for (int32_t k = ptr[c]; k < ptr[c + 1]; k++) {
+        const int32_t r = idx[k];
+        if (r == c)
+            continue;
+        int32_t lo = ptr[r], hi = ptr[r + 1] - 1; // rowval is ascending inside a column (SparseMatrixCSC's contract)
+        bool found = false;
+        double w = 0.0;
+        while (lo <= hi) {
+            const int32_t mid = lo + ((hi - lo) >> 1);
+            const int32_t v = idx[mid];
+            if (v == (int32_t)c) {
+                found = true;
+                w = vals[mid];
+                break;
+            }
+            if (v < (int32_t)c)
+                lo = mid + 1;
+            else
+                hi = mid - 1;
+        }
+        if (!found) // unsorted input: fall back to a scan
+            for (int32_t j = ptr[r]; j < ptr[r + 1]; j++)
+                if (idx[j] == (int32_t)c) {
+                    found = true;
+                    w = vals[j];
+                    break;
+                }
+        const double v0 = vals[k];
+        const bool same = found ? fabs(v0 - w) <= 1e-12 * (fabs(v0) + fabs(w)) : v0 == 0.0;
+        if (!same)
+            atomicMin(first_bad, k);
+    }
+}
+
 extern "C" int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t *colptr, const int64_t *rowval,
                                           const double *nzval, fv_problem **out)
 {
@@ -919,6 +962,30 @@ extern "C" int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t 
                                p->vals.p, p->diagpos.p, p->diagA.p);
             hipLaunchKernelGGL(iota_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, p->nodemap.p, n);
             hipLaunchKernelGGL(iota_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, p->f2n.p, n);
+        }
+        if (n > 0 && nnz > 0) {
+            DevBuf<int32_t> firstbad;
+            if ((rc = firstbad.alloc(ctx, 1)))
+                break;
+            int32_t h = 0x7fffffff;
+            if (hipMemcpyAsync(firstbad.p, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+                rc = FV_ERR_HIP;
+                break;
+            }
+            hipLaunchKernelGGL(csc_symmetry_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)p->rowptr.p,
+                               (const int32_t *)p->colind.p, (const double *)p->vals.p, firstbad.p);
+            if (hipMemcpyAsync(&h, firstbad.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = FV_ERR_HIP;
+                break;
+            }
+            if (h != 0x7fffffff) {
+                fv_set_error(ctx, "fv_problem_create_from_csc: the matrix is not symmetric (stored entry %d has no equal transposed partner); "
+                                  "the device solver is a conjugate gradient and needs a symmetric positive definite operator — "
+                                  "pass a host linearsolver such as (A, b, x0) -> A \\ b for this matrix", h + 1);
+                rc = FV_ERR_ARG;
+                break;
+            }
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
             rc = FV_ERR_HIP;

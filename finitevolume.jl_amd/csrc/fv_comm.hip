@@ -22,6 +22,17 @@ static_assert(sizeof(ncclUniqueId) == FV_COMM_ID_BYTES, "ncclUniqueId size");
         }                                                                                                      \
     } while (0)
 
+// between ncclGroupStart and ncclGroupEnd: a failing call must not leave the group open behind it
+#define FV_NCCL_IN_GROUP(ctx, call)                                                                            \
+    do {                                                                                                       \
+        ncclResult_t r__ = (call);                                                                             \
+        if (r__ != ncclSuccess) {                                                                              \
+            fv_set_error(ctx, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r__), __FILE__, __LINE__);    \
+            (void)ncclGroupEnd();                                                                              \
+            return FV_ERR_COMM;                                                                                \
+        }                                                                                                      \
+    } while (0)
+
 extern "C" int fv_comm_unique_id(char id[FV_COMM_ID_BYTES])
 {
     if (!id)
@@ -200,9 +211,9 @@ int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, 
         const int64_t sc = d->send_counts[(size_t)q], rcnt = d->recv_counts[(size_t)q];
         if (q != d->rank) {
             if (sc > 0)
-                FV_NCCL(ctx, ncclSend(sendbuf + soff, (size_t)sc, ncclDouble, q, comm, stream));
+                FV_NCCL_IN_GROUP(ctx, ncclSend(sendbuf + soff, (size_t)sc, ncclDouble, q, comm, stream));
             if (rcnt > 0)
-                FV_NCCL(ctx, ncclRecv(recv_base + roff, (size_t)rcnt, ncclDouble, q, comm, stream));
+                FV_NCCL_IN_GROUP(ctx, ncclRecv(recv_base + roff, (size_t)rcnt, ncclDouble, q, comm, stream));
         }
         soff += sc;
         roff += rcnt;
@@ -231,12 +242,13 @@ extern "C" int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok)
     FV_TRY(a.alloc(ctx, (size_t)count));
     FV_TRY(b.alloc(ctx, (size_t)count));
     FV_HIP(ctx, hipMemcpy(a.p, host.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
-    FV_HIP(ctx, hipMemset(b.p, 0, (size_t)count * sizeof(double)));
+    // cleared on the stream the receive runs on: stream2 is non-blocking, a memset on the null stream could land after the data
+    FV_HIP(ctx, hipMemsetAsync(b.p, 0, (size_t)count * sizeof(double), ctx->stream2));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
     const int next = (ctx->rank + 1) % ctx->nranks, prev = (ctx->rank + ctx->nranks - 1) % ctx->nranks;
     FV_NCCL(ctx, ncclGroupStart());
-    FV_NCCL(ctx, ncclSend(a.p, (size_t)count, ncclDouble, next, comm, ctx->stream2));
-    FV_NCCL(ctx, ncclRecv(b.p, (size_t)count, ncclDouble, prev, comm, ctx->stream2));
+    FV_NCCL_IN_GROUP(ctx, ncclSend(a.p, (size_t)count, ncclDouble, next, comm, ctx->stream2));
+    FV_NCCL_IN_GROUP(ctx, ncclRecv(b.p, (size_t)count, ncclDouble, prev, comm, ctx->stream2));
     FV_NCCL(ctx, ncclGroupEnd());
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     std::vector<double> got((size_t)count);

@@ -27,6 +27,29 @@ extern "C" int fv_abi_version(void) { return FVHIP_ABI_VERSION; }
 // reported something since: then that message is the one the failing call produced
 extern "C" const char *fv_last_error(fv_ctx *ctx) { return (ctx && ctx->err_seq > g_err_noctx_seq) ? ctx->err.c_str() : g_err.c_str(); }
 
+static int ctx_init(fv_ctx *ctx)
+{
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    hipDeviceProp_t prop;
+    FV_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->total_mem = (int64_t)prop.totalGlobalMem;
+    ctx->name = prop.name;
+    if (ctx->name.empty())
+        ctx->name = prop.gcnArchName; // some ROCm builds leave the marketing name blank
+    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+    FV_HIP(ctx, hipEventCreate(&ctx->ev0));
+    FV_HIP(ctx, hipEventCreate(&ctx->ev1));
+    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
+    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comp, hipEventDisableTiming));
+    ctx->pinned_bytes = 4096;
+    FV_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    return FV_OK;
+}
+
+extern "C" void fv_ctx_destroy(fv_ctx *ctx);
+
 extern "C" int fv_ctx_create(int device, fv_ctx **out)
 {
     if (!out)
@@ -45,22 +68,12 @@ extern "C" int fv_ctx_create(int device, fv_ctx **out)
     }
     fv_ctx *ctx = new fv_ctx();
     ctx->device = device;
-    FV_HIP(ctx, hipSetDevice(device));
-    hipDeviceProp_t prop;
-    FV_HIP(ctx, hipGetDeviceProperties(&prop, device));
-    ctx->num_cus = prop.multiProcessorCount;
-    ctx->total_mem = (int64_t)prop.totalGlobalMem;
-    ctx->name = prop.name;
-    if (ctx->name.empty())
-        ctx->name = prop.gcnArchName; // some ROCm builds leave the marketing name blank
-    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    FV_HIP(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-    FV_HIP(ctx, hipEventCreate(&ctx->ev0));
-    FV_HIP(ctx, hipEventCreate(&ctx->ev1));
-    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_halo, hipEventDisableTiming));
-    FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comp, hipEventDisableTiming));
-    ctx->pinned_bytes = 4096;
-    FV_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    const int rc = ctx_init(ctx);
+    if (rc != FV_OK) { // hand the message over to the context-free slot and release whatever was created
+        fv_set_error(nullptr, "%s", ctx->err.c_str());
+        fv_ctx_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
     return FV_OK;
 }

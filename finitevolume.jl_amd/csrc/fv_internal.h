@@ -169,6 +169,19 @@ struct fv_problem {
     int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
     double dia_tag = 0.0;
     bool dia_built = false;
+    bool dia_partial = false; // dia_vals holds only the slices of sym_rest (the symmetric marching kernel does the others)
+
+    // symmetric DIA copy of a plane-structured operator (fv_spmv.hip, symdia_*): the stored diagonal and the three upper
+    // diagonals at the operator-wide offsets sym_d[0] < sym_d[1] < sym_d[2] (= the plane stride) as four zero-padded arrays
+    // of sym_ld doubles; row 0 of each array sits sym_front doubles into it.  The lower arm a(i, i-d) is read as the upper
+    // value of row i-d (A is symmetric bit for bit, checked when the copy is filled).
+    DevBuf<double> sym_vals;
+    DevBuf<uint8_t> sym_ok;   // per 64-row slice: every stored offset of the slice is 0 or +-sym_d[k]
+    DevBuf<int32_t> sym_rest; // the DIA slices where that does not hold (slice-by-slice kernel)
+    int64_t sym_d[3] = {0, 0, 0}, sym_ld = 0, sym_front = 0, sym_nrest = 0, sym_epoch = -1;
+    double sym_tag = 0.0;
+    int last_form = -1; // FV_SPMV_* of the most recent spmv_apply (fv_spmv_form)
+    int sym_state = -1; // -1 not looked at yet, 0 not applicable (no such structure, or not symmetric), 1 built
 
     // numeric
     DevBuf<double> cond, vals, b, diagA, dheads;

@@ -247,9 +247,11 @@ struct SparseRhs {
 // besides alpha, x_out = x_in + alpha p, r -= alpha q and the partials of the convergence test, it prepares the NEXT
 // step the way pcg_carry_init_kernel would: r0' = r + D (x_out - x_in)/dt is what it leaves in r, p' = M^-1 r0' goes to
 // pnext, and the partials of r0'.M^-1 r0', r0'.r0', rhs'.rhs' (rhs' = b' + D x_out/dt) to the spec_* arrays.  If the
-// step does converge here, the next step starts straight at its K1 (80 B/row instead of 56 + 64).  If it does not,
+// step does converge here, the next step starts straight at its K1.  Streams: x_in, q, M^-1, D, r in (p is M^-1 r0 on the first
+// iteration of a step, so it is re-formed in registers and only the sparse-b gather blocks read the stored one); x_out, r, p'
+// out: 64 B per row (+8 when a dense b' is streamed too) instead of K2's 56 + K0''s 64.  If it does not,
 // pcg_pupdate_kernel<true> takes the D (x_out - x_in)/dt term out of r again before it builds the next direction.
-template <int NT> // streaming hints: bit 0 = the read-once inputs x_in, q, M^-1, D, r; bit 1 = x_out and r; bit 2 = p too (p' stays cacheable: the next K1 reads it)
+template <int NT> // streaming hints: bit 0 = the read-once inputs x_in, q, M^-1, D, r; bit 1 = x_out and r (p' stays cacheable: the next K1 reads it)
 __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, const double *__restrict__ xin, double *__restrict__ xout,
                                                                     double *__restrict__ r, const double *__restrict__ pv,
                                                                     const double *__restrict__ q, const double *__restrict__ minv,
@@ -314,7 +316,6 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
     double2 *xo2 = reinterpret_cast<double2 *>(xout);
     double2 *r2 = reinterpret_cast<double2 *>(r);
-    const double2 *p2 = reinterpret_cast<const double2 *>(pv);
     const double2 *q2 = reinterpret_cast<const double2 *>(q);
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
     const double2 *D2 = reinterpret_cast<const double2 *>(D);
@@ -324,19 +325,20 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
         double2 xv, pvv, qv, mv, dv, rv;
         if (NT & 1) {
             xv = nt_load2(xi2 + i);
-            pvv = (NT & 4) ? nt_load2(p2 + i) : p2[i];
             qv = nt_load2(q2 + i);
             mv = nt_load2(m2 + i);
             dv = nt_load2(D2 + i);
             rv = nt_load2(r2 + i);
         } else {
             xv = xi2[i];
-            pvv = p2[i];
             qv = q2[i];
             mv = m2[i];
             dv = D2[i];
             rv = r2[i];
         }
+        // this is the first iteration of its step, so the direction is p = M^-1 r0 and r still holds r0: the product is
+        // formed again (the same multiplication that produced the stored p, bit for bit) instead of streaming p in
+        pvv = make_double2(mv.x * rv.x, mv.y * rv.y);
         const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
         const double xnx = xv.x + alpha * pvv.x, xny = xv.y + alpha * pvv.y;
         rv.x -= alpha * qv.x;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double xn = xin[i] + alpha * pv[i];
+        const double xn = xin[i] + alpha * (minv[i] * r[i]);
         const double ri = r[i] - alpha * q[i];
         arz += ri * (minv[i] * ri);
         arr += ri * ri;
@@ -893,9 +895,9 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
     FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int ndone = hs->done == 3 ? hs->chain_step : nsteps;
-    if (p->profile && !p->prof_ev.empty() && !p->dist)
+    if (p->profile && !p->prof_ev.empty())
         for (int k = 0; k < nsteps && k <= ndone && k < 32; k++)
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < (p->dist ? 2 : 3); c++) { // the row-block driver times the SpMV and K2 / K2S only
                 if (c == 2 && k == ndone)
                     continue; // the p-update of an interrupted step did real work; it is counted when the step resumes
                 float ms = 0.f;
@@ -1254,13 +1256,27 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         chunk = 1;
         maxiter = 1;
     }
+    // per-kernel timing (fv_profile_enable), as in fv_pcg_solve: event pairs around the block SpMV (pack, interior pass,
+    // the wait for the halo, boundary pass) and around K2 / K2S of every iteration; the reductions, collectives and K3 /
+    // boundary launches in between are not timed
+    const int64_t kprof = chained ? chain_index : 0;
+    if (p->profile && p->prof_ev.empty()) {
+        p->prof_ev.resize((size_t)(6 * 32));
+        for (hipEvent_t &e : p->prof_ev)
+            FV_HIP(ctx, hipEventCreate(&e));
+    }
+#define FV_PROF(idx)                                                                                            \
+    if (p->profile)                                                                                             \
+    FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
             const bool spec = iter == 0 && speculate;
             int npq = 0;
+            FV_PROF(0);
             FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true, false, (defer_in && iter == 0) ? &npq : nullptr));
+            FV_PROF(1);
             if (defer_in && iter == 0) {
                 // one reduction launch for the six sums of the merged collective: this step's p.q and the five the previous
                 // step's K2S left in its partial arrays (nothing has written them since)
@@ -1289,6 +1305,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             SumSet sums{};
             sums.a[0] = p->part_rz.p;
             sums.a[1] = p->part_rr.p;
+            FV_PROF(2);
             if (spec) {
                 hipLaunchKernelGGL(k2s_kernel(), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
@@ -1306,6 +1323,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)nullptr,
                                    x_next ? x_next : u, p->r.p, p->pvec.p, p->q.p, p->minv.p, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p);
+            FV_PROF(3);
             if (defer_out && spec)
                 continue; // summed and all-reduced with the next step's p.q, judged there
             const int nsums = spec ? 5 : 2;
@@ -1329,13 +1347,25 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             p->spec_valid = true;
             return FV_OK;
         }
+        const int32_t iters_before = (p->profile && it > m) ? hs->iters : (int32_t)(resume ? resume_it : 0);
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (p->profile) { // only launches that did real work
+            const int64_t live = (int64_t)hs->iters - iters_before;
+            for (int64_t k = 0; k < m && k < live; k++)
+                for (int c = 0; c < 2; c++) {
+                    float ms = 0.f;
+                    FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k + 2 * c)], p->prof_ev[(size_t)(6 * k + 2 * c + 1)]));
+                    p->prof_ms[c] += ms;
+                    p->prof_launches[c]++;
+                }
+        }
         if (hs->done)
             break;
         if (chunk < 32)
             chunk *= 2;
     }
+#undef FV_PROF
     if (it == 0) {
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));

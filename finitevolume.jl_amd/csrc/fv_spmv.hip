@@ -272,15 +272,19 @@ static int g_march = 1;      // plane-marching sliced-DIA kernel on structured g
 static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
+static int g_symdia = 1; // fv_tune key 27: symmetric plane-marching form where the marching kernel runs (0 off)
+static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
+static int g_symdia_nt = 4; // fv_tune key 28: streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
 extern int g_chain_steps;                      // fv_transient.hip
 
+static int g_blocks_per_cu = 8; // fv_tune key 30 (experiments): blocks per CU the SpMV grids are sized for
 // blocks that are all resident at 8 waves per SIMD: 8 per CU (2048 on the 256-CU MI355X; fewer on a partitioned device)
 static int g_resident_blocks = FV_MAX_PARTIALS;
 static void set_resident_blocks(const fv_ctx *ctx)
 {
-    int64_t b = (int64_t)ctx->num_cus * 8 / 8 * 8;
+    int64_t b = (int64_t)ctx->num_cus * g_blocks_per_cu / 8 * 8;
     if (b < 8)
         b = 8;
     g_resident_blocks = b > FV_MAX_PARTIALS ? FV_MAX_PARTIALS : (int)b;
@@ -338,6 +342,14 @@ extern "C" int fv_tune(int key, int value)
         g_chain_steps = value;
     else if (key == 14 && value >= -1 && value < 32)
         g_chain_test_break = value;
+    else if (key == 27 && (value == 0 || value == 1))
+        g_symdia = value;
+    else if (key == 28 && value >= 0 && value <= 7)
+        g_symdia_nt = value;
+    else if (key == 29 && value >= 0 && value <= 15)
+        g_symdia_dbg = value;
+    else if (key == 30 && value >= 1 && value <= 8)
+        g_blocks_per_cu = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -761,9 +773,12 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
 __device__ inline double2 march_window(const double *__restrict__ x, int64_t slice, int lane, int32_t ncols)
 {
     int32_t i = (int32_t)(slice << 6) - 32 + 2 * lane;
-    const int32_t hi = (ncols - 2) & ~1;
+    const int32_t hi = (ncols - 1) & ~1; // odd ncols: the pair (ncols - 1, ncols) — every vector carries FV_VEC_PAD doubles of slack
     i = i < 0 ? 0 : (i > hi ? hi : i);
-    return *reinterpret_cast<const double2 *>(x + i);
+    double2 w = *reinterpret_cast<const double2 *>(x + i);
+    if (i + 1 >= ncols)
+        w.y = 0.0; // ... whose contents are not defined
+    return w;
 }
 // element j (0..127, per lane) of such a window
 __device__ inline double march_window_elem(double2 w, int j)
@@ -921,6 +936,387 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
     }
 }
 
+// ------------------------------------------------------------------ symmetric plane-marching form
+// A is symmetric (FiniteVolume.jl:96-99 adds -c to (i,j) and (j,i) from the same face), so of the seven diagonals of a
+// structured grid's operator only four need to be streamed: the stored diagonal and the upper ones at +d1 (next cell of a
+// line), +d2 (next line), +d3 (next plane), each kept as a plain zero-padded array indexed by row.  The lower arm of row i
+// is the upper value of row i-d:
+//      a(i, i-d1) = U1[i-d1]   an unaligned 512-byte access next to the aligned one (same cache lines but one)
+//      a(i, i-d2) = U2[i-d2]   the lines a neighbouring pencil of this XCD streams at about the same time (L2)
+//      a(i, i-d3) = U3[i-d3]   the U3 values this wave held one plane step ago: kept in registers, moved by `s` lanes
+// which leaves 32 B of matrix per row on the HBM side instead of 56 (7.13 -> 4.75 GB per launch at 464^3).  The march is
+// spmv_dia_march_kernel's: a wave owns a pencil of slices `step` apart, plane stride = 64 step + s with a SIGNED lane
+// shift s in [-32, 32] (so every stride is covered), and one 16-byte-per-lane access of the 128-element window
+// [64 slice - 32, 64 slice + 96) brings a slice's centre together with the |s| elements either side of it — for x (centre,
+// +plane arm of the slice before, -plane arm of the slice after) and for U3 (the +plane value now, the -plane value of the
+// next step).  Rows are summed in ascending column order with absent entries stored as zeros, so the result is bit for
+// bit the sliced-DIA / CSR kernels' (adding +-0 changes nothing).  Window accesses are clamped per lane (x) or land in the
+// arrays' zero padding (U1..U3), so no access depends on a slice being the first or last of its pencil.
+// Slices whose offsets are not all in {0, +-d1, +-d2, +-d3} (sym_ok = 0: next to Dirichlet cells inside the domain, say)
+// are walked through here and computed by the slice-by-slice kernel from the sliced-DIA copy.
+__device__ inline double2 sym_window(const double *__restrict__ a, int64_t slice, int lane)
+{
+    return *reinterpret_cast<const double2 *>(a + ((slice << 6) - 32 + 2 * lane)); // padded array: no clamp
+}
+
+// Addressing: "array base in scalar registers + 32-bit byte offset per lane" (the device arrays have int32 indices and
+// < 2^31 stored entries, so an operator has at most ~3e8 rows and every byte offset fits 32 bits; the host checks).  One
+// offset register per access instead of a 64-bit address pair is what keeps the kernel at 8 waves per SIMD.
+template <int HINT>
+__device__ inline double ld_off(const double *__restrict__ base, uint32_t byteoff)
+{
+    const double *q = reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+    return HINT ? __builtin_nontemporal_load(q) : *q;
+}
+template <int HINT>
+__device__ inline double2 ld2_off(const double *__restrict__ base, uint32_t byteoff)
+{
+    const double *q = reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byteoff);
+    return HINT ? make_double2(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1)) : *reinterpret_cast<const double2 *>(q);
+}
+
+// v of the lane below / above (DPP wave shift: no LDS traffic); lane 0 / lane 63 get `edge`
+__device__ inline double wave_from_below(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false); // wave_shr:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double wave_from_above(double v, double edge)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x130, 0xf, 0xf, false); // wave_shl:1
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// dg, u1, u2, u3: starts of the padded arrays (row 0 is `front` doubles in).  The kernel has no per-lane clamps: slices
+// whose own window, or the window one plane step either side, would reach outside x (the first and the last plane) carry
+// sym_ok = 0 and are left to the slice-by-slice kernel like the irregular ones; here their windows are simply not loaded.
+// D1: the first in-plane offset is 1 (consecutive cells of a grid line are consecutive rows) — the +-1 arms of x and the
+// -1 matrix value are then the neighbouring lanes' centre x / U1 value (DPP wave shift) plus one scalar load for the lane at
+// the slice's edge: three vector loads fewer per step (-6 % at 464^3, and fewer lines for the L2 to keep).
+template <bool DOT, int NT, bool WIN, bool D1> // NT bit 0: diag / U3 streams non-temporal, bit 1: U1 / U2 too, bit 2: y store
+__global__ __launch_bounds__(FV_BLOCK, 8) void spmv_symdia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int s, int32_t d1,
+                                                                          int32_t d2, int seglen, int segs_per_xcd, uint32_t front, int dbg,
+                                                                          const uint8_t *__restrict__ sym_ok, const double *__restrict__ dg,
+                                                                          const double *__restrict__ u1, const double *__restrict__ u2,
+                                                                          const double *__restrict__ u3, const double *__restrict__ x,
+                                                                          double *__restrict__ y, const double *__restrict__ dshift, double sigma,
+                                                                          double *__restrict__ partials, const PcgScalars *__restrict__ scal)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double smem[4];
+    if (scal && scal->done)
+        return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t wstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t nitems = (int64_t)segs_per_xcd * step;
+    const uint32_t fb = front * 8u, d1b = (uint32_t)d1 * 8u, d2b = (uint32_t)d2 * 8u, stepb = (uint32_t)(step << 9);
+    const int64_t wmax = ncols - 96; // a slice's window [64 t - 32, 64 t + 96) lies inside x iff 32 <= 64 t <= wmax
+    // the three window elements a lane takes: centre, +s, -s
+    const int jc = 32 + (int)lane, jp = 32 + s + (int)lane, jm = 32 - s + (int)lane;
+    double dacc = 0.0;
+    for (int64_t item = (int64_t)(blockIdx.x >> 3) * WPB + wave; item < nitems; item += wstride) {
+        const int64_t seg = (int64_t)xcd * segs_per_xcd + item / step;
+        const int64_t pc = item % step;
+        int64_t sl = pc + seg * seglen * step;
+        if (sl >= nslices)
+            continue;
+        // The row of a slice is computed in two halves, one plane step apart: when the slice's own window arrives, every
+        // term but the +plane one (its centre, in-plane arms and matrix values are all loaded in THIS step — the step in
+        // which the neighbouring pencils of the XCD stream exactly these lines, so the arm loads find them in L2; read a
+        // step later, as a straightforward loop would, they have been evicted: a 4 MiB L2 holds about one step of the XCD's
+        // waves, and the arms cost 1.7 GB of extra fabric reads per launch at 464^3); the +plane term and the epilogue
+        // follow when the next slice's window brings x[row + d3].  Same terms in the same order, so the same bits.
+        // Carried from step to step: for the slice about to start, its -plane x arm (xm) and -plane matrix value (am); for
+        // the slice waiting for its last term, the partial sum, its +plane matrix value (a3p) and centre x (cp).
+        double xm = 0.0, am = 0.0, part = 0.0, a3p = 0.0, cp = 0.0;
+        int okp = 0;
+        {
+            const int64_t bp = (sl - step) << 6;
+            if (WIN) {
+                if (bp >= 32) { // (and bp < 64 sl <= wmax wherever a slice of this pencil is computed at all)
+                    xm = march_window_elem(ld2_off<0>(x, ((uint32_t)bp - 32u) * 8u + lane * 16u), jm);
+                    am = march_window_elem(ld2_off<0>(u3, fb + ((uint32_t)bp - 32u) * 8u + lane * 16u), jm);
+                }
+            } else if (bp >= 0) { // plane stride a multiple of 64: the arms are whole slices
+                xm = ld_off<0>(x, (uint32_t)bp * 8u + lane * 8u);
+                am = ld_off<0>(u3, fb + (uint32_t)bp * 8u + lane * 8u);
+            }
+        }
+        int nx_ok = (int)sym_ok[sl];
+        // one more round than slices: the last slice of the segment gets its +plane term from the window of the slice after it
+        for (int k = 0;; k++, sl += step) {
+            const int64_t base = sl << 6;
+            const bool fin = k == seglen || sl >= nslices; // no slice starts in this round: it only completes the one before
+            const int ok = fin ? 0 : __builtin_amdgcn_readfirstlane(nx_ok);
+            if (fin && !okp)
+                break;
+            uint32_t rb = (uint32_t)base * 8u + lane * 8u; // byte offset of the lane's row
+            // opaque to the optimiser: otherwise it splits every offset into a loop-invariant per-lane part (one register
+            // each, kept across the loop and spilled) and a scalar that changes per step, instead of one add from rb
+            asm volatile("" : "+v"(rb));
+            double c = 0.0, xp = 0.0, xmn = 0.0, a3 = 0.0, amn = 0.0, vd = 0.0, v1 = 0.0, v2 = 0.0, v1m = 0.0, v2m = 0.0, x2m = 0.0, x1m = 0.0, x1p = 0.0,
+                   x2p = 0.0;
+            if (ok) { // issued first: the longest-latency (HBM) streams of the step
+                vd = ld_off<NT & 1>(dg, fb + rb);
+                v1 = ld_off<NT & 2>(u1, fb + rb);
+                v2 = ld_off<NT & 2>(u2, fb + rb);
+                if (!(dbg & 2)) { // (diagnosis switches, fv_tune key 29: results are wrong when set)
+                    if (!D1)
+                        v1m = ld_off<0>(u1, fb + rb - d1b); // padded in front: rows < d read zeros
+                    v2m = ld_off<0>(u2, fb + rb - d2b);
+                }
+                if (!(dbg & 1)) {
+                    x2m = ld_off<0>(x, rb - d2b);
+                    x2p = ld_off<0>(x, rb + d2b);
+                    if (!D1) {
+                        x1m = ld_off<0>(x, rb - d1b);
+                        x1p = ld_off<0>(x, rb + d1b);
+                    }
+                }
+            }
+            double e1 = 0.0, exm = 0.0, exp_ = 0.0; // D1: the elements just outside the slice (wave-uniform addresses: scalar loads)
+            if (D1 && ok) {
+                e1 = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(u1) + (fb + (uint32_t)base * 8u - 8u));
+                exm = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((uint32_t)base * 8u - 8u)); // base >= d2 >= 1 where ok
+                exp_ = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + ((uint32_t)base * 8u + 512u));
+            }
+            if (WIN) {
+                if (base >= 32 && base <= wmax) { // always so where a slice of this round or the one before is computed
+                    const double2 w = ld2_off<0>(x, rb + lane * 8u - 256u); // this slice's window: 16 bytes per lane from row - 32
+                    if (dbg & 4) { // no shuffles
+                        c = w.x;
+                        xp = w.y;
+                        xmn = w.x;
+                    } else {
+                        c = march_window_elem(w, jc);
+                        xp = march_window_elem(w, jp);
+                        xmn = march_window_elem(w, jm);
+                    }
+                }
+                if (!fin) {
+                    const double2 w3 = ld2_off<NT & 1>(u3, fb + rb + lane * 8u - 256u);
+                    if (dbg & 4) {
+                        a3 = w3.x;
+                        amn = w3.y;
+                    } else {
+                        a3 = march_window_elem(w3, jc);
+                        amn = march_window_elem(w3, jm);
+                    }
+                }
+            } else {
+                if (base + 64 <= ncols)
+                    c = ld_off<0>(x, rb);
+                xp = c;
+                xmn = c;
+                if (!fin)
+                    a3 = ld_off<NT & 1>(u3, fb + rb);
+                amn = a3;
+            }
+            if (!fin && sl + step < nslices && k + 1 < seglen)
+                nx_ok = (int)sym_ok[sl + step];
+            if (okp) { // the slice one plane step back: its last term and the epilogue
+                const double sum0 = part + a3p * xp;
+                const uint32_t rbp = rb - stepb;
+                if (base - (step << 6) + lane < n) {
+                    double sum = sum0;
+                    if (dshift)
+                        sum += sigma * ld_off<0>(dshift, rbp) * cp;
+                    double *yq = reinterpret_cast<double *>(reinterpret_cast<char *>(y) + rbp);
+                    if (NT & 4)
+                        __builtin_nontemporal_store(sum, yq);
+                    else
+                        *yq = sum;
+                    if (DOT)
+                        dacc += cp * sum;
+                }
+            }
+            if (ok) {
+                if (D1) {
+                    v1m = wave_from_below(v1, e1);
+                    x1m = wave_from_below(c, exm);
+                    x1p = wave_from_above(c, exp_);
+                }
+                double sum = 0.0;
+                sum += am * xm;
+                sum += v2m * x2m;
+                sum += v1m * x1m;
+                sum += vd * c;
+                sum += v1 * x1p;
+                sum += v2 * x2p;
+                part = sum;
+            }
+            if (fin)
+                break;
+            okp = ok;
+            a3p = a3;
+            cp = c;
+            xm = xmn;
+            am = amn;
+        }
+    }
+    if (DOT) {
+        const double tsum = block_sum(dacc, smem);
+        if (threadIdx.x == 0)
+            partials[blockIdx.x] = tsum;
+    }
+}
+
+// per slice: are all of its stored offsets among 0, +-d1, +-d2, +-d3?  rest = it is a DIA slice but not such a one
+__global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+                                                                int32_t d1, int32_t d2, int32_t d3, int64_t step, int64_t ncols,
+                                                                uint8_t *__restrict__ ok, int32_t *__restrict__ rest)
+{
+    const int64_t sl = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (sl >= nslices)
+        return;
+    const int noff = sl_noff[sl];
+    // the marching kernel's unclamped accesses: the slice's in-plane arms and the 128-element windows of the slice itself and
+    // of the slices one plane step before and after it must lie inside [0, ncols)
+    const int64_t base = sl << 6, bp = (sl - step) << 6, bn = (sl + step) << 6;
+    bool good = noff > 0 && bp >= 32 && bn + 96 <= ncols && base >= d2 && base + 64 + d2 <= ncols;
+    for (int k = 0; k < noff; k++) {
+        int32_t o = sl_off[sl * DIA_K + k];
+        o = o < 0 ? -o : o;
+        good = good && (o == 0 || o == d1 || o == d2 || o == d3);
+    }
+    ok[sl] = good ? 1 : 0;
+    rest[sl] = (noff > 0 && !good) ? 1 : 0;
+}
+
+// the four arrays from the (possibly diagonal-folded) CSR values; absent entries keep the zeros of the allocation
+__global__ __launch_bounds__(FV_BLOCK) void symdia_fill_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                const double *__restrict__ vals, int32_t d1, int32_t d2, int32_t d3,
+                                                                double *__restrict__ dg, double *__restrict__ u1, double *__restrict__ u2,
+                                                                double *__restrict__ u3)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    for (int32_t j = rowptr[r], e = rowptr[r + 1]; j < e; j++) {
+        const int64_t off = (int64_t)colind[j] - r;
+        const double v = vals[j];
+        if (off == 0)
+            dg[r] = v;
+        else if (off == d1)
+            u1[r] = v;
+        else if (off == d2)
+            u2[r] = v;
+        else if (off == d3)
+            u3[r] = v;
+    }
+}
+
+// a(i, i-d) must be the bits of a(i-d, i) wherever the symmetric kernel will take one for the other
+__global__ __launch_bounds__(FV_BLOCK) void symdia_check_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                 const double *__restrict__ vals, int32_t d1, int32_t d2, int32_t d3,
+                                                                 const double *__restrict__ u1, const double *__restrict__ u2,
+                                                                 const double *__restrict__ u3, int *__restrict__ mismatch)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    bool bad = false;
+    for (int32_t j = rowptr[r], e = rowptr[r + 1]; j < e; j++) {
+        const int64_t off = r - (int64_t)colind[j];
+        const double *u = off == d1 ? u1 : (off == d2 ? u2 : (off == d3 ? u3 : nullptr));
+        if (u)
+            bad = bad || __double_as_longlong(u[r - off]) != __double_as_longlong(vals[j]);
+    }
+    if (bad)
+        *mismatch = 1;
+}
+
+
+// Decide whether the operator has the symmetric three-offset structure and allocate the copy (once per problem).
+static int build_symdia(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    p->sym_state = 0;
+    const int64_t ns = (p->n + 63) >> 6;
+    if (p->dist || p->nhalo > 0 || p->ndia <= 0 || p->order_stride < 4096 || p->n >= (int64_t)0x7fffffff - 4096)
+        return FV_OK;
+    // the offsets of an interior slice: 7 of them, symmetric, the largest the plane stride.  Slices next to a boundary lack
+    // some (the middle slice of a grid whose lines are a whole number of slices can be the first line of its plane), so a
+    // handful of slices spread over the operator are looked at until one has all seven.
+    std::vector<uint8_t> hn((size_t)ns);
+    FV_HIP(ctx, hipMemcpy(hn.data(), p->sl_noff.p, (size_t)ns, hipMemcpyDeviceToHost));
+    int32_t off[DIA_K];
+    bool found = false;
+    for (int64_t j = 0; j < 4096 && j < ns && !found; j++) {
+        const int64_t cand = (ns / 2 + j * 977) % ns; // 977: a stride unrelated to grid line lengths
+        if (hn[(size_t)cand] != 7)
+            continue;
+        FV_HIP(ctx, hipMemcpy(off, p->sl_off.p + cand * DIA_K, sizeof off, hipMemcpyDeviceToHost));
+        found = off[3] == 0 && off[0] == -off[6] && off[1] == -off[5] && off[2] == -off[4] && off[6] == p->order_stride;
+    }
+    if (!found)
+        return FV_OK;
+    const int32_t d1 = off[4], d2 = off[5], d3 = off[6];
+    FV_TRY(p->sym_ok.alloc(ctx, (size_t)ns));
+    DevBuf<int32_t> restflag;
+    FV_TRY(restflag.alloc(ctx, (size_t)ns));
+    int sh = (int)(d3 % 64);
+    if (sh > 32)
+        sh -= 64; // signed lane shift of the march (spmv_apply computes the same)
+    hipLaunchKernelGGL(symdia_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const uint8_t *)p->sl_noff.p,
+                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n + p->nhalo, p->sym_ok.p, restflag.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(p->sym_rest.alloc(ctx, (size_t)ns));
+    FV_TRY(fv_compact_flags(ctx, restflag.p, ns, p->sym_rest.p, &p->sym_nrest));
+    if ((p->ndia - p->sym_nrest) * 10 < ns * 9) { // too few slices of that shape to bother
+        p->sym_ok.release();
+        p->sym_rest.release();
+        return FV_OK;
+    }
+    p->sym_d[0] = d1;
+    p->sym_d[1] = d2;
+    p->sym_d[2] = d3;
+    p->sym_front = ((int64_t)d3 + 128 + 63) / 64 * 64;
+    p->sym_ld = p->sym_front + (ns << 6) + 256;
+    if (p->sym_ld * 8 >= ((int64_t)1 << 32) || (p->n + p->nhalo + 256) * 8 >= ((int64_t)1 << 32)) // the kernel's 32-bit byte offsets
+        return FV_OK;
+    FV_TRY(p->sym_vals.alloc(ctx, (size_t)(4 * p->sym_ld)));
+    FV_HIP(ctx, hipMemsetAsync(p->sym_vals.p, 0, (size_t)(4 * p->sym_ld) * sizeof(double), ctx->stream));
+    p->sym_epoch = -1;
+    p->sym_state = 1;
+    return FV_OK;
+}
+
+static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->sym_epoch == p->assemble_epoch && p->sym_tag == src_tag)
+        return FV_OK;
+    double *dg = p->sym_vals.p + p->sym_front, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld;
+    const int32_t d1 = (int32_t)p->sym_d[0], d2 = (int32_t)p->sym_d[1], d3 = (int32_t)p->sym_d[2];
+    hipLaunchKernelGGL(symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
+                       (const int32_t *)p->colind.p, src, d1, d2, d3, dg, u1, u2, u3);
+    FV_LAUNCH_CHECK(ctx);
+    if (p->sym_epoch != p->assemble_epoch) { // new values: the lower triangle must mirror the upper one exactly
+        DevBuf<int> bad;
+        FV_TRY(bad.alloc(ctx, 1));
+        FV_TRY(bad.zero(ctx));
+        hipLaunchKernelGGL(symdia_check_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
+                           (const int32_t *)p->colind.p, src, d1, d2, d3, (const double *)u1, (const double *)u2, (const double *)u3, bad.p);
+        FV_LAUNCH_CHECK(ctx);
+        int h = 0;
+        FV_HIP(ctx, hipMemcpyAsync(&h, bad.p, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (h) { // a caller-supplied matrix (fv_problem_create_from_csc) that is not symmetric: the general forms serve it
+            p->sym_state = 0;
+            p->sym_vals.release();
+            return FV_OK;
+        }
+    }
+    p->sym_epoch = p->assemble_epoch;
+    p->sym_tag = src_tag;
+    return FV_OK;
+}
+
 // values are packed: slice i of the list holds sl_noff lane-major blocks of 64 doubles, one after the other
 __global__ __launch_bounds__(FV_BLOCK) void dia_len_kernel(int64_t ndia, const int32_t *__restrict__ dia_list, const uint8_t *__restrict__ sl_noff,
                                                             int pad_to, int32_t *__restrict__ len)
@@ -1023,16 +1419,21 @@ int fv_build_dia(fv_problem *p)
 }
 
 // lane-major values for the current assembly; src_tag identifies the source array (0 = plain, else the folded sigma)
-static int ensure_dia_vals(fv_problem *p, const double *src, double src_tag)
+// only_rest: just the slices the symmetric marching kernel leaves to the slice-by-slice one (p->sym_rest)
+static int ensure_dia_vals(fv_problem *p, const double *src, double src_tag, bool only_rest = false)
 {
     fv_ctx *ctx = p->ctx;
-    if (p->dia_epoch == p->assemble_epoch && p->dia_tag == src_tag)
+    if (p->dia_epoch == p->assemble_epoch && p->dia_tag == src_tag && (only_rest || !p->dia_partial))
         return FV_OK;
-    hipLaunchKernelGGL(dia_fill_kernel, dim3(fv_blocks(p->ndia, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->ndia, p->dia_list.p,
-                       p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, (const int32_t *)p->dia_pos.p, p->dia_vals.p);
+    const int64_t cnt = only_rest ? p->sym_nrest : p->ndia;
+    const int32_t *list = only_rest ? p->sym_rest.p : p->dia_list.p;
+    if (cnt > 0)
+        hipLaunchKernelGGL(dia_fill_kernel, dim3(fv_blocks(cnt, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, cnt, list,
+                           p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, (const int32_t *)p->dia_pos.p, p->dia_vals.p);
     FV_LAUNCH_CHECK(ctx);
     p->dia_epoch = p->assemble_epoch;
     p->dia_tag = src_tag;
+    p->dia_partial = only_rest;
     return FV_OK;
 }
 
@@ -1112,9 +1513,11 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         FV_TRY(spmv_launch_impl(p, x, y, sigma, mode == SPMV_DOT ? partials : nullptr, use_done, vals_override, nullptr, -1, &G));
         if (nparts)
             *nparts = G;
+        p->last_form = FV_SPMV_CSR;
         return FV_OK;
     }
     if (subset && !(g_use_dia && p->ndia > 0)) { // subset of a pure-CSR operator: everything is in subset->csr
+        p->last_form = FV_SPMV_CSR;
         const int G = stream_grid(subset->ncsr);
         if (subset->ncsr > 0)
             FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, subset->csr, subset->ncsr, epi));
@@ -1123,7 +1526,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         return FV_OK;
     }
     if (g_use_dia && p->ndia > 0) {
-        FV_TRY(ensure_dia_vals(p, vals, vals_override ? p->shifted_sigma : 0.0));
+        const double vals_tag = vals_override ? p->shifted_sigma : 0.0;
         const int32_t *dlist = subset ? subset->dia : ((g_use_order && p->dia_list_ord.p) ? p->dia_list_ord.p : p->dia_list.p);
         const int64_t dcount = subset ? subset->ndia : p->ndia;
         const int32_t *clist = subset ? subset->csr : p->csr_list.p;
@@ -1139,32 +1542,54 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         // 5e7, ~2000 vs 1600 on 1e8 (tools/march_vs_dia.py, profiles/r01_march_vs_dia.log); inside the stepping loop, where the
         // vector pass between two SpMVs evicts x, ms per step slices vs marching: 216^3 0.306 / 0.330, 256^3 0.509 / 0.517,
         // 280^3 0.710 / 0.705, 320^3 1.067 / 1.056, 380^3 1.785 / 1.738 (tools/step_ab.py 9 0 2, profiles/r01_step_ab_march.log)
-        const bool march_pays = g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
-        const bool march = g_march && march_pays && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
+        // The symmetric marching form streams 32 instead of 56 bytes of matrix per row and wins at every size measured, also
+        // where x fits the last-level cache (back-to-back launches, slices / seven-diagonal marching / symmetric marching:
+        // 216^3 0.139 / 0.170 / 0.107 ms, a 58-plane share of the bench box 0.172 / 0.211 / 0.142, 116 planes 0.344 / 0.354 /
+        // 0.275, 320^3 0.494 / 0.496 / 0.340, 464^3 - / 1.51 / 1.00; profiles/r02_sym_sizes.log): wherever the operator has that
+        // shape the size rule does not apply.
+        const bool may_march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
+        bool sym = false;
+        if (may_march && g_symdia && !subset) {
+            if (p->sym_state < 0)
+                FV_TRY(build_symdia(p));
+            if (p->sym_state == 1)
+                FV_TRY(ensure_symdia_vals(p, vals, vals_tag));
+            sym = p->sym_state == 1;
+        }
+        const bool march_pays = sym || g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
+        const bool march = may_march && march_pays;
+        // the lane-major copy of all seven diagonals: everything, or just the slices the symmetric kernel leaves out
+        FV_TRY(ensure_dia_vals(p, vals, vals_tag, sym));
         int GM = 0;
         if (g_trace_spmv > 0) { // fv_tune key 25 / FV_TRACE_SPMV: the next N kernel choices to stderr
             g_trace_spmv--;
             fprintf(stderr, "[fvhip] sliced-DIA SpMV: %s kernel, n %lld (+%lld halo), %lld slices%s, plane stride %lld, window [%lld, %lld)\n",
-                    march ? "plane-marching" : "slice-by-slice", (long long)p->n, (long long)p->nhalo, (long long)dcount,
+                    sym ? "symmetric plane-marching" : (march ? "plane-marching" : "slice-by-slice"), (long long)p->n, (long long)p->nhalo, (long long)dcount,
                     subset ? " (subset)" : "", (long long)p->order_stride, subset ? (long long)subset->win_lo : 0LL,
                     subset ? (long long)subset->win_hi : 0LL);
         }
         if (march) {
             const int64_t ns = (p->n + 63) >> 6;
-            const int sh = (int)(p->order_stride % 64);
+            int sh = (int)(p->order_stride % 64);
+            if (sym && sh > 32)
+                sh -= 64; // the symmetric kernel takes a signed lane shift: stride = 64 step + sh, |sh| <= 32
             const int64_t step = (p->order_stride - sh) / 64;
             const int64_t nk = (ns + step - 1) / step;                     // plane steps of the longest pencil
             // m segments per XCD: a static partition pays for a partly filled last round of the XCD's resident waves, short
             // segments pay for their start-up loads: the smallest m whose m * step (pencil, segment) items fill >= 95 % of
             // whole rounds, else the best filling one
+            // the symmetric kernel runs best with 6 of the 8 blocks a CU could hold: fewer waves streaming at once leave the
+            // lines its arm loads re-use in L2 a little longer (464^3: 1.157 ms at 8 per CU, 1.10 at 6 and 5, 1.18 at 4,
+            // profiles/r02_sym_ab.log); fv_tune key 30 overrides
+            const int resident = (sym && g_blocks_per_cu == 8) ? g_resident_blocks / 8 * 6 / 8 * 8 : g_resident_blocks;
             int segs_per_xcd = g_march_segs;
             if (segs_per_xcd <= 0) {
                 double best = 0.0;
                 for (int m = 1; m <= 8; m++) {
                     const int64_t items = (int64_t)m * step;
                     int64_t gg = ((items + 3) / 4) * 8;
-                    if (gg > g_resident_blocks)
-                        gg = g_resident_blocks;
+                    if (gg > resident)
+                        gg = resident;
                     const int64_t waves = gg / 8 * 4;
                     const double eff = (double)items / (double)(((items + waves - 1) / waves) * waves);
                     if (eff > best) {
@@ -1178,8 +1603,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             const int seglen = (int)((nk + 8 * segs_per_xcd - 1) / (8 * segs_per_xcd));
             const int64_t per_xcd = (int64_t)segs_per_xcd * step;
             int64_t g = ((per_xcd + 3) / 4) * 8;
-            if (g > g_resident_blocks)
-                g = g_resident_blocks;
+            if (g > resident)
+                g = resident;
             GM = (int)g;
 #define FV_MARCH_W(D_, N_, W_)                                                                                                                 \
     hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_, W_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
@@ -1192,7 +1617,43 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         else                                                                                                                                  \
             FV_MARCH_W(D_, N_, false);                                                                                                        \
     } while (0)
-            if (mode == SPMV_DOT) {
+            if (sym) {
+                const double *dg = p->sym_vals.p, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld; // array starts; row 0 is sym_front in
+#define FV_SYM1(D_, N_, W_, O_)                                                                                                               \
+    hipLaunchKernelGGL((spmv_symdia_march_kernel<D_, N_, W_, O_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, \
+                       (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], seglen, segs_per_xcd, (uint32_t)p->sym_front, g_symdia_dbg, (const uint8_t *)p->sym_ok.p, dg, u1, u2, u3, x, y, \
+                       shift, sigma, partials, scal)
+#define FV_SYM(D_, N_, W_)                                                                                                                    \
+    do {                                                                                                                                      \
+        if (p->sym_d[0] == 1 && !(g_symdia_dbg & 8))                                                                                          \
+            FV_SYM1(D_, N_, W_, true);                                                                                                        \
+        else                                                                                                                                  \
+            FV_SYM1(D_, N_, W_, false);                                                                                                       \
+    } while (0)
+#define FV_SYM_N(D_, W_)                                                                                                                      \
+    do {                                                                                                                                      \
+        switch (g_nt ? g_symdia_nt : 0) {                                                                                                     \
+        case 1: FV_SYM(D_, 1, W_); break;                                                                                                     \
+        case 4: FV_SYM(D_, 4, W_); break;                                                                                                     \
+        case 5: FV_SYM(D_, 5, W_); break;                                                                                                     \
+        default: FV_SYM(D_, 0, W_); break;                                                                                                    \
+        }                                                                                                                                     \
+    } while (0)
+                if (mode == SPMV_DOT) {
+                    if (sh != 0)
+                        FV_SYM_N(true, true);
+                    else
+                        FV_SYM_N(true, false);
+                } else {
+                    if (sh != 0)
+                        FV_SYM_N(false, true);
+                    else
+                        FV_SYM_N(false, false);
+                }
+#undef FV_SYM_N
+#undef FV_SYM
+#undef FV_SYM1
+            } else if (mode == SPMV_DOT) {
                 if (g_nt)
                     FV_MARCH(true, true);
                 else
@@ -1205,6 +1666,28 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             }
 #undef FV_MARCH_W
 #undef FV_MARCH
+        }
+        int GR = 0; // partials of the slices the symmetric kernel left to the slice-by-slice one
+        if (sym && p->sym_nrest > 0) {
+            FV_LAUNCH_CHECK(ctx);
+            GR = stream_grid(p->sym_nrest);
+            double *parts_rest = partials ? partials + GM : nullptr;
+#define FV_DIA_REST(D_, N_)                                                                                                                   \
+    hipLaunchKernelGGL((spmv_dia_kernel<D_, N_, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,       \
+                       (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, shift, sigma, parts_rest, \
+                       scal, epi)
+            if (mode == SPMV_DOT) {
+                if (g_nt)
+                    FV_DIA_REST(true, true);
+                else
+                    FV_DIA_REST(true, false);
+            } else {
+                if (g_nt)
+                    FV_DIA_REST(false, true);
+                else
+                    FV_DIA_REST(false, false);
+            }
+#undef FV_DIA_REST
         }
         if (dcount > 0 && !march) {
         if (mode == SPMV_INIT) {
@@ -1226,7 +1709,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         }
 #undef FV_DIA
         FV_LAUNCH_CHECK(ctx);
-        const int GD = march ? GM : GA; // partials written by the DIA part
+        p->last_form = sym ? FV_SPMV_SYM_MARCH : (march ? FV_SPMV_DIA_MARCH : FV_SPMV_DIA);
+        const int GD = march ? GM + GR : GA; // partials written by the DIA part
         int GB = 0;
         if (ccount > 0) {
             GB = stream_grid(ccount);
@@ -1239,12 +1723,37 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
     }
     const int G = stream_grid(ngroups);
     const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
+    p->last_form = FV_SPMV_CSR;
     FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, order, ngroups, epi));
     if (nparts)
         *nparts = G;
     return FV_OK;
 }
 
+
+extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch)
+{
+    if (!p || !form || !bytes_per_launch)
+        return FV_ERR_ARG;
+    *form = p->last_form;
+    const int64_t n = p->n, ns = (n + 63) >> 6;
+    const int64_t csr_all = 12 * p->nnz + 20 * n;
+    int64_t bytes = csr_all;
+    if (p->last_form > FV_SPMV_CSR && ns > 0 && p->ndia > 0) {
+        const int64_t blocks = p->dia_vals.n / 64;                           // lane-major blocks of all DIA slices
+        const int64_t meta = 37;                                               // per slice: sl_noff 1, sl_off 32, dia_pos 4
+        const int64_t dia_all = blocks * 512 + p->ndia * meta;                // matrix side of the sliced-DIA form
+        const int64_t csr_part = csr_all / ns * p->ncsr_groups;               // the CSR groups' share, by group count
+        const int64_t vec = 16 * (p->ndia * 64 < n ? p->ndia * 64 : n);       // x once, y once over the DIA rows
+        if (p->last_form == FV_SPMV_SYM_MARCH) {
+            const int64_t nok = p->ndia - p->sym_nrest;
+            bytes = nok * (4 * 512 + 1) + (p->sym_nrest > 0 ? dia_all / p->ndia * p->sym_nrest : 0) + vec + csr_part;
+        } else
+            bytes = dia_all + vec + csr_part;
+    }
+    *bytes_per_launch = bytes;
+    return FV_OK;
+}
 
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold, int *npartials)
 {

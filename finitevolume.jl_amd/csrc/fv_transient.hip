@@ -477,7 +477,8 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                 prev = u; // converged on entry: state unchanged, zero increment
         }
     }
-    if (pingpong && rc == FV_OK) { // hand the buffers back: the caller's slot owns the current state
+    if (pingpong && alt) { // hand the buffers back: the caller's slot owns the current state — also after a failed step, where
+        // u is the last state a step completed from (the failed step wrote, if anything, into alt)
         p->slots[(size_t)slot] = u;
         p->slots[(size_t)p->pingpong_slot] = alt;
     }
@@ -628,6 +629,11 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
             rc = FV_ERR_HIP;
         if (rc == FV_ERR_HIP)
             fv_set_error(ctx, "fv_transient_run_adaptive: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc == FV_OK && t < tfinal) { // the reference always reaches tfinal (transient.jl:143-152): never hand u(t) back as u(tfinal)
+            fv_set_error(ctx, "fv_transient_run_adaptive: %lld outer steps (max_outer) taken and t = %.17g < tfinal = %.17g; the state is u(t)",
+                         (long long)nout, t, tfinal);
+            rc = FV_ERR_STATE;
+        }
     }
     for (int i = 0; i < 4; i++)
         if (scratch[i] >= 0)

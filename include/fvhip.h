@@ -109,7 +109,9 @@ int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], const doubl
 /* A general symmetric operator given as SparseMatrixCSC (1-based), for the
  * generic integrator entry backwardeulerintegrate(u0, A, b, dt0, t0, tfinal)
  * (transient.jl:123-154) and for the adjoint's transpose(A) (transient.jl:193):
- * all n unknowns are free, D = I. */
+ * all n unknowns are free, D = I.  The arrays are taken as CSR as they stand, so the matrix must be symmetric (checked on
+ * the device, 1e-12 relative): FV_ERR_ARG with a message naming the first unmatched entry otherwise — the reference's
+ * own non-symmetric cases (test/ode.jl:36) go through a host `linearsolver`, never through the device PCG. */
 int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t *colptr, const int64_t *rowval,
                                const double *nzval, fv_problem **out);
 void fv_problem_destroy(fv_problem *p);
@@ -174,7 +176,8 @@ int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, int64_t nstep
 /* backwardeulerintegrate with the default stepper adaptivebackwardeulerstep! (transient.jl:78-121,136-154) and a
  * constant b, without leaving the device: step doubling (one step of dt against two of dt/2, accept below atol, grow
  * x2 below atol/4, on failure halve and sub-step to the requested time without overshoot), final step clipped to
- * tfinal.  The slot is advanced from t0 to tfinal (or by max_outer outer steps, whichever comes first); ts_out
+ * tfinal.  The slot is advanced from t0 to tfinal; if max_outer outer steps do not get there the call returns FV_ERR_STATE
+ * with the slot at u(t), t = ts_out[*n_outer] < tfinal (the reference never stops short, transient.jl:143-152); ts_out
  * (max_outer + 1 entries) receives the reference's `ts`: t0 and the time after every outer step; *n_outer their
  * count - 1, *n_solves the number of linear solves. */
 int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, double atol, double rtol,
@@ -257,10 +260,31 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      all-reduces a step's five sums together with the next step's p.q (one 6-double collective per step, not two) [1]
  *  25: print the next N choices between the two sliced-DIA kernels to stderr (also FV_TRACE_SPMV=N in the environment) [0]
  *  26: streaming hints of the fused vector pass of key 8: bit 0 = its read-once inputs bypass the caches, bit 1 = its
- *      x and r outputs too (the next SpMV's input stays cacheable), 7 = the search direction as well [3] */
+ *      x and r outputs too (the next SpMV's input stays cacheable), 7 = the search direction as well [3]
+ *  27: symmetric plane-marching SpMV (stored diagonal + three upper diagonals, the lower arms read from the upper
+ *      arrays) wherever the plane-marching kernel of key 9 runs and the operator is a symmetric 7-point one [1]
+ *  28: streaming hints of that kernel: bit 0 = diagonal and plane-diagonal streams, bit 1 = the two in-plane upper
+ *      diagonals (re-read as lower arms), bit 2 = the y store [4]
+ *  29: diagnosis switches of that kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no
+ *      window shuffles; results are wrong when set), bit 3: load the +-1 arms instead of taking them from the neighbouring
+ *      lanes [0]
+ *  30: blocks per CU the SpMV grids are sized for (the symmetric kernel takes 6 when this is left at 8) [8] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
+/* Storage form the most recent SpMV of this problem ran in (the `A * x` inside cg!, src/FiniteVolume.jl:161 and
+ * src/transient.jl:52) and the bytes one launch of it has to move when every array is touched once:
+ *   FV_SPMV_CSR      wave-stream CSR: 12 nnz + 20 n (SURVEY 8d's accounting)
+ *   FV_SPMV_DIA      sliced-DIA, slice by slice: 8 B per stored lane-major value (zeros included) + 16 n + slice metadata
+ *   FV_SPMV_DIA_MARCH  the same values, plane-marching traversal (x arms from registers)
+ *   FV_SPMV_SYM_MARCH  symmetric plane-marching: 32 n (diagonal + 3 upper diagonals) + 16 n
+ * Slices left to another form (CSR groups of an irregular part, slices the symmetric kernel hands to the slice kernel)
+ * are counted in their own form, pro rata by slice count.  *form = -1 before the first SpMV. */
+#define FV_SPMV_CSR 0
+#define FV_SPMV_DIA 1
+#define FV_SPMV_DIA_MARCH 2
+#define FV_SPMV_SYM_MARCH 3
+int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

@@ -158,10 +158,13 @@ def test_synthetic_464_cubed_operator_identities(fv):
     assert abs(float(y @ ax) - float(x @ ay)) / (np.linalg.norm(x) * np.linalg.norm(ay)) < 1e-13  # symmetry
 
 
-@pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192]])  # plane strides 39 600 (= 48 mod 64: centre + edge loads), 36 100 (= 4 mod 64: 16-byte windows), 36 864 (= 0 mod 64)
+# plane strides 39 600 (= 48 mod 64: centre + edge loads; lane shift -16 of the symmetric kernel), 36 100 (= 4 mod 64: 16-byte
+# windows), 36 864 (= 0 mod 64: whole-slice arms), 36 477 (odd number of rows: the last window pair straddles the end of x)
+@pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192], [41, 195, 189]])
 def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd):
-    """>= 2^20 unknowns with a plane stride: the plane-marching sliced-DIA kernel (default), the slice-by-slice DIA
-    kernel and the CSR wave-stream form against a float64 CSR product on the host; the p.q epilogue against numpy."""
+    """>= 2^20 unknowns with a plane stride: the symmetric plane-marching kernel (default above the size rule), the
+    plane-marching sliced-DIA kernel, the slice-by-slice DIA kernel and the CSR wave-stream form against a float64 CSR
+    product on the host, and bit for bit against each other; the p.q epilogue against numpy."""
     import scipy.sparse as sp
 
     # planes of (n2 - 2) x n3 rows (>= 32 768: the operator counts as plane-structured), 38 of them
@@ -170,7 +173,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
     p = fv.Problem.regulargrid(mins, maxs, ns, dn)
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
     p.transient_begin(0.1, None, np.full(p.N, 1e3))
-    assert p.n >= 1 << 20 and p.n == 38 * (ns[1] - 2) * ns[2]
+    assert p.n >= 1 << 20 and p.n == (ns[0] - 2) * (ns[1] - 2) * ns[2]
     A = p.csc()
     As = sp.csc_matrix((A.nzval, A.rowval - 1, A.colptr - 1), shape=(p.n, p.n)).tocsr()
     _, _, _, vol = fv.regulargrid(mins, maxs, ns)
@@ -183,19 +186,32 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
     scale = np.abs(ref).max()
     lib = fv.load()
     try:
-        for name, knobs in (("march", {9: 2, 6: 1, 18: 1}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}), ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
+        ys = {}
+        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1}), ("sym march m=1", {9: 2, 10: 1, 27: 1}), ("sym march m=5", {9: 2, 10: 5}), ("sym march, plain loads", {9: 2, 28: 0}),
+                            ("march", {9: 2, 6: 1, 18: 1, 27: 0}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}),
+                            ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
                 assert lib.fv_tune(k, v) == 0
             lib.fv_tune(25, 1)
             y = p.spmv(x, sigma)
             trace = capfd.readouterr().err
-            assert ("plane-marching kernel" in trace) == name.startswith("march") and ("slice-by-slice kernel" in trace) == (name == "slices"), (name, trace)
+            assert ("symmetric plane-marching kernel" in trace) == name.startswith("sym"), (name, trace)
+            assert (" plane-marching kernel" in trace and "symmetric" not in trace) == name.startswith("march"), (name, trace)
+            assert ("slice-by-slice kernel" in trace) == (name == "slices"), (name, trace)
             assert np.abs(y - ref).max() <= 1e-13 * scale, name
             assert abs(p.dot(x, y) - x @ y) <= 1e-12 * abs(x @ y)
+            assert p.spmv_form()[0] == (3 if name.startswith("sym") else 2 if name.startswith("march") else 1 if name == "slices" else 0)
+            ys[name] = y
             lib.fv_tune(10, 0)
+            lib.fv_tune(28, 5)
+        # the DIA forms sum a row's terms in ascending column order with fused multiply-adds, absent entries as zeros: the same
+        # bits (the CSR stream rounds every product on its way through LDS, so it only agrees to rounding)
+        for name in ys:
+            if name != "csr":
+                assert np.array_equal(ys[name], ys["slices"]), name
         # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
         heads = {}
-        for name, knobs in (("march", {9: 2, 6: 1}), ("slices", {9: 0, 6: 1})):
+        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
             for k, v in knobs.items():
                 lib.fv_tune(k, v)
             st = p.new_state()
@@ -204,11 +220,14 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
             assert info.converged
             heads[name] = st.node_values()
         assert np.abs(heads["march"] - heads["slices"]).max() <= 1e-9
+        assert np.abs(heads["sym march"] - heads["slices"]).max() <= 1e-9
     finally:
         lib.fv_tune(9, 1)
         lib.fv_tune(6, 1)
         lib.fv_tune(10, 0)
         lib.fv_tune(18, 1)
+        lib.fv_tune(27, 1)
+        lib.fv_tune(28, 5)
 
 
 def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv, capfd):

@@ -229,6 +229,40 @@ def test_ode_dense_user_linearsolver_seam(fv):
         assert np.linalg.norm(yy - y(t)) <= 1e-4
 
 
+def test_nonsymmetric_matrix_is_refused_by_the_device_solver(fv):
+    """The device path is a conjugate gradient on the caller's CSC arrays read as CSR: a non-symmetric A (test/ode.jl:31-40's
+    oscillator; transpose(D^-1 A) with unequal volumes) must not be solved as A' silently — it is refused with a message that
+    points at the host linearsolver seam; symmetric-to-rounding input passes."""
+    A = fv.SparseMatrixCSC.fromdense(-np.array([[0.5, -1.0], [1.0, -1.0]]))
+    with pytest.raises(fv.FVError, match="not symmetric.*linearsolver"):
+        fv.backwardeulerintegrate(np.ones(2), A, np.zeros(2), 1e-2, 0.0, 1.0)
+    # structurally unsymmetric: an entry without a partner
+    B = fv.SparseMatrixCSC(2, 2, np.array([1, 3, 4]), np.array([1, 2, 2]), np.array([2.0, -1.0, 2.0]))
+    with pytest.raises(fv.FVError, match="not symmetric"):
+        fv.Problem.from_csc(B)
+    # D^-1 A with unequal volumes, transposed: what adjointintegrate(A, ...) would be handed for a scaled host matrix
+    L = np.array([[2.0, -1.0, 0.0], [-1.0, 2.0, -1.0], [0.0, -1.0, 2.0]])
+    with pytest.raises(fv.FVError, match="not symmetric"):
+        fv.Problem.from_csc(fv.SparseMatrixCSC.fromdense((np.diag(1.0 / np.array([1.0, 2.0, 3.0])) @ L).T))
+    C = L.copy()
+    C[0, 1] *= 1 + 1e-15  # rounding-level asymmetry is what a scaled symmetric matrix looks like
+    p = fv.Problem.from_csc(fv.SparseMatrixCSC.fromdense(C))
+    assert p.n == 3
+
+
+def test_adaptive_run_that_cannot_reach_tfinal_fails_loudly(fv):
+    """fv_transient_run_adaptive stops after max_outer outer steps: it must not hand u(t < tfinal) back as u(tfinal)."""
+    c = refcases.onenode(0.0)
+    nb = np.stack([c["node1"], c["node2"]], 1)
+    p = fv.Problem.create(nb, c["aol"], len(c["sources"]), c["dnodes"])
+    p.assemble(c["K"], c["sources"], c["dheads"], None, True)
+    st = p.transient_begin(c["Ss"], c["volumes"], c["u0"])
+    with pytest.raises(fv.FVError, match="max_outer.*< tfinal"):
+        p.run_adaptive(st, 0.0, 10.0, dt0=1e-3, atol=1e-6, max_outer=5)
+    ts, nsolves, info = p.run_adaptive(st, 0.0, 0.5, dt0=1e-2, atol=1e-4)
+    assert ts[-1] == 0.5
+
+
 def test_nonpositive_dt_raises(fv):
     A = fv.SparseMatrixCSC(1, 1, np.array([1, 2]), np.array([1]), np.array([1.0]))
     with pytest.raises(fv.FVError, match="time step must be positive"):

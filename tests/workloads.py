@@ -1,83 +1,13 @@
-"""Synthetic inputs for the BASELINE.json configurations.  Data only:
-numpy arrays in the reference's conventions (1-based int64 indices)."""
-import numpy as np
+"""The synthetic BASELINE.json inputs live in the package (finitevolume.jl_amd/workloads.py) so that bench.py does not
+import from tests/; re-exported here for the tests."""
+import importlib.util
+import os
+import sys
 
-
-def smooth_gaussian_field(ns, seed=0, radius_cells=(10, 10, 10), passes=3):
-    """Stand-in for the reference's Matern field (GaussianRandomFields is not available):
-    unit-variance field from separable box smoothing of N(0,1) noise, shape (n3,n2,n1) like
-    the reference's node arrays; returned flattened in node order."""
-    n1, n2, n3 = ns
-    rng = np.random.default_rng(seed)
-    g = rng.standard_normal((n1, n2, n3)).astype(np.float64)
-    for axis, r in enumerate(radius_cells):
-        r = int(max(1, min(r, ns[axis] // 2)))
-        for _ in range(passes):
-            c = np.cumsum(g, axis=axis)
-            pad = [(0, 0)] * 3
-            pad[axis] = (r + 1, r)
-            cp = np.pad(c, pad, mode="edge")
-            hi = np.take(cp, np.arange(2 * r + 1, 2 * r + 1 + ns[axis]), axis=axis)
-            lo = np.take(cp, np.arange(0, ns[axis]), axis=axis)
-            g = (hi - lo) / (2 * r + 1)
-    g -= g.mean()
-    g /= g.std()
-    return g.reshape(-1)  # C order of (n1,n2,n3) == node order i3 + n3*(i2 + n2*i1)
-
-
-def box_model_dirichlet(ns):
-    """Dirichlet 1.0 on x = xmin, 0.0 on x = xmax (examples/box_model/ex.jl:29-37)."""
-    n1, n2, n3 = ns
-    plane = n2 * n3
-    left = np.arange(plane) + 1
-    right = (n1 - 1) * plane + np.arange(plane) + 1
-    dn = np.r_[left, right].astype(np.int64)
-    dh = np.r_[np.ones(plane), np.zeros(plane)]
-    return dn, dh
-
-
-def fractures_like(nfrac=20, m=500, seed=0):
-    """DFN-style irregular connectivity: `nfrac` triangular lattices (interior degree 6) of
-    m x m nodes, node order randomly permuted inside each fracture, pairs of fractures tied
-    node-to-node along an intersection line (degree up to ~14).  aol log-uniform in
-    [3e-9, 3e-5], K = 1e-12, volumes log-uniform over a decade, heads 2e6 / 1e6 on the two
-    extreme lattice columns of every fracture (examples/fractures/setupmesh.jl:55)."""
-    rng = np.random.default_rng(seed)
-    per = m * m
-    N = nfrac * per
-    ii, jj = np.meshgrid(np.arange(m), np.arange(m), indexing="ij")
-    lid = (ii * m + jj).astype(np.int64)
-    e1 = [lid[:-1, :].ravel(), lid[:, :-1].ravel(), lid[:-1, 1:].ravel()]
-    e2 = [lid[1:, :].ravel(), lid[:, 1:].ravel(), lid[1:, :-1].ravel()]
-    a_loc, b_loc = np.concatenate(e1), np.concatenate(e2)
-    n1, n2, dn, dh = [], [], [], []
-    perms = []
-    for f in range(nfrac):
-        perm = rng.permutation(per).astype(np.int64)
-        perms.append(perm)
-        off = f * per
-        n1.append(off + perm[a_loc])
-        n2.append(off + perm[b_loc])
-        dn.append(off + perm[lid[:, 0]])
-        dh.append(np.full(m, 2e6))
-        dn.append(off + perm[lid[:, m - 1]])
-        dh.append(np.full(m, 1e6))
-    for f in range(nfrac - 1):  # intersection lines: row of fracture f tied to a column of fracture f+1
-        g = f + 1
-        r = int(rng.integers(m // 4, 3 * m // 4))
-        c = int(rng.integers(m // 4, 3 * m // 4))
-        for shift in range(3):  # a few parallel ties -> nodes of degree up to 6 + 2*3
-            n1.append(f * per + perms[f][lid[min(r + shift, m - 1), 1 : m - 1]])
-            n2.append(g * per + perms[g][lid[1 : m - 1, c]])
-    n1 = np.concatenate(n1)
-    n2 = np.concatenate(n2)
-    lo, hi = np.minimum(n1, n2), np.maximum(n1, n2)
-    order = np.lexsort((hi, lo))  # the reference meshes list faces sorted with first < second
-    n1, n2 = lo[order] + 1, hi[order] + 1
-    F = len(n1)
-    aol = np.exp(rng.uniform(np.log(3e-9), np.log(3e-5), F))
-    K = np.full(F, 1e-12)
-    vol = np.exp(rng.uniform(np.log(1e-3), np.log(1e-2), N))
-    dn = np.concatenate(dn) + 1
-    dh = np.concatenate(dh)
-    return dict(N=N, node1=n1.astype(np.int64), node2=n2.astype(np.int64), aol=aol, K=K, volumes=vol, dnodes=dn.astype(np.int64), dheads=dh)
+_pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "finitevolume.jl_amd", "workloads.py")
+_spec = importlib.util.spec_from_file_location("fv_workloads", _pkg)
+_mod = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(_mod)
+smooth_gaussian_field = _mod.smooth_gaussian_field
+box_model_dirichlet = _mod.box_model_dirichlet
+fractures_like = _mod.fractures_like
