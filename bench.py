@@ -165,35 +165,35 @@ def other_baseline_configs(fv, ctx):
     row("watertable-like 216^3 transient, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, time.perf_counter() - t0,
         pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged))
     p.close()
-    # configs[3]: fractures-like 5 M cells, irregular CSR (cells numbered at random inside each fracture), 100 implicit steps
+    # configs[3]: fractures-like 5 M cells, irregular CSR (cells numbered at random inside each fracture), 100 implicit steps.
+    # The mesh is handed over as it is numbered; fv_problem_create re-numbers the free cells for locality by itself
+    # (reverse Cuthill-McKee inside the library, invisible at the ABI).  Second row: the same with that switched off.
     w = workloads.fractures_like(20, 500, seed=0)
-    p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], w["N"], w["dnodes"], ctx)
-    p.assemble(w["K"], np.zeros(w["N"]), w["dheads"])
-    st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
-    p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    iters, info, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
-    ctx.synchronize()
-    row("fractures-like 5M cells (irregular CSR, as numbered), transient, 100 steps, dt=1s, Jacobi-PCG rtol 1e-10", p.N, 100, time.perf_counter() - t0,
-        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged))
-    p.close()
-    # the same mesh after the locality re-numbering of meshio.locality_order (host pre-processing, reverse Cuthill-McKee)
-    t0 = time.perf_counter()
-    order, rank = fv.meshio.locality_order(w["node1"], w["node2"], w["N"])
-    t_rcm = time.perf_counter() - t0
-    w2 = fv.meshio.reorder_mesh(dict(node1=w["node1"], node2=w["node2"], aol=w["aol"], K=w["K"], volumes=w["volumes"], dnodes=w["dnodes"], dheads=w["dheads"]), rank)
-    p = fv.Problem.create((w2["node1"], w2["node2"]), w2["aol"], w["N"], w2["dnodes"], ctx)
-    p.assemble(w2["K"], np.zeros(w["N"]), w2["dheads"])
-    st = p.transient_begin(1e-9, w2["volumes"], np.full(w["N"], 1.5e6))
-    p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    iters, info, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
-    ctx.synchronize()
-    row("fractures-like 5M cells re-numbered for locality (meshio.locality_order), transient, 100 steps, dt=1s", p.N, 100, time.perf_counter() - t0,
-        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), renumbering_host_s=t_rcm)
-    p.close()
+    for label, mode in (("as numbered; fv_problem_create re-numbers the free cells for locality inside the library", 1),
+                        ("as numbered, the library's re-numbering switched off (fv_tune(31, 0))", 0)):
+        fv.load().fv_tune(31, mode)
+        try:
+            t0 = time.perf_counter()
+            p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], w["N"], w["dnodes"], ctx)
+            t_create = time.perf_counter() - t0
+        finally:
+            fv.load().fv_tune(31, 1)
+        info = p.reorder_info()
+        p.assemble(w["K"], np.zeros(w["N"]), w["dheads"])
+        st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
+        p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        iters, sinfo, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
+        ctx.synchronize()
+        sec = time.perf_counter() - t0
+        ms = p.bench_spmv(1.0, 20)
+        form_id, form_name, form_bytes = p.spmv_form()
+        row("fractures-like 5M cells (irregular CSR, %s), transient, 100 steps, dt=1s, Jacobi-PCG rtol 1e-10" % label, p.N, 100, sec,
+            pcg_iters_per_step=float(iters.mean()), converged=bool(sinfo.converged), problem_create_s=t_create,
+            renumbered=info["reordered"], renumbering_s=info["seconds"], mean_face_distance=[info["mean_before"], info["mean_after"]],
+            spmv={"form": form_name, "ms": ms, "GB/s": form_bytes / (ms * 1e-3) / 1e9, "frac_of_peak": form_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        p.close()
     return rows
 
 

@@ -287,6 +287,12 @@ class Problem:
     SPMV_FORMS = {-1: "none yet", 0: "CSR wave-stream", 1: "sliced-DIA, slice by slice", 2: "sliced-DIA, plane-marching",
                   3: "symmetric plane-marching (diagonal + 3 upper diagonals)"}
 
+    def reorder_info(self):
+        """fv_problem_reorder_info -> dict(reordered, mean_before, mean_after, seconds)."""
+        r, a, b, t = C.c_int32(), C.c_double(), C.c_double(), C.c_double()
+        self.check(load().fv_problem_reorder_info(self.handle, C.byref(r), C.byref(a), C.byref(b), C.byref(t)))
+        return dict(reordered=bool(r.value), mean_before=a.value, mean_after=b.value, seconds=t.value)
+
     def spmv_form(self):
         """(form id, form name, bytes one launch of it must move) of the most recent SpMV (fv_spmv_form)."""
         form, nbytes = C.c_int32(), C.c_int64()

@@ -1003,7 +1003,7 @@ extern "C" int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, d
         return FV_ERR_STATE;
     }
     FV_TRY(fv_pcg_prepare(p));
-    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, r_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_free_in(p, p->tmp.p, r_free));
     FV_TRY(fv_amg_apply_device(p, p->tmp.p, p->rhs.p, sigma));
-    return fv_copy(ctx, z_free, p->rhs.p, (size_t)p->n * sizeof(double));
+    return fv_free_out(p, z_free, p->rhs.p);
 }

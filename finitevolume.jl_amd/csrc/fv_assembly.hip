@@ -11,6 +11,9 @@
 // Compiled with -ffp-contract=off (Julia does not fuse a*b+c).
 #include "fv_internal.h"
 
+#include <chrono>
+#include <cmath>
+
 constexpr uint32_t SLOT_DIRICHLET = 0x7fffffffu;
 constexpr uint32_t SLOT_FIRST = 0x80000000u;
 
@@ -88,7 +91,143 @@ int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes)
     return FV_OK;
 }
 
-__global__ __launch_bounds__(FV_BLOCK) void export_maps_kernel(const int32_t *__restrict__ nodemap, int64_t N,
+// ------------------------------------------------------------------ locality re-numbering of the free cells
+int g_reorder = 1; // fv_tune key 31: 0 never, 1 when the mesh is numbered badly and the re-numbering helps, 2 always (tests)
+
+__global__ __launch_bounds__(FV_BLOCK) void apply_perm_kernel(int64_t N, const int32_t *__restrict__ perm, int32_t *__restrict__ nodemap,
+                                                               int32_t *__restrict__ f2n, int32_t *__restrict__ iperm)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= N)
+        return;
+    const int32_t c = nodemap[i]; // canonical free index
+    if (c >= 0) {
+        const int32_t r = perm[c];
+        nodemap[i] = r;
+        f2n[r] = (int32_t)i;
+        iperm[r] = c;
+    }
+}
+
+// dst[perm[i] + k n] = src[i + k n] (SCATTER = in) or dst[i + k n] = src[perm[i] + k n] (out)
+template <bool SCATTER>
+__global__ __launch_bounds__(FV_BLOCK) void permute_kernel(int64_t n, int64_t count, const int32_t *__restrict__ perm, const double *__restrict__ src,
+                                                            double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const int64_t r = perm[i];
+    for (int64_t k = 0; k < count; k++) {
+        if (SCATTER)
+            dst[k * n + r] = src[k * n + i];
+        else
+            dst[k * n + i] = src[k * n + r];
+    }
+}
+
+int fv_free_in(fv_problem *p, double *dst_dev, const double *src, int64_t count)
+{
+    fv_ctx *ctx = p->ctx;
+    const size_t bytes = (size_t)(p->n * count) * sizeof(double);
+    if (bytes == 0)
+        return FV_OK;
+    if (!p->reordered) {
+        FV_HIP(ctx, hipMemcpyAsync(dst_dev, src, bytes, hipMemcpyDefault, ctx->stream));
+        return FV_OK;
+    }
+    if (p->stage.n < (size_t)(p->n * count))
+        FV_TRY(p->stage.alloc(ctx, (size_t)(p->n * count)));
+    FV_HIP(ctx, hipMemcpyAsync(p->stage.p, src, bytes, hipMemcpyDefault, ctx->stream));
+    hipLaunchKernelGGL(permute_kernel<true>, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, count, (const int32_t *)p->perm.p,
+                       (const double *)p->stage.p, dst_dev);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+int fv_free_out(fv_problem *p, double *dst, const double *src_dev, int64_t count)
+{
+    fv_ctx *ctx = p->ctx;
+    const size_t bytes = (size_t)(p->n * count) * sizeof(double);
+    if (bytes == 0)
+        return FV_OK;
+    if (!p->reordered)
+        return fv_copy(ctx, dst, src_dev, bytes);
+    if (p->stage.n < (size_t)(p->n * count))
+        FV_TRY(p->stage.alloc(ctx, (size_t)(p->n * count)));
+    hipLaunchKernelGGL(permute_kernel<false>, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, count, (const int32_t *)p->perm.p, src_dev,
+                       p->stage.p);
+    FV_LAUNCH_CHECK(ctx);
+    return fv_copy(ctx, dst, p->stage.p, bytes);
+}
+
+// Looks at how far apart the two cells of a face are numbered; when that is far worse than a mesh of this size needs
+// (mean |i - j| above 2 n^(2/3), the scale of a well-numbered 3-D grid) a reverse Cuthill-McKee order of the free cells is
+// computed (host, fv_host_locality_order) and adopted if it at least halves that distance.  The fractures-like 5M-cell
+// mesh of the bench — cells numbered at random inside each fracture, as DFN generators leave them — goes from a mean
+// distance of ~8e4 to ~5e2, its SpMV from 2.2 to 5 TB/s (profiles/r02_reorder_fractures.log).  Called between
+// fv_build_maps and fv_build_symbolic: everything built afterwards is in the new numbering.
+static int fv_reorder_free(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t n = p->n, F = p->F, N = p->N;
+    if (g_reorder == 0 || n < 2 || F < 1 || (g_reorder == 1 && n < 65536))
+        return FV_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int32_t> a((size_t)F), b((size_t)F), map((size_t)N);
+    FV_HIP(ctx, hipMemcpy(a.data(), p->node1.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, hipMemcpy(b.data(), p->node2.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, hipMemcpy(map.data(), p->nodemap.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int64_t m = 0;
+    double sum = 0.0;
+    for (int64_t k = 0; k < F; k++) { // faces between two free cells, in canonical free indices
+        const int32_t fa = map[(size_t)a[(size_t)k]], fb = map[(size_t)b[(size_t)k]];
+        if (fa >= 0 && fb >= 0 && fa != fb) {
+            a[(size_t)m] = fa;
+            b[(size_t)m] = fb;
+            sum += fabs((double)fa - (double)fb);
+            m++;
+        }
+    }
+    if (m == 0)
+        return FV_OK;
+    p->reorder_mean_before = sum / (double)m;
+    if (g_reorder == 1 && p->reorder_mean_before <= 2.0 * pow((double)n, 2.0 / 3.0))
+        return FV_OK; // numbered like a grid (or better): nothing to gain
+    std::vector<int32_t> perm((size_t)n);
+    double before = 0.0, after = 0.0;
+    FV_TRY(fv_host_locality_order(n, m, a.data(), b.data(), perm.data(), &before, &after));
+    p->reorder_mean_after = after;
+    if (g_reorder == 1 && after * 2.0 >= before)
+        return FV_OK;
+    FV_TRY(p->perm.alloc(ctx, (size_t)n));
+    FV_TRY(p->iperm.alloc(ctx, (size_t)n));
+    FV_HIP(ctx, hipMemcpy(p->perm.p, perm.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(apply_perm_kernel, dim3(fv_blocks(N)), dim3(FV_BLOCK), 0, ctx->stream, N, (const int32_t *)p->perm.p, p->nodemap.p, p->f2n.p,
+                       p->iperm.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->reordered = true;
+    p->reorder_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return FV_OK;
+}
+
+extern "C" int fv_problem_reorder_info(fv_problem *p, int32_t *reordered, double *mean_before, double *mean_after, double *seconds)
+{
+    if (!p)
+        return FV_ERR_ARG;
+    if (reordered)
+        *reordered = p->reordered ? 1 : 0;
+    if (mean_before)
+        *mean_before = p->reorder_mean_before;
+    if (mean_after)
+        *mean_after = p->reorder_mean_after;
+    if (seconds)
+        *seconds = p->reorder_seconds;
+    return FV_OK;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void export_maps_kernel(const int32_t *__restrict__ nodemap, const int32_t *__restrict__ iperm, int64_t N,
                                                                 uint8_t *__restrict__ freenode, int64_t *__restrict__ n2f)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
@@ -96,7 +235,7 @@ __global__ __launch_bounds__(FV_BLOCK) void export_maps_kernel(const int32_t *__
         return;
     const int32_t m = nodemap[i];
     freenode[i] = m >= 0;
-    n2f[i] = m >= 0 ? (int64_t)m + 1 : -1; // FiniteVolume.jl:35-41
+    n2f[i] = m >= 0 ? (int64_t)(iperm ? iperm[m] : m) + 1 : -1; // FiniteVolume.jl:35-41: the rank among the free nodes
 }
 
 __global__ __launch_bounds__(FV_BLOCK) void export_dirmap_kernel(const int32_t *__restrict__ nodemap, int64_t N,
@@ -114,7 +253,8 @@ static int export_free_maps(fv_problem *p, uint8_t *freenode, int64_t *nodei2fre
     DevBuf<int64_t> dm;
     FV_TRY(df.alloc(ctx, (size_t)p->N));
     FV_TRY(dm.alloc(ctx, (size_t)p->N));
-    hipLaunchKernelGGL(export_maps_kernel, dim3(fv_blocks(p->N)), dim3(FV_BLOCK), 0, ctx->stream, p->nodemap.p, p->N, df.p, dm.p);
+    hipLaunchKernelGGL(export_maps_kernel, dim3(fv_blocks(p->N)), dim3(FV_BLOCK), 0, ctx->stream, (const int32_t *)p->nodemap.p,
+                       p->reordered ? (const int32_t *)p->iperm.p : (const int32_t *)nullptr, p->N, df.p, dm.p);
     FV_LAUNCH_CHECK(ctx);
     if (freenode)
         FV_TRY(fv_copy(ctx, freenode, df.p, (size_t)p->N));
@@ -503,10 +643,12 @@ extern "C" int fv_assemble(fv_problem *p, int64_t nK, const double *conductiviti
 }
 
 // ------------------------------------------------------------------ problem lifecycle
-static int finish_problem(fv_problem *p, const int64_t *dirichletnodes)
+static int finish_problem(fv_problem *p, const int64_t *dirichletnodes, bool face_list = false)
 {
     fv_ctx *ctx = p->ctx;
     FV_TRY(fv_build_maps(p, dirichletnodes));
+    if (face_list) // a mesh given as a face list may be numbered any way; regulargrid's numbering is the structured kernels' own
+        FV_TRY(fv_reorder_free(p));
     // keep the Dirichlet nodes (0-based, caller order) for the source validation
     FV_TRY(p->dnodes0.alloc(ctx, (size_t)p->ndir));
     if (p->ndir > 0) {
@@ -574,7 +716,7 @@ extern "C" int fv_problem_create(fv_ctx *ctx, int64_t N, int64_t F, const int64_
             if ((rc = fv_copy(ctx, p->aol.p, areasoverlengths, (size_t)F * sizeof(double))))
                 break;
         }
-        rc = finish_problem(p, dirichletnodes);
+        rc = finish_problem(p, dirichletnodes, true);
     } while (0);
     if (rc != FV_OK) {
         delete p;
@@ -740,6 +882,81 @@ extern "C" int fv_problem_get_grid(fv_problem *p, int64_t *node1, int64_t *node2
 }
 
 // ------------------------------------------------------------------ exports
+// A re-numbered problem exports the matrix in the caller's (canonical) numbering: column i of the CSC is internal row
+// perm[i], its entries go back through iperm and are put in ascending canonical order — the same arrays, bit for bit, the
+// un-numbered problem would have produced (values are folded per entry in face order, which no numbering changes).
+__global__ __launch_bounds__(FV_BLOCK) void canon_len_kernel(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ rowptr,
+                                                              int32_t *__restrict__ len)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n) {
+        const int32_t r = perm[i];
+        len[i] = rowptr[r + 1] - rowptr[r];
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void canon_rows_kernel(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ iperm,
+                                                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                               const double *__restrict__ vals, const int32_t *__restrict__ start,
+                                                               int64_t *__restrict__ colptr_out, int64_t *__restrict__ rowval_out,
+                                                               double *__restrict__ nzval_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i > n)
+        return;
+    if (colptr_out)
+        colptr_out[i] = (int64_t)start[i] + 1;
+    if (i == n || !rowval_out)
+        return;
+    const int32_t r = perm[i], s0 = rowptr[r], len = rowptr[r + 1] - s0;
+    const int64_t o = start[i];
+    for (int32_t k = 0; k < len; k++) { // insertion sort by canonical column (rows are short)
+        const int64_t c = (int64_t)iperm[colind[s0 + k]] + 1;
+        const double v = vals ? vals[s0 + k] : 0.0;
+        int32_t j = k;
+        while (j > 0 && rowval_out[o + j - 1] > c) {
+            rowval_out[o + j] = rowval_out[o + j - 1];
+            if (nzval_out)
+                nzval_out[o + j] = nzval_out[o + j - 1];
+            j--;
+        }
+        rowval_out[o + j] = c;
+        if (nzval_out)
+            nzval_out[o + j] = v;
+    }
+}
+
+static int get_csc_canonical(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t n = p->n, nnz = p->nnz;
+    DevBuf<int32_t> len, start;
+    DevBuf<int64_t> cp, rv;
+    DevBuf<double> nz;
+    FV_TRY(len.alloc(ctx, (size_t)n));
+    FV_TRY(start.alloc(ctx, (size_t)n + 1));
+    hipLaunchKernelGGL(canon_len_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)p->perm.p, (const int32_t *)p->rowptr.p,
+                       len.p);
+    FV_LAUNCH_CHECK(ctx);
+    int64_t total = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, len.p, start.p, n, &total));
+    FV_TRY(cp.alloc(ctx, (size_t)n + 1));
+    FV_TRY(rv.alloc(ctx, (size_t)nnz));
+    if (nzval)
+        FV_TRY(nz.alloc(ctx, (size_t)nnz));
+    hipLaunchKernelGGL(canon_rows_kernel, dim3(fv_blocks(n + 1)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)p->perm.p,
+                       (const int32_t *)p->iperm.p, (const int32_t *)p->rowptr.p, (const int32_t *)p->colind.p,
+                       nzval ? (const double *)p->vals.p : (const double *)nullptr, (const int32_t *)start.p, cp.p, rv.p, nzval ? nz.p : (double *)nullptr);
+    FV_LAUNCH_CHECK(ctx);
+    if (colptr)
+        FV_TRY(fv_copy(ctx, colptr, cp.p, (size_t)(n + 1) * sizeof(int64_t)));
+    if (rowval)
+        FV_TRY(fv_copy(ctx, rowval, rv.p, (size_t)nnz * sizeof(int64_t)));
+    if (nzval)
+        FV_TRY(fv_copy(ctx, nzval, nz.p, (size_t)nnz * sizeof(double)));
+    return FV_OK;
+}
+
 extern "C" int fv_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval)
 {
     if (!p)
@@ -750,6 +967,8 @@ extern "C" int fv_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, doubl
         fv_set_error(ctx, "fv_get_csc: call fv_assemble first");
         return FV_ERR_STATE;
     }
+    if (p->reordered)
+        return get_csc_canonical(p, colptr, rowval, nzval);
     DevBuf<int64_t> w;
     if (colptr) {
         FV_TRY(w.alloc(ctx, (size_t)p->n + 1));
@@ -775,7 +994,7 @@ extern "C" int fv_get_b(fv_problem *p, double *b)
         fv_set_error(p->ctx, "fv_get_b: call fv_assemble first");
         return FV_ERR_STATE;
     }
-    return fv_copy(p->ctx, b, p->b.p, (size_t)p->n * sizeof(double));
+    return fv_free_out(p, b, p->b.p);
 }
 
 // freenodes2nodes: FiniteVolume.jl:146-153
@@ -831,7 +1050,7 @@ extern "C" int fv_freenodes2nodes(fv_problem *p, const double *result_free, doub
     DevBuf<double> uf, hd;
     FV_TRY(uf.alloc(ctx, (size_t)p->n));
     FV_TRY(hd.alloc(ctx, (size_t)p->N));
-    FV_HIP(ctx, hipMemcpyAsync(uf.p, result_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_free_in(p, uf.p, result_free));
     FV_TRY(fv_scatter_nodes(p, uf.p, hd.p));
     return fv_copy(ctx, head_nodes, hd.p, (size_t)p->N * sizeof(double));
 }

@@ -150,6 +150,11 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
         fv_set_error(ctx, "fv_dist_setup: problem is already a row block");
         return FV_ERR_STATE;
     }
+    if (pg->reordered) { // row ranges are ranges of the caller's free-cell numbering; a re-numbered problem has another one inside
+        fv_set_error(ctx, "fv_dist_setup: the problem's free cells were re-numbered for locality at creation; create it with fv_tune(31, 0) "
+                          "to cut row blocks in the caller's numbering");
+        return FV_ERR_STATE;
+    }
     const int64_t n = pg->n;
     fv_dist *d = new fv_dist();
     d->nranks = nranks;

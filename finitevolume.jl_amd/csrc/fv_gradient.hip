@@ -135,8 +135,8 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
     int accumulate = 0;
     for (int64_t k0 = 0; k0 + 1 < nt; k0 += chunk - 1) {
         const int64_t kc = nt - k0 < chunk ? nt - k0 : chunk;
-        FV_HIP(ctx, hipMemcpyAsync(X.p, x_knots + k0 * n, (size_t)(kc * n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        FV_HIP(ctx, hipMemcpyAsync(L.p, lam_knots + k0 * n, (size_t)(kc * n) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        FV_TRY(fv_free_in(p, X.p, x_knots + k0 * n, kc)); // the knots arrive in the caller's numbering of the free cells
+        FV_TRY(fv_free_in(p, L.p, lam_knots + k0 * n, kc));
         FV_HIP(ctx, hipMemcpyAsync(T.p, ts + k0, (size_t)kc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (F > 0)
             hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, (const double *)T.p,
@@ -152,6 +152,6 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
     }
     FV_HIP(ctx, hipMemcpy(face_k, gk.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
     FV_HIP(ctx, hipMemcpy(face_dir, gd.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
-    FV_HIP(ctx, hipMemcpy(row_src, gs.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    FV_TRY(fv_free_out(p, row_src, gs.p));
     return FV_OK;
 }

@@ -149,6 +149,15 @@ struct fv_problem {
     DevBuf<int32_t> nodemap; // N: >= 0 free index, < 0: -(dirichlet position + 1), last occurrence wins
     DevBuf<int32_t> f2n;     // n: free index -> node
     DevBuf<int32_t> dnodes0; // ndir: Dirichlet nodes, 0-based, caller order
+    // Locality re-numbering of the free cells (fv_reorder_free, face-list meshes that arrive numbered at random): every
+    // device array indexed by free cell — nodemap's values, f2n, the CSR, b, D, the state vectors — is in the internal
+    // numbering; perm[canonical] = internal, iperm[internal] = canonical, canonical = rank among the free nodes
+    // (FiniteVolume.jl:32-44).  Free-indexed data crosses the C ABI in the canonical numbering (fv_free_in / fv_free_out,
+    // fv_get_csc, fv_problem_get_free_maps), so callers never see the difference.
+    DevBuf<int32_t> perm, iperm;
+    DevBuf<double> stage; // n doubles: staging of permuted transfers
+    bool reordered = false;
+    double reorder_mean_before = 0.0, reorder_mean_after = 0.0, reorder_seconds = 0.0;
 
     // symbolic structure of assembleA
     DevBuf<int32_t> incptr;    // n+1: incident (face,end) entries per free row
@@ -260,6 +269,12 @@ int fv_narrow_indices(fv_ctx *ctx, const int64_t *src, int32_t *dst, int64_t n, 
 int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count); // ascending indices of the set flags
 int fv_scatter_nodes(fv_problem *p, const double *ufree_dev, double *head_dev); // freenodes2nodes on device buffers
 int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev);  // u[freenodes]
+// free-indexed vectors across the ABI: src/dst_host_or_dev are in the canonical numbering of the free cells, the device
+// side in the problem's internal one (the same unless p->reordered).  count vectors of n doubles, one after the other.
+int fv_free_in(fv_problem *p, double *dst_dev, const double *src_host_or_dev, int64_t count = 1);
+int fv_free_out(fv_problem *p, double *dst_host_or_dev, const double *src_dev, int64_t count = 1);
+// fv_host.cpp
+int fv_host_locality_order(int64_t n, int64_t m, const int32_t *ea, const int32_t *eb, int32_t *perm, double *mean_before, double *mean_after);
 
 // ---- fv_pcg.hip
 int fv_pcg_prepare(fv_problem *p);

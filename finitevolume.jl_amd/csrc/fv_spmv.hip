@@ -293,6 +293,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt;        // fv_pcg.hip
+extern int g_reorder;                       // fv_assembly.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -350,6 +351,8 @@ extern "C" int fv_tune(int key, int value)
         g_symdia_dbg = value;
     else if (key == 30 && value >= 1 && value <= 8)
         g_blocks_per_cu = value;
+    else if (key == 31 && value >= 0 && value <= 2)
+        g_reorder = value;
     else
         return FV_ERR_ARG;
     return FV_OK;

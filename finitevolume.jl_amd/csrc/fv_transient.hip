@@ -68,7 +68,7 @@ extern "C" int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol
     }
     double *x = p->tmp.p;
     if (x0_free)
-        FV_HIP(ctx, hipMemcpyAsync(x, x0_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+        FV_TRY(fv_free_in(p, x, x0_free));
     fv_solve_info local;
     double *saved_hist = p->hist.p;
     const int64_t saved_cap = p->hist_cap;
@@ -119,7 +119,7 @@ extern "C" int fv_solve_steady(fv_problem *p, const double *x0_free, double rtol
         local.resnorm_len = len;
     }
     if (result_free)
-        FV_TRY(fv_copy(ctx, result_free, x, (size_t)p->n * sizeof(double)));
+        FV_TRY(fv_free_out(p, result_free, x));
     if (head_nodes) {
         DevBuf<double> hd;
         FV_TRY(hd.alloc(ctx, (size_t)p->N));
@@ -239,7 +239,9 @@ extern "C" int fv_state_set_free(fv_problem *p, int32_t slot, const double *u_fr
     FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
     double *d;
     FV_TRY(slot_ptr(p, slot, &d));
-    return fv_copy(p->ctx, d, u_free, (size_t)p->n * sizeof(double));
+    FV_TRY(fv_free_in(p, d, u_free));
+    FV_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    return FV_OK;
 }
 
 extern "C" int fv_state_get_nodes(fv_problem *p, int32_t slot, double *u_nodes)
@@ -263,7 +265,7 @@ extern "C" int fv_state_get_free(fv_problem *p, int32_t slot, double *u_free)
     FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
     double *d;
     FV_TRY(slot_ptr(p, slot, &d));
-    return fv_copy(p->ctx, u_free, d, (size_t)p->n * sizeof(double));
+    return fv_free_out(p, u_free, d);
 }
 
 extern "C" int fv_state_copy(fv_problem *p, int32_t src, int32_t dst)
@@ -370,7 +372,7 @@ extern "C" int fv_transient_step(fv_problem *p, int32_t src, int32_t dst, double
     const double *bh = nullptr;
     if (bhat_free) {
         FV_TRY(dbh.alloc(ctx, (size_t)p->n));
-        FV_HIP(ctx, hipMemcpyAsync(dbh.p, bhat_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+        FV_TRY(fv_free_in(p, dbh.p, bhat_free));
         bh = dbh.p;
     }
     FV_TRY(step_impl(p, a, b, dt, bh, mode, rtol, maxiter, info, true));
@@ -658,9 +660,9 @@ extern "C" int fv_spmv(fv_problem *p, const double *x_free, double sigma, double
     if (sigma != 0.0)
         FV_TRY(need_transient(p, "fv_spmv with sigma != 0"));
     FV_TRY(fv_pcg_prepare(p));
-    FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, x_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(fv_free_in(p, p->tmp.p, x_free));
     FV_TRY(fv_spmv_launch(p, p->tmp.p, p->rhs.p, sigma, nullptr));
-    return fv_copy(ctx, y_free, p->rhs.p, (size_t)p->n * sizeof(double));
+    return fv_free_out(p, y_free, p->rhs.p);
 }
 
 extern "C" int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *avg_ms)
@@ -693,6 +695,7 @@ extern "C" int fv_dot(fv_problem *p, const double *a_free, const double *b_free,
     fv_ctx *ctx = p->ctx;
     FV_HIP(ctx, hipSetDevice(ctx->device));
     FV_TRY(fv_pcg_prepare(p));
+    // (both vectors in the caller's numbering: a dot product does not care which)
     FV_HIP(ctx, hipMemcpyAsync(p->tmp.p, a_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
     FV_HIP(ctx, hipMemcpyAsync(p->rhs.p, b_free, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
     return fv_dot_device(p, p->tmp.p, p->rhs.p, out);

@@ -107,7 +107,11 @@ def partial_problem(neighbors, areasoverlengths, N, dirichletnodes, nranks, rank
 
     sel, bounds = rank_faces(neighbors, N, dirichletnodes, nranks, rank, bounds)
     n1, n2 = _split_neighbors(neighbors)
-    p = Problem.create(_np.stack([n1[sel], n2[sel]], axis=1), _np.asarray(areasoverlengths, dtype=_np.float64)[sel], N, dirichletnodes, ctx)
+    load().fv_tune(31, 0)  # row blocks are ranges of the caller's free-cell numbering: no locality re-numbering inside
+    try:
+        p = Problem.create(_np.stack([n1[sel], n2[sel]], axis=1), _np.asarray(areasoverlengths, dtype=_np.float64)[sel], N, dirichletnodes, ctx)
+    finally:
+        load().fv_tune(31, 1)
     return p, bounds, sel
 
 

@@ -115,6 +115,11 @@ int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], const doubl
 int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t *colptr, const int64_t *rowval,
                                const double *nzval, fv_problem **out);
 void fv_problem_destroy(fv_problem *p);
+/* Whether fv_problem_create re-numbered the free cells for locality (reverse Cuthill-McKee; what the users of the reference
+ * do by hand for DFN meshes numbered at random, examples/fractures), the mean |i - j| over the faces between free cells
+ * before and after, and the seconds it took.  Purely internal: every free-indexed array crosses this ABI in the caller's
+ * numbering (rank among the free nodes, FiniteVolume.jl:32-44), fv_get_csc / fv_get_b bit for bit as without it. */
+int fv_problem_reorder_info(fv_problem *p, int32_t *reordered, double *mean_before, double *mean_after, double *seconds);
 /* N cells, F faces, n free cells, nnz stored entries of A */
 int fv_problem_sizes(fv_problem *p, int64_t *N, int64_t *F, int64_t *n, int64_t *nnz);
 int fv_problem_get_free_maps(fv_problem *p, uint8_t *freenode, int64_t *nodei2freenodei);
@@ -268,7 +273,10 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *  29: diagnosis switches of that kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no
  *      window shuffles; results are wrong when set), bit 3: load the +-1 arms instead of taking them from the neighbouring
  *      lanes [0]
- *  30: blocks per CU the SpMV grids are sized for (the symmetric kernel takes 6 when this is left at 8) [8] */
+ *  30: blocks per CU the SpMV grids are sized for (the symmetric kernel takes 6 when this is left at 8) [8]
+ *  31: locality re-numbering of the free cells of face-list meshes at fv_problem_create (fv_problem_reorder_info): 0 never,
+ *      1 when the mesh is numbered far worse than its size needs and the new order at least halves the mean distance
+ *      between the two cells of a face, 2 always; read when the problem is created [1] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
