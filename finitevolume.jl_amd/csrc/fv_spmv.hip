@@ -1171,11 +1171,17 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_symdia_march_kernel(int64_t 
 // per slice: are all of its stored offsets among 0, +-d1, +-d2, +-d3?  rest = it is a DIA slice but not such a one
 __global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                 int32_t d1, int32_t d2, int32_t d3, int64_t step, int64_t ncols,
-                                                                uint8_t *__restrict__ ok, int32_t *__restrict__ rest)
+                                                                int64_t win_lo, int64_t win_hi, uint8_t *__restrict__ ok,
+                                                                int32_t *__restrict__ rest)
 {
     const int64_t sl = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (sl >= nslices)
         return;
+    if (sl < win_lo || sl >= win_hi) { // outside the window this form serves (a row block's boundary slices): not ours either way
+        ok[sl] = 0;
+        rest[sl] = 0;
+        return;
+    }
     const int noff = sl_noff[sl];
     // the marching kernel's unclamped accesses: the slice's in-plane arms and the 128-element windows of the slice itself and
     // of the slices one plane step before and after it must lie inside [0, ncols)
@@ -1240,7 +1246,16 @@ static int build_symdia(fv_problem *p)
     fv_ctx *ctx = p->ctx;
     p->sym_state = 0;
     const int64_t ns = (p->n + 63) >> 6;
-    if (p->dist || p->nhalo > 0 || p->ndia <= 0 || p->order_stride < 4096 || p->n >= (int64_t)0x7fffffff - 4096)
+    if (p->ndia <= 0 || p->order_stride < 4096 || p->n >= (int64_t)0x7fffffff - 4096)
+        return FV_OK;
+    // a row block: only its interior pass (the slices that touch no halo slot, one contiguous window for x-slabs)
+    int64_t win_lo = 0, win_hi = ns;
+    if (p->dist) {
+        if (!p->dist->split_built || p->dist->int_hi <= p->dist->int_lo)
+            return FV_OK;
+        win_lo = p->dist->int_lo;
+        win_hi = p->dist->int_hi;
+    } else if (p->nhalo > 0)
         return FV_OK;
     // the offsets of an interior slice: 7 of them, symmetric, the largest the plane stride.  Slices next to a boundary lack
     // some (the middle slice of a grid whose lines are a whole number of slices can be the first line of its plane), so a
@@ -1266,11 +1281,11 @@ static int build_symdia(fv_problem *p)
     if (sh > 32)
         sh -= 64; // signed lane shift of the march (spmv_apply computes the same)
     hipLaunchKernelGGL(symdia_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const uint8_t *)p->sl_noff.p,
-                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n + p->nhalo, p->sym_ok.p, restflag.p);
+                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n + p->nhalo, win_lo, win_hi, p->sym_ok.p, restflag.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY(p->sym_rest.alloc(ctx, (size_t)ns));
     FV_TRY(fv_compact_flags(ctx, restflag.p, ns, p->sym_rest.p, &p->sym_nrest));
-    if ((p->ndia - p->sym_nrest) * 10 < ns * 9) { // too few slices of that shape to bother
+    if (!p->dist && (p->ndia - p->sym_nrest) * 10 < ns * 9) { // too few slices of that shape to bother
         p->sym_ok.release();
         p->sym_rest.release();
         return FV_OK;
@@ -1552,7 +1567,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         // shape the size rule does not apply.
         const bool may_march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         bool sym = false;
-        if (may_march && g_symdia && !subset) {
+        if (may_march && g_symdia && (!subset || (p->dist && subset->win_hi > subset->win_lo))) { // the whole operator, or a row block's interior pass
             if (p->sym_state < 0)
                 FV_TRY(build_symdia(p));
             if (p->sym_state == 1)
@@ -1562,7 +1577,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         const bool march_pays = sym || g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
         const bool march = may_march && march_pays;
         // the lane-major copy of all seven diagonals: everything, or just the slices the symmetric kernel leaves out
-        FV_TRY(ensure_dia_vals(p, vals, vals_tag, sym));
+        FV_TRY(ensure_dia_vals(p, vals, vals_tag, sym && !p->dist)); // (a row block's boundary pass needs its slices' values too)
         int GM = 0;
         if (g_trace_spmv > 0) { // fv_tune key 25 / FV_TRACE_SPMV: the next N kernel choices to stderr
             g_trace_spmv--;
@@ -1712,7 +1727,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         }
 #undef FV_DIA
         FV_LAUNCH_CHECK(ctx);
-        p->last_form = sym ? FV_SPMV_SYM_MARCH : (march ? FV_SPMV_DIA_MARCH : FV_SPMV_DIA);
+        if (!subset || subset->win_hi > subset->win_lo) // (a row block reports the form of its interior pass, not of the boundary slices)
+            p->last_form = sym ? FV_SPMV_SYM_MARCH : (march ? FV_SPMV_DIA_MARCH : FV_SPMV_DIA);
         const int GD = march ? GM + GR : GA; // partials written by the DIA part
         int GB = 0;
         if (ccount > 0) {
@@ -1749,8 +1765,10 @@ extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_lau
         const int64_t csr_part = csr_all / ns * p->ncsr_groups;               // the CSR groups' share, by group count
         const int64_t vec = 16 * (p->ndia * 64 < n ? p->ndia * 64 : n);       // x once, y once over the DIA rows
         if (p->last_form == FV_SPMV_SYM_MARCH) {
-            const int64_t nok = p->ndia - p->sym_nrest;
-            bytes = nok * (4 * 512 + 1) + (p->sym_nrest > 0 ? dia_all / p->ndia * p->sym_nrest : 0) + vec + csr_part;
+            // slices the symmetric kernel computes; the other DIA slices (irregular ones, first / last plane, a row block's
+            // boundary slices) in the sliced-DIA form
+            const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - p->sym_nrest;
+            bytes = nok * (4 * 512 + 1) + dia_all / p->ndia * (p->ndia - nok) + vec + csr_part;
         } else
             bytes = dia_all + vec + csr_part;
     }

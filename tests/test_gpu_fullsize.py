@@ -247,9 +247,11 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     st = p.transient_begin(0.1, None, u0)
     x = rng.standard_normal(p.n)
     lib = fv.load()
-    lib.fv_tune(25, 64)  # the kernel choices of the first block products go to stderr: the marching kernel must really run on a block's window
-    for sigma, forced in ((0.0, 2), (1 / 60.0, 2), (1 / 60.0, 1)):  # 2: marching at any size; 1: the library's choice (slices at this size)
+    lib.fv_tune(25, 200)  # the kernel choices of the first block products go to stderr: the marching kernel must really run on a block's window
+    # 9 = 2: marching at any size; 1: the library's choice; 27: the symmetric marching kernel (default; it marches at any size)
+    for sigma, forced, sym in ((0.0, 2, 1), (1 / 60.0, 2, 1), (1 / 60.0, 2, 0), (1 / 60.0, 1, 1)):
         lib.fv_tune(9, forced)
+        lib.fv_tune(27, sym)
         y_global = p.spmv(x, sigma)
         for nranks in (2, 3):
             for rank in range(nranks):
@@ -261,8 +263,10 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
                 assert np.abs(y - y_global[blk.lo : blk.hi]).max() <= 1e-13 * np.abs(y_global).max(), (nranks, rank, sigma)
                 blk.close()
     lib.fv_tune(25, 0)
+    lib.fv_tune(27, 1)
     trace = capfd.readouterr().err
-    assert "plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
+    assert "SpMV: symmetric plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
+    assert "SpMV: plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
     assert "slice-by-slice kernel, n 1227600 (+39600 halo), 620 slices (subset)" in trace  # the boundary pass of the same block
     ctx = p.ctx
     dist.comm_init(ctx, 1, 0, dist.comm_unique_id())
