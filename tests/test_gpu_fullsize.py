@@ -158,6 +158,78 @@ def test_synthetic_464_cubed_operator_identities(fv):
     assert abs(float(y @ ax) - float(x @ ay)) / (np.linalg.norm(x) * np.linalg.norm(ay)) < 1e-13  # symmetry
 
 
+def test_synthetic_464_cubed_transient_properties(fv):
+    """configs[4] as a config: the bench's 10^8-cell transient on one GPU.  Without pumping the initial state is a fixed
+    point of every step; with pumping Q and 2Q the drawdowns scale by exactly 2 (20 steps at the bench's dt = 60 s, one PCG
+    iteration each, then 5 steps at dt = 1 h, ~10 iterations each); the bench's own kernels (symmetric marching K1, K2S,
+    bursts of unpolled steps) run here."""
+    ns = [464, 464, 464]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    dh = np.full(len(dn), 1e3)
+    u0 = np.full(p.N, 1e3)
+    p.assemble(np.array([1e-5]), np.zeros(p.N), dh)
+    st = p.transient_begin(0.1, None, u0)
+    iters, info, _ = p.run_fixed(st, 60.0, 4, 1e-10)
+    assert info.converged and np.abs(st.free_values() - 1e3).max() < 1e-9
+    draw, its = [], []
+    for q in (1.0, 2.0):
+        p.assemble(np.array([1e-5]), q * src, dh)
+        st = p.transient_begin(0.1, None, u0)
+        i1, info1, _ = p.run_fixed(st, 60.0, 20, 1e-10)
+        i2, info2, _ = p.run_fixed(st, 3600.0, 5, 1e-10)
+        assert info1.converged and info2.converged
+        assert p.spmv_form()[0] == 3  # the symmetric plane-marching kernel
+        its.append((i1.copy(), i2.copy()))
+        draw.append(1e3 - st.free_values())
+    assert (its[0][0] == 1).all() and 5 <= its[0][1].mean() <= 20, its[0]
+    assert draw[0].max() > 1e-4 and draw[0].min() > -2.5e-6  # pumping only lowers heads (to the solver tolerance: 25 steps x 1e-10 x |u| ~ 1e3)
+    # linear in Q: to the solver tolerance, which is relative to the heads (1e-10 x 1e3 per step)
+    assert np.linalg.norm(draw[1] - 2 * draw[0]) / (1e3 * np.sqrt(p.n)) < 1e-8
+    assert np.linalg.norm(draw[1] - 2 * draw[0]) / np.linalg.norm(draw[1]) < 1e-3
+    # the drawdown cone sits at the well column
+    nodes = st.node_values().reshape(ns)
+    c1, c2 = ns[0] // 2, ns[1] // 2
+    assert nodes[c1, c2].min() == nodes.min() and nodes[c1, c2].max() < 1e3 - 0.4
+
+
+def test_bench_decomposition_eight_slab_assembled_ranks(fv):
+    """bench.py --gpus 8 in small: 464 x 232 x 232 cells cut into the bench's eight x-slabs of 58 planes, every rank
+    assembling only its own planes, the row-block driver with the merged 6-double all-reduce over the loopback transport
+    (eight contexts on one GPU) against the single-GPU loop: same iteration counts, states within 1e-11."""
+    from fvamd import dist
+    from tests.test_gpu_solve import _run_ranks_in_threads, relerr
+
+    ns, nranks = [464, 232, 232], 8
+    schedule = [(60.0, 20), (3600.0, 3)]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    ref = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    ref.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    u0 = np.full(ref.N, 1e3) + np.random.default_rng(1).standard_normal(ref.N)
+    st = ref.transient_begin(0.1, None, u0)
+    ref_its = np.concatenate([ref.run_fixed(st, dt, k, 1e-12)[0] for dt, k in schedule])
+    want = st.free_values()
+    ref.close()
+    planes = dist.slab_planes(ns[0], nranks)
+    assert [b - a for a, b in zip(planes, planes[1:])] == [58] * 8
+
+    def make_slab(ctx, rank):
+        p, bounds = dist.slab_problem(mins, maxs, ns, dn, nranks, rank, ctx)
+        p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+        p.transient_begin(0.1, None, u0)
+        return p, bounds
+
+    assert fv.load().fv_tune(22, 1) == 0  # one merged all-reduce per one-iteration step (the default)
+    out = _run_ranks_in_threads(fv, nranks, 464, make_slab, schedule, 1e-12, by_rank=True)
+    got = np.empty_like(want)
+    for lo, hi, state, its in out:
+        got[lo:hi] = state
+        assert np.abs(its.astype(int) - ref_its.astype(int)).max() <= 1, (its, ref_its)
+    assert relerr(got, want) < 1e-11
+
+
 # plane strides 39 600 (= 48 mod 64: centre + edge loads; lane shift -16 of the symmetric kernel), 36 100 (= 4 mod 64: 16-byte
 # windows), 36 864 (= 0 mod 64: whole-slice arms), 36 477 (odd number of rows: the last window pair straddles the end of x)
 @pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192], [41, 195, 189]])
