@@ -211,12 +211,18 @@ def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neigh
     def G(p):
         limit = max(300 // 21, 50)  # quadgk(...; maxevals=3*10^2, order=21) in the reference
         if callable(p):
-            return quad(lambda t: g(p, t), tspan[0], tspan[1], limit=limit)[0]
+            # the integrand is a polynomial between the knots of the two interpolants: integrate piece by piece
+            knots = {float(tspan[0]), float(tspan[1])}
+            for f in (p, uobs):
+                knots |= {float(t) for t in getattr(f, "ts", ()) if tspan[0] < t < tspan[1]}
+            cuts = sorted(knots)
+            if len(cuts) > 2:  # knots known: a 6-point Gauss-Legendre rule per piece is exact for these polynomials
+                xs, ws = np.polynomial.legendre.leggauss(6)
+                return float(sum(0.5 * (b - a) * sum(w * g(p, 0.5 * (a + b) + 0.5 * (b - a) * x) for x, w in zip(xs, ws)) for a, b in zip(cuts[:-1], cuts[1:])))
+            return quad(lambda t: g(p, t), tspan[0], tspan[1], limit=limit)[0]  # opaque callables: adaptive Gauss-Kronrod, as QuadGK
         pK, ps, pd = split(p)
         us_p, ts_p = backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity, **kwargs)
-        uc_p = getcontinuoussolution(us_p, ts_p)
-        # the integrand is piecewise smooth between the stored steps: integrate interval by interval
-        return float(sum(quad(lambda t: g(uc_p, t), a, b, limit=limit)[0] for a, b in zip(ts_p[:-1], ts_p[1:])))
+        return G(getcontinuoussolution(us_p, ts_p))
 
     return g, dgdu, dfdp, dgdp, du0dp, G
 

@@ -8,10 +8,14 @@
 #
 # NOTE: written without a Julia runtime (none exists in the build image, SURVEY.md
 # §8c) as a 1:1 mirror of the tested Python binding finitevolume.jl_amd/{_lib,core,
-# transient}.py.  Every ccall below names a symbol declared in include/fvhip.h.
+# transient,adjoint}.py.  Every ccall below names a symbol declared in include/fvhip.h, and
+# every function of the reference's call surface (tests/golden/reference_api.json: name and
+# positional arities taken from src/*.jl) is defined here with that arity — both checked by
+# tests/test_cabi_exports.py.
 module FiniteVolumeHIP
 
 import Libdl
+import LinearAlgebra
 import SparseArrays
 
 const libfvhip = get(ENV, "FVHIP_LIB", joinpath(@__DIR__, "..", "libfvhip.so"))
@@ -203,11 +207,31 @@ function solvediffusion(neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::V
 	return head, ch, getcsc(p), getb(p), freenode
 end
 
-# ---------------------------------------------------------------- transient, src/transient.jl:60-174
+# ---------------------------------------------------------------- transient, src/transient.jl:1-174
+# Two kinds of operator go through the same steppers, with the reference's stepper protocol
+#     stepper!(rhs, A, getb, u_k, t, dt, linearsolver, atol, callback) -> (u_new, laststeptime, increasestepsize):
+#   * a DeviceOperator (the assembled, volume-scaled operator resident on the GPU; states are DeviceVector slots) with the
+#     DevicePCG "linear solver" — the default of every method below;
+#   * a host matrix (Matrix or SparseMatrixCSC) with a user `linearsolver(A, rhs, x0) -> x`, e.g. (A, b, x0)->A \ b
+#     (test/ode.jl:36): the reference's own host sequence, nothing touches the GPU.
 struct DeviceVector          # a state slot of a Problem
 	problem::Problem
 	slot::Int32
 end
+
+struct DeviceOperator        # (D/dt + A) of a Problem after fv_transient_begin; adjoint: the transposed scaled operator
+	problem::Problem
+	adjoint::Bool
+end
+LinearAlgebra.transpose(A::DeviceOperator) = DeviceOperator(A.problem, !A.adjoint)
+Base.size(A::DeviceOperator, i::Integer) = A.problem.n
+Base.copy(A::DeviceOperator) = A             # transient.jl:140 copies A because it edits the diagonal; the device shift is not stored
+
+struct DevicePCG             # the `linearsolver` of device operators: Jacobi-PCG (or the AMG V-cycle, fv_precond_set)
+	rtol::Float64
+	maxiter::Int
+end
+DevicePCG(; rtol=sqrt(eps(Float64)), maxiter=1000) = DevicePCG(rtol, maxiter)
 
 function newstate(p::Problem)
 	s = Ref{Int32}(0)
@@ -215,6 +239,7 @@ function newstate(p::Problem)
 	return DeviceVector(p, s[])
 end
 freestate(v::DeviceVector) = v.slot == 0 ? nothing : check(v.problem.ctx, ccall((:fv_state_free, libfvhip), Cint, (Ptr{Cvoid}, Int32), v.problem.handle, v.slot))
+freestate(v) = nothing
 
 function nodevalues(v::DeviceVector)
 	out = Array{Float64}(undef, v.problem.N)
@@ -222,43 +247,105 @@ function nodevalues(v::DeviceVector)
 	return out
 end
 
-function normdiff(a::DeviceVector, b::DeviceVector)
+function freevalues(v::DeviceVector)
+	out = Array{Float64}(undef, v.problem.n)
+	check(v.problem.ctx, ccall((:fv_state_get_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), v.problem.handle, v.slot, out))
+	return out
+end
+
+function setfree!(v::DeviceVector, u)
+	check(v.problem.ctx, ccall((:fv_state_set_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), v.problem.handle, v.slot, Float64[u...]))
+	return v
+end
+
+function statedistance(a::DeviceVector, b::DeviceVector)   # norm(onestep - twostep), transient.jl:81
 	out = Ref{Float64}(0.0)
 	check(a.problem.ctx, ccall((:fv_state_norm2_diff, libfvhip), Cint, (Ptr{Cvoid}, Int32, Int32, Ref{Float64}), a.problem.handle, a.slot, b.slot, out))
 	return out[]
 end
+statedistance(a::AbstractVector, b::AbstractVector) = LinearAlgebra.norm(a - b)
 
-# backwardeuleronestep!, transient.jl:60-76 — b === nothing uses the assembled b on the device,
-# otherwise b is the volume-scaled vector getb(t) of the reference
-function backwardeuleronestep!(p::Problem, b, u_k::DeviceVector, dt; rtol=sqrt(eps(Float64)), maxiter=1000, mode=0)
+# diagonalupdate!, transient.jl:1-5,37-48 (host matrices; the device operator carries its shift in the kernels)
+function diagonalupdate!(A::Array{T, 2}, increment) where {T}
+	for k = 1:size(A, 1)
+		A[k, k] += increment
+	end
+end
+
+function diagonalupdate!(A::SparseArrays.SparseMatrixCSC, increment)
+	rv = SparseArrays.rowvals(A)
+	nz = SparseArrays.nonzeros(A)
+	for col = 1:size(A, 2), k in SparseArrays.nzrange(A, col)
+		rv[k] == col && (nz[k] += increment)
+	end
+end
+
+# scalebyvolume!, transient.jl:7-35: b and the rows of A divided by the storage of the cell behind each free unknown;
+# the Transpose method divides parent column i by volumes[i] — by the free index, as the reference does
+function scalebyvolume!(b::Vector, volumes, freenodei2nodei)
+	for k = 1:length(b)
+		b[k] /= volumes[freenodei2nodei[k]]
+	end
+end
+
+function scalebyvolume!(A::SparseArrays.SparseMatrixCSC, volumes, freenodei2nodei)
+	rv = SparseArrays.rowvals(A)
+	nz = SparseArrays.nonzeros(A)
+	for col = 1:size(A, 2), k in SparseArrays.nzrange(A, col)
+		nz[k] /= volumes[freenodei2nodei[rv[k]]]
+	end
+end
+
+function scalebyvolume!(A::LinearAlgebra.Transpose{T, S}, volumes, freenodei2nodei) where {T, S <: SparseArrays.SparseMatrixCSC}
+	nz = SparseArrays.nonzeros(A.parent)
+	for col = 1:size(A.parent, 2), k in SparseArrays.nzrange(A.parent, col)
+		nz[k] /= volumes[col]
+	end
+end
+
+# backwardeuleronestep!, transient.jl:60-76.  Device operator: b === nothing means the assembled b resident on the device,
+# otherwise b is the volume-scaled vector getb(t) of the reference (free-indexed, host).
+function backwardeuleronestep!(rhs, A::DeviceOperator, b, u_k::DeviceVector, dt, linearsolver::DevicePCG, atol)
 	dt <= 0 && error("time step must be positive")
+	p = A.problem
 	dst = newstate(p)
 	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
 	check(p.ctx, ccall((:fv_transient_step, libfvhip), Cint, (Ptr{Cvoid}, Int32, Int32, Float64, Ptr{Float64}, Cint, Float64, Int64, Ref{SolveInfo}),
-		p.handle, u_k.slot, dst.slot, dt, b === nothing ? C_NULL : Float64[b...], mode, rtol, maxiter, info))
+		p.handle, u_k.slot, dst.slot, dt, b === nothing ? Ptr{Float64}(C_NULL) : Float64[b...], A.adjoint ? 1 : 0, linearsolver.rtol, linearsolver.maxiter, info))
 	return dst
 end
 
-# Step doubling (backwardeulertwostep!, transient.jl:78-87): one full step against two half steps;
-# accept the two-half-step state when they agree to atol, otherwise hand back the first half step.
-function backwardeulertwostep!(p::Problem, getb::Function, u_k, t, dt, atol, full=nothing; kwargs...)
+function backwardeuleronestep!(rhs, A, b, u_k, dt, linearsolver, atol)   # host matrix + user linearsolver
+	dt <= 0 && error("time step must be positive")
+	@. rhs = b + u_k / dt
+	diagonalupdate!(A, 1 / dt)
+	onestep = linearsolver(A, rhs, u_k)
+	diagonalupdate!(A, -1 / dt)
+	return onestep
+end
+
+backwardeuleronestep!(rhs, A, getb::Function, u_k, t, dt, linearsolver, atol) = backwardeuleronestep!(rhs, A, getb(t), u_k, dt, linearsolver, atol)
+
+# Step doubling (backwardeulertwostep!, transient.jl:78-87): one full step against two half steps; accept the
+# two-half-step state when they agree to atol, otherwise hand back the first half step.
+function backwardeulertwostep!(rhs, A, getb, u_k, t, dt, linearsolver, atol, full=nothing)
 	if full === nothing
-		full = backwardeuleronestep!(p, getb(t), u_k, dt; kwargs...)
+		full = backwardeuleronestep!(rhs, A, getb(t), u_k, dt, linearsolver, atol)
 	end
 	half = 0.5 * dt
-	firsthalf = backwardeuleronestep!(p, getb(t), u_k, half; kwargs...)
-	secondhalf = backwardeuleronestep!(p, getb(t + half), firsthalf, half; kwargs...)
-	mismatch = normdiff(full, secondhalf)
+	firsthalf = backwardeuleronestep!(rhs, A, getb(t), u_k, half, linearsolver, atol)
+	secondhalf = backwardeuleronestep!(rhs, A, getb(t + half), firsthalf, half, linearsolver, atol)
+	mismatch = statedistance(full, secondhalf)
 	mismatch < atol && return secondhalf, dt, mismatch < atol / 4
 	return firsthalf, half, false
 end
 
-# adaptivebackwardeulerstep! (transient.jl:89-121): try the requested dt; when it is rejected, cover
-# it with accepted sub-steps (halving on rejection, doubling when the error is below atol/4, never
-# overshooting), reusing a rejected trial's half-step state as the next trial's full step.
-function adaptivebackwardeulerstep!(p::Problem, getb::Function, u_k, t, dt, atol, callback; kwargs...)
+# adaptivebackwardeulerstep! (transient.jl:89-121): try the requested dt; when it is rejected, cover it with accepted
+# sub-steps (halving on rejection, doubling when the error is below atol/4, never overshooting), reusing a rejected
+# trial's half-step state as the next trial's full step.
+function adaptivebackwardeulerstep!(rhs, A, getb, u_k, t, dt, linearsolver, atol, callback)
 	callback(t, dt)
-	state, taken, grow = backwardeulertwostep!(p, getb, u_k, t, dt, atol; kwargs...)
+	state, taken, grow = backwardeulertwostep!(rhs, A, getb, u_k, t, dt, linearsolver, atol)
 	taken < dt || return state, taken, grow
 	covered = 0.0
 	base = u_k
@@ -266,7 +353,7 @@ function adaptivebackwardeulerstep!(p::Problem, getb::Function, u_k, t, dt, atol
 	reuse = true
 	while covered < dt
 		callback(t, dt)
-		state, taken, grow = backwardeulertwostep!(p, getb, base, t + covered, want, atol, reuse ? state : nothing; kwargs...)
+		state, taken, grow = backwardeulertwostep!(rhs, A, getb, base, t + covered, want, linearsolver, atol, reuse ? state : nothing)
 		if taken == want
 			covered += taken
 			base = state
@@ -283,143 +370,312 @@ function adaptivebackwardeulerstep!(p::Problem, getb::Function, u_k, t, dt, atol
 	return state, taken, grow
 end
 
-function fixedbackwardeulerstep!(p::Problem, getb::Function, u_k, t, dt, atol, callback; kwargs...)
+function fixedbackwardeulerstep!(rhs, A, getb, u_k, t, dt, linearsolver, atol, callback)
 	callback(t, dt)
-	return backwardeuleronestep!(p, getb(t), u_k, dt; kwargs...), dt, false
+	return backwardeuleronestep!(rhs, A, getb(t), u_k, dt, linearsolver, atol), dt, false
 end
 
-# backwardeulerintegrate, transient.jl:156-174 (constant-b and getb::Function methods)
-function backwardeulerintegrate(u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; kwargs...)
-	return backwardeulerintegrate(u0, tspan, t->nothing, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity; kwargs...)
+nocallback(t, dt) = nothing
+
+# A symmetric host matrix as a device operator (D = I): the generic entry with the default solver
+function deviceoperator(A::Union{SparseArrays.SparseMatrixCSC, Matrix})
+	ctx = context()
+	S = SparseArrays.SparseMatrixCSC{Float64, Int64}(SparseArrays.sparse(A))
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	# (refused with a message that points at `linearsolver` when A is not symmetric: the device solver is a CG)
+	check(ctx, ccall((:fv_problem_create_from_csc, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+		ctx.handle, size(S, 2), S.colptr, S.rowval, S.nzval, h))
+	p = Problem(h[], ctx)
+	check(ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, 1.0, Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL)))
+	return DeviceOperator(p, false)
+end
+deviceoperator(A::DeviceOperator) = A
+deviceoperator(A::LinearAlgebra.Transpose) = deviceoperator(SparseArrays.sparse(A))
+
+# backwardeulerintegrate(u0, A, b | getb, dt0, t0, tfinal; ...), transient.jl:123-154.  Returns (us, ts) with host vectors
+# over the unknowns of A, as the reference (history = :device keeps DeviceVector handles for the methods built on it).
+function backwardeulerintegrate(u0, A, b::Vector, dt0, t0, tfinal; kwargs...)
+	return backwardeulerintegrate(u0, A, t->b, dt0, t0, tfinal; kwargs...)
 end
 
-function backwardeulerintegrate(u0, tspan, getb::Function, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, stepper! =adaptivebackwardeulerstep!, atol=1e-4, callback=(t, dt)->nothing, rtol=sqrt(eps(Float64)), maxiter=1000)
-	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
-	assemble!(p, conductivities, sources, dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
-	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], Float64[u0...]))
-	us = DeviceVector[DeviceVector(p, Int32(0))]
-	ts = [tspan[1]]
-	dt = min(dt0, tspan[2] - tspan[1])
-	while ts[end] < tspan[2]   # transient.jl:142-152
-		solution, laststeptime, increasestepsize = stepper!(p, getb, us[end], ts[end], dt, atol, callback; rtol=rtol, maxiter=maxiter)
+function backwardeulerintegrate(u0, A, getb::Function, dt0, t0, tfinal; stepper! =adaptivebackwardeulerstep!, linearsolver=DevicePCG(), atol=1e-4, callback=nocallback, history=:host)
+	device = linearsolver isa DevicePCG
+	if device
+		A = deviceoperator(A)
+		first = u0 isa DeviceVector ? u0 : setfree!(newstate(A.problem), u0)
+		rhs = nothing
+	else
+		A isa DeviceOperator && error("a user linearsolver needs a host matrix")
+		A = copy(A)                        # transient.jl:140: the steps edit the diagonal
+		first = Float64[u0...]
+		rhs = similar(first)
+	end
+	us = Any[first]
+	ts = [t0]
+	dt = min(dt0, tfinal - t0)
+	while ts[end] < tfinal
+		solution, laststeptime, increasestepsize = stepper!(rhs, A, getb, us[end], ts[end], dt, linearsolver, atol, callback)
 		push!(us, solution)
 		push!(ts, ts[end] + dt)
-		dt = increasestepsize ? min(tspan[2] - ts[end], 2 * laststeptime) : min(tspan[2] - ts[end], laststeptime)
+		dt = increasestepsize ? min(tfinal - ts[end], 2 * laststeptime) : min(tfinal - ts[end], laststeptime)
 	end
+	if device && history == :host
+		result = map(freevalues, us)
+		foreach(freestate, us)
+		return result, ts
+	end
+	return us, ts
+end
+
+function transientproblem(u0, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
+	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
+	assemble!(p, conductivities, sources, dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
+	# assembleA + assembleb + scalebyvolume!, transient.jl:157-169: D = Ss * volumes[free] lives beside the operator
+	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], u0 === nothing ? Ptr{Float64}(C_NULL) : Float64[u0...]))
+	return p
+end
+
+# backwardeulerintegrate(u0, tspan, [getb,] Ss, volumes, neighbors, ...), transient.jl:156-174.
+# keep = :all stores every outer step like the reference (100 steps of 10^7 cells are 8 GB of device slots, then of host
+# memory); keep = :last runs the default stepper with a constant b entirely on the device and returns ([u0, u(tfinal)], ts).
+function backwardeulerintegrate(u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, keep=:all, atol=1e-4, rtol=sqrt(eps(Float64)), maxiter=1000, maxsteps=1 << 20, kwargs...)
+	if keep == :last
+		isempty(kwargs) || error("keep = :last runs the default adaptive stepper with the device PCG and a constant b")
+		p = transientproblem(u0, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
+		ts = Array{Float64}(undef, maxsteps + 1)
+		nouter = Ref{Int64}(0)
+		nsolves = Ref{Int64}(0)
+		info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
+		check(p.ctx, ccall((:fv_transient_run_adaptive, libfvhip), Cint, (Ptr{Cvoid}, Int32, Float64, Float64, Float64, Float64, Float64, Int64, Int64, Ptr{Float64}, Ref{Int64}, Ref{Int64}, Ref{SolveInfo}),
+			p.handle, Int32(0), tspan[1], tspan[2], dt0, atol, rtol, maxiter, maxsteps, ts, nouter, nsolves, info))
+		return [Float64[u0...], nodevalues(DeviceVector(p, Int32(0)))], ts[1:nouter[] + 1]
+	end
+	keep == :all || error("keep must be :all or :last")
+	return backwardeulerintegrate(u0, tspan, t->nothing, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity; dt0=dt0, atol=atol, rtol=rtol, maxiter=maxiter, kwargs...)
+end
+
+function backwardeulerintegrate(u0, tspan, getb::Function, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, rtol=sqrt(eps(Float64)), maxiter=1000, linearsolver=DevicePCG(rtol, maxiter), kwargs...)
+	linearsolver isa DevicePCG || error("the assembled operator lives on the device: pass a host matrix to backwardeulerintegrate(u0, A, b, dt0, t0, tfinal; linearsolver=...) to use a custom linearsolver")
+	p = transientproblem(u0, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
+	us, ts = backwardeulerintegrate(DeviceVector(p, Int32(0)), DeviceOperator(p, false), getb, dt0, tspan[1], tspan[2]; linearsolver=linearsolver, history=:device, kwargs...)
 	result = map(nodevalues, us)   # freenodes2nodes, transient.jl:172
 	foreach(freestate, us)
 	return result, ts
 end
 
-# The same integration (default stepper, constant b) entirely on the device: only u(tfinal) comes back, with the
-# reference's `ts`.  For grids where the reference's per-step history (`us`) would not fit the host.
-function backwardeulerintegrate_last(u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, atol=1e-4, rtol=sqrt(eps(Float64)), maxiter=1000, maxsteps=1 << 20)
-	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
-	assemble!(p, conductivities, sources, dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
-	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], Float64[u0...]))
-	ts = Array{Float64}(undef, maxsteps + 1)
-	nouter = Ref{Int64}(0)
-	nsolves = Ref{Int64}(0)
-	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
-	check(p.ctx, ccall((:fv_transient_run_adaptive, libfvhip), Cint, (Ptr{Cvoid}, Int32, Float64, Float64, Float64, Float64, Float64, Int64, Int64, Ptr{Float64}, Ref{Int64}, Ref{Int64}, Ref{SolveInfo}),
-		p.handle, Int32(0), tspan[1], tspan[2], dt0, atol, rtol, maxiter, maxsteps, ts, nouter, nsolves, info))
-	return nodevalues(DeviceVector(p, Int32(0))), ts[1:nouter[] + 1]
-end
+backwardeulerintegrate_last(args...; kwargs...) = (r = backwardeulerintegrate(args...; keep=:last, kwargs...); (r[1][2], r[2]))
 
 # ---------------------------------------------------------------- adjoint hooks, transient.jl:176-216
-# getcontinuoussolution: the piecewise-linear-in-time interpolants (Interpolations.jl in the reference; written out here)
-function getcontinuoussolution(us::Vector{T}, ts::Vector) where {T <: AbstractArray}
-	return t->begin
-		(t < ts[1] || t > ts[end]) && throw(BoundsError(ts, t))
-		lininterp(us, ts, t)
-	end
+# getcontinuoussolution: the piecewise-linear-in-time interpolants (Interpolations.jl in the reference).  Callable objects
+# that keep their knots, so that integrals of products of two of them can be done exactly.
+struct LinearInterpolant{D}
+	us::Vector
+	ts::Vector{Float64}
 end
 
-function getcontinuoussolution(us::Vector{T}, ts::Vector, ::Type{Val{2}}) where {T <: AbstractArray}
-	return (i, t)->begin
-		(t < ts[1] || t > ts[end]) && throw(BoundsError(ts, t))
-		lininterp(us, ts, t)[i]
-	end
-end
-
-function freevalues(v::DeviceVector)
-	out = Array{Float64}(undef, v.problem.n)
-	check(v.problem.ctx, ccall((:fv_state_get_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), v.problem.handle, v.slot, out))
-	return out
-end
-
-# adjointintegrate(getdgdu, tspan, Ss, volumes, ...) — transient.jl:188-205.  gamma(t) = lambda(T - t) obeys
-# dgamma/dt = transpose(D^-1 A) gamma + dgdu(T - t); with w = D^-1 gamma every implicit step is the same SPD solve as a
-# forward step, which is what FV_STEP_ADJOINT (mode = 1) of fv_transient_step does.  The steppers above are reused as
-# they are; states stay on the device, lambda comes back free-indexed and reversed in time like the reference's.
-function adjointintegrate(getdgdu::Function, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, stepper! =adaptivebackwardeulerstep!, atol=1e-4, callback=(t, dt)->nothing, rtol=sqrt(eps(Float64)), maxiter=1000)
-	p = createproblem(neighbors, areasoverlengths, length(sources), dirichletnodes)
-	assemble!(p, conductivities, zeros(length(sources)), dirichletheads, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
-	check(p.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), p.handle, Ss, Float64[volumes...], Ptr{Float64}(C_NULL)))
-	check(p.ctx, ccall((:fv_state_set_free, libfvhip), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), p.handle, Int32(0), zeros(p.n)))   # gamma0 = 0
-	T = tspan[2]
-	getb = t->getdgdu(T - t)
-	gammas = DeviceVector[DeviceVector(p, Int32(0))]
-	tsgamma = [tspan[1]]
-	dt = min(dt0, tspan[2] - tspan[1])
-	while tsgamma[end] < tspan[2]
-		solution, laststeptime, increasestepsize = stepper!(p, getb, gammas[end], tsgamma[end], dt, atol, callback; rtol=rtol, maxiter=maxiter, mode=1)
-		push!(gammas, solution)
-		push!(tsgamma, tsgamma[end] + dt)
-		dt = increasestepsize ? min(tspan[2] - tsgamma[end], 2 * laststeptime) : min(tspan[2] - tsgamma[end], laststeptime)
-	end
-	result = map(freevalues, gammas)
-	foreach(freestate, gammas)
-	return reverse(result), reverse(T .- tsgamma)
-end
-
-# gradientintegrate(lambda0, du0dp, dgdp, integrateddfdplambda, tspan) — transient.jl:213-216; the integral of dgdp by
-# the composite Simpson rule over 64 panels (QuadGK in the reference; dgdp is identically zero in its workflows)
-function gradientintegrate(lambda0::Vector, du0dp, dgdp, integrateddfdplambda::Vector, tspan; kwargs...)
-	m = 64
-	h = (tspan[2] - tspan[1]) / m
-	I1 = (dgdp(tspan[1]) + dgdp(tspan[2])) * (h / 3)
-	for k = 1:m - 1
-		I1 += dgdp(tspan[1] + k * h) * ((isodd(k) ? 4 : 2) * h / 3)
-	end
-	return du0dp * lambda0 + I1 + integrateddfdplambda
-end
-
-# ---------------------------------------------------------------- gradients, transientadjointutils.jl:57-63
-# integratedfdplambda with the reference's argument list (u2: the getcontinuoussolution(us, ts, 2) object is replaced by
-# the stored states themselves, `us`/`ts_u`): the integral over tspan of dfdp(t)' * lambda(t) with the COMPLETE Jacobian
-# b_p - A_p u (every face; D^-1 by node volume), exact for the piecewise-linear u and lambda (fv_param_gradient_integral).
 function lininterp(vs::Vector, ts::Vector, t)
+	(t < ts[1] || t > ts[end]) && throw(BoundsError(ts, t))
 	k = clamp(searchsortedlast(ts, t), 1, length(ts) - 1)
 	w = (t - ts[k]) / (ts[k + 1] - ts[k])
 	return (1 - w) * vs[k] + w * vs[k + 1]
 end
+(uc::LinearInterpolant{1})(t) = lininterp(uc.us, uc.ts, t)
+(uc::LinearInterpolant{2})(i, t) = lininterp(uc.us, uc.ts, t)[i]
 
-function integratedfdplambda(us::Vector, ts_u::Vector, p::Vector, lambdas::Vector, ts_lambda::Vector, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity::Bool=false)
+getcontinuoussolution(us::Vector{T}, ts::Vector) where {T <: AbstractArray} = LinearInterpolant{1}(us, Float64[ts...])
+getcontinuoussolution(us::Vector{T}, ts::Vector, ::Type{Val{2}}) where {T <: AbstractArray} = LinearInterpolant{2}(us, Float64[ts...])
+
+# adjointintegrate(getdgdu, tspan, Ss, volumes, ...) — transient.jl:188-199: the transposed scaled operator on the device
+# (with w = D^-1 gamma every implicit step is the same SPD solve as a forward step: FV_STEP_ADJOINT of fv_transient_step)
+function adjointintegrate(getdgdu::Function, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; rtol=sqrt(eps(Float64)), maxiter=1000, kwargs...)
+	p = transientproblem(nothing, Ss, volumes, neighbors, areasoverlengths, conductivities, zeros(length(sources)), dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
+	return adjointintegrate(DeviceOperator(p, true), getdgdu, tspan; linearsolver=DevicePCG(rtol, maxiter), kwargs...)
+end
+
+# adjointintegrate(A, getdgdu, tspan) — transient.jl:201-205: gamma(t) = lambda(T - t) obeys dgamma/dt = A gamma + dgdu(T - t)
+# with A the transposed operator; returned in terms of lambda (reversed in time).  A host matrix takes the host path when a
+# `linearsolver` is given (A is rarely symmetric), a symmetric one without it is uploaded.
+function adjointintegrate(A, getdgdu::Function, tspan; dt0=1.0, kwargs...)
+	gamma0 = zeros(size(A, 2))
+	T = tspan[2]
+	gammas, tsgamma = backwardeulerintegrate(gamma0, A, t->getdgdu(T - t), dt0, tspan[1], tspan[2]; kwargs...)
+	return reverse(gammas), reverse(T .- tsgamma)
+end
+
+# Integral of a vector-valued f over [lo, hi] cut at `knots` (where interpolants have kinks): 6-point Gauss-Legendre on
+# every piece, halved until two levels agree to rtol — QuadGK.quadgk in the reference (transient.jl:208,214)
+const GLX = (0.2386191860831969, 0.6612093864662645, 0.9324695142031521)
+const GLW = (0.46791393457269104, 0.3607615730481386, 0.17132449237917036)
+function gausspiece(f, a, b)
+	c, h = 0.5 * (a + b), 0.5 * (b - a)
+	acc = nothing
+	for k = 1:3
+		v = (f(c - h * GLX[k]) + f(c + h * GLX[k])) * (GLW[k] * h)
+		acc = acc === nothing ? v : acc + v
+	end
+	return acc
+end
+function integratepiece(f, a, b, rtol, depth)
+	whole = gausspiece(f, a, b)
+	m = 0.5 * (a + b)
+	halves = gausspiece(f, a, m) + gausspiece(f, m, b)
+	(depth >= 12 || LinearAlgebra.norm(whole - halves) <= rtol * max(LinearAlgebra.norm(halves), eps(Float64))) && return halves
+	return integratepiece(f, a, m, rtol, depth + 1) + integratepiece(f, m, b, rtol, depth + 1)
+end
+function integratevector(f, lo, hi, knots=Float64[]; rtol=sqrt(eps(Float64)))
+	cuts = sort(unique(vcat([lo, hi], filter(t->lo < t < hi, knots))))
+	total = nothing
+	for k = 1:length(cuts) - 1
+		v = integratepiece(f, cuts[k], cuts[k + 1], rtol, 0)
+		total = total === nothing ? v : total + v
+	end
+	return total
+end
+knotsof(f) = f isa LinearInterpolant ? f.ts : Float64[]
+
+# gradientintegrate, transient.jl:207-216 (both methods)
+function gradientintegrate(lambdac::Function, du0dp, dgdp, dfdp::Function, tspan; kwargs...)
+	I2 = integratevector(t->dfdp(t) * lambdac(t), tspan[1], tspan[2])
+	return gradientintegrate(lambdac(0), du0dp, dgdp, I2, tspan; kwargs...)
+end
+function gradientintegrate(lambdac::LinearInterpolant{1}, du0dp, dgdp, dfdp::Function, tspan; kwargs...)
+	I2 = integratevector(t->dfdp(t) * lambdac(t), tspan[1], tspan[2], lambdac.ts)
+	return gradientintegrate(lambdac(0), du0dp, dgdp, I2, tspan; kwargs...)
+end
+function gradientintegrate(lambda0::Vector, du0dp, dgdp, integrateddfdplambda::Vector, tspan; kwargs...)
+	I1 = integratevector(t->dgdp(t), tspan[1], tspan[2])
+	return du0dp * lambda0 + I1 + integrateddfdplambda
+end
+
+# ---------------------------------------------------------------- src/transientadjointutils.jl
+# d(b - A x)/dp for p = [conductivities; sources; dirichletheads] at fixed x (free-indexed), as a sparse (np x nfree) matrix:
+# what the LinearAdjoints-generated assembleb_p / assembleA_px of the reference (transientadjointutils.jl:27-28) return,
+# written out from the assembly loops at FiniteVolume.jl:75-139.
+function parameterjacobian(x, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
 	nK, N, nd = length(conductivities), length(sources), length(dirichletheads)
-	pK, pd = p[1:nK], p[nK + N + 1:nK + N + nd]
-	prob = createproblem(neighbors, areasoverlengths, N, dirichletnodes)
-	assemble!(prob, pK, zeros(N), pd, identitymetaindex(metaindex) ? nothing : metaindex, logtransformconductivity)
-	check(prob.ctx, ccall((:fv_transient_begin, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}, Ptr{Float64}), prob.handle, Ss, Float64[volumes...], zeros(N)))
-	freenodes, nodei2freenodei = getfreenodes(N, dirichletnodes)
-	knots = sort(unique(filter(t->tspan[1] <= t <= tspan[2], vcat(ts_u, ts_lambda, [tspan[1], tspan[2]]))))
-	X = hcat([lininterp(us, ts_u, t)[freenodes] for t in knots]...)      # n x nt, column-major = knot after knot
-	L = hcat([lininterp(lambdas, ts_lambda, t) for t in knots]...)
-	facek = Array{Float64}(undef, prob.F); facedir = Array{Float64}(undef, prob.F); rowsrc = Array{Float64}(undef, prob.n)
-	check(prob.ctx, ccall((:fv_param_gradient_integral, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
-		prob.handle, length(knots), knots, X, L, 1, logtransformconductivity ? 1 : 0, facek, facedir, rowsrc))
-	result = zeros(nK + N + nd)
-	nodei2dirichleti = getnodei2dirichleti(sources, dirichletnodes)
+	freenode, nodei2freenodei = getfreenodes(N, dirichletnodes)
+	nodei2dirichleti = getnodei2dirichleti(zeros(N), dirichletnodes)
+	I = Int[]; J = Int[]; V = Float64[]
+	entry(i, j, v) = (push!(I, i); push!(J, j); push!(V, v))
+	for node = 1:N
+		freenode[node] && entry(nK + node, nodei2freenodei[node], 1.0)
+	end
 	for (i, (node1, node2)) in enumerate(neighbors)
-		result[metaindex === nothing ? i : metaindex(i)] += facek[i]
-		if freenodes[node1] != freenodes[node2]
-			result[nK + N + nodei2dirichleti[freenodes[node1] ? node2 : node1]] += facedir[i]
+		m = identitymetaindex(metaindex) ? i : metaindex(i)
+		c = logtransformconductivity ? exp(conductivities[m]) * areasoverlengths[i] : conductivities[m] * areasoverlengths[i]
+		dc = logtransformconductivity ? c : areasoverlengths[i]
+		if freenode[node1] && freenode[node2]
+			f1, f2 = nodei2freenodei[node1], nodei2freenodei[node2]
+			entry(m, f1, -dc * (x[f1] - x[f2]))
+			entry(m, f2, -dc * (x[f2] - x[f1]))
+		elseif freenode[node1] || freenode[node2]
+			fr, di = freenode[node1] ? (node1, node2) : (node2, node1)
+			f, d = nodei2freenodei[fr], nodei2dirichleti[di]
+			entry(m, f, dc * dirichletheads[d] - dc * x[f])
+			entry(nK + N + d, f, c)
 		end
 	end
-	for node = 1:N
-		if freenodes[node]
-			result[nK + node] = rowsrc[nodei2freenodei[node]]
+	return SparseArrays.sparse(I, J, V, nK + N + nd, sum(freenode))
+end
+
+function getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; kwargs...)
+	nK, N, nd = length(conductivities), length(sources), length(dirichletheads)
+	freenodes, nodei2freenodei = getfreenodes(length(u0), dirichletnodes)
+	freenodei2nodei = Dict(nodei2freenodei[node]=>node for node = 1:length(u0) if freenodes[node])
+	nfree = sum(freenodes)
+	function g(u, t)
+		uo, ue = uobs(t), u(t)
+		return sum(sigma(i, t)^2 * (ue[freenodei2nodei[i]] - uo[freenodei2nodei[i]])^2 for i in obsfreenodes)
+	end
+	function dgdu(u, t)
+		uo, ue = uobs(t), u(t)
+		result = zeros(nfree)
+		for i in obsfreenodes
+			result[i] = 2 * sigma(i, t)^2 * (ue[freenodei2nodei[i]] - uo[freenodei2nodei[i]])
 		end
+		return result
+	end
+	splitp(p) = (p[1:nK], p[nK + 1:nK + N], p[nK + N + 1:nK + N + nd])
+	function dfdp(u, t, p)
+		pK, ps, pd = splitp(p)
+		M = parameterjacobian(u(t)[freenodes], neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity)
+		# scalebyvolume!(transpose(b_p - A_px), Ss * volumes, ...), transientadjointutils.jl:29: the entries of free unknown i
+		# divided by (Ss * volumes)[i] — the FREE index, as the reference's Transpose method does (transient.jl:25-34)
+		return M * SparseArrays.spdiagm(0=>1 ./ (Ss .* volumes[1:nfree]))
+	end
+	dgdpval = zeros(nK + N + nd)
+	dgdp(u, t, p) = dgdpval
+	du0dp = SparseArrays.spzeros(nK + N + nd, nfree)
+	function G(p::Vector)
+		pK, ps, pd = splitp(p)
+		us_p, ts_p = backwardeulerintegrate(u0, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity; kwargs...)
+		return G(getcontinuoussolution(us_p, ts_p))
+	end
+	G(uc_p) = integratevector(t->[g(uc_p, t)], tspan[1], tspan[2], vcat(knotsof(uc_p), knotsof(uobs)))[1]
+	return g, dgdu, dfdp, dgdp, du0dp, G
+end
+
+# simpleintegrate, FiniteVolume.jl:262-269: the trapezoid rule over the stored knots
+function simpleintegrate(fs, ts)
+	result = 0.5 * ((ts[2] - ts[1]) * fs[1] + (ts[end] - ts[end - 1]) * fs[end])
+	for k = 2:length(ts) - 1
+		result += 0.5 * (ts[k + 1] - ts[k - 1]) * fs[k]
+	end
+	return result
+end
+
+# integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, ...), transientadjointutils.jl:57-63 ->
+# FiniteVolume.jl:271-377.  u2 = getcontinuoussolution(us, ts, Val{2}).
+#   complete = false (default): the reference's hand-unrolled terms, exactly the ones it carries — sources; for faces with
+#     one Dirichlet end the head and conductivity terms with volumes taken by FREE index and the u product entering with a
+#     plus sign; no free|free face terms; "not supported" without the log transform;
+#   complete = true: the whole Jacobian b_p - A_p u, every face, D^-1 by node volume, integrated exactly on the device
+#     (fv_param_gradient_integral) — the quantity gradientintegrate(lambdac, du0dp, dgdp, dfdp, tspan) integrates.
+function integratedfdplambda(u2, p::Vector, lambdas::Vector, ts_lambda::Vector, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; complete=false)
+	nK, N, nd = length(conductivities), length(sources), length(dirichletheads)
+	pK, pd = p[1:nK], p[nK + N + 1:nK + N + nd]
+	freenodes, nodei2freenodei = getfreenodes(N, dirichletnodes)
+	nodei2dirichleti = getnodei2dirichleti(zeros(N), dirichletnodes)
+	result = zeros(nK + N + nd)
+	mi(i) = identitymetaindex(metaindex) ? i : metaindex(i)
+	if complete
+		u2 isa LinearInterpolant || error("complete = true needs the stored solution: pass getcontinuoussolution(us, ts, Val{2})")
+		prob = transientproblem(nothing, Ss, volumes, neighbors, areasoverlengths, pK, zeros(N), dirichletnodes, pd, metaindex, logtransformconductivity)
+		knots = sort(unique(filter(t->tspan[1] <= t <= tspan[2], vcat(u2.ts, ts_lambda, [tspan[1], tspan[2]]))))
+		X = hcat([lininterp(u2.us, u2.ts, t)[freenodes] for t in knots]...)      # n x nt, column-major = knot after knot
+		L = hcat([lininterp(lambdas, ts_lambda, t) for t in knots]...)
+		facek = Array{Float64}(undef, prob.F); facedir = Array{Float64}(undef, prob.F); rowsrc = Array{Float64}(undef, prob.n)
+		check(prob.ctx, ccall((:fv_param_gradient_integral, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Cint, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+			prob.handle, length(knots), knots, X, L, 1, logtransformconductivity ? 1 : 0, facek, facedir, rowsrc))
+		for (i, (node1, node2)) in enumerate(neighbors)
+			result[mi(i)] += facek[i]
+			if freenodes[node1] != freenodes[node2]
+				result[nK + N + nodei2dirichleti[freenodes[node1] ? node2 : node1]] += facedir[i]
+			end
+		end
+		for node = 1:N
+			freenodes[node] && (result[nK + node] = rowsrc[nodei2freenodei[node]])
+		end
+		return result
+	end
+	logtransformconductivity || error("not supported")
+	lambda2 = getcontinuoussolution(lambdas, ts_lambda, Val{2})
+	lambdaintegral = simpleintegrate(lambdas, ts_lambda)
+	products = Dict{Int, Float64}()                  # the reference memoises the product integral per node
+	productintegral(node) = get!(products, node) do
+		integratevector(t->[lambda2(nodei2freenodei[node], t) * u2(node, t)], tspan[1], tspan[2], vcat(ts_lambda, knotsof(u2)))[1]
+	end
+	for node = 1:N
+		freenodes[node] && (result[nK + node] += lambdaintegral[nodei2freenodei[node]] / (Ss * volumes[node]))
+	end
+	for (i, (node1, node2)) in enumerate(neighbors)
+		freenodes[node1] == freenodes[node2] && continue
+		fr, di = freenodes[node1] ? (node1, node2) : (node2, node1)
+		f, d = nodei2freenodei[fr], nodei2dirichleti[di]
+		c = exp(pK[mi(i)]) * areasoverlengths[i]
+		storage = Ss * volumes[f]                     # by the free index, as the reference writes it
+		result[mi(i)] += c * pd[d] * lambdaintegral[f] / storage + c * productintegral(fr) / storage
+		result[nK + N + d] += c * lambdaintegral[f] / storage
 	end
 	return result
 end
