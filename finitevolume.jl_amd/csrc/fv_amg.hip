@@ -650,18 +650,17 @@ static int amg_build(fv_problem *p)
             if (amg_verbose())
                 fprintf(stderr, "[amg]   Galerkin: nnz %lld -> %lld (%.3f s)\n", (long long)nnz_cur, (long long)nnzc, amg_now() - tg0);
             if (pass == 0) {
-                std::swap(agg_total.p, agg.p);
-                std::swap(agg_total.n, agg.n);
+                agg_total.swap(agg);
             } else {
                 hipLaunchKernelGGL(amg_compose_kernel, dim3(fv_blocks(L->n)), dim3(FV_BLOCK), 0, ctx->stream, L->n, agg_total.p,
                                    (const int32_t *)agg.p);
                 FV_LAUNCH_CHECK(ctx);
                 FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
-            std::swap(cur_rowptr.p, nrp.p), std::swap(cur_rowptr.n, nrp.n);
-            std::swap(cur_colind.p, nci.p), std::swap(cur_colind.n, nci.n);
-            std::swap(cur_vals.p, nva.p), std::swap(cur_vals.n, nva.n);
-            std::swap(cur_D.p, nD.p), std::swap(cur_D.n, nD.n);
+            cur_rowptr.swap(nrp);
+            cur_colind.swap(nci);
+            cur_vals.swap(nva);
+            cur_D.swap(nD);
             rp = cur_rowptr.p;
             ci = cur_colind.p;
             va = cur_vals.p;
@@ -676,16 +675,16 @@ static int amg_build(fv_problem *p)
         AmgLevel *C = new AmgLevel();
         C->n = ncur;
         C->nnz = nnz_cur;
-        std::swap(C->o_rowptr.p, cur_rowptr.p), std::swap(C->o_rowptr.n, cur_rowptr.n);
-        std::swap(C->o_colind.p, cur_colind.p), std::swap(C->o_colind.n, cur_colind.n);
-        std::swap(C->o_vals.p, cur_vals.p), std::swap(C->o_vals.n, cur_vals.n);
-        std::swap(C->o_D.p, cur_D.p), std::swap(C->o_D.n, cur_D.n);
+        C->o_rowptr.swap(cur_rowptr);
+        C->o_colind.swap(cur_colind);
+        C->o_vals.swap(cur_vals);
+        C->o_D.swap(cur_D);
         C->rowptr = C->o_rowptr.p;
         C->colind = C->o_colind.p;
         C->vals = C->o_vals.p;
         C->D = L->D ? C->o_D.p : nullptr;
         L->nc = ncur;
-        std::swap(L->agg.p, agg_total.p), std::swap(L->agg.n, agg_total.n);
+        L->agg.swap(agg_total);
         FV_TRY(amg_members(ctx, L->n, L->agg.p, L->nc, L->memptr, L->mem));
         FV_TRY(C->x.alloc(ctx, (size_t)C->n));
         FV_TRY(C->b.alloc(ctx, (size_t)C->n));

@@ -328,6 +328,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
             rc = FV_ERR_NOMEM;
             break;
         }
+        pl->slot_bases.push_back(s0);
         pl->slots.push_back(s0);
         pl->slot_used.push_back(1);
         if (hipMemsetAsync(s0, 0, ((size_t)nloc + (size_t)nhalo + FV_VEC_PAD) * sizeof(double), ctx->stream) != hipSuccess ||

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -58,19 +59,27 @@ void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
 
 #define FV_LAUNCH_CHECK(ctx) FV_HIP(ctx, hipGetLastError())
 
+// Large arrays are handed out at staggered offsets inside their allocations (fv_tune key 32: bytes per step of the
+// stagger, 0 = off): the streaming kernels walk up to nine arrays at the same index at the same time, and when all of
+// them start at the same offset of their (2 MiB-aligned) allocations they land on the same HBM channels together.
+extern int g_alloc_skew_bytes;
+extern int g_alloc_skew_count;
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    void *base = nullptr; // what hipMalloc returned (p = base + stagger)
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release()
     {
-        if (p)
-            (void)hipFree(p);
+        if (base)
+            (void)hipFree(base);
         p = nullptr;
+        base = nullptr;
         n = 0;
     }
     int alloc(fv_ctx *ctx, size_t count)
@@ -78,14 +87,25 @@ struct DevBuf {
         release();
         if (count == 0)
             count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        size_t skew = 0;
+        if (g_alloc_skew_bytes > 0 && count * sizeof(T) >= ((size_t)1 << 22)) // arrays of 4 MiB and more
+            skew = (size_t)(g_alloc_skew_count++ % 16) * (size_t)g_alloc_skew_bytes;
+        hipError_t e = hipMalloc(&base, count * sizeof(T) + skew);
         if (e != hipSuccess) {
             p = nullptr;
+            base = nullptr;
             fv_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
             return FV_ERR_NOMEM;
         }
+        p = reinterpret_cast<T *>(static_cast<char *>(base) + skew);
         n = count;
         return FV_OK;
+    }
+    void swap(DevBuf &o)
+    {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+        std::swap(base, o.base);
     }
     int zero(fv_ctx *ctx) { FV_HIP(ctx, hipMemsetAsync(p, 0, n * sizeof(T), ctx->stream)); return FV_OK; }
 };
@@ -208,6 +228,7 @@ struct fv_problem {
     double Ss = 1.0;
     DevBuf<double> D; // Ss * volumes[free]
     std::vector<double *> slots;
+    std::vector<void *> slot_bases; // what hipMalloc returned for every state vector ever created (slots are staggered and swapped)
     std::vector<char> slot_used;
     int64_t storage_epoch = 0;  // bumped by fv_transient_begin (D changed)
     int32_t pingpong_slot = -1; // hidden state vector the fixed-dt run alternates with the caller's slot
@@ -241,7 +262,7 @@ struct fv_problem {
 
     ~fv_problem()
     {
-        for (double *s : slots)
+        for (void *s : slot_bases)
             if (s)
                 (void)hipFree(s);
         for (hipEvent_t e : prof_ev)

@@ -700,8 +700,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         // nothing to set up: r, p and the scalars are those of the interrupted solve
     } else if (use_spec) {
         in_nbb = Gv + p->spec_extra_bb;
-        std::swap(p->pvec.p, p->pnext.p);
-        std::swap(p->pvec.n, p->pnext.n);
+        p->pvec.swap(p->pnext);
         in_rz += FV_VEC_PARTIALS;
         in_rr += FV_VEC_PARTIALS;
         in_bb += FV_VEC_PARTIALS;
@@ -1178,17 +1177,30 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, i
 // vectors) and the new step's scalars follow the merged all-reduce.  A step that did not converge stops the chain there
 // as before: K1 of the step after it has run for nothing, everything later is skipped by the done flag.  The last step
 // of a burst reduces its sums itself, so the host poll sees a finished state.
+// What a row-block solve is asked for beyond the fixed-dt step with the assembled b: an explicit system
+// (A + sigma D) x = rhs (the steady solve: sigma = 0, rhs = b), or an implicit step whose forcing is a caller's
+// volume-scaled vector (b' = D * bhat, the getb(t) of transient.jl:165-174).
+struct DistSystem {
+    bool explicit_system = false;
+    double sigma = 0.0;          // explicit_system only
+    const double *rhs = nullptr; // explicit: the right-hand side; implicit: bhat (null = the assembled b)
+};
+
 static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t maxiter, fv_solve_info *info, double *x_next = nullptr,
                      const double *carry_prev = nullptr, bool speculate_in = false, bool use_spec_in = false, int chain_index = -1,
-                     int resume_it = 0, bool last_in_burst = true)
+                     int resume_it = 0, bool last_in_burst = true, const DistSystem *ds = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
     const int64_t n = p->n;
     const int Gv = vec_grid(n);
-    const double sigma = 1.0 / dt;
+    const bool explicit_sys = ds && ds->explicit_system;
+    const double sigma = explicit_sys ? ds->sigma : 1.0 / dt;
+    const double *bprime = (ds && ds->rhs) ? ds->rhs : (const double *)p->b.p;
+    const int b_times_D = (ds && !explicit_sys && ds->rhs) ? 1 : 0;
     const double *folded = nullptr;
-    FV_TRY(ensure_folded(p, sigma, &folded));
+    if (sigma != 0.0)
+        FV_TRY(ensure_folded(p, sigma, &folded));
     const double sig_mv = folded ? 0.0 : sigma;
     const int compute_minv = !(p->minv_valid && p->minv_sigma == sigma && p->minv_epoch == p->assemble_epoch);
     p->minv_valid = true;
@@ -1216,24 +1228,29 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         // r, p and the scalars are those of the interrupted solve
     } else if (use_spec) {
         // r, p' and the all-reduced set-up scalars (red[3..5]) were left by the previous step's K2S
-        std::swap(p->pvec.p, p->pnext.p);
-        std::swap(p->pvec.n, p->pnext.n);
+        p->pvec.swap(p->pnext);
         if (!defer_in) {
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
                                (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
             FV_LAUNCH_CHECK(ctx);
         }
     } else {
-        if (carry_prev && !compute_minv) {
+        if (carry_prev && !compute_minv && !ds) {
             // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
             hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->D.p,
                                dt, (const double *)u, carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
                                p->part_bb.p);
+        } else if (explicit_sys) {
+            // q = (A + sigma D) x, r0 = rhs - q
+            FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
+            hipLaunchKernelGGL(pcg_init_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, bprime, (const double *)p->q.p, p->diagA.p,
+                               sigma != 0.0 ? (const double *)p->D.p : (const double *)nullptr, sigma, 0.0, 0, (const double *)nullptr, compute_minv, 0,
+                               p->r.p, p->pvec.p, p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
         } else {
             // q = (A + sigma D) u with the matrix the iterations use (folded when available), r0 = rhs - q
             FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
-            hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->q.p,
-                               p->diagA.p, (const double *)p->D.p, sigma, dt, 0, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
+            hipLaunchKernelGGL(pcg_init_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, bprime, (const double *)p->q.p,
+                               p->diagA.p, (const double *)p->D.p, sigma, dt, b_times_D, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
                                p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
         }
         SumSet init{};
@@ -1438,8 +1455,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
                     u = snap_u[completed];
                     alt = snap_alt[completed];
                     if ((L - 1 - completed) & 1) {
-                        std::swap(p->pvec.p, p->pnext.p);
-                        std::swap(p->pvec.n, p->pnext.n);
+                        p->pvec.swap(p->pnext);
                     }
                     rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, nullptr, false, false, -1, 1);
                     if (iters_per_step)
@@ -1482,6 +1498,204 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    if (last_info)
+        *last_info = inf;
+    return rc;
+}
+
+// ------------------------------------------------------------------ row blocks beyond the fixed-dt run (collective calls)
+// solvediffusion on row blocks (FiniteVolume.jl:157-165): Jacobi-PCG on A x = b from x0 (null = 0), every rank its rows.
+extern "C" int fv_dist_solve_steady(fv_problem *p, const double *x0_local, double rtol, int64_t maxiter, double *x_local, fv_solve_info *info)
+{
+    if (!p || !p->dist || !x_local)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(fv_pcg_prepare(p));
+    double *x = p->tmp.p; // n + nhalo + pad
+    if (x0_local)
+        FV_HIP(ctx, hipMemcpyAsync(x, x0_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+    else
+        FV_HIP(ctx, hipMemsetAsync(x, 0, (size_t)p->n * sizeof(double), ctx->stream));
+    DistSystem ds;
+    ds.explicit_system = true;
+    ds.sigma = 0.0;
+    ds.rhs = p->b.p;
+    p->last_iters = 0;
+    p->spec_valid = false;
+    fv_solve_info inf = {};
+    FV_TRY(dist_step(p, x, 1.0, rtol, maxiter, &inf, nullptr, nullptr, false, false, -1, 0, true, &ds));
+    if (info)
+        *info = inf;
+    return fv_copy(ctx, x_local, x, (size_t)p->n * sizeof(double));
+}
+
+// One implicit step of the block's state (slot 0) with a caller's forcing: bhat_local = the rank's rows of the
+// volume-scaled vector getb(t) of the reference (null = the assembled b), transient.jl:60-76,165-174.
+extern "C" int fv_dist_step(fv_problem *p, double dt, const double *bhat_local, double rtol, int64_t maxiter, fv_solve_info *info)
+{
+    if (!p || !p->dist)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!(dt > 0)) {
+        fv_set_error(ctx, "time step must be positive");
+        return FV_ERR_DT;
+    }
+    FV_TRY(fv_pcg_prepare(p));
+    DistSystem ds;
+    if (bhat_local) {
+        FV_HIP(ctx, hipMemcpyAsync(p->rhs.p, bhat_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
+        ds.rhs = p->rhs.p;
+    }
+    p->spec_valid = false;
+    fv_solve_info inf = {};
+    FV_TRY(dist_step(p, p->slots[0], dt, rtol, maxiter, &inf, nullptr, nullptr, false, false, -1, 0, true, &ds));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (info)
+        *info = inf;
+    return FV_OK;
+}
+
+// || a - b ||_2 over all ranks (the step-doubling error of transient.jl:81: one more all-reduce per trial)
+static int dist_norm2_diff(fv_problem *p, const double *a, const double *b, double *out)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    int G = vec_grid(p->n);
+    if (G > FV_VEC_PARTIALS - 1)
+        G = FV_VEC_PARTIALS - 1;
+    hipLaunchKernelGGL(diff2_kernel, dim3(G), dim3(FV_BLOCK), 0, ctx->stream, p->n, a, b, p->part_bb.p);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_bb.p, G, d->red.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, d->red.p, 1, ctx->stream));
+    double *h = reinterpret_cast<double *>(ctx->pinned);
+    FV_HIP(ctx, hipMemcpyAsync(h, d->red.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = sqrt(*h);
+    return FV_OK;
+}
+
+// The default stepper of backwardeulerintegrate (step doubling, transient.jl:78-121,136-154) with constant b on row blocks:
+// the control flow of fv_transient_run_adaptive, every solve a dist_step, every error norm all-reduced, so all ranks take
+// the same decisions.  The block's state (slot 0) is advanced to tfinal; ts_out as the reference's `ts`.
+extern "C" int fv_dist_run_adaptive(fv_problem *p, double t0, double tfinal, double dt0, double atol, double rtol, int64_t maxiter,
+                                    int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves, fv_solve_info *last_info)
+{
+    if (!p || !p->dist || !(tfinal >= t0) || max_outer < 0 || (max_outer > 0 && !ts_out))
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    if (!(dt0 > 0)) {
+        fv_set_error(ctx, "time step must be positive");
+        return FV_ERR_DT;
+    }
+    FV_TRY(fv_pcg_prepare(p));
+    int32_t scratch[4] = {-1, -1, -1, -1};
+    for (int i = 0; i < 4; i++)
+        FV_TRY(fv_slot_new(p, &scratch[i]));
+    double *U = p->slots[0];
+    double *E = p->slots[(size_t)scratch[0]], *S1 = p->slots[(size_t)scratch[1]], *S2 = p->slots[(size_t)scratch[2]], *S3 = p->slots[(size_t)scratch[3]];
+    const size_t bytes = (size_t)p->n * sizeof(double);
+    fv_solve_info inf = {};
+    int64_t nout = 0, nsolves = 0;
+    p->spec_valid = false;
+    DistSystem plain; // the assembled b, no carried residual: every solve of a trial starts from its own state
+    auto solve = [&](const double *src, double *dst, double dt) -> int {
+        FV_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        nsolves++;
+        return dist_step(p, dst, dt, rtol, maxiter, &inf, nullptr, nullptr, false, false, -1, 0, true, &plain);
+    };
+    struct Trial {
+        double *result;
+        double last;
+        bool increase;
+    };
+    auto twostep = [&](const double *uk, double dt, double *onestep, bool have_onestep, double *two1, double *two, Trial *out) -> int {
+        if (!have_onestep)
+            FV_TRY(solve(uk, onestep, dt));
+        FV_TRY(solve(uk, two1, 0.5 * dt));
+        FV_TRY(solve(two1, two, 0.5 * dt));
+        double err = 0.0;
+        FV_TRY(dist_norm2_diff(p, onestep, two, &err));
+        if (err < atol)
+            *out = Trial{two, dt, err < atol / 4};
+        else
+            *out = Trial{two1, 0.5 * dt, false};
+        return FV_OK;
+    };
+    int rc = FV_OK;
+    double t = t0;
+    double dt = dt0 < tfinal - t0 ? dt0 : tfinal - t0;
+    if (ts_out && max_outer > 0)
+        ts_out[0] = t0;
+    while (rc == FV_OK && t < tfinal && nout < max_outer) {
+        Trial tr{};
+        if ((rc = twostep(U, dt, S1, false, S2, S3, &tr)) != FV_OK)
+            break;
+        const double *unew = tr.result;
+        if (tr.last < dt) { // rejected: cover dt with accepted sub-steps, transient.jl:93-120
+            bool failed = true;
+            double elapsed = 0.0, target = tr.last;
+            if (hipMemcpyAsync(E, U, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                rc = FV_ERR_HIP;
+                break;
+            }
+            std::swap(S1, S2); // the half step just computed is the next trial's full step
+            while (rc == FV_OK && elapsed < dt) {
+                if ((rc = twostep(E, target, S1, failed, S2, S3, &tr)) != FV_OK)
+                    break;
+                if (tr.last == target) {
+                    elapsed += tr.last;
+                    if (hipMemcpyAsync(E, tr.result, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+                        rc = FV_ERR_HIP;
+                        break;
+                    }
+                    if (tr.increase)
+                        target = 2 * tr.last;
+                    failed = false;
+                } else if (tr.last < target) {
+                    target = tr.last;
+                    failed = true;
+                    std::swap(S1, S2);
+                } else {
+                    fv_set_error(ctx, "Code is broken -- laststeptime should never be greater than targetdt");
+                    rc = FV_ERR_STATE;
+                    break;
+                }
+                if (dt - elapsed < target)
+                    target = dt - elapsed;
+            }
+            unew = E;
+        }
+        if (rc != FV_OK)
+            break;
+        if (hipMemcpyAsync(U, unew, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            rc = FV_ERR_HIP;
+            break;
+        }
+        t += dt;
+        nout++;
+        if (ts_out)
+            ts_out[nout] = t;
+        const double remaining = tfinal - t;
+        const double want = tr.increase ? 2 * tr.last : tr.last;
+        dt = remaining < want ? remaining : want;
+    }
+    if (rc == FV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc = FV_ERR_HIP;
+    if (rc == FV_ERR_HIP)
+        fv_set_error(ctx, "fv_dist_run_adaptive: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+    if (rc == FV_OK && t < tfinal) {
+        fv_set_error(ctx, "fv_dist_run_adaptive: %lld outer steps (max_outer) taken and t = %.17g < tfinal = %.17g; the state is u(t)", (long long)nout, t, tfinal);
+        rc = FV_ERR_STATE;
+    }
+    for (int i = 0; i < 4; i++)
+        p->slot_used[(size_t)scratch[i]] = 0;
+    if (n_outer)
+        *n_outer = nout;
+    if (n_solves)
+        *n_solves = nsolves;
     if (last_info)
         *last_info = inf;
     return rc;

@@ -37,12 +37,16 @@ int fv_slot_new(fv_problem *p, int32_t *slot)
             *slot = (int32_t)i;
             return FV_OK;
         }
-    double *d = nullptr;
-    hipError_t e = hipMalloc((void **)&d, ((size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD) * sizeof(double));
+    void *base = nullptr;
+    const size_t bytes = ((size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD) * sizeof(double);
+    const size_t skew = (g_alloc_skew_bytes > 0 && bytes >= ((size_t)1 << 22)) ? (size_t)(g_alloc_skew_count++ % 16) * (size_t)g_alloc_skew_bytes : 0;
+    hipError_t e = hipMalloc(&base, bytes + skew);
     if (e != hipSuccess) {
         fv_set_error(p->ctx, "hipMalloc of a state vector failed: %s", hipGetErrorString(e));
         return FV_ERR_NOMEM;
     }
+    double *d = reinterpret_cast<double *>(static_cast<char *>(base) + skew);
+    p->slot_bases.push_back(base);
     p->slots.push_back(d);
     p->slot_used.push_back(1);
     *slot = (int32_t)p->slots.size() - 1;
@@ -442,8 +446,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                     u = snap_u[completed];
                     alt = snap_alt[completed];
                     if ((L - 1 - completed) & 1) { // direction vectors: undo the swaps of the no-op steps behind it
-                        std::swap(p->pvec.p, p->pnext.p);
-                        std::swap(p->pvec.n, p->pnext.n);
+                        p->pvec.swap(p->pnext);
                     }
                     rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, true, alt, nullptr, false, -1, 1);
                     if (iters_per_step)

@@ -152,6 +152,29 @@ class RowBlock:
         self.ctx.check(load().fv_dist_run_fixed(self.handle, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
         return iters[: int(nsteps)], info, ms.value
 
+    def solve_steady(self, x0_local=None, rtol=1e-8, maxiter=1000):
+        """fv_dist_solve_steady (collective): Jacobi-PCG on A x = b over all ranks -> (the rank's rows of x, info)."""
+        x0 = _lib.af64(x0_local) if x0_local is not None else None
+        x = np.empty(self.nloc, np.float64)
+        info = SolveInfo()
+        self.ctx.check(load().fv_dist_solve_steady(self.handle, ptr(x0), float(rtol), int(maxiter), ptr(x), C.byref(info)))
+        return x, info
+
+    def step(self, dt, bhat_local=None, rtol=1e-8, maxiter=1000):
+        """fv_dist_step (collective): one implicit step of the block's state, optionally with the rank's rows of getb(t)."""
+        bh = _lib.af64(bhat_local) if bhat_local is not None else None
+        info = SolveInfo()
+        self.ctx.check(load().fv_dist_step(self.handle, float(dt), ptr(bh), float(rtol), int(maxiter), C.byref(info)))
+        return info
+
+    def run_adaptive(self, t0, tfinal, dt0=1.0, atol=1e-4, rtol=1e-8, maxiter=1000, max_outer=1 << 20):
+        """fv_dist_run_adaptive (collective): the default step-doubling stepper on row blocks -> (ts, nsolves, info)."""
+        ts = np.empty(int(max_outer) + 1, np.float64)
+        nout, nsol = C.c_int64(), C.c_int64()
+        info = SolveInfo()
+        self.ctx.check(load().fv_dist_run_adaptive(self.handle, float(t0), float(tfinal), float(dt0), float(atol), float(rtol), int(maxiter), int(max_outer), ptr(ts), C.byref(nout), C.byref(nsol), C.byref(info)))
+        return ts[: nout.value + 1].copy(), nsol.value, info
+
     def spmv(self, x_local, sigma=0.0):
         x = _lib.af64(x_local)
         y = np.empty(self.nloc, np.float64)

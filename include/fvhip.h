@@ -276,7 +276,9 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *  30: blocks per CU the SpMV grids are sized for (the symmetric kernel takes 6 when this is left at 8) [8]
  *  31: locality re-numbering of the free cells of face-list meshes at fv_problem_create (fv_problem_reorder_info): 0 never,
  *      1 when the mesh is numbered far worse than its size needs and the new order at least halves the mean distance
- *      between the two cells of a face, 2 always; read when the problem is created [1] */
+ *      between the two cells of a face, 2 always; read when the problem is created [1]
+ *  32: experiment: large device arrays are handed out staggered by k x `value` bytes inside their allocations, so that the
+ *      streams of a vector kernel do not start on the same HBM channels (no effect beyond run-to-run noise measured) [0] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
@@ -340,6 +342,16 @@ int fv_dist_get_plan(fv_problem *block, int64_t *rowptr_loc, int64_t *colind_loc
  * scalars by ncclAllReduce.  Collective: every rank must call it with the same arguments. */
 int fv_dist_run_fixed(fv_problem *block, double dt, int64_t nsteps, double rtol, int64_t maxiter, int32_t *iters_per_step,
                       fv_solve_info *last_info, double *total_ms);
+/* Beyond the fixed-dt run, all collective (every rank calls them with the same scalars):
+ * solvediffusion on row blocks (FiniteVolume.jl:157-165): Jacobi-PCG on A x = b from x0_local (NULL = 0), x_local = the
+ * rank's rows of the solution;  one implicit step of the block's state with a caller's forcing, bhat_local = the rank's
+ * rows of the volume-scaled getb(t) (NULL = the assembled b; transient.jl:60-76,165-174);  the default adaptive stepper
+ * (step doubling, transient.jl:78-121,136-154, one extra all-reduce per trial for norm(onestep - twostep)) with the
+ * semantics of fv_transient_run_adaptive. */
+int fv_dist_solve_steady(fv_problem *block, const double *x0_local, double rtol, int64_t maxiter, double *x_local, fv_solve_info *info);
+int fv_dist_step(fv_problem *block, double dt, const double *bhat_local, double rtol, int64_t maxiter, fv_solve_info *info);
+int fv_dist_run_adaptive(fv_problem *block, double t0, double tfinal, double dt0, double atol, double rtol, int64_t maxiter,
+                         int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves, fv_solve_info *last_info);
 int fv_dist_spmv(fv_problem *block, const double *x_local, double sigma, double *y_local); /* collective */
 /* Same kernels (interior pass + boundary pass) with the halo values supplied by the caller instead of
  * received from peers: lets one GPU rehearse any rank of an N-way partition.  Not a collective. */

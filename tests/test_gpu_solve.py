@@ -953,6 +953,83 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol, by
     return out
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_row_blocks_steady_solve_adaptive_stepper_and_host_forcing(fv, oracle, nranks):
+    """Row blocks beyond the fixed-dt run (loopback transport, one thread per rank): fv_dist_solve_steady against the
+    single-GPU steady solve and the oracle's direct solve; fv_dist_run_adaptive against fv_transient_run_adaptive (same `ts`,
+    same number of solves — every rank takes the same step-doubling decisions from all-reduced error norms); fv_dist_step
+    with a caller's volume-scaled forcing against fv_transient_step with the same bhat."""
+    import threading
+
+    from fvamd import dist
+
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (14, 11, 9), sigma=1.0)
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -3e-4
+    u0 = np.full(N, 0.5) + 0.01 * np.random.default_rng(2).standard_normal(N)
+    Ss = 0.1
+
+    def make(ctx):
+        p = fv.Problem.create(nb, aol, N, dn, ctx).assemble(K, src, dh)
+        p.transient_begin(Ss, vol, u0)
+        return p
+
+    ref = make(fv.default_context())
+    st = fv.DeviceVector(ref, 0, owned=False)
+    head_ref, x_ref, ch = ref.solve_steady(None, 1e-13, 5000, want_resnorm=False)
+    ohead = oracle.solvediffusion(nb[:, 0], nb[:, 1], aol, K, src, dn, dh, solver="direct")[0]
+    assert ch.isconverged and relerr(head_ref, ohead) < HEAD_RTOL
+    ts_ref, nsolves_ref, _ = ref.run_adaptive(st, 0.0, 4.0e3, dt0=50.0, atol=1e-5, rtol=1e-13)
+    u_adapt = st.free_values()
+    freenode, _ = ref.free_maps()
+    bhat = 1e-3 * np.random.default_rng(3).standard_normal(ref.n)
+    st.set_nodes(u0)
+    ref.step(st, st, 120.0, bhat, rtol=1e-13)
+    u_bhat = st.free_values()
+    ref.close()
+    out, errors = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = fv.Context(0)
+            dist.comm_init_local(ctx, nranks, rank, 700 + nranks)
+            p = make(ctx)
+            blk = dist.RowBlock(p, nranks, rank)
+            p.close()
+            x, info = blk.solve_steady(None, 1e-13, 5000)
+            assert info.converged
+            ts, nsolves, info = blk.run_adaptive(0.0, 4.0e3, dt0=50.0, atol=1e-5, rtol=1e-13)
+            ua = blk.state()
+            blk.close()
+            # a fresh block for the forced step (the state restarts from u0)
+            p = make(ctx)
+            blk = dist.RowBlock(p, nranks, rank)
+            p.close()
+            info = blk.step(120.0, bhat[blk.lo : blk.hi], rtol=1e-13)
+            assert info.converged
+            out[rank] = (blk.lo, blk.hi, x, ts, nsolves, ua, blk.state())
+            blk.close()
+            fv.load().fv_comm_destroy(ctx.handle)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    xs, ua, ub = np.empty_like(x_ref), np.empty_like(x_ref), np.empty_like(x_ref)
+    for lo, hi, x, ts, nsolves, a, b in out:
+        xs[lo:hi], ua[lo:hi], ub[lo:hi] = x, a, b
+        assert np.array_equal(ts, ts_ref) and nsolves == nsolves_ref
+    assert relerr(xs, x_ref) < 1e-10
+    assert relerr(ua, u_adapt) < 1e-9
+    assert relerr(ub, u_bhat) < 1e-11
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 16])  # 16: blocks thinner than a grid plane, i.e. more than two peers per rank
 def test_multi_rank_driver_over_the_loopback_transport(fv, nranks):
     import bench
