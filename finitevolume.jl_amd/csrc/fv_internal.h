@@ -232,6 +232,21 @@ struct fv_problem {
     std::vector<char> slot_used;
     int64_t storage_epoch = 0;  // bumped by fv_transient_begin (D changed)
     int32_t pingpong_slot = -1; // hidden state vector the fixed-dt run alternates with the caller's slot
+    // A fixed-dt run that ends in the carried / speculated regime leaves everything the next call needs to go on as if
+    // the two were one (the final residual in r, the prepared set-up of the next step, the previous state in the
+    // ping-pong vector): a caller stepping in chunks then pays the fresh residual (an SpMV + a vector pass) once per
+    // refresh period instead of once per call.  Valid only for the same slot, dt, assembly, storage and switches, and
+    // only until anything else touches the state or the solver's workspace (resume_ok is cleared by fv_pcg_solve's other
+    // callers and by every state setter).
+    struct FixedRunResume {
+        bool ok = false;
+        int32_t slot = -1;
+        double dt = 0.0;
+        int64_t assemble_epoch = -1, storage_epoch = -1;
+        const double *prev = nullptr; // state the last solve started from
+        int64_t steps_since_refresh = 0;
+        int refresh = 0, speculate = 0;
+    } resume;
 
     // preconditioner of the PCG: FV_PRECOND_JACOBI (fused into the vector kernels) or FV_PRECOND_AMG (fv_amg.hip)
     int precond = 0;

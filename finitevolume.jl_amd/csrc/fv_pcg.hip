@@ -19,7 +19,7 @@
 #include "fv_device.h"
 #include "fv_spmv.h"
 
-extern int g_carry_refresh, g_carry_speculate, g_chain_steps; // fv_transient.hip
+extern int g_carry_refresh, g_carry_speculate, g_chain_steps, g_resume_runs; // fv_transient.hip
 int g_defer_reduce = 1; // fv_tune key 22: bursts of chained steps take a step's verdict and the next step's scalars in one launch; row-block runs also merge their two all-reduces (see dist_step)
 int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
 int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index of every burst is treated as not converged
@@ -649,6 +649,7 @@ int fv_pcg_prepare(fv_problem *p)
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it)
 {
     fv_ctx *ctx = p->ctx;
+    p->resume.ok = false; // any solve overwrites what a finished fixed-dt run left for its successor (the run sets it again at its end)
     FV_TRY(fv_pcg_prepare(p));
     if (maxiter < 0)
         maxiter = 0;
@@ -1426,12 +1427,22 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     double *u = p->slots[0];
     double *alt = (pingpong && rc == FV_OK) ? p->slots[(size_t)p->pingpong_slot] : nullptr;
     const double *prev = nullptr;
+    int64_t s_base = 0; // go on where the previous call left off (fv_problem::resume, as fv_transient_run_fixed)
+    {
+        const fv_problem::FixedRunResume &rs = p->resume;
+        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == 0 && rs.dt == dt && rs.assemble_epoch == p->assemble_epoch &&
+            rs.storage_epoch == p->storage_epoch && rs.refresh == (int)refresh && rs.speculate == g_carry_speculate && (rs.prev == u || rs.prev == alt)) {
+            prev = rs.prev;
+            s_base = rs.steps_since_refresh;
+        }
+        p->resume.ok = false;
+    }
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         // bursts of unpolled one-iteration steps, as in fv_transient_run_fixed: with collectives in every step the host
         // needs tens of microseconds to enqueue one, which the device would otherwise spend idle after every poll
         if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
             int L = 0;
-            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s + L) % refresh) != 0)
+            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s_base + s + L) % refresh) != 0)
                 L++;
             if (L >= 2) {
                 double *snap_u[32], *snap_alt[32];
@@ -1469,7 +1480,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
                 continue;
             }
         }
-        const bool carry = prev != nullptr && (s % refresh) != 0;
+        const bool carry = prev != nullptr && ((s_base + s) % refresh) != 0;
         rc = dist_step(p, u, dt, rtol, maxiter, &inf, alt, carry ? prev : nullptr, pingpong && g_carry_speculate, carry);
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
@@ -1485,6 +1496,18 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     if (pingpong && rc == FV_OK) {
         p->slots[0] = u;
         p->slots[(size_t)p->pingpong_slot] = alt;
+        if (prev != nullptr) {
+            fv_problem::FixedRunResume &rs = p->resume;
+            rs.ok = true;
+            rs.slot = 0;
+            rs.dt = dt;
+            rs.assemble_epoch = p->assemble_epoch;
+            rs.storage_epoch = p->storage_epoch;
+            rs.prev = prev;
+            rs.steps_since_refresh = (s_base + nsteps) % refresh;
+            rs.refresh = (int)refresh;
+            rs.speculate = g_carry_speculate;
+        }
     }
     if (rc == FV_OK) {
         float ms = 0.f;
@@ -1512,6 +1535,7 @@ extern "C" int fv_dist_solve_steady(fv_problem *p, const double *x0_local, doubl
     fv_ctx *ctx = p->ctx;
     FV_HIP(ctx, hipSetDevice(ctx->device));
     FV_TRY(fv_pcg_prepare(p));
+    p->resume.ok = false;
     double *x = p->tmp.p; // n + nhalo + pad
     if (x0_local)
         FV_HIP(ctx, hipMemcpyAsync(x, x0_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
@@ -1543,6 +1567,7 @@ extern "C" int fv_dist_step(fv_problem *p, double dt, const double *bhat_local, 
         return FV_ERR_DT;
     }
     FV_TRY(fv_pcg_prepare(p));
+    p->resume.ok = false;
     DistSystem ds;
     if (bhat_local) {
         FV_HIP(ctx, hipMemcpyAsync(p->rhs.p, bhat_local, (size_t)p->n * sizeof(double), hipMemcpyDefault, ctx->stream));
@@ -1591,6 +1616,7 @@ extern "C" int fv_dist_run_adaptive(fv_problem *p, double t0, double tfinal, dou
         return FV_ERR_DT;
     }
     FV_TRY(fv_pcg_prepare(p));
+    p->resume.ok = false;
     int32_t scratch[4] = {-1, -1, -1, -1};
     for (int i = 0; i < 4; i++)
         FV_TRY(fv_slot_new(p, &scratch[i]));

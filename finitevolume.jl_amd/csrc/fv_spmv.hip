@@ -277,7 +277,7 @@ static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmet
 static int g_symdia_nt = 4; // fv_tune key 28: streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
-extern int g_chain_steps;                      // fv_transient.hip
+extern int g_chain_steps, g_resume_runs;        // fv_transient.hip
 
 int g_alloc_skew_bytes = 0, g_alloc_skew_count = 0; // fv_tune key 32 (fv_internal.h, DevBuf)
 static int g_blocks_per_cu = 8; // fv_tune key 30 (experiments): blocks per CU the SpMV grids are sized for
@@ -354,6 +354,8 @@ extern "C" int fv_tune(int key, int value)
         g_blocks_per_cu = value;
     else if (key == 31 && value >= 0 && value <= 2)
         g_reorder = value;
+    else if (key == 33 && (value == 0 || value == 1))
+        g_resume_runs = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else

@@ -227,6 +227,7 @@ extern "C" int fv_state_set_nodes(fv_problem *p, int32_t slot, const double *u_n
     fv_ctx *ctx = p->ctx;
     FV_HIP(ctx, hipSetDevice(ctx->device));
     double *d;
+    p->resume.ok = false; // the state (or the vector it alternates with) changes under a fixed-dt run's feet
     FV_TRY(slot_ptr(p, slot, &d));
     DevBuf<double> du;
     FV_TRY(du.alloc(ctx, (size_t)p->N));
@@ -242,6 +243,7 @@ extern "C" int fv_state_set_free(fv_problem *p, int32_t slot, const double *u_fr
         return FV_ERR_ARG;
     FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
     double *d;
+    p->resume.ok = false; // the state (or the vector it alternates with) changes under a fixed-dt run's feet
     FV_TRY(slot_ptr(p, slot, &d));
     FV_TRY(fv_free_in(p, d, u_free));
     FV_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
@@ -278,6 +280,7 @@ extern "C" int fv_state_copy(fv_problem *p, int32_t src, int32_t dst)
         return FV_ERR_ARG;
     FV_HIP(p->ctx, hipSetDevice(p->ctx->device));
     double *a, *b;
+    p->resume.ok = false; // the state (or the vector it alternates with) changes under a fixed-dt run's feet
     FV_TRY(slot_ptr(p, src, &a));
     FV_TRY(slot_ptr(p, dst, &b));
     if (a != b)
@@ -313,6 +316,7 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
 int g_carry_refresh = 32; // fv_tune key 7: 0 = every step computes its residual with an SpMV
 int g_carry_speculate = 1; // fv_tune key 8: the first K2 of a step also prepares the next step (pcg_update_spec_kernel)
 int g_chain_steps = 8;     // fv_tune key 13: one-iteration steps enqueued per device poll (< 2: poll every step)
+int g_resume_runs = 1;     // fv_tune key 33: a fixed-dt run goes on from the residual / set-up the previous call on the same slot left (fv_problem::resume)
 
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
                      int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
@@ -417,12 +421,24 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             alt = p->slots[(size_t)p->pingpong_slot];
     }
     const double *prev = nullptr; // state the last solve started from, while p->r holds that solve's final residual
+    // go on where the previous call on this slot left off (see fv_problem::resume): its residual, set-up and refresh count
+    int64_t s_base = 0;
+    {
+        const fv_problem::FixedRunResume &rs = p->resume;
+        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == slot && rs.dt == dt && rs.assemble_epoch == p->assemble_epoch &&
+            rs.storage_epoch == p->storage_epoch && rs.refresh == (int)refresh && rs.speculate == g_carry_speculate &&
+            (rs.prev == u || rs.prev == alt)) {
+            prev = rs.prev;
+            s_base = rs.steps_since_refresh;
+        }
+        p->resume.ok = false;
+    }
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         // One-iteration regime: a burst of steps is enqueued without polling the device in between (each step is the
         // prepared set-up + K1 + K2S + K3; a step that does not converge in its iteration stops the chain on the device).
         if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
             int L = 0;
-            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s + L) % refresh) != 0)
+            while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s_base + s + L) % refresh) != 0)
                 L++;
             if (L >= 2) {
                 double *snap_u[32], *snap_alt[32];
@@ -467,7 +483,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             prev = nullptr;
             continue;
         }
-        const bool carry = prev != nullptr && (s % refresh) != 0;
+        const bool carry = prev != nullptr && ((s_base + s) % refresh) != 0;
         rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,
                        pingpong && g_carry_speculate); // also on the last step: a 2-step warm-up then runs every kernel of the loop
         if (iters_per_step)
@@ -486,6 +502,18 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
         // u is the last state a step completed from (the failed step wrote, if anything, into alt)
         p->slots[(size_t)slot] = u;
         p->slots[(size_t)p->pingpong_slot] = alt;
+        if (rc == FV_OK && prev != nullptr && fv_step_precond(p) != FV_PRECOND_AMG) { // the next call may go on from here
+            fv_problem::FixedRunResume &rs = p->resume;
+            rs.ok = true;
+            rs.slot = slot;
+            rs.dt = dt;
+            rs.assemble_epoch = p->assemble_epoch;
+            rs.storage_epoch = p->storage_epoch;
+            rs.prev = prev;
+            rs.steps_since_refresh = (s_base + nsteps) % refresh;
+            rs.refresh = (int)refresh;
+            rs.speculate = g_carry_speculate;
+        }
     }
     if (rc == FV_OK) {
         hipError_t e = hipEventRecord(e1, ctx->stream);

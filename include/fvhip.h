@@ -278,7 +278,10 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      1 when the mesh is numbered far worse than its size needs and the new order at least halves the mean distance
  *      between the two cells of a face, 2 always; read when the problem is created [1]
  *  32: experiment: large device arrays are handed out staggered by k x `value` bytes inside their allocations, so that the
- *      streams of a vector kernel do not start on the same HBM channels (no effect beyond run-to-run noise measured) [0] */
+ *      streams of a vector kernel do not start on the same HBM channels (no effect beyond run-to-run noise measured) [0]
+ *  33: a fixed-dt run (fv_transient_run_fixed / fv_dist_run_fixed) goes on from the residual, the prepared set-up and the
+ *      refresh count the previous call on the same slot left, when dt, assembly and storage are unchanged and nothing else
+ *      has touched the state or solved in between: stepping in chunks then costs what one long call costs [1] */
 int fv_tune(int key, int value);
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);

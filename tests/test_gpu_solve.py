@@ -809,6 +809,51 @@ def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle,
             lib.fv_tune(14, -1)
 
 
+@pytest.mark.parametrize("dt", [0.0009765625, 40.0])
+def test_run_fixed_in_chunks_goes_on_where_the_previous_call_stopped(fv, dt):
+    """Stepping in chunks (to look at the state in between, as a driver that stores every k-th step does) costs what one
+    long call costs: a call picks up the residual, the prepared set-up and the refresh count the previous call on the same
+    slot left (fv_tune key 33) — the same iterations and bit for bit the same state as one call of 70 steps — unless
+    something else touched the state or solved in between, in which case it starts afresh (and still lands on the same
+    heads to the solver tolerance)."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (15, 13, 11), sigma=1.0)
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    u0 = np.full(N, 0.5)
+    rtol = 1e-13
+
+    def run(chunks, between=None, resume=1):
+        fv.load().fv_tune(33, resume)
+        try:
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+            st = p.transient_begin(0.1, vol, u0)
+            its = []
+            for k, n in enumerate(chunks):
+                it, info, _ = p.run_fixed(st, dt, n, rtol=rtol)
+                assert info.converged
+                its.append(it.copy())
+                if between is not None and k + 1 < len(chunks):
+                    between(p, st)
+            return st.node_values(), np.concatenate(its)
+        finally:
+            fv.load().fv_tune(33, 1)
+
+    whole, its_whole = run([70])
+    chunked, its_chunked = run([7, 2, 29, 32], between=lambda p, st: st.node_values())  # reading the state does not disturb anything
+    assert np.array_equal(its_whole, its_chunked) and np.array_equal(whole, chunked)
+    single, its_single = run([7, 1, 30, 32])  # a one-step call takes the plain path (no ping-pong, unfolded shift): rounding differs
+    assert relerr(single, whole) < 1e-11 and np.abs(its_single - its_whole).max() <= 1
+    fresh, its_fresh = run([7, 2, 29, 32], resume=0)  # every call starts from a fresh residual
+    assert relerr(fresh, whole) < 1e-11 and np.abs(its_fresh - its_whole).max() <= 1
+    # a write to the state between two calls must be noticed
+    poked, _ = run([35, 35], between=lambda p, st: st.set_nodes(st.node_values()))
+    assert relerr(poked, whole) < 1e-11
+    # ... and so must another solve on the same problem (it overwrites the residual the run left)
+    other, _ = run([35, 35], between=lambda p, st: p.run_fixed(p.new_state().set_nodes(u0), 2 * dt, 2, rtol=rtol))
+    assert relerr(other, whole) < 1e-11
+
+
 def test_run_fixed_at_steady_state_takes_zero_iterations(fv):
     """A state that already solves every step (no sources, u0 = the uniform Dirichlet head): each solve converges on
     entry, the ping-pong must leave the state where it is."""
