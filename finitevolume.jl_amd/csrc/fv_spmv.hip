@@ -1000,11 +1000,14 @@ __device__ inline double wave_from_above(double v, double edge)
 // dg, u1, u2, u3: starts of the padded arrays (row 0 is `front` doubles in).  The kernel has no per-lane clamps: slices
 // whose own window, or the window one plane step either side, would reach outside x (the first and the last plane) carry
 // sym_ok = 0 and are left to the slice-by-slice kernel like the irregular ones; here their windows are simply not loaded.
+// Launch bounds: 6 waves per SIMD — the grid is sized for 6 blocks per CU anyway (see spmv_apply), and 68 registers instead
+// of 64 keep everything out of scratch.  (Tried on top: touch loads of the next step's lines one step ahead, one dword per
+// lane and stream: +19 % — more loads in flight hurt, the kernel is bound by the memory pipeline, not by latency.)
 // D1: the first in-plane offset is 1 (consecutive cells of a grid line are consecutive rows) — the +-1 arms of x and the
 // -1 matrix value are then the neighbouring lanes' centre x / U1 value (DPP wave shift) plus one scalar load for the lane at
 // the slice's edge: three vector loads fewer per step (-6 % at 464^3, and fewer lines for the L2 to keep).
 template <bool DOT, int NT, bool WIN, bool D1> // NT bit 0: diag / U3 streams non-temporal, bit 1: U1 / U2 too, bit 2: y store
-__global__ __launch_bounds__(FV_BLOCK, 8) void spmv_symdia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int s, int32_t d1,
+__global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int s, int32_t d1,
                                                                           int32_t d2, int seglen, int segs_per_xcd, uint32_t front, int dbg,
                                                                           const uint8_t *__restrict__ sym_ok, const double *__restrict__ dg,
                                                                           const double *__restrict__ u1, const double *__restrict__ u2,
