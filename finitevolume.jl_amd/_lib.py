@@ -118,6 +118,7 @@ SIGNATURES = {
     "fv_dist_solve_steady": (C.c_int, [c_prob, _f64p, C.c_double, C.c_int64, _f64p, P(SolveInfo)]),
     "fv_dist_step": (C.c_int, [c_prob, C.c_double, _f64p, C.c_double, C.c_int64, P(SolveInfo)]),
     "fv_dist_run_adaptive": (C.c_int, [c_prob, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, _f64p, P(C.c_int64), P(C.c_int64), P(SolveInfo)]),
+    "fv_comm_stats": (C.c_int, [c_ctx, P(C.c_int64), P(C.c_int64), C.c_int]),
     "fv_dist_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
     "fv_dist_spmv_halo": (C.c_int, [c_prob, _f64p, _f64p, C.c_double, _f64p]),
     "fv_dist_state_get": (C.c_int, [c_prob, _f64p]),

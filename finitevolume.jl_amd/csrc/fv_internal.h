@@ -37,6 +37,7 @@ struct fv_ctx {
     void *local_group = nullptr; // loopback transport for single-device rehearsals (fv_comm_init_local)
     int local_group_id = 0;
     int nranks = 1, rank = 0;
+    int64_t n_allreduce = 0, n_halo = 0; // collectives issued through this context (fv_comm_stats)
 };
 
 void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
@@ -257,6 +258,8 @@ struct fv_problem {
 
     // PCG workspace
     DevBuf<double> r, pvec, q, minv, rhs, tmp;
+    DevBuf<double> cg_u;     // one-reduction CG on row blocks: u = M^-1 r (the SpMV's input there; s = A p lives in pnext)
+    DevBuf<double> cg_scal;  // its device scalars: alpha, beta, gamma
     DevBuf<double> pnext;    // p' of a speculatively prepared next step (swapped with pvec when used)
     bool spec_valid = false; // r, pnext and the upper halves of part_rz/rr/bb hold the next step's set-up
     int spec_extra_bb = 0;   // extra rhs.rhs partials behind the speculative half (sparse-b gather)

@@ -1178,6 +1178,94 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, i
 // vectors) and the new step's scalars follow the merged all-reduce.  A step that did not converge stops the chain there
 // as before: K1 of the step after it has run for nothing, everything later is skipped by the done flag.  The last step
 // of a burst reduces its sums itself, so the host poll sees a finished state.
+// ------------------------------------------------------------------ one-reduction PCG (Chronopoulos & Gear) on row blocks
+// The classic loop needs two global sums per iteration one after the other (p.q before alpha, r.M^-1 r before beta): two
+// all-reduce latencies on the wire.  With u = M^-1 r, w = A u and the recurrences p = u + beta p, s = w + beta s (= A p)
+// both sums of an iteration — gamma = r.u and delta = w.u, plus r.r for the stopping test — are known after ONE SpMV and
+// travel in one 3-double all-reduce:  beta = gamma'/gamma,  alpha = gamma' / (delta - beta gamma'/alpha_prev).
+// Per iteration: one fused vector pass (96 B/row: p, s, x, r, u, w, M^-1 in; p, s, x, r, u out), the block SpMV w = A u with
+// its halo exchange, one reduction launch, one all-reduce, one scalar launch.  fv_tune key 34; the classic form stays the
+// default (north_star names it; on one GPU it moves 8 B/row less).
+int g_cg_one_reduction = 0;
+
+struct CgcgScalars { // cg_scal: alpha, beta, gamma (= r.u of the iterate the current direction was built from)
+    double alpha, beta, gamma;
+};
+
+__global__ __launch_bounds__(FV_BLOCK) void cgcg_vector_kernel(int64_t n, int first, double *__restrict__ x, double *__restrict__ r,
+                                                                double *__restrict__ u, const double *__restrict__ w, double *__restrict__ pv,
+                                                                double *__restrict__ s, const double *__restrict__ minv,
+                                                                const CgcgScalars *__restrict__ cg, const PcgScalars *__restrict__ scal,
+                                                                double *__restrict__ part_g, double *__restrict__ part_rr)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    const double alpha = cg->alpha, beta = first ? 0.0 : cg->beta;
+    double ag = 0.0, arr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
+        const double pi = first ? u[i] : u[i] + beta * pv[i];
+        const double si = first ? w[i] : w[i] + beta * s[i];
+        pv[i] = pi;
+        s[i] = si;
+        x[i] += alpha * pi;
+        const double ri = r[i] - alpha * si;
+        r[i] = ri;
+        const double ui = minv[i] * ri;
+        u[i] = ui;
+        ag += ri * ui;
+        arr += ri * ri;
+    }
+    const double t0 = block_sum(ag, smem);
+    const double t1 = block_sum(arr, smem);
+    if (threadIdx.x == 0) {
+        part_g[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+    }
+}
+
+// red[0] = delta = w.u, red[1] = gamma' = r.u, red[2] = r.r (all-reduced).  init: the sums before the first iteration
+// (delta0 only; gamma0 = scal->rz[0] from the set-up): alpha0 = gamma0 / delta0.
+__global__ void cgcg_scalar_kernel(const double *__restrict__ red, int init, int it, CgcgScalars *__restrict__ cg, PcgScalars *__restrict__ scal,
+                                   double *__restrict__ hist, int64_t hist_cap)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || scal->done)
+        return;
+    const double delta = red[0];
+    if (init) {
+        if (!(delta > 0.0)) {
+            scal->pq = delta;
+            scal->done = 2;
+            return;
+        }
+        cg->gamma = scal->rz[0];
+        cg->alpha = cg->gamma / delta;
+        cg->beta = 0.0;
+        scal->pq = delta;
+        return;
+    }
+    const double gn = red[1], rr = red[2];
+    scal->rr = rr;
+    scal->iters = it + 1;
+    if (hist && it < hist_cap)
+        hist[it] = sqrt(rr);
+    if (rr <= scal->tol2) {
+        scal->done = 1;
+        return;
+    }
+    const double beta = gn / cg->gamma;
+    const double denom = delta - beta * gn / cg->alpha;
+    if (!(denom > 0.0)) { // breakdown: not positive definite, or the recurrences have drifted
+        scal->pq = denom;
+        scal->done = 2;
+        return;
+    }
+    cg->beta = beta;
+    cg->alpha = gn / denom;
+    cg->gamma = gn;
+    scal->pq = denom;
+}
+
 // What a row-block solve is asked for beyond the fixed-dt step with the assembled b: an explicit system
 // (A + sigma D) x = rhs (the steady solve: sigma = 0, rhs = b), or an implicit step whose forcing is a caller's
 // volume-scaled vector (b' = D * bhat, the getb(t) of transient.jl:165-174).
@@ -1273,6 +1361,72 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     if (chained) {
         chunk = 1;
         maxiter = 1;
+    }
+    if (g_cg_one_reduction && !speculate && !chained && !resume && maxiter > 0) {
+        // ---- one-reduction form: see cgcg_vector_kernel.  The iterate lives in x_next when the caller ping-pongs.
+        double *xx = u;
+        if (x_next) {
+            FV_HIP(ctx, hipMemcpyAsync(x_next, u, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+            xx = x_next;
+        }
+        if (!p->cg_u.p) {
+            FV_TRY(p->cg_u.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+            FV_TRY(p->cg_u.zero(ctx));
+            FV_TRY(p->cg_scal.alloc(ctx, 4));
+        }
+        if (!p->pnext.p)
+            FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+        CgcgScalars *cg = reinterpret_cast<CgcgScalars *>(p->cg_scal.p);
+        double *uu = p->cg_u.p, *ss = p->pnext.p, *ww = p->q.p;
+        // u0 = M^-1 r0 is what the set-up left in pvec; w0 = A u0, delta0 = w0.u0
+        FV_HIP(ctx, hipMemcpyAsync(uu, p->pvec.p, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        FV_TRY(dist_spmv(p, uu, ww, sig_mv, folded, true, true));
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
+        hipLaunchKernelGGL(cgcg_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)red, 1, 0, cg, p->scal.p, (double *)nullptr, (int64_t)0);
+        FV_LAUNCH_CHECK(ctx);
+        int64_t it1 = 0, chunk1 = p->last_iters > 0 ? p->last_iters : 1;
+        if (chunk1 > 32)
+            chunk1 = 32;
+        while (it1 < maxiter) {
+            const int64_t m = (maxiter - it1 < chunk1) ? (maxiter - it1) : chunk1;
+            for (int64_t k = 0; k < m; k++) {
+                const int iter = (int)(it1 + k);
+                hipLaunchKernelGGL(cgcg_vector_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter == 0 ? 1 : 0, xx, p->r.p, uu, (const double *)ww,
+                                   p->pvec.p, ss, (const double *)p->minv.p, (const CgcgScalars *)cg, (const PcgScalars *)p->scal.p, p->part_rz.p,
+                                   p->part_rr.p);
+                FV_LAUNCH_CHECK(ctx);
+                FV_TRY(dist_spmv(p, uu, ww, sig_mv, folded, true, true)); // red[0] = the local w.u
+                SumSet two{};
+                two.a[0] = p->part_rz.p;
+                two.a[1] = p->part_rr.p;
+                hipLaunchKernelGGL(final_sum_multi_kernel, dim3(2), dim3(FV_BLOCK), 0, ctx->stream, two, Gv, red + 1);
+                FV_LAUNCH_CHECK(ctx);
+                FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 3, ctx->stream)); // THE collective of the iteration: delta, gamma', r.r
+                hipLaunchKernelGGL(cgcg_scalar_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)red, 0, iter, cg, p->scal.p, (double *)nullptr,
+                                   (int64_t)0);
+                FV_LAUNCH_CHECK(ctx);
+            }
+            it1 += m;
+            FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (hs->done)
+                break;
+            if (chunk1 < 32)
+                chunk1 *= 2;
+        }
+        p->last_iters = hs->iters;
+        p->spec_valid = false;
+        if (info) {
+            info->converged = hs->done == 1;
+            info->iters = hs->iters;
+            info->bnorm = sqrt(hs->bnorm2);
+            info->relres = hs->bnorm2 > 0 ? sqrt(hs->rr / hs->bnorm2) : sqrt(hs->rr);
+            info->solve_ms = 0.0;
+            info->resnorm_len = 0;
+        }
+        if (hs->done == 2)
+            fv_set_error(ctx, "PCG breakdown in the one-reduction form: %g is not positive (operator not SPD, or drift of the recurrences)", hs->pq);
+        return FV_OK;
     }
     // per-kernel timing (fv_profile_enable), as in fv_pcg_solve: event pairs around the block SpMV (pack, interior pass,
     // the wait for the halo, boundary pass) and around K2 / K2S of every iteration; the reductions, collectives and K3 /

@@ -31,6 +31,13 @@ def comm_selftest(ctx, count=1 << 16):
     return bool(ok.value)
 
 
+def comm_stats(ctx, reset=False):
+    """(all-reduces, halo exchanges) issued through the context so far (fv_comm_stats)."""
+    a, h = C.c_int64(), C.c_int64()
+    ctx.check(load().fv_comm_stats(ctx.handle, C.byref(a), C.byref(h), int(bool(reset))))
+    return a.value, h.value
+
+
 def comm_init_local(ctx, nranks, rank, group_id=0):
     """Loopback transport: `nranks` threads of this process, one context each on the same device (rehearsals/tests)."""
     ctx.check(load().fv_comm_init_local(ctx.handle, int(nranks), int(rank), int(group_id)))

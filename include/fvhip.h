@@ -279,6 +279,9 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      between the two cells of a face, 2 always; read when the problem is created [1]
  *  32: experiment: large device arrays are handed out staggered by k x `value` bytes inside their allocations, so that the
  *      streams of a vector kernel do not start on the same HBM channels (no effect beyond run-to-run noise measured) [0]
+ *  34: PCG of the row-block driver in the many-iteration regime: 0 = the classic form north_star names (two all-reduces per
+ *      iteration: p.q, then r.M^-1 r with r.r), 1 = the one-reduction form of Chronopoulos and Gear (one 3-double all-reduce
+ *      per iteration; 96 instead of 88 bytes of vector traffic per row and a recurrence for A p) [0]
  *  33: a fixed-dt run (fv_transient_run_fixed / fv_dist_run_fixed) goes on from the residual, the prepared set-up and the
  *      refresh count the previous call on the same slot left, when dt, assembly and storage are unchanged and nothing else
  *      has touched the state or solved in between: stepping in chunks then costs what one long call costs [1] */
@@ -304,6 +307,10 @@ int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
 int fv_comm_unique_id(char id[FV_COMM_ID_BYTES]);
 int fv_comm_init(fv_ctx *ctx, int nranks, int rank, const char id[FV_COMM_ID_BYTES]);
 int fv_comm_destroy(fv_ctx *ctx);
+/* All-reduces and halo exchanges issued through this context so far (also counted with one rank, where nothing travels);
+ * reset != 0 zeroes the counters.  For tests of the collective pattern: two all-reduces per PCG iteration in the classic
+ * form, one in the one-reduction form (fv_tune key 34), one per step in the one-iteration regime. */
+int fv_comm_stats(fv_ctx *ctx, int64_t *allreduces, int64_t *halo_exchanges, int reset);
 /* Health check of the RCCL transport, to run once after fv_comm_init on every rank: a ring of ncclSend/ncclRecv (the halo
  * exchange's call pattern, on the halo stream) and an ncclAllReduce of `count` doubles; *ok = 1 when the data arrived. */
 int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok);

@@ -998,6 +998,77 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol, by
     return out
 
 
+@pytest.mark.parametrize("nranks", [1, 3])
+def test_one_reduction_pcg_on_row_blocks(fv, oracle, nranks):
+    """fv_tune key 34: the Chronopoulos-Gear form of the PCG in the many-iteration regime of the row-block driver — one
+    3-double all-reduce per iteration instead of two all-reduces — against the classic form: same heads (and the oracle's
+    direct solve), iteration counts within a few, and the collective pattern counted (fv_comm_stats)."""
+    import threading
+
+    from fvamd import dist
+
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (14, 11, 9), sigma=1.0)
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -3e-4
+    u0 = np.full(N, 0.5)
+    ohead = oracle.solvediffusion(nb[:, 0], nb[:, 1], aol, K, src, dn, dh, solver="direct")[0]
+    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, 5 * 400.0), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=400.0, linearsolver=oracle.directlinearsolver)
+    results = {}
+    for form in (0, 1):
+        out, errors = [None] * nranks, []
+
+        def worker(rank):
+            try:
+                ctx = fv.Context(0)
+                dist.comm_init_local(ctx, nranks, rank, 900 + 10 * form + nranks)
+                p = fv.Problem.create(nb, aol, N, dn, ctx).assemble(K, src, dh)
+                p.transient_begin(0.1, vol, u0)
+                blk = dist.RowBlock(p, nranks, rank)
+                p.close()
+                dist.comm_stats(ctx, reset=True)
+                x, info = blk.solve_steady(None, 1e-12, 5000)
+                ar_steady, _ = dist.comm_stats(ctx, reset=True)
+                its, info2, _ = blk.run_fixed(400.0, 5, 1e-12, 5000)
+                ar_steps, _ = dist.comm_stats(ctx, reset=True)
+                assert info.converged and info2.converged
+                out[rank] = (blk.lo, blk.hi, x, info.iters, ar_steady, blk.state(), its.copy(), ar_steps)
+                blk.close()
+                fv.load().fv_comm_destroy(ctx.handle)
+            except BaseException as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        assert fv.load().fv_tune(34, form) == 0
+        try:
+            threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join(timeout=300)
+        finally:
+            fv.load().fv_tune(34, 0)
+        assert not errors, errors
+        n = out[-1][1]
+        xs, us = np.empty(n), np.empty(n)
+        for lo, hi, x, it, ar, u, its, ar2 in out:
+            xs[lo:hi], us[lo:hi] = x, u
+        results[form] = (xs, out[0][3], out[0][4], us, out[0][6], out[0][7])
+    freenode = np.ones(N, bool)
+    freenode[dn - 1] = False
+    for form in (0, 1):
+        xs, it, ar, us, its, ar2 = results[form]
+        assert relerr(xs, ohead[freenode]) < HEAD_RTOL and relerr(us, ous[-1][freenode]) < HEAD_RTOL, form
+    it0, ar0, its0, ars0 = results[0][1], results[0][2], results[0][4], results[0][5]
+    it1, ar1, its1, ars1 = results[1][1], results[1][2], results[1][4], results[1][5]
+    assert it0 > 20 and abs(it1 - it0) <= 3 and np.abs(its1.astype(int) - its0.astype(int)).max() <= 2
+    # classic: set-up (1) + two per iteration (the last iteration's second one included);  one-reduction: set-up (1) + delta0 (1)
+    # + one per iteration enqueued (iterations are enqueued in chunks, so a few surplus no-op rounds may follow convergence)
+    assert 2 * it0 <= ar0 <= 2 * it0 + 2 * 32 + 2
+    assert it1 + 2 <= ar1 <= it1 + 32 + 2
+    assert ar1 < 0.6 * ar0 and ars1 < 0.7 * ars0
+    assert relerr(results[1][0], results[0][0]) < 1e-9 and relerr(results[1][3], results[0][3]) < 1e-9
+
+
 @pytest.mark.parametrize("nranks", [2, 3])
 def test_row_blocks_steady_solve_adaptive_stepper_and_host_forcing(fv, oracle, nranks):
     """Row blocks beyond the fixed-dt run (loopback transport, one thread per rank): fv_dist_solve_steady against the
