@@ -59,6 +59,8 @@ struct fv_amg {
     int64_t storage_epoch = -1; // which fv_transient_begin the aggregated D belongs to
     bool fold = false;        // level-0 SpMVs use the folded value array (fixed-dt runs), as the PCG around them
     DevBuf<double> z;         // preconditioned residual of the PCG
+    DevBuf<int32_t> loc_rowptr, loc_colind; // row blocks: the rank's diagonal block as the level-0 structure
+    DevBuf<double> loc_vals;
     ~fv_amg()
     {
         for (AmgLevel *l : lev)
@@ -601,12 +603,43 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
 static bool amg_verbose() { return getenv("FV_AMG_VERBOSE") != nullptr; }
 static double amg_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Row blocks of a distributed operator: the hierarchy is built on the rank's own diagonal block (the entries whose column is
+// one of its rows) — block-Jacobi with the V-cycle as the block solver, no communication inside the preconditioner; the
+// couplings across ranks stay with the PCG's SpMV around it.
+__global__ __launch_bounds__(FV_BLOCK) void amg_local_count_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                    int32_t *__restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    int32_t c = 0;
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; k++)
+        c += colind[k] < (int32_t)n;
+    cnt[r] = c;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_local_fill_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                   const double *__restrict__ vals, const int32_t *__restrict__ start,
+                                                                   int32_t *__restrict__ ci, double *__restrict__ va)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    int32_t o = start[r];
+    for (int32_t k = rowptr[r]; k < rowptr[r + 1]; k++)
+        if (colind[k] < (int32_t)n) {
+            ci[o] = colind[k];
+            va[o] = vals[k];
+            o++;
+        }
+}
+
 static int amg_build(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
     const double t_start = amg_now();
-    if (p->dist || p->nhalo) {
-        fv_set_error(ctx, "the AMG preconditioner is not available for row blocks of a distributed operator");
+    if (p->nhalo && !p->dist) {
+        fv_set_error(ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;
     }
     fv_amg_free(p->amg);
@@ -615,10 +648,30 @@ static int amg_build(fv_problem *p)
     AmgLevel *L = new AmgLevel();
     a->lev.push_back(L);
     L->n = p->n;
-    L->nnz = p->nnz;
-    L->rowptr = p->rowptr.p;
-    L->colind = p->colind.p;
-    L->vals = p->vals.p;
+    if (p->dist) {
+        DevBuf<int32_t> cnt;
+        FV_TRY(cnt.alloc(ctx, (size_t)p->n));
+        FV_TRY(a->loc_rowptr.alloc(ctx, (size_t)p->n + 1));
+        hipLaunchKernelGGL(amg_local_count_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
+                           (const int32_t *)p->colind.p, cnt.p);
+        FV_LAUNCH_CHECK(ctx);
+        int64_t nloc = 0;
+        FV_TRY(fv_exclusive_scan_i32(ctx, cnt.p, a->loc_rowptr.p, p->n, &nloc));
+        FV_TRY(a->loc_colind.alloc(ctx, (size_t)nloc + 2));
+        FV_TRY(a->loc_vals.alloc(ctx, (size_t)nloc + 2));
+        hipLaunchKernelGGL(amg_local_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
+                           (const int32_t *)p->colind.p, (const double *)p->vals.p, (const int32_t *)a->loc_rowptr.p, a->loc_colind.p, a->loc_vals.p);
+        FV_LAUNCH_CHECK(ctx);
+        L->nnz = nloc;
+        L->rowptr = a->loc_rowptr.p;
+        L->colind = a->loc_colind.p;
+        L->vals = a->loc_vals.p;
+    } else {
+        L->nnz = p->nnz;
+        L->rowptr = p->rowptr.p;
+        L->colind = p->colind.p;
+        L->vals = p->vals.p;
+    }
     L->D = p->D.p; // may be null (steady solve before fv_transient_begin)
     for (int depth = 0; depth < 24; depth++) {
         L = a->lev.back();
@@ -705,7 +758,8 @@ static int amg_build(fv_problem *p)
         FV_TRY(a->gjrow.alloc(ctx, (size_t)a->nco));
         FV_TRY(a->gjcol.alloc(ctx, (size_t)a->nco));
     }
-    FV_TRY(a->z.alloc(ctx, (size_t)p->n + FV_VEC_PAD));
+    FV_TRY(a->z.alloc(ctx, (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD)); // (a row block's halo slots stay zero: the cycle is block-local)
+    FV_TRY(a->z.zero(ctx));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->epoch = p->assemble_epoch;
     a->storage_epoch = p->storage_epoch;
@@ -763,6 +817,14 @@ int fv_amg_prepare(fv_problem *p, double sigma)
     return amg_set_sigma(p, sigma);
 }
 
+// level 0 uses the problem's own SpMV; on a row block the product with the rank's diagonal block (x's halo slots are zero)
+static int amg_top_spmv(fv_problem *p, const double *x, double *t, double sigma)
+{
+    if (p->dist)
+        return fv_dist_local_spmv(p, const_cast<double *>(x), t, sigma, p->amg->fold);
+    return fv_spmv_launch(p, x, t, sigma, nullptr, p->amg->fold);
+}
+
 // x_l = V(b_l) on level l (x, b: the level's vectors; level 0: the caller's)
 // dot_part (top level only): per-block partials of b.x, i.e. the PCG's r.z, written by the last smoothing pass
 static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part = nullptr)
@@ -781,7 +843,7 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
         hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, x);
         for (int s = 1; s < g_coarse_sweeps; s++) {
             if (l == 0)
-                FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+                FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
             else
                 FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
             hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
@@ -793,7 +855,7 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, x);
     FV_LAUNCH_CHECK(ctx);
     if (l == 0)
-        FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+        FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
     else
         FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
     hipLaunchKernelGGL(amg_restrict_kernel, dim3(fv_blocks(C->n, FV_BLOCK / 8)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
@@ -803,7 +865,7 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     hipLaunchKernelGGL(amg_prolong_kernel, g, blk, 0, ctx->stream, L->n, (const int32_t *)L->agg.p, (const double *)C->x.p, x);
     FV_LAUNCH_CHECK(ctx);
     if (l == 0)
-        FV_TRY(fv_spmv_launch(p, x, L->t.p, sigma, nullptr, a->fold));
+        FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
     else
         FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
     if (dot_part)
@@ -959,9 +1021,13 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
 {
     if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG && kind != FV_PRECOND_AUTO))
         return FV_ERR_ARG;
-    if (kind != FV_PRECOND_JACOBI && (p->dist || p->nhalo)) {
-        fv_set_error(p->ctx, "the AMG preconditioner is not available for row blocks of a distributed operator");
+    if (kind != FV_PRECOND_JACOBI && p->nhalo && !p->dist) {
+        fv_set_error(p->ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;
+    }
+    if (kind == FV_PRECOND_AUTO && p->dist) {
+        fv_set_error(p->ctx, "row blocks take FV_PRECOND_JACOBI or FV_PRECOND_AMG (every rank must make the same choice: no automatic switch)");
+        return FV_ERR_ARG;
     }
     p->precond = kind;
     p->auto_steps_amg = false;

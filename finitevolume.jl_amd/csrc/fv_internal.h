@@ -372,6 +372,8 @@ int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma)
 // runs the V-cycle-preconditioned CG from the set-up left in the workspace (r, scal); x is updated in place
 int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t maxiter, PcgScalars *hs);
 
+// y = (A_local + sigma D) x with the row block's own columns only: the caller keeps x's halo slots at zero (fv_pcg.hip)
+int fv_dist_local_spmv(fv_problem *p, double *x_with_zero_halo, double *y, double sigma, bool fold, bool want_dot = false);
 // ---- fv_comm.hip (RCCL); all are no-ops for a single rank
 int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream);
 int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream);

@@ -1178,6 +1178,89 @@ __global__ __launch_bounds__(FV_BLOCK) void final_sum_multi_kernel(SumSet set, i
 // vectors) and the new step's scalars follow the merged all-reduce.  A step that did not converge stops the chain there
 // as before: K1 of the step after it has run for nothing, everything later is skipped by the done flag.  The last step
 // of a burst reduces its sums itself, so the host poll sees a finished state.
+int fv_dist_local_spmv(fv_problem *p, double *x, double *y, double sigma, bool fold, bool want_dot)
+{
+    const double *folded = nullptr;
+    if (fold && sigma != 0.0)
+        FV_TRY(ensure_folded(p, sigma, &folded));
+    return dist_spmv(p, x, y, folded ? 0.0 : sigma, folded, want_dot, false, true); // interior + boundary passes, no exchange
+}
+
+// ------------------------------------------------------------------ PCG with the block-Jacobi AMG V-cycle on row blocks
+// z = V_local(r) on every rank's diagonal block (fv_amg.hip; no communication), the PCG around it as on one GPU with its
+// three sums all-reduced: p.q, r.r (the stopping test, before the next V-cycle is spent) and r.z.
+__global__ __launch_bounds__(FV_BLOCK) void dist_amg_direction_kernel(int64_t n, int first, const double *__restrict__ z, double *__restrict__ pv,
+                                                                       const double *__restrict__ rz_new, int it, PcgScalars *__restrict__ scal)
+{
+    if (scal->done)
+        return;
+    const double rzn = *rz_new;
+    const double beta = first ? 0.0 : rzn / scal->rz[it & 1];
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        pv[i] = first ? z[i] : z[i] + beta * pv[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        scal->rz[first ? 0 : ((it + 1) & 1)] = rzn;
+}
+
+__global__ void dist_amg_check_kernel(const double *__restrict__ rr, int it, PcgScalars *__restrict__ scal)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0 || scal->done)
+        return;
+    scal->rr = *rr;
+    scal->iters = it + 1;
+    if (*rr <= scal->tol2)
+        scal->done = 1;
+}
+
+static int dist_amg_loop(fv_problem *p, double *x, double sigma, double sig_mv, const double *folded, int64_t maxiter, PcgScalars *hs)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    const int64_t n = p->n;
+    const int Gv = vec_grid(n);
+    double *red = d->red.p;
+    FV_TRY(fv_amg_prepare(p, sigma));
+    if (!p->cg_u.p) { // z: n + halo + pad, halo slots zero for ever (the V-cycle's level-0 products are block-local)
+        FV_TRY(p->cg_u.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+        FV_TRY(p->cg_u.zero(ctx));
+        FV_TRY(p->cg_scal.alloc(ctx, 4));
+    }
+    double *z = p->cg_u.p;
+    FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hs->done || maxiter <= 0)
+        return FV_OK;
+    auto precondition = [&](int first, int it) -> int {
+        FV_TRY(fv_amg_apply_device(p, p->r.p, z, sigma));
+        hipLaunchKernelGGL(dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)z, p->part_rz.p);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
+        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 1, ctx->stream));
+        hipLaunchKernelGGL(dist_amg_direction_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, first, (const double *)z, p->pvec.p,
+                           (const double *)(red + 1), it, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    };
+    FV_TRY(precondition(1, 0));
+    for (int64_t it = 0; it < maxiter; it++) {
+        FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true)); // red[0] = the local p.q
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
+        hipLaunchKernelGGL(pcg_update_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, (const double *)nullptr, x, p->r.p, p->pvec.p,
+                           p->q.p, p->minv.p, (const double *)red, 1, p->scal.p, p->part_rz.p, p->part_rr.p);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rr.p, Gv, red + 2);
+        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 2, 1, ctx->stream));
+        hipLaunchKernelGGL(dist_amg_check_kernel, dim3(1), dim3(64), 0, ctx->stream, (const double *)(red + 2), (int)it, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
+        FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hs->done)
+            break;
+        FV_TRY(precondition(0, (int)it));
+    }
+    return FV_OK;
+}
+
 // ------------------------------------------------------------------ one-reduction PCG (Chronopoulos & Gear) on row blocks
 // The classic loop needs two global sums per iteration one after the other (p.q before alpha, r.M^-1 r before beta): two
 // all-reduce latencies on the wire.  With u = M^-1 r, w = A u and the recurrences p = u + beta p, s = w + beta s (= A p)
@@ -1361,6 +1444,28 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     if (chained) {
         chunk = 1;
         maxiter = 1;
+    }
+    if (fv_step_precond(p) == FV_PRECOND_AMG && !resume) { // the block-Jacobi V-cycle: plain in-place solves (no ping-pong, no carried residual)
+        if (x_next || chained || speculate) {
+            fv_set_error(ctx, "internal: the AMG path of the row-block driver steps in place");
+            return FV_ERR_STATE;
+        }
+        FV_TRY(dist_amg_loop(p, u, sigma, sig_mv, folded, maxiter, hs));
+        FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        p->last_iters = hs->iters;
+        p->spec_valid = false;
+        if (info) {
+            info->converged = hs->done == 1;
+            info->iters = hs->iters;
+            info->bnorm = sqrt(hs->bnorm2);
+            info->relres = hs->bnorm2 > 0 ? sqrt(hs->rr / hs->bnorm2) : sqrt(hs->rr);
+            info->solve_ms = 0.0;
+            info->resnorm_len = 0;
+        }
+        if (hs->done == 2)
+            fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs->pq);
+        return FV_OK;
     }
     if (g_cg_one_reduction && !speculate && !chained && !resume && maxiter > 0) {
         // ---- one-reduction form: see cgcg_vector_kernel.  The iterate lives in x_next when the caller ping-pongs.
@@ -1575,7 +1680,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     // ping-pong state + residual carry-over, as in fv_transient_run_fixed (identical decisions on every rank:
     // they depend only on the step index and on the all-reduced iteration count)
     const int64_t refresh = g_carry_refresh;
-    const bool pingpong = refresh > 0 && nsteps >= 2;
+    const bool pingpong = refresh > 0 && nsteps >= 2 && fv_step_precond(p) != FV_PRECOND_AMG;
     if (pingpong && p->pingpong_slot < 0)
         rc = fv_slot_new(p, &p->pingpong_slot);
     double *u = p->slots[0];

@@ -1577,7 +1577,9 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         // shape the size rule does not apply.
         const bool may_march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         bool sym = false;
-        if (may_march && g_symdia && (!subset || (p->dist && subset->win_hi > subset->win_lo))) { // the whole operator, or a row block's interior pass
+        // the whole operator, or a row block's interior pass (a row block as a whole — no subset — keeps the seven-diagonal
+        // forms: its sym_ok flags only cover the interior window)
+        if (may_march && g_symdia && ((!subset && !p->dist) || (subset && p->dist && subset->win_hi > subset->win_lo))) {
             if (p->sym_state < 0)
                 FV_TRY(build_symdia(p));
             if (p->sym_state == 1)

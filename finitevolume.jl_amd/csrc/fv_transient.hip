@@ -706,11 +706,17 @@ extern "C" int fv_bench_spmv(fv_problem *p, double sigma, int32_t reps, double *
     if (sigma != 0.0)
         FV_TRY(need_transient(p, "fv_bench_spmv with sigma != 0"));
     FV_TRY(fv_pcg_prepare(p));
-    // the PCG's own kernel: SpMV with the p.q epilogue, on the resident search direction
-    FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true)); // warm (and fold the shift if enabled)
+    // the PCG's own kernel: SpMV with the p.q epilogue, on the resident search direction (a row block: its interior and
+    // boundary passes without the exchange)
+    auto once = [&]() -> int {
+        if (p->dist)
+            return fv_dist_local_spmv(p, p->pvec.p, p->q.p, sigma, true, true);
+        return fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true);
+    };
+    FV_TRY(once()); // warm (and fold the shift if enabled)
     FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int32_t i = 0; i < reps; i++)
-        FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, true));
+        FV_TRY(once());
     FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     FV_HIP(ctx, hipEventSynchronize(ctx->ev1));
     float ms = 0.f;

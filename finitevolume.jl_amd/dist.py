@@ -159,6 +159,12 @@ class RowBlock:
         self.ctx.check(load().fv_dist_run_fixed(self.handle, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
         return iters[: int(nsteps)], info, ms.value
 
+    def set_preconditioner(self, kind):
+        """"jacobi" (default) or "amg": block-Jacobi with the aggregation-AMG V-cycle of the rank's diagonal block as the
+        block solver (no communication inside the preconditioner).  Every rank must make the same choice."""
+        self.ctx.check(load().fv_precond_set(self.handle, Problem.PRECONDITIONERS[kind]))
+        return self
+
     def solve_steady(self, x0_local=None, rtol=1e-8, maxiter=1000):
         """fv_dist_solve_steady (collective): Jacobi-PCG on A x = b over all ranks -> (the rank's rows of x, info)."""
         x0 = _lib.af64(x0_local) if x0_local is not None else None

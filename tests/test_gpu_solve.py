@@ -998,6 +998,63 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol, by
     return out
 
 
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_block_jacobi_amg_on_row_blocks(fv, oracle, nranks):
+    """FV_PRECOND_AMG on row blocks: every rank builds the aggregation-AMG hierarchy of its own diagonal block and the
+    V-cycle preconditions the distributed PCG (block-Jacobi, nothing travels inside the preconditioner).  High-contrast box:
+    the heads are the oracle's direct solve, far fewer iterations than Jacobi-PCG, also in implicit steps with a large dt."""
+    import threading
+
+    from fvamd import dist
+
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (24, 20, 16), sigma=2.0)
+    N = len(vol)
+    src = np.zeros(N)
+    u0 = np.zeros(N)
+    ohead = oracle.solvediffusion(nb[:, 0], nb[:, 1], aol, K, src, dn, dh, solver="direct")[0]
+    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, 3 * 3.0e4), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=3.0e4, linearsolver=oracle.directlinearsolver)
+    res = {}
+    for kind in ("jacobi", "amg"):
+        out, errors = [None] * nranks, []
+
+        def worker(rank):
+            try:
+                ctx = fv.Context(0)
+                dist.comm_init_local(ctx, nranks, rank, 1100 + 10 * nranks + (kind == "amg"))
+                p = fv.Problem.create(nb, aol, N, dn, ctx).assemble(K, src, dh)
+                p.transient_begin(0.1, vol, u0)
+                blk = dist.RowBlock(p, nranks, rank).set_preconditioner(kind)
+                p.close()
+                x, info = blk.solve_steady(None, 1e-12, 20000)
+                assert info.converged
+                its, info2, _ = blk.run_fixed(3.0e4, 3, 1e-12, 20000)
+                assert info2.converged
+                out[rank] = (blk.lo, blk.hi, x, info.iters, blk.state(), its.copy())
+                blk.close()
+                fv.load().fv_comm_destroy(ctx.handle)
+            except BaseException as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not errors, errors
+        n = out[-1][1]
+        xs, us = np.empty(n), np.empty(n)
+        for lo, hi, x, it, u, its in out:
+            xs[lo:hi], us[lo:hi] = x, u
+        res[kind] = (xs, out[0][3], us, out[0][5])
+    freenode = np.ones(N, bool)
+    freenode[dn - 1] = False
+    for kind in res:
+        assert relerr(res[kind][0], ohead[freenode]) < HEAD_RTOL, kind
+        assert relerr(res[kind][2], ous[-1][freenode]) < HEAD_RTOL, kind
+    print("steady iterations: Jacobi-PCG", res["jacobi"][1], "block-Jacobi AMG-PCG", res["amg"][1], "; steps", res["jacobi"][3], res["amg"][3])
+    assert res["amg"][1] * 4 < res["jacobi"][1] and res["amg"][3].sum() * 3 < res["jacobi"][3].sum()
+
+
 @pytest.mark.parametrize("nranks", [1, 3])
 def test_one_reduction_pcg_on_row_blocks(fv, oracle, nranks):
     """fv_tune key 34: the Chronopoulos-Gear form of the PCG in the many-iteration regime of the row-block driver — one
