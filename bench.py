@@ -400,7 +400,7 @@ def roofline_block(p, prof, iters_per_step, ns):
         roof.update(achieved=form_bytes / t / 1e9, frac=form_bytes / t / 1e9 / HBM_PEAK_GBS, avg_launch_ms=ms / cnt, launches=cnt)
         roof["effective_csr"] = {"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / t / 1e9, "frac": csr_bytes / t / 1e9 / HBM_PEAK_GBS}
         tune = dict(kv.split("=") for kv in os.environ.get("FV_TUNE", "").split(",") if "=" in kv)
-        fused = tune.get("7", "32") != "0" and tune.get("8", "1") != "0" and iters_per_step == 1.0
+        fused = tune.get("7", "128") != "0" and tune.get("8", "1") != "0" and iters_per_step == 1.0
         # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel): 5 streams in, 3 out
         # (p is recomputed as M^-1 r; +8 when the assembled b is dense instead of gathered over its support)
         fused_bytes = K2S_BYTES_PER_ROW if tune.get("12", "1") != "0" else K2S_BYTES_PER_ROW + 8

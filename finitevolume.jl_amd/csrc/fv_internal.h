@@ -242,7 +242,8 @@ struct fv_problem {
     struct FixedRunResume {
         bool ok = false;
         int32_t slot = -1;
-        double dt = 0.0;
+        double dt = 0.0, rtol = 0.0; // (rtol too: under a tighter tolerance a state that sat converged at its set-up iterates
+                                     // again, and after zero-iteration steps of a burst the direction vectors may sit swapped)
         int64_t assemble_epoch = -1, storage_epoch = -1;
         const double *prev = nullptr; // state the last solve started from
         int64_t steps_since_refresh = 0;

@@ -1689,7 +1689,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     int64_t s_base = 0; // go on where the previous call left off (fv_problem::resume, as fv_transient_run_fixed)
     {
         const fv_problem::FixedRunResume &rs = p->resume;
-        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == 0 && rs.dt == dt && rs.assemble_epoch == p->assemble_epoch &&
+        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == 0 && rs.dt == dt && rs.rtol == rtol && rs.assemble_epoch == p->assemble_epoch &&
             rs.storage_epoch == p->storage_epoch && rs.refresh == (int)refresh && rs.speculate == g_carry_speculate && (rs.prev == u || rs.prev == alt)) {
             prev = rs.prev;
             s_base = rs.steps_since_refresh;
@@ -1760,6 +1760,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
             rs.ok = true;
             rs.slot = 0;
             rs.dt = dt;
+            rs.rtol = rtol;
             rs.assemble_epoch = p->assemble_epoch;
             rs.storage_epoch = p->storage_epoch;
             rs.prev = prev;

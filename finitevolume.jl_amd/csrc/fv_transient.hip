@@ -313,7 +313,7 @@ __global__ __launch_bounds__(FV_BLOCK) void scale_kernel(int64_t n, const double
         x[i] = divide ? x[i] / D[i] : x[i] * D[i];
 }
 
-int g_carry_refresh = 32; // fv_tune key 7: 0 = every step computes its residual with an SpMV
+int g_carry_refresh = 128; // fv_tune key 7: 0 = every step computes its residual with an SpMV (128: drift of the carried residual 4e-13 of the heads over 1 500 steps at 216^3, tools/carry_drift.py; 32 until round 2)
 int g_carry_speculate = 1; // fv_tune key 8: the first K2 of a step also prepares the next step (pcg_update_spec_kernel)
 int g_chain_steps = 8;     // fv_tune key 13: one-iteration steps enqueued per device poll (< 2: poll every step)
 int g_resume_runs = 1;     // fv_tune key 33: a fixed-dt run goes on from the residual / set-up the previous call on the same slot left (fv_problem::resume)
@@ -425,7 +425,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     int64_t s_base = 0;
     {
         const fv_problem::FixedRunResume &rs = p->resume;
-        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == slot && rs.dt == dt && rs.assemble_epoch == p->assemble_epoch &&
+        if (g_resume_runs && rs.ok && pingpong && alt && rs.slot == slot && rs.dt == dt && rs.rtol == rtol && rs.assemble_epoch == p->assemble_epoch &&
             rs.storage_epoch == p->storage_epoch && rs.refresh == (int)refresh && rs.speculate == g_carry_speculate &&
             (rs.prev == u || rs.prev == alt)) {
             prev = rs.prev;
@@ -507,6 +507,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             rs.ok = true;
             rs.slot = slot;
             rs.dt = dt;
+            rs.rtol = rtol;
             rs.assemble_epoch = p->assemble_epoch;
             rs.storage_epoch = p->storage_epoch;
             rs.prev = prev;

@@ -240,7 +240,7 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *   2: plane-blocked group order [1];  3: fold sigma*D into a diagonal copy for fixed-dt runs [1]
  *   4: non-temporal matrix streams [1];  5: fuse the step set-up into the first SpMV's epilogue [0]
  *   6: sliced-DIA SpMV for grid-like 64-row slices [1]
- *   7: fixed-dt runs carry the residual from step to step and recompute it from scratch every `value` steps [32];
+ *   7: fixed-dt runs carry the residual from step to step and recompute it from scratch every `value` steps [128];
  *      0 = every step computes its initial residual with an SpMV
  *   8: in such runs, after a one-iteration step, the first vector update of a step also prepares the next step's
  *      set-up, so a step is SpMV + one fused vector pass [1]

@@ -775,7 +775,7 @@ def test_run_fixed_residual_carry_matches_fresh_residuals_and_oracle(fv, oracle,
             p.run_fixed(st2, dts[0], 3, rtol=rtol)
             assert relerr(st2.node_values(), ous1[3]) < HEAD_RTOL
     finally:
-        lib.fv_tune(7, 32)
+        lib.fv_tune(7, 128)
         lib.fv_tune(8, 1)
     base = its[(0, 0)]
     if schedule == "several_iterations":

@@ -16,7 +16,7 @@ for seed in range(10):
     schedule = [(float(rng.choice(dts)), int(rng.integers(1, 46)), float(rng.choice(rtols))) for _ in range(int(rng.integers(3, 9)))]
     out = {}
     for name, key, val in (("base", 26, 3), ("no hints", 26, 0), ("p streamed", 26, 7), ("b dense", 12, 0), ("b gather in vector blocks", 12, 2), ("no speculation", 8, 0), ("no carry", 7, 0)):
-        lib.fv_tune(26, 3); lib.fv_tune(12, 1); lib.fv_tune(8, 1); lib.fv_tune(7, 32)
+        lib.fv_tune(26, 3); lib.fv_tune(12, 1); lib.fv_tune(8, 1); lib.fv_tune(7, 128)
         lib.fv_tune(key, val)
         p = fv.Problem.regulargrid(mins, maxs, ns, dn)
         K = 1e-5 * np.exp(np.random.default_rng(100 + seed).standard_normal(p.F))
@@ -32,5 +32,5 @@ for seed in range(10):
         flag = ""
         if name in ("no hints", "p streamed") and not same: flag = "  <-- expected bitwise"; bad += 1
         print("seed %d %-28s bitwise %s  rel diff %.2e  iteration-count diff %d%s" % (seed, name, same, rel, dit, flag), flush=True)
-lib.fv_tune(26, 3); lib.fv_tune(12, 1); lib.fv_tune(8, 1); lib.fv_tune(7, 32)
+lib.fv_tune(26, 3); lib.fv_tune(12, 1); lib.fv_tune(8, 1); lib.fv_tune(7, 128)
 print("unexpected:", bad)
