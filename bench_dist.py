@@ -63,7 +63,7 @@ def run_distributed(fv, args, world, rank):
     if args.warmup > 0:
         blk.run_fixed(args.dt, args.warmup, args.rtol, args.maxiter)
     if not args.no_profile:
-        prob.profile(True)
+        prob.profile(1)
     ctx.synchronize()
     dist.barrier()
     t0 = time.perf_counter()

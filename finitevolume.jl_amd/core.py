@@ -300,7 +300,8 @@ class Problem:
         return form.value, self.SPMV_FORMS.get(form.value, "?"), nbytes.value
 
     def profile(self, on=True):
-        self.check(load().fv_profile_enable(self.handle, int(bool(on))))
+        """True / 1: time K1, K2 and K3 launches; 2: the SpMV (K1) only; False: off."""
+        self.check(load().fv_profile_enable(self.handle, int(on)))
 
     def profile_get(self):
         """{kernel: (total_ms, launches)} measured with HIP events around every PCG launch."""

@@ -275,6 +275,8 @@ struct fv_problem {
     // optional per-kernel timing of the PCG loop (fv_profile_enable): HIP event pairs
     // around every K1/K2/K3 launch on the launch stream, harvested at each poll.
     bool profile = false;
+    int profile_level = 1; // 1: event pairs around K1, K2 / K2S and K3; 2: around K1 only (two events per iteration instead of six:
+                           // every event is a barrier between two launches, ~10 us each at 464^3)
     std::vector<hipEvent_t> prof_ev; // 6 per iteration of a chunk
     double prof_ms[3] = {0, 0, 0};   // spmv_dot, update, pupdate
     int64_t prof_launches[3] = {0, 0, 0};

@@ -782,7 +782,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_HIP(ctx, hipEventCreate(&e));
     }
 #define FV_PROF(idx)                                                                                            \
-    if (p->profile)                                                                                             \
+    if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
@@ -845,7 +845,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         if (p->profile) { // only launches that did real work (not the post-convergence no-ops)
             const int64_t live = (int64_t)hs->iters - iters_before;
             for (int64_t k = 0; k < m && k < live; k++)
-                for (int c = 0; c < 3; c++) {
+                for (int c = 0; c < (p->profile_level == 1 ? 3 : 1); c++) {
                     float ms = 0.f;
                     FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k + 2 * c)], p->prof_ev[(size_t)(6 * k + 2 * c + 1)]));
                     p->prof_ms[c] += ms;
@@ -897,7 +897,7 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
     const int ndone = hs->done == 3 ? hs->chain_step : nsteps;
     if (p->profile && !p->prof_ev.empty())
         for (int k = 0; k < nsteps && k <= ndone && k < 32; k++)
-            for (int c = 0; c < (p->dist ? 2 : 3); c++) { // the row-block driver times the SpMV and K2 / K2S only
+            for (int c = 0; c < (p->profile_level != 1 ? 1 : (p->dist ? 2 : 3)); c++) { // the row-block driver times the SpMV and K2 / K2S only
                 if (c == 2 && k == ndone)
                     continue; // the p-update of an interrupted step did real work; it is counted when the step resumes
                 float ms = 0.f;
@@ -1543,7 +1543,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             FV_HIP(ctx, hipEventCreate(&e));
     }
 #define FV_PROF(idx)                                                                                            \
-    if (p->profile)                                                                                             \
+    if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
@@ -1630,7 +1630,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         if (p->profile) { // only launches that did real work
             const int64_t live = (int64_t)hs->iters - iters_before;
             for (int64_t k = 0; k < m && k < live; k++)
-                for (int c = 0; c < 2; c++) {
+                for (int c = 0; c < (p->profile_level == 1 ? 2 : 1); c++) {
                     float ms = 0.f;
                     FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k + 2 * c)], p->prof_ev[(size_t)(6 * k + 2 * c + 1)]));
                     p->prof_ms[c] += ms;

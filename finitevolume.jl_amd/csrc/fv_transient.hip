@@ -745,6 +745,7 @@ extern "C" int fv_profile_enable(fv_problem *p, int on)
     if (!p)
         return FV_ERR_ARG;
     p->profile = on != 0;
+    p->profile_level = on == 2 ? 2 : 1; // 2: the SpMV only
     for (int c = 0; c < 3; c++) {
         p->prof_ms[c] = 0;
         p->prof_launches[c] = 0;

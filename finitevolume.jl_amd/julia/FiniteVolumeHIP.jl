@@ -468,7 +468,7 @@ backwardeulerintegrate_last(args...; kwargs...) = (r = backwardeulerintegrate(ar
 # ---------------------------------------------------------------- adjoint hooks, transient.jl:176-216
 # getcontinuoussolution: the piecewise-linear-in-time interpolants (Interpolations.jl in the reference).  Callable objects
 # that keep their knots, so that integrals of products of two of them can be done exactly.
-struct LinearInterpolant{D}
+struct LinearInterpolant{D} <: Function   # callable, and a Function for the reference's ::Function signatures
 	us::Vector
 	ts::Vector{Float64}
 end

@@ -286,6 +286,8 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      refresh count the previous call on the same slot left, when dt, assembly and storage are unchanged and nothing else
  *      has touched the state or solved in between: stepping in chunks then costs what one long call costs [1] */
 int fv_tune(int key, int value);
+/* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event
+ * between two launches is a barrier (~10 us each at 464^3), so the timed region of the bench uses 2; 0: off. */
 int fv_profile_enable(fv_problem *p, int on);
 int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launches);
 /* Storage form the most recent SpMV of this problem ran in (the `A * x` inside cg!, src/FiniteVolume.jl:161 and

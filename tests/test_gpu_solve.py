@@ -160,6 +160,29 @@ def test_fixed_steps_vs_oracle_direct(fv, oracle):
     assert relerr(st.node_values(), ous[-1]) < HEAD_RTOL and (iters > 0).all() and info.converged
 
 
+def test_profile_levels_time_the_kernels_they_name_and_leave_the_heads_alone(fv):
+    """fv_profile_enable: 1 = event pairs around K1, K2 / K2S and K3, 2 = around K1 only (the bench's timed region),
+    0 = none; the heads of a run are the same bits at every level."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (24, 20, 16), sigma=1.0)
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    heads, counts = [], []
+    for level in (0, 1, 2):
+        p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+        st = p.transient_begin(0.1, vol, np.full(N, 0.5))
+        p.profile(level)
+        iters, info, ms = p.run_fixed(st, 100.0, 6, rtol=1e-10)
+        counts.append((p.profile_get(), int(iters.sum())))
+        heads.append(st.node_values())
+        p.profile(False)
+    assert np.array_equal(heads[0], heads[1]) and np.array_equal(heads[0], heads[2])
+    off, full, k1 = counts
+    assert all(v == (0.0, 0) for v in off[0].values())
+    assert full[0]["spmv_dot"][1] >= full[1] and full[0]["update"][1] > 0 and full[0]["spmv_dot"][0] > 0
+    assert k1[0]["spmv_dot"][1] == full[0]["spmv_dot"][1] and k1[0]["update"] == (0.0, 0) and k1[0]["pupdate"] == (0.0, 0)
+
+
 def test_time_dependent_getb_method(fv, oracle):
     """transient.jl:165-174: caller supplies the volume-scaled b(t)."""
     coords, nb, aol, vol, K, dn, dh = _box(fv, (8, 8, 6), sigma=0.5)
