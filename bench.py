@@ -26,7 +26,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
-K2S_BYTES_PER_ROW = 64  # pcg_update_spec_kernel: x_in, q, M^-1, D, r in; x_out, r, p' out (p = M^-1 r is recomputed, b' gathered)
 KERNEL_NAMES = {  # fv_spmv_form id -> kernel(s) that ran
     0: "spmv_wstream_kernel<512,true,true> (wave-private CSR stream)",
     1: "spmv_dia_kernel<true,true,false> (sliced-DIA, slice by slice: x fits the last-level cache at this size)",
@@ -405,11 +404,10 @@ def roofline_block(p, prof, iters_per_step, ns):
         t = ms / cnt * 1e-3
         roof.update(achieved=form_bytes / t / 1e9, frac=form_bytes / t / 1e9 / HBM_PEAK_GBS, avg_launch_ms=ms / cnt, launches=cnt)
         roof["effective_csr"] = {"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / t / 1e9, "frac": csr_bytes / t / 1e9 / HBM_PEAK_GBS}
-        tune = dict(kv.split("=") for kv in os.environ.get("FV_TUNE", "").split(",") if "=" in kv)
-        fused = tune.get("7", "128") != "0" and tune.get("8", "1") != "0" and iters_per_step == 1.0
-        # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel): 5 streams in, 3 out
-        # (p is recomputed as M^-1 r; +8 when the assembled b is dense instead of gathered over its support)
-        fused_bytes = K2S_BYTES_PER_ROW if tune.get("12", "1") != "0" else K2S_BYTES_PER_ROW + 8
+        # K2 in the one-iteration regime also prepares the next step (pcg_update_spec_kernel); the library says which
+        # streams its last launch moved (fv_update_form: 64 B per row, -8 with a uniform storage term, +8 with a dense b')
+        fused_bytes = p.update_form()
+        fused = fused_bytes > 0 and iters_per_step == 1.0
         for k, bytes_ in (("update", (fused_bytes if fused else 56) * p.n), ("pupdate", 32 * p.n)):
             kms, kc = prof[k]
             if kc:

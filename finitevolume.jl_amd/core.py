@@ -299,6 +299,12 @@ class Problem:
         self.check(load().fv_spmv_form(self.handle, C.byref(form), C.byref(nbytes)))
         return form.value, self.SPMV_FORMS.get(form.value, "?"), nbytes.value
 
+    def update_form(self):
+        """Bytes per row the most recent K2S launch streams (fv_update_form); 0 before the first."""
+        b = C.c_int32()
+        self.check(load().fv_update_form(self.handle, C.byref(b)))
+        return b.value
+
     def profile(self, on=True):
         """True / 1: time K1, K2 and K3 launches; 2: the SpMV (K1) only; False: off."""
         self.check(load().fv_profile_enable(self.handle, int(on)))

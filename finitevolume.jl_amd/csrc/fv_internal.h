@@ -155,6 +155,18 @@ struct fv_dist {
 struct fv_amg; // fv_amg.hip
 void fv_amg_free(fv_amg *a);
 
+// the distinct values of the storage term D, when there are few (storage_form in fv_pcg.hip), and how K2S is handed D:
+// its stream, or (D = nullptr) one-byte codes into the table, or (code = nullptr too) the single value tab.v[0]
+constexpr int FV_STORAGE_CODES = 16;
+struct StorageTable {
+    double v[FV_STORAGE_CODES];
+};
+struct StorageArg {
+    const double *D;
+    const uint8_t *code;
+    StorageTable tab;
+};
+
 struct fv_problem {
     fv_ctx *ctx = nullptr;
     int64_t N = 0, F = 0, n = 0, nnz = 0, ndir = 0, E = 0;
@@ -266,6 +278,20 @@ struct fv_problem {
     int spec_extra_bb = 0;   // extra rhs.rhs partials behind the speculative half (sparse-b gather)
     DevBuf<int32_t> bnz_idx; // rows where the assembled b is non-zero
     int64_t bnz_count = 0, bnz_epoch = -1;
+    // D as one-byte codes into a table of its distinct values (storage_form in fv_pcg.hip): dcode_n = 0 too many values (keep
+    // the stream), 1 uniform, else the table size.  Valid for (dcode_epoch, dcode_ptr) = (storage_epoch, D.p)
+    DevBuf<uint8_t> dcode;
+    StorageTable dtable = {};
+    int dcode_n = 0;
+    int64_t dcode_epoch = -1;
+    const double *dcode_ptr = nullptr;
+    int32_t k2s_bytes = 0; // bytes per row the most recent K2S launch streams (fv_update_form)
+    // z-form K2S (fv_pcg.hip): where the residual of the state between two steps lives: 0 = in r; 1 / 2 = Jacobi-scaled in
+    // pvec / pnext (r = that vector / M^-1, r itself stale)
+    int z_where = 0;
+    bool zf_minv_ok = false; // M^-1 > 0 on every row, for (zf_minv_sigma, zf_minv_epoch, zf_storage_epoch)
+    double zf_minv_sigma = -1.0;
+    int64_t zf_minv_epoch = -2, zf_storage_epoch = -2;
     DevBuf<double> part_pq, part_rz, part_rr, part_bb;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;

@@ -84,11 +84,14 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_kernel(int64_t n, const dou
 // operator and b', rhs_new - rhs_old = sigma D (x - x_prev), so r0 = r_final + sigma D (x - x_prev) needs no SpMV.
 // Everything else as pcg_init_kernel<true>: p = M^-1 r0 and the partials of r.M^-1 r, r.r, rhs.rhs with
 // rhs = b' + D x/dt.  Streams: r, D, x, x_prev, b', M^-1 in; r, p out (64 B per row).
+// zsrc: the previous step's final residual is not in r but, Jacobi-scaled, in zsrc (a z-form K2S left it there: see
+// pcg_update_spec_kernel); it is r = zsrc / M^-1, the value every consumer of such a state takes.
 __global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, const double *__restrict__ bprime, const double *__restrict__ D,
                                                                    double dt, const double *__restrict__ x, const double *__restrict__ xprev,
                                                                    const double *__restrict__ minv, double *__restrict__ r,
-                                                                   double *__restrict__ pv, double *__restrict__ part_rz,
-                                                                   double *__restrict__ part_rr, double *__restrict__ part_bb)
+                                                                   double *pv, double *__restrict__ part_rz,
+                                                                   double *__restrict__ part_rr, double *__restrict__ part_bb,
+                                                                   const double *zsrc = nullptr)
 {
     __shared__ double smem[4];
     double arz = 0.0, arr = 0.0, abb = 0.0;
@@ -103,7 +106,12 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, con
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
         const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
         const double2 dv = D2[i], xv = x2[i], ov = o2[i], mv = m2[i];
-        double2 rv = r2[i];
+        double2 rv;
+        if (zsrc) {
+            const double2 zv = reinterpret_cast<const double2 *>(zsrc)[i];
+            rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+        } else
+            rv = r2[i];
         rv.x += dv.x * ((xv.x - ov.x) / dt);
         rv.y += dv.y * ((xv.y - ov.y) / dt);
         const double hx = bv.x + dv.x * (xv.x / dt), hy = bv.y + dv.y * (xv.y / dt);
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_carry_init_kernel(int64_t n, con
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double ri = r[i] + D[i] * ((x[i] - xprev[i]) / dt);
+        const double ri = (zsrc ? zsrc[i] / minv[i] : r[i]) + D[i] * ((x[i] - xprev[i]) / dt);
         const double hi = (bprime ? bprime[i] : 0.0) + D[i] * (x[i] / dt);
         const double zi = minv[i] * ri;
         r[i] = ri;
@@ -251,18 +259,37 @@ struct SparseRhs {
 // iteration of a step, so it is re-formed in registers and only the sparse-b gather blocks read the stored one); x_out, r, p'
 // out: 64 B per row (+8 when a dense b' is streamed too) instead of K2's 56 + K0''s 64.  If it does not,
 // pcg_pupdate_kernel<true> takes the D (x_out - x_in)/dt term out of r again before it builds the next direction.
-template <int NT> // streaming hints: bit 0 = the read-once inputs x_in, q, M^-1, D, r; bit 1 = x_out and r (p' stays cacheable: the next K1 reads it)
+// The storage term D comes as its stream, as a one-byte code per row into a small table, or as one double (StorageArg,
+// storage_form below): 8, 1 or 0 B per row.
+//
+// ZF, the z-form (fv_tune key 36): at the first iteration of a step the direction IS the Jacobi-scaled residual, p = z = M^-1 r0,
+// so a state between two one-iteration steps needs one vector, not two: this kernel takes r0 := z / M^-1 from the direction
+// it is handed (whoever set the step up: z in instead of r in), and leaves only p' = M^-1 r0' for the next step — no r
+// stream out: 56 B per row (x_in, q, M^-1, D, z in; x_out, p' out).  r is written again by whoever needs it after such a step: the K3 / boundary launch of a step that did not
+// converge here, or the next step's pcg_carry_init_kernel (zsrc).  The sums of the next step's set-up are taken on r0'
+// as computed here (before the product with M^-1), which differs from p' / M^-1 in the last bit at most.  Needs M^-1 > 0
+// on every row (minv_positive).
+template <int NT, bool ZF> // streaming hints: bit 0 = the read-once inputs x_in, q, M^-1, D, r; bit 1 = x_out and r (p' stays cacheable: the next K1 reads it)
 __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, const double *__restrict__ xin, double *__restrict__ xout,
                                                                     double *__restrict__ r, const double *__restrict__ pv,
                                                                     const double *__restrict__ q, const double *__restrict__ minv,
-                                                                    const double *__restrict__ D, const double *__restrict__ bprime, double dt,
-                                                                    const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
+                                                                    StorageArg sa, const double *__restrict__ bprime,
+                                                                    double dt, const double *__restrict__ part_pq, int npq,
+                                                                    PcgScalars *__restrict__ scal,
                                                                     double *__restrict__ part_rz, double *__restrict__ part_rr,
                                                                     double *__restrict__ pnext, double *__restrict__ spec_rz,
                                                                     double *__restrict__ spec_rr, double *__restrict__ spec_bb,
                                                                     SparseRhs sb, int chain_index)
 {
     __shared__ double smem[4];
+    __shared__ double dtab[FV_STORAGE_CODES];
+    const double *__restrict__ D = sa.D;
+    const double Dc = sa.tab.v[0];
+    if (sa.code) {
+        if (threadIdx.x < FV_STORAGE_CODES)
+            dtab[threadIdx.x] = sa.tab.v[threadIdx.x];
+        __syncthreads();
+    }
     if (scal->done) {
         // A chained step that was already converged at its set-up (the carried residual is within the tolerance): the host
         // flips the two state vectors after every chained step without looking, so the iterate is handed over unchanged.
@@ -270,14 +297,22 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
         if (scal->done == 1 && chain_index >= 0 && scal->iters == 0) {
             const int gmain0 = (int)gridDim.x - sb.nblocks;
             if ((int)blockIdx.x < gmain0) {
+                // ... and the direction of the set-up (= the scaled residual) goes into the other direction vector too, which the
+                // host swaps in at the next chained step without looking: from here on both hold it
                 const int64_t n2c = n >> 1;
                 const double2 *xi2c = reinterpret_cast<const double2 *>(xin);
                 double2 *xo2c = reinterpret_cast<double2 *>(xout);
-                for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2c; i += (int64_t)gmain0 * FV_BLOCK)
+                const double2 *pv2c = reinterpret_cast<const double2 *>(pv);
+                double2 *pn2c = reinterpret_cast<double2 *>(pnext);
+                for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2c; i += (int64_t)gmain0 * FV_BLOCK) {
                     xo2c[i] = xi2c[i];
+                    pn2c[i] = pv2c[i];
+                }
                 if (blockIdx.x == 0 && threadIdx.x == 0) {
-                    if (n & 1)
+                    if (n & 1) {
                         xout[n - 1] = xin[n - 1];
+                        pnext[n - 1] = pv[n - 1];
+                    }
                     scal->zero_mask |= 1u << chain_index;
                 }
             }
@@ -303,7 +338,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
             const int32_t i = sb.idx[k];
             const double bi = sb.b[i];
             const double xn = xin[i] + alpha * pv[i];
-            acc += bi * (2.0 * (D[i] * (xn / dt)) + bi);
+            acc += bi * (2.0 * ((D ? D[i] : sa.code ? dtab[sa.code[i]] : Dc) * (xn / dt)) + bi);
         }
         const double t = block_sum(acc, smem);
         if (threadIdx.x == 0)
@@ -322,23 +357,34 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     const double2 *b2 = reinterpret_cast<const double2 *>(bprime);
     double2 *pn2 = reinterpret_cast<double2 *>(pnext);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += stride) {
-        double2 xv, pvv, qv, mv, dv, rv;
+        double2 xv, pvv, qv, mv, dv = make_double2(Dc, Dc), rv;
+        if (sa.code) {
+            const unsigned c = reinterpret_cast<const uint16_t *>(sa.code)[i];
+            dv = make_double2(dtab[c & 255u], dtab[c >> 8]);
+        }
         if (NT & 1) {
             xv = nt_load2(xi2 + i);
             qv = nt_load2(q2 + i);
             mv = nt_load2(m2 + i);
-            dv = nt_load2(D2 + i);
-            rv = nt_load2(r2 + i);
+            if (D)
+                dv = nt_load2(D2 + i);
+            rv = nt_load2((ZF ? reinterpret_cast<const double2 *>(pv) : r2) + i);
         } else {
             xv = xi2[i];
             qv = q2[i];
             mv = m2[i];
-            dv = D2[i];
-            rv = r2[i];
+            if (D)
+                dv = D2[i];
+            rv = (ZF ? reinterpret_cast<const double2 *>(pv) : r2)[i];
         }
-        // this is the first iteration of its step, so the direction is p = M^-1 r0 and r still holds r0: the product is
-        // formed again (the same multiplication that produced the stored p, bit for bit) instead of streaming p in
-        pvv = make_double2(mv.x * rv.x, mv.y * rv.y);
+        if (ZF) {
+            // the direction p = z is what was streamed in; the residual it stands for is z / M^-1
+            pvv = rv;
+            rv = make_double2(pvv.x / mv.x, pvv.y / mv.y);
+        } else
+            // this is the first iteration of its step, so the direction is p = M^-1 r0 and r still holds r0: the product is
+            // formed again (the same multiplication that produced the stored p, bit for bit) instead of streaming p in
+            pvv = make_double2(mv.x * rv.x, mv.y * rv.y);
         const double2 bv = bprime ? b2[i] : make_double2(0.0, 0.0);
         const double xnx = xv.x + alpha * pvv.x, xny = xv.y + alpha * pvv.y;
         rv.x -= alpha * qv.x;
@@ -351,10 +397,12 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
         const double zx = mv.x * cx, zy = mv.y * cy;
         if (NT & 2) {
             nt_store2(xo2 + i, make_double2(xnx, xny));
-            nt_store2(r2 + i, make_double2(cx, cy));
+            if (!ZF)
+                nt_store2(r2 + i, make_double2(cx, cy));
         } else {
             xo2[i] = make_double2(xnx, xny);
-            r2[i] = make_double2(cx, cy);
+            if (!ZF)
+                r2[i] = make_double2(cx, cy);
         }
         pn2[i] = make_double2(zx, zy);
         srz += cx * zx + cy * zy;
@@ -363,15 +411,18 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        const double xn = xin[i] + alpha * (minv[i] * r[i]);
-        const double ri = r[i] - alpha * q[i];
+        const double r0 = ZF ? pv[i] / minv[i] : r[i];
+        const double xn = xin[i] + alpha * (ZF ? pv[i] : minv[i] * r0);
+        const double ri = r0 - alpha * q[i];
+        const double di = D ? D[i] : sa.code ? dtab[sa.code[i]] : Dc;
         arz += ri * (minv[i] * ri);
         arr += ri * ri;
-        const double c = ri + D[i] * ((xn - xin[i]) / dt);
-        const double h = (bprime ? bprime[i] : 0.0) + D[i] * (xn / dt);
+        const double c = ri + di * ((xn - xin[i]) / dt);
+        const double h = (bprime ? bprime[i] : 0.0) + di * (xn / dt);
         const double z = minv[i] * c;
         xout[i] = xn;
-        r[i] = c;
+        if (!ZF)
+            r[i] = c;
         pnext[i] = z;
         srz += c * z;
         srr += c * c;
@@ -383,7 +434,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
             const int32_t i = sb.idx[k];
             const double bi = sb.b[i];
             const double xn = xin[i] + alpha * pv[i];
-            sgather += bi * (2.0 * (D[i] * (xn / dt)) + bi);
+            sgather += bi * (2.0 * ((D ? D[i] : sa.code ? dtab[sa.code[i]] : Dc) * (xn / dt)) + bi);
         }
     const double t0 = block_sum(arz, smem);
     const double t1 = block_sum(arr, smem);
@@ -405,19 +456,20 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
 }
 
 int g_k2s_nt = 3; // fv_tune key 26: streaming hints of K2S (see pcg_update_spec_kernel): the read-once streams bypass the caches, so that p' and x survive for the next K1 (-8 % per step at 216^3, -10 % on a 1.2e7-row block, -1.5 % at 464^3)
-static auto k2s_kernel() -> decltype(&pcg_update_spec_kernel<0>)
+int g_zform = 1; // fv_tune key 36: K2S in the z-form (see pcg_update_spec_kernel) where it applies
+static auto k2s_kernel(bool zf) -> decltype(&pcg_update_spec_kernel<0, false>)
 {
     switch (g_k2s_nt) {
     case 1:
-        return pcg_update_spec_kernel<1>;
+        return zf ? pcg_update_spec_kernel<1, true> : pcg_update_spec_kernel<1, false>;
     case 2:
-        return pcg_update_spec_kernel<2>;
+        return zf ? pcg_update_spec_kernel<2, true> : pcg_update_spec_kernel<2, false>;
     case 3:
-        return pcg_update_spec_kernel<3>;
+        return zf ? pcg_update_spec_kernel<3, true> : pcg_update_spec_kernel<3, false>;
     case 7:
-        return pcg_update_spec_kernel<7>;
+        return zf ? pcg_update_spec_kernel<7, true> : pcg_update_spec_kernel<7, false>;
     default:
-        return pcg_update_spec_kernel<0>;
+        return zf ? pcg_update_spec_kernel<0, true> : pcg_update_spec_kernel<0, false>;
     }
 }
 
@@ -478,6 +530,141 @@ static int ensure_b_support(fv_problem *p, int64_t *count)
     return FV_OK;
 }
 
+// How K2S gets the storage term D = Ss * volumes.  On a regular grid with a scalar Ss it takes a handful of values (the
+// cell volume, halved on the faces of the box, quartered on its edges, an eighth at its corners), on other meshes with even
+// volumes one: then K2S streams a one-byte code per row (or nothing) instead of the double, and looks the value up in a
+// table of at most FV_STORAGE_CODES doubles in LDS — the same doubles, so nothing else changes.  Built once per D
+// (fv_transient_begin bumps storage_epoch; a row block's D is a slice copied at set-up): each pass over D codes the rows
+// whose value is in the table and one row that is not offers its value as the next entry; a mesh with more than
+// FV_STORAGE_CODES distinct values keeps the stream.
+int g_uniform_storage = 1; // fv_tune key 35: 0 = K2S always streams D
+__global__ __launch_bounds__(FV_BLOCK) void storage_code_kernel(int64_t n, const double *__restrict__ D, StorageTable tab, int ntab,
+                                                                 uint8_t *__restrict__ code, int32_t *__restrict__ claim,
+                                                                 double *__restrict__ offered)
+{
+    bool offered_one = false;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
+        const long long bits = __double_as_longlong(D[i]);
+        int c = -1;
+        for (int k = 0; k < ntab; k++)
+            if (__double_as_longlong(tab.v[k]) == bits)
+                c = k;
+        if (c >= 0)
+            code[i] = (uint8_t)c;
+        else if (!offered_one) {
+            offered_one = true; // one try per thread: whoever gets the claim decides the next table entry
+            if (atomicCAS(claim, 0, 1) == 0)
+                *offered = D[i];
+        }
+    }
+}
+static int storage_form(fv_problem *p, StorageArg *out, int *bytes_saved)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->dcode_epoch != p->storage_epoch || p->dcode_ptr != p->D.p) {
+        p->dcode_n = 0; // 0: keep the stream
+        if (p->n > 0 && p->D.p) {
+            FV_TRY(p->dcode.alloc(ctx, (size_t)p->n + 16));
+            FV_TRY(p->dcode.zero(ctx));
+            DevBuf<int32_t> claim;
+            DevBuf<double> offered;
+            FV_TRY(claim.alloc(ctx, 1));
+            FV_TRY(offered.alloc(ctx, 1));
+            int ntab = 0;
+            for (;;) {
+                FV_TRY(claim.zero(ctx));
+                hipLaunchKernelGGL(storage_code_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->D.p,
+                                   p->dtable, ntab, p->dcode.p, claim.p, offered.p);
+                FV_LAUNCH_CHECK(ctx);
+                int32_t h = 0;
+                FV_TRY(fv_copy(ctx, &h, claim.p, sizeof h));
+                if (!h) { // every row has its code
+                    p->dcode_n = ntab;
+                    break;
+                }
+                if (ntab == FV_STORAGE_CODES)
+                    break; // too many distinct values
+                FV_TRY(fv_copy(ctx, &p->dtable.v[ntab], offered.p, sizeof(double)));
+                ntab++;
+            }
+            if (p->dcode_n == 0)
+                p->dcode.release();
+        }
+        p->dcode_epoch = p->storage_epoch;
+        p->dcode_ptr = p->D.p;
+    }
+    *out = StorageArg{};
+    out->D = p->D.p;
+    *bytes_saved = 0;
+    if (g_uniform_storage && p->dcode_n > 0) {
+        out->D = nullptr;
+        out->tab = p->dtable;
+        out->code = p->dcode_n > 1 ? p->dcode.p : nullptr; // one value: no stream at all
+        *bytes_saved = p->dcode_n > 1 ? 7 : 8;
+    }
+    return FV_OK;
+}
+
+// The z-form divides by M^-1: every row must have one (a free cell without faces and without storage has M^-1 = 0).
+// Checked once per Jacobi diagonal.
+__global__ __launch_bounds__(FV_BLOCK) void minv_bad_kernel(int64_t n, const double *__restrict__ minv, int32_t *__restrict__ bad)
+{
+    int b = 0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
+        const double m = minv[i];
+        b |= !(m > 0.0 && m < 1.0e300);
+    }
+    if (__any(b) && (threadIdx.x & 63) == 0)
+        atomicOr(bad, 1);
+}
+static int minv_positive(fv_problem *p, bool *ok)
+{
+    fv_ctx *ctx = p->ctx;
+    if (!(p->zf_minv_sigma == p->minv_sigma && p->zf_minv_epoch == p->minv_epoch && p->zf_storage_epoch == p->storage_epoch)) {
+        DevBuf<int32_t> flag;
+        FV_TRY(flag.alloc(ctx, 1));
+        FV_TRY(flag.zero(ctx));
+        hipLaunchKernelGGL(minv_bad_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->minv.p, flag.p);
+        FV_LAUNCH_CHECK(ctx);
+        int32_t h = 1;
+        FV_TRY(fv_copy(ctx, &h, flag.p, sizeof h));
+        p->zf_minv_ok = h == 0;
+        p->zf_minv_sigma = p->minv_sigma;
+        p->zf_minv_epoch = p->minv_epoch;
+        p->zf_storage_epoch = p->storage_epoch;
+    }
+    *ok = p->zf_minv_ok;
+    return FV_OK;
+}
+
+// r = z / M^-1 from the direction vector that holds the scaled residual of the state (fv_problem::z_where), for a consumer
+// that wants r in its own array
+__global__ __launch_bounds__(FV_BLOCK) void unscale_kernel(int64_t n, const double *__restrict__ z, const double *__restrict__ minv,
+                                                            double *__restrict__ r)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        r[i] = z[i] / minv[i];
+}
+static int residual_to_r(fv_problem *p)
+{
+    if (p->z_where == 0)
+        return FV_OK;
+    fv_ctx *ctx = p->ctx;
+    const double *z = p->z_where == 1 ? p->pvec.p : p->pnext.p;
+    hipLaunchKernelGGL(unscale_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, z, (const double *)p->minv.p, p->r.p);
+    FV_LAUNCH_CHECK(ctx);
+    p->z_where = 0;
+    return FV_OK;
+}
+
+extern "C" int fv_update_form(fv_problem *p, int32_t *bytes_per_row)
+{
+    if (!p || !bytes_per_row)
+        return FV_ERR_ARG;
+    *bytes_per_row = p->k2s_bytes;
+    return FV_OK;
+}
+
 // K3.  UNSPEC: the K2 before it was pcg_update_spec_kernel and the step did not converge there: r carries the next
 // step's D (x_out - x_in)/dt term, which is taken out again here (same expression, same operands).
 template <bool UNSPEC>
@@ -486,8 +673,10 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
                                                                 const double *__restrict__ part_rr, int nparts, PcgScalars *__restrict__ scal,
                                                                 double *__restrict__ hist, int64_t hist_cap, const double *__restrict__ xin,
                                                                 const double *__restrict__ xout, const double *__restrict__ D, double dt,
-                                                                int chain_index = -1, int force_unconverged = 0)
+                                                                int chain_index = -1, int force_unconverged = 0,
+                                                                const double *__restrict__ zsrc = nullptr)
 {
+    // zsrc (UNSPEC only): the K2S was a z-form one: what it left is p' = M^-1 r0' in zsrc and nothing in r
     __shared__ double smem[4];
     if (scal->done)
         return;
@@ -505,8 +694,13 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     const double2 *xo2 = reinterpret_cast<const double2 *>(xout);
     const double2 *D2 = reinterpret_cast<const double2 *>(D);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
-        double2 rv = r2[i];
+        double2 rv;
         const double2 mv = m2[i];
+        if (UNSPEC && zsrc) {
+            const double2 zv = reinterpret_cast<const double2 *>(zsrc)[i];
+            rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+        } else
+            rv = r2[i];
         if (UNSPEC) {
             const double2 a = xi2[i], b = xo2[i], dv = D2[i];
             rv.x -= dv.x * ((b.x - a.x) / dt);
@@ -520,7 +714,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
     }
     if (!converged && (n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const int64_t i = n - 1;
-        double ri = r[i];
+        double ri = (UNSPEC && zsrc) ? zsrc[i] / minv[i] : r[i];
         if (UNSPEC) {
             ri -= D[i] * ((xout[i] - xin[i]) / dt);
             r[i] = ri;
@@ -556,7 +750,8 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
                                                                        double *__restrict__ pv, BoundarySums sums, double rtol,
                                                                        PcgScalars *scal, const double *__restrict__ xin,
                                                                        const double *__restrict__ xout, const double *__restrict__ D, double dt,
-                                                                       int prev_index, int force_unconverged)
+                                                                       int prev_index, int force_unconverged,
+                                                                       const double *__restrict__ zsrc = nullptr)
 {
     __shared__ double smem[4];
     if (scal->done)
@@ -574,8 +769,13 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
         const double2 *xo2 = reinterpret_cast<const double2 *>(xout);
         const double2 *D2 = reinterpret_cast<const double2 *>(D);
         for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
-            double2 rv = r2[i];
+            double2 rv;
             const double2 mv = m2[i];
+            if (zsrc) { // z-form K2S before this launch: see pcg_pupdate_kernel
+                const double2 zv = reinterpret_cast<const double2 *>(zsrc)[i];
+                rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+            } else
+                rv = r2[i];
             const double2 a = xi2[i], b = xo2[i], dv = D2[i];
             rv.x -= dv.x * ((b.x - a.x) / dt);
             rv.y -= dv.y * ((b.y - a.y) / dt);
@@ -587,7 +787,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
         }
         if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
             const int64_t i = n - 1;
-            double ri = r[i];
+            double ri = zsrc ? zsrc[i] / minv[i] : r[i];
             ri -= D[i] * ((xout[i] - xin[i]) / dt);
             r[i] = ri;
             pv[i] = minv[i] * ri + beta * pv[i];
@@ -695,6 +895,13 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_TRY(ensure_b_support(p, &bsupport));
     int Gx = 0, Gs = 0; // extra blocks of the K2S launch, extra rhs.rhs partials it leaves
     const SparseRhs sbarg = sparse_b_arg(p, bsupport, Gv, &Gx, &Gs);
+    StorageArg sarg{};
+    int Dsaved = 0;
+    if (speculate)
+        FV_TRY(storage_form(p, &sarg, &Dsaved));
+    bool zf = false; // this step's K2S in the z-form
+    if (speculate && g_zform && !p->dist)
+        FV_TRY(minv_positive(p, &zf));
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
     if (resume) {
@@ -702,13 +909,19 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     } else if (use_spec) {
         in_nbb = Gv + p->spec_extra_bb;
         p->pvec.swap(p->pnext);
+        if (p->z_where)
+            p->z_where = 3 - p->z_where; // the scaled residual a z-form K2S left moves with its vector
         in_rz += FV_VEC_PARTIALS;
         in_rr += FV_VEC_PARTIALS;
         in_bb += FV_VEC_PARTIALS;
+        if (!zf)
+            FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
     } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
+        const double *zsrc = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : nullptr;
         hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
                            (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
-                           p->part_bb.p);
+                           p->part_bb.p, zsrc);
+        p->z_where = 0;
     } else if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
         // the whole set-up in the epilogue of ONE SpMV: with the folded matrix q = (A + sigma D) x0 and
         // r0 = rhs - q; otherwise q = A x0 (plain) and r0 = b' - q (the D x0/dt terms cancel)
@@ -747,6 +960,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
+    if (!resume && !use_spec)
+        p->z_where = 0; // every other set-up has written r
     if (!resume)
         if (!(chained && sys.chain_index > 0 && g_defer_reduce)) // ... unless the previous chained step's boundary launch wrote them
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p,
@@ -798,12 +1013,14 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_PROF(2);
             const bool spec = iter == 0 && speculate;
             if (spec) {
-                hipLaunchKernelGGL(k2s_kernel(), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
-                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
+                hipLaunchKernelGGL(k2s_kernel(zf), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
+                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p,
+                                   sarg,
                                    bsupport >= 0 ? (const double *)nullptr : sys.rhs, sys.dt, (const double *)p->part_pq.p, npq, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
                                    p->part_bb.p + FV_VEC_PARTIALS, sbarg, chained ? sys.chain_index : -1);
                 p->spec_extra_bb = Gs;
+                p->k2s_bytes = (zf ? 56 : 64) - Dsaved + (bsupport >= 0 || !sys.rhs ? 0 : 8);
             }
             else if (iter == 0 && sys.x_next)
                 hipLaunchKernelGGL(pcg_update_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, (const double *)x, sys.x_next,
@@ -820,12 +1037,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                                       p->part_bb.p + FV_VEC_PARTIALS, Gv, Gv, Gv + Gs};
                 hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, bs, rtol, p->scal.p, (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt,
-                                   sys.chain_index, (sys.chain_index == g_chain_test_break) ? 1 : 0);
+                                   sys.chain_index, (sys.chain_index == g_chain_test_break) ? 1 : 0, zf ? (const double *)p->pnext.p : nullptr);
             } else if (spec)
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
                                    (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt, sys.chain_index,
-                                   (chained && sys.chain_index == g_chain_test_break) ? 1 : 0);
+                                   (chained && sys.chain_index == g_chain_test_break) ? 1 : 0, zf ? (const double *)p->pnext.p : nullptr);
             else
                 hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)p->part_rz.p, (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap,
@@ -837,6 +1054,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         if (chained) { // the caller polls once per burst (fv_pcg_chain_poll)
             p->last_iters = 1;
             p->spec_valid = true;
+            p->z_where = zf ? 2 : 0; // unless the chain stops on the device (the poll then says so)
             return FV_OK;
         }
         FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
@@ -866,6 +1084,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     p->last_iters = hs->iters;
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it
+    if (speculate && zf && hs->iters >= 1)
+        p->z_where = p->spec_valid ? 2 : 0; // a z-form K2S ran: its p' stands for the residual, unless the K3 behind it had to go on (it wrote r)
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
@@ -910,6 +1130,7 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
         *zero_mask = hs->zero_mask;
     if (hs->done == 3) {
         p->spec_valid = false;
+        p->z_where = 0; // the launch that stopped the chain wrote r
         p->last_iters = 2; // at least
         const int32_t zero = 0;
         FV_HIP(ctx, hipMemcpyAsync(&p->scal.p->done, &zero, sizeof zero, hipMemcpyHostToDevice, ctx->stream));
@@ -1394,6 +1615,10 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         FV_TRY(ensure_b_support(p, &bsupport));
     int Gx = 0, Gs = 0; // extra blocks of the K2S launch, extra rhs.rhs partials it leaves
     const SparseRhs sbarg = sparse_b_arg(p, bsupport, Gv, &Gx, &Gs);
+    StorageArg sarg{};
+    int Dsaved = 0;
+    if (speculate)
+        FV_TRY(storage_form(p, &sarg, &Dsaved));
     const bool defer_in = chained && chain_index > 0 && g_defer_reduce && speculate && carry_prev;   // red[1..5]: the previous step's local sums
     const bool defer_out = chained && !last_in_burst && g_defer_reduce && speculate; // leave this step's sums to the next one
     if (resume) {
@@ -1584,11 +1809,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             sums.a[1] = p->part_rr.p;
             FV_PROF(2);
             if (spec) {
-                hipLaunchKernelGGL(k2s_kernel(), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
-                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p, (const double *)p->D.p,
+                hipLaunchKernelGGL(k2s_kernel(false), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
+                                   (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p,
+                                   sarg,
                                    bsupport >= 0 ? (const double *)nullptr : (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
                                    p->part_bb.p + FV_VEC_PARTIALS, sbarg, chained ? chain_index : -1);
+                p->k2s_bytes = 64 - Dsaved + (bsupport >= 0 ? 0 : 8);
                 sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
                 sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
                 sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;

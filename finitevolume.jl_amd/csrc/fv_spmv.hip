@@ -293,7 +293,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
-extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction; // fv_pcg.hip
+extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder;                       // fv_assembly.hip
 
 extern "C" int fv_tune(int key, int value)
@@ -358,6 +358,10 @@ extern "C" int fv_tune(int key, int value)
         g_resume_runs = value;
     else if (key == 34 && (value == 0 || value == 1))
         g_cg_one_reduction = value;
+    else if (key == 35 && (value == 0 || value == 1))
+        g_uniform_storage = value;
+    else if (key == 36 && (value == 0 || value == 1))
+        g_zform = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else

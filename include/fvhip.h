@@ -279,12 +279,18 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      between the two cells of a face, 2 always; read when the problem is created [1]
  *  32: experiment: large device arrays are handed out staggered by k x `value` bytes inside their allocations, so that the
  *      streams of a vector kernel do not start on the same HBM channels (no effect beyond run-to-run noise measured) [0]
+ *  33: a fixed-dt run (fv_transient_run_fixed / fv_dist_run_fixed) goes on from the residual, the prepared set-up and the
+ *      refresh count the previous call on the same slot left, when dt, assembly and storage are unchanged and nothing else
+ *      has touched the state or solved in between: stepping in chunks then costs what one long call costs [1]
  *  34: PCG of the row-block driver in the many-iteration regime: 0 = the classic form north_star names (two all-reduces per
  *      iteration: p.q, then r.M^-1 r with r.r), 1 = the one-reduction form of Chronopoulos and Gear (one 3-double all-reduce
  *      per iteration; 96 instead of 88 bytes of vector traffic per row and a recurrence for A p) [0]
- *  33: a fixed-dt run (fv_transient_run_fixed / fv_dist_run_fixed) goes on from the residual, the prepared set-up and the
- *      refresh count the previous call on the same slot left, when dt, assembly and storage are unchanged and nothing else
- *      has touched the state or solved in between: stepping in chunks then costs what one long call costs [1] */
+ *  35: K2S takes the storage term Ss * volumes as one-byte codes into a table when it has at most 16 distinct values (a
+ *      regular grid with a scalar Ss: the cell volume and its half, quarter and eighth on the faces, edges and corners of
+ *      the box), as one double when it has one, instead of streaming it: 7 or 8 bytes per row fewer; 0 = always stream [1]
+ *  36: K2S in the z-form: between two one-iteration steps only the Jacobi-scaled residual z = M^-1 r (which is the next
+ *      step's first direction) is kept, and r is taken from it as z / M^-1 where it is needed: 56 instead of 64 bytes per
+ *      row; single-GPU runs, needs M^-1 > 0 on every row; 0 = keep r and z [1] */
 int fv_tune(int key, int value);
 /* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event
  * between two launches is a barrier (~10 us each at 464^3), so the timed region of the bench uses 2; 0: off. */
@@ -303,6 +309,11 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
 #define FV_SPMV_DIA_MARCH 2
 #define FV_SPMV_SYM_MARCH 3
 int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
+/* Bytes per row the most recent K2S launch (the fused vector update of a fixed-dt step in the one-iteration regime:
+ * x += alpha p, r -= alpha q, the convergence sums and the next step's set-up) streams: 56 in the z-form (fv_tune key 36:
+ * x_in, q, M^-1, D, z in and x_out, z' out), 64 otherwise (x_in, q, M^-1, D, r in and x_out, r, p' out); 7 / 8 fewer when the
+ * storage term comes as codes / one double (key 35), 8 more when a dense b' is streamed too.  0 before the first such launch. */
+int fv_update_form(fv_problem *p, int32_t *bytes_per_row);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

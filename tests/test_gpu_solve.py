@@ -183,6 +183,72 @@ def test_profile_levels_time_the_kernels_they_name_and_leave_the_heads_alone(fv)
     assert k1[0]["spmv_dot"][1] == full[0]["spmv_dot"][1] and k1[0]["update"] == (0.0, 0) and k1[0]["pupdate"] == (0.0, 0)
 
 
+def test_storage_term_as_codes_or_one_double_gives_the_same_bits(fv):
+    """fv_tune key 35: K2S takes D = Ss * volumes as one double when it is the same on every row, as one-byte codes into a
+    table when it takes a few values (regulargrid's own volumes: halved on the faces of the box, quartered on its edges),
+    and as its stream otherwise: 8, 7 or 0 bytes per row fewer, the same run bit for bit."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (32, 24, 21), sigma=1.0)  # odd n
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    lib = fv.load()
+    assert 2 <= len(np.unique(vol)) <= 8
+    volumes = {"even": np.full(N, vol.max()), "grid": vol, "many": vol * (1.0 + 1e-3 * (np.arange(N) % 50))}
+    out = {}
+    try:
+        assert lib.fv_tune(36, 0) == 0
+        for name, v in volumes.items():
+            for switch in (1, 0):
+                assert lib.fv_tune(35, switch) == 0
+                p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+                st = p.transient_begin(0.1, v, np.full(N, 0.5))
+                iters, info, ms = p.run_fixed(st, 0.0009765625, 40, rtol=1e-13)  # one PCG iteration per step: every step is a K2S
+                assert info.converged and (iters == 1).all()
+                out[(name, switch)] = (st.node_values(), p.update_form())
+    finally:
+        lib.fv_tune(35, 1)
+        lib.fv_tune(36, 1)
+    assert [out[(name, 1)][1] for name in volumes] == [56, 57, 64] and all(out[(name, 0)][1] == 64 for name in volumes)
+    for name in volumes:
+        assert np.array_equal(out[(name, 1)][0], out[(name, 0)][0])
+
+
+def test_zform_update_keeps_one_vector_between_one_iteration_steps(fv, oracle):
+    """fv_tune key 36: between two one-iteration steps the Jacobi-scaled residual (= the first direction) is the only
+    vector K2S leaves; r is taken from it (56 instead of 64 bytes per row).  Same iterations, heads equal to rounding
+    and within the solver tolerance of the oracle's direct solves; a step that does not converge in its one iteration, a
+    step that is converged at its set-up and a change of dt in between all find the residual they need."""
+    coords, nb, aol, vol, K, dn, dh = _box(fv, (15, 13, 11), sigma=1.0)  # odd n: scalar tails
+    N = len(vol)
+    src = np.zeros(N)
+    src[N // 2] = -1e-4
+    u0 = np.full(N, 0.5)
+    dt = 0.0009765625
+    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, 40 * dt), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep, dt0=dt, linearsolver=oracle.directlinearsolver)
+    lib = fv.load()
+    out = {}
+    try:
+        for zf in (1, 0):
+            assert lib.fv_tune(36, zf) == 0
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+            st = p.transient_begin(0.1, vol, u0)
+            it1, info, _ = p.run_fixed(st, dt, 40, rtol=1e-13)
+            form = p.update_form()
+            h1 = st.node_values()
+            assert info.converged and relerr(h1, ous[-1]) < HEAD_RTOL
+            it2, info, _ = p.run_fixed(st, 40.0, 5, rtol=1e-13)      # the first step speculates and misses
+            it3, info, _ = p.run_fixed(st, dt, 12, rtol=1e-13)
+            it4, info, _ = p.run_fixed(st, dt, 30, rtol=1e-3)        # loose tolerance: steps converged at their set-up
+            assert info.converged
+            out[zf] = (h1, st.node_values(), np.r_[it1, it2, it3, it4], form)
+    finally:
+        lib.fv_tune(36, 1)
+    assert out[1][3] == 49 and out[0][3] == 57  # regulargrid volumes: D comes as codes (-7) in both
+    assert (out[1][2][:40] == 1).all() and (out[1][2][40:45] > 1).all() and (out[1][2][-30:] == 0).any()
+    assert np.abs(out[1][2] - out[0][2]).max() <= 1
+    assert relerr(out[1][0], out[0][0]) < 1e-12 and relerr(out[1][1], out[0][1]) < 1e-9
+
+
 def test_time_dependent_getb_method(fv, oracle):
     """transient.jl:165-174: caller supplies the volume-scaled b(t)."""
     coords, nb, aol, vol, K, dn, dh = _box(fv, (8, 8, 6), sigma=0.5)
