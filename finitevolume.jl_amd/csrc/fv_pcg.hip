@@ -900,7 +900,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (speculate)
         FV_TRY(storage_form(p, &sarg, &Dsaved));
     bool zf = false; // this step's K2S in the z-form
-    if (speculate && g_zform && !p->dist)
+    if (speculate && g_zform)
         FV_TRY(minv_positive(p, &zf));
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
@@ -1619,6 +1619,10 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     int Dsaved = 0;
     if (speculate)
         FV_TRY(storage_form(p, &sarg, &Dsaved));
+    bool zf = false; // this step's K2S in the z-form (each rank decides for its own rows: the arithmetic is per row)
+    if (speculate && g_zform)
+        FV_TRY(minv_positive(p, &zf));
+    const double *prev_z = nullptr; // use_spec: where the previous step's z-form K2S left its p' (nullptr: it wrote r)
     const bool defer_in = chained && chain_index > 0 && g_defer_reduce && speculate && carry_prev;   // red[1..5]: the previous step's local sums
     const bool defer_out = chained && !last_in_burst && g_defer_reduce && speculate; // leave this step's sums to the next one
     if (resume) {
@@ -1626,6 +1630,11 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     } else if (use_spec) {
         // r, p' and the all-reduced set-up scalars (red[3..5]) were left by the previous step's K2S
         p->pvec.swap(p->pnext);
+        if (p->z_where)
+            p->z_where = 3 - p->z_where;
+        if (!zf)
+            FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
+        prev_z = p->z_where == 1 ? p->pvec.p : nullptr;
         if (!defer_in) {
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
                                (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
@@ -1634,9 +1643,10 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     } else {
         if (carry_prev && !compute_minv && !ds) {
             // r0 = r_final + sigma D (u - u_prev): purely local, no halo of u needed
+            const double *zsrc = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : nullptr;
             hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->b.p, (const double *)p->D.p,
                                dt, (const double *)u, carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
-                               p->part_bb.p);
+                               p->part_bb.p, zsrc);
         } else if (explicit_sys) {
             // q = (A + sigma D) x, r0 = rhs - q
             FV_TRY(dist_spmv(p, u, p->q.p, sig_mv, folded, false, false));
@@ -1650,6 +1660,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                                p->diagA.p, (const double *)p->D.p, sigma, dt, b_times_D, (const double *)u, compute_minv, 1, p->r.p, p->pvec.p,
                                p->minv.p, p->part_rz.p, p->part_rr.p, p->part_bb.p);
         }
+        p->z_where = 0; // each of these set-ups has written r
         SumSet init{};
         init.a[0] = p->part_rz.p;
         init.a[1] = p->part_rr.p;
@@ -1800,7 +1811,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 const BoundarySums bs{red + 1, red + 2, red + 3, red + 4, red + 5, 1, 1, 1};
                 hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
                                    p->pnext.p, bs, rtol, p->scal.p, carry_prev, (const double *)u, (const double *)p->D.p, dt,
-                                   chain_index - 1, (chain_index - 1 == g_chain_test_break) ? 1 : 0);
+                                   chain_index - 1, (chain_index - 1 == g_chain_test_break) ? 1 : 0, prev_z);
                 FV_LAUNCH_CHECK(ctx);
             } else
                 FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
@@ -1809,13 +1820,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             sums.a[1] = p->part_rr.p;
             FV_PROF(2);
             if (spec) {
-                hipLaunchKernelGGL(k2s_kernel(false), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
+                hipLaunchKernelGGL(k2s_kernel(zf), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)u, x_next, p->r.p,
                                    (const double *)p->pvec.p, (const double *)p->q.p, (const double *)p->minv.p,
                                    sarg,
                                    bsupport >= 0 ? (const double *)nullptr : (const double *)p->b.p, dt, (const double *)red, 1, p->scal.p,
                                    p->part_rz.p, p->part_rr.p, p->pnext.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
                                    p->part_bb.p + FV_VEC_PARTIALS, sbarg, chained ? chain_index : -1);
-                p->k2s_bytes = 64 - Dsaved + (bsupport >= 0 ? 0 : 8);
+                p->k2s_bytes = (zf ? 56 : 64) - Dsaved + (bsupport >= 0 ? 0 : 8);
                 sums.a[2] = p->part_rz.p + FV_VEC_PARTIALS;
                 sums.a[3] = p->part_rr.p + FV_VEC_PARTIALS;
                 sums.a[4] = p->part_bb.p + FV_VEC_PARTIALS;
@@ -1838,7 +1849,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
                                    (const double *)u, (const double *)x_next, (const double *)p->D.p, dt, chain_index,
-                                   (chained && chain_index == g_chain_test_break) ? 1 : 0);
+                                   (chained && chain_index == g_chain_test_break) ? 1 : 0, zf ? (const double *)p->pnext.p : nullptr);
             else
                 hipLaunchKernelGGL(pcg_pupdate_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0,
@@ -1849,6 +1860,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         if (chained) { // polled once per burst by the caller
             p->last_iters = 1;
             p->spec_valid = true;
+            p->z_where = zf ? 2 : 0; // unless the chain stops on the device (the poll then says so)
             return FV_OK;
         }
         const int32_t iters_before = (p->profile && it > m) ? hs->iters : (int32_t)(resume ? resume_it : 0);
@@ -1876,6 +1888,8 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     }
     p->last_iters = hs->iters;
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1;
+    if (speculate && zf && hs->iters >= 1)
+        p->z_where = p->spec_valid ? 2 : 0; // as in fv_pcg_solve
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
