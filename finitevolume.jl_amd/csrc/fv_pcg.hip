@@ -18,6 +18,7 @@
 #include "fv_internal.h"
 #include "fv_device.h"
 #include "fv_spmv.h"
+#include <cstring>
 
 extern int g_carry_refresh, g_carry_speculate, g_chain_steps, g_resume_runs; // fv_transient.hip
 int g_defer_reduce = 1; // fv_tune key 22: bursts of chained steps take a step's verdict and the next step's scalars in one launch; row-block runs also merge their two all-reduces (see dist_step)
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(FV_BLOCK) void storage_code_kernel(int64_t n, const
             code[i] = (uint8_t)c;
         else if (!offered_one) {
             offered_one = true; // one try per thread: whoever gets the claim decides the next table entry
-            if (atomicCAS(claim, 0, 1) == 0)
+            if (*reinterpret_cast<volatile int32_t *>(claim) == 0 && atomicCAS(claim, 0, 1) == 0)
                 *offered = D[i];
         }
     }
@@ -563,7 +564,19 @@ static int storage_form(fv_problem *p, StorageArg *out, int *bytes_saved)
     fv_ctx *ctx = p->ctx;
     if (p->dcode_epoch != p->storage_epoch || p->dcode_ptr != p->D.p) {
         p->dcode_n = 0; // 0: keep the stream
-        if (p->n > 0 && p->D.p) {
+        // two samples first: a mesh with uneven volumes shows more than FV_STORAGE_CODES values at once
+        bool few = p->n > 0 && p->D.p;
+        if (few) {
+            const size_t m = (size_t)(p->n < 2048 ? p->n : 2048);
+            std::vector<double> h(2 * m);
+            FV_TRY(fv_copy(ctx, h.data(), p->D.p, m * sizeof(double)));
+            FV_TRY(fv_copy(ctx, h.data() + m, p->D.p + ((size_t)p->n - m) / 2, m * sizeof(double)));
+            std::vector<uint64_t> bits(2 * m);
+            memcpy(bits.data(), h.data(), 2 * m * sizeof(double));
+            std::sort(bits.begin(), bits.end());
+            few = std::unique(bits.begin(), bits.end()) - bits.begin() <= FV_STORAGE_CODES;
+        }
+        if (few) {
             FV_TRY(p->dcode.alloc(ctx, (size_t)p->n + 16));
             FV_TRY(p->dcode.zero(ctx));
             DevBuf<int32_t> claim;
