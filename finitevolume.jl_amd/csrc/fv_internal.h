@@ -222,6 +222,11 @@ struct fv_problem {
     DevBuf<int32_t> sym_rest; // the DIA slices where that does not hold (slice-by-slice kernel)
     int64_t sym_d[3] = {0, 0, 0}, sym_ld = 0, sym_front = 0, sym_nrest = 0, sym_epoch = -1;
     double sym_tag = 0.0;
+    // slices whose diagonal the symmetric kernel re-derives from the six arms it holds (bit 1 of sym_ok; symdia_rowsum_kernel)
+    int64_t sym_nderived = 0;
+    int sym_rowsum_switch = -1;   // fv_tune key 37 as it was when the flags were set
+    int sym_shift_mode = 0;       // 0: the derived diagonal carries no shift; 1: + sym_shift.v[code of the row]; 2: + sym_shift.v[0]
+    StorageTable sym_shift = {};  // sigma x the distinct values of D, for the sigma folded into the copy
     int last_form = -1; // FV_SPMV_* of the most recent spmv_apply (fv_spmv_form)
     int sym_state = -1; // -1 not looked at yet, 0 not applicable (no such structure, or not symmetric), 1 built
 
@@ -379,6 +384,9 @@ struct PcgSystem {
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
+// how K2S (and the symmetric K1, for the shift folded into a diagonal it re-derives) is handed the storage term D: see
+// StorageArg; *bytes_saved = bytes per row against streaming the doubles; ignore_switch: whatever fv_tune key 35 says
+int fv_storage_form(fv_problem *p, StorageArg *out, int *bytes_saved, bool ignore_switch);
 int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info, uint32_t *zero_mask = nullptr);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,

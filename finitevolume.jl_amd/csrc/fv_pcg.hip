@@ -559,7 +559,7 @@ __global__ __launch_bounds__(FV_BLOCK) void storage_code_kernel(int64_t n, const
         }
     }
 }
-static int storage_form(fv_problem *p, StorageArg *out, int *bytes_saved)
+int fv_storage_form(fv_problem *p, StorageArg *out, int *bytes_saved, bool ignore_switch)
 {
     fv_ctx *ctx = p->ctx;
     if (p->dcode_epoch != p->storage_epoch || p->dcode_ptr != p->D.p) {
@@ -609,7 +609,7 @@ static int storage_form(fv_problem *p, StorageArg *out, int *bytes_saved)
     *out = StorageArg{};
     out->D = p->D.p;
     *bytes_saved = 0;
-    if (g_uniform_storage && p->dcode_n > 0) {
+    if ((g_uniform_storage || ignore_switch) && p->dcode_n > 0) {
         out->D = nullptr;
         out->tab = p->dtable;
         out->code = p->dcode_n > 1 ? p->dcode.p : nullptr; // one value: no stream at all
@@ -911,7 +911,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     StorageArg sarg{};
     int Dsaved = 0;
     if (speculate)
-        FV_TRY(storage_form(p, &sarg, &Dsaved));
+        FV_TRY(fv_storage_form(p, &sarg, &Dsaved, false));
     bool zf = false; // this step's K2S in the z-form
     if (speculate && g_zform)
         FV_TRY(minv_positive(p, &zf));
@@ -1631,7 +1631,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     StorageArg sarg{};
     int Dsaved = 0;
     if (speculate)
-        FV_TRY(storage_form(p, &sarg, &Dsaved));
+        FV_TRY(fv_storage_form(p, &sarg, &Dsaved, false));
     bool zf = false; // this step's K2S in the z-form (each rank decides for its own rows: the arithmetic is per row)
     if (speculate && g_zform)
         FV_TRY(minv_positive(p, &zf));

@@ -274,6 +274,7 @@ static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune
 int g_fold_shift = 1;
 static int g_symdia = 1; // fv_tune key 27: symmetric plane-marching form where the marching kernel runs (0 off)
 static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
+static int g_sym_rowsum = 1; // fv_tune key 37: 0 = the symmetric kernel always streams the diagonal (see symdia_rowsum_kernel)
 static int g_symdia_nt = 4; // fv_tune key 28: streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
@@ -362,6 +363,8 @@ extern "C" int fv_tune(int key, int value)
         g_uniform_storage = value;
     else if (key == 36 && (value == 0 || value == 1))
         g_zform = value;
+    else if (key == 37 && (value == 0 || value == 1))
+        g_sym_rowsum = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -1019,12 +1022,19 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
                                                                           const double *__restrict__ u1, const double *__restrict__ u2,
                                                                           const double *__restrict__ u3, const double *__restrict__ x,
                                                                           double *__restrict__ y, const double *__restrict__ dshift, double sigma,
-                                                                          double *__restrict__ partials, const PcgScalars *__restrict__ scal)
+                                                                          double *__restrict__ partials, const PcgScalars *__restrict__ scal,
+                                                                          const uint8_t *__restrict__ dcode, StorageTable tshift, int shift_mode)
 {
     constexpr int WPB = FV_BLOCK / 64;
     __shared__ double smem[4];
+    __shared__ double dtab[FV_STORAGE_CODES];
     if (scal && scal->done)
         return;
+    if (shift_mode) { // the shift folded into a re-derived diagonal (sym_ok bit 1): sigma x the row's storage value, by code
+        if (threadIdx.x < FV_STORAGE_CODES)
+            dtab[threadIdx.x] = tshift.v[threadIdx.x];
+        __syncthreads();
+    }
     const uint32_t lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int xcd = (int)(blockIdx.x & 7);
@@ -1077,8 +1087,12 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
             asm volatile("" : "+v"(rb));
             double c = 0.0, xp = 0.0, xmn = 0.0, a3 = 0.0, amn = 0.0, vd = 0.0, v1 = 0.0, v2 = 0.0, v1m = 0.0, v2m = 0.0, x2m = 0.0, x1m = 0.0, x1p = 0.0,
                    x2p = 0.0;
+            uint32_t cd = 0;
             if (ok) { // issued first: the longest-latency (HBM) streams of the step
-                vd = ld_off<NT & 1>(dg, fb + rb);
+                if (!(ok & 2))
+                    vd = ld_off<NT & 1>(dg, fb + rb);
+                else if (shift_mode == 1) // zero row sum: the diagonal follows from the six arms (below); only its shift needs the row's code
+                    cd = dcode[(uint32_t)base + lane];
                 v1 = ld_off<NT & 2>(u1, fb + rb);
                 v2 = ld_off<NT & 2>(u2, fb + rb);
                 if (!(dbg & 2)) { // (diagnosis switches, fv_tune key 29: results are wrong when set)
@@ -1156,6 +1170,19 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
                     v1m = wave_from_below(v1, e1);
                     x1m = wave_from_below(c, exm);
                     x1p = wave_from_above(c, exp_);
+                }
+                if (ok & 2) {
+                    // a row without a Dirichlet neighbour: the diagonal is minus the sum of its off-diagonals, added in the order
+                    // the faces were assembled in (-plane, -line, -1, +plane, +line, +1), plus the folded shift — the stored
+                    // double bit for bit (checked per slice by symdia_rowsum_kernel whenever the copy is filled)
+                    double so = am + v2m;
+                    so += v1m;
+                    so += a3;
+                    so += v2;
+                    so += v1;
+                    vd = -so;
+                    if (shift_mode)
+                        vd += dtab[cd];
                 }
                 double sum = 0.0;
                 sum += am * xm;
@@ -1254,6 +1281,44 @@ __global__ __launch_bounds__(FV_BLOCK) void symdia_check_kernel(int64_t n, const
 }
 
 
+// Zero row sum: on a row without a Dirichlet neighbour the assembled diagonal is the sum of the conductances of its faces,
+// i.e. minus the sum of its off-diagonals — bit for bit when added in the order the assembly added them (face order:
+// for the numbering of regulargrid -plane, -line, -1, +plane, +line, +1) — plus sigma D when the shift is folded in.  Rows
+// where that reproduces the stored double need no diagonal stream.  Per slice: bad[slice] = 1 if any of its rows differs.
+__global__ __launch_bounds__(FV_BLOCK) void symdia_rowsum_kernel(int64_t n, int32_t d1, int32_t d2, int32_t d3, const double *__restrict__ dg,
+                                                                  const double *__restrict__ u1, const double *__restrict__ u2,
+                                                                  const double *__restrict__ u3, const uint8_t *__restrict__ dcode,
+                                                                  StorageTable tshift, int shift_mode, const uint8_t *__restrict__ ok,
+                                                                  uint8_t *__restrict__ bad)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n || !(ok[r >> 6] & 1))
+        return;
+    double so = u3[r - d3] + u2[r - d2]; // (the arrays are zero-padded in front and behind: absent arms add 0)
+    so += u1[r - d1];
+    so += u3[r];
+    so += u2[r];
+    so += u1[r];
+    double cand = -so;
+    if (shift_mode)
+        cand += tshift.v[shift_mode == 1 ? dcode[r] : 0];
+    if (__double_as_longlong(cand) != __double_as_longlong(dg[r]))
+        bad[r >> 6] = 1;
+}
+__global__ __launch_bounds__(FV_BLOCK) void symdia_rowsum_flag_kernel(int64_t nslices, const uint8_t *__restrict__ bad, int on, uint8_t *__restrict__ ok,
+                                                                       int32_t *__restrict__ count)
+{
+    const int64_t sl = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    int derived = 0;
+    if (sl < nslices && (ok[sl] & 1)) {
+        derived = on && !bad[sl];
+        ok[sl] = (uint8_t)(1 | (derived ? 2 : 0));
+    }
+    const unsigned long long m = __ballot(derived);
+    if ((threadIdx.x & 63) == 0 && m)
+        atomicAdd(count, (int32_t)__popcll(m));
+}
+
 // Decide whether the operator has the symmetric three-offset structure and allocate the copy (once per problem).
 static int build_symdia(fv_problem *p)
 {
@@ -1321,8 +1386,9 @@ static int build_symdia(fv_problem *p)
 static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
 {
     fv_ctx *ctx = p->ctx;
-    if (p->sym_epoch == p->assemble_epoch && p->sym_tag == src_tag)
+    if (p->sym_epoch == p->assemble_epoch && p->sym_tag == src_tag && p->sym_rowsum_switch == g_sym_rowsum)
         return FV_OK;
+    p->sym_rowsum_switch = g_sym_rowsum;
     double *dg = p->sym_vals.p + p->sym_front, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld;
     const int32_t d1 = (int32_t)p->sym_d[0], d2 = (int32_t)p->sym_d[1], d3 = (int32_t)p->sym_d[2];
     hipLaunchKernelGGL(symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
@@ -1343,6 +1409,42 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
             p->sym_vals.release();
             return FV_OK;
         }
+    }
+    // which slices can do without the diagonal stream (bit 1 of sym_ok)
+    {
+        const int64_t ns = (p->n + 63) >> 6;
+        int mode = 0;
+        StorageArg sa{};
+        bool on = g_sym_rowsum != 0;
+        if (on && src_tag != 0.0) { // sigma D folded into the diagonal: the kernel needs sigma D of the row, by code
+            int saved = 0;
+            FV_TRY(fv_storage_form(p, &sa, &saved, true));
+            if (sa.D)
+                on = false; // too many distinct storage values for codes: keep the stream
+            else {
+                mode = sa.code ? 1 : 2;
+                for (int k = 0; k < FV_STORAGE_CODES; k++)
+                    p->sym_shift.v[k] = src_tag * sa.tab.v[k]; // the product fold_shift_kernel formed
+            }
+        }
+        DevBuf<uint8_t> bad;
+        DevBuf<int32_t> cnt;
+        FV_TRY(bad.alloc(ctx, (size_t)ns));
+        FV_TRY(bad.zero(ctx));
+        FV_TRY(cnt.alloc(ctx, 1));
+        FV_TRY(cnt.zero(ctx));
+        if (on) {
+            hipLaunchKernelGGL(symdia_rowsum_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, d1, d2, d3, (const double *)dg,
+                               (const double *)u1, (const double *)u2, (const double *)u3, sa.code, p->sym_shift, mode, (const uint8_t *)p->sym_ok.p, bad.p);
+            FV_LAUNCH_CHECK(ctx);
+        }
+        hipLaunchKernelGGL(symdia_rowsum_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const uint8_t *)bad.p, on ? 1 : 0,
+                           p->sym_ok.p, cnt.p);
+        FV_LAUNCH_CHECK(ctx);
+        int32_t h = 0;
+        FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
+        p->sym_nderived = h;
+        p->sym_shift_mode = h > 0 ? mode : 0;
     }
     p->sym_epoch = p->assemble_epoch;
     p->sym_tag = src_tag;
@@ -1656,7 +1758,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 #define FV_SYM1(D_, N_, W_, O_)                                                                                                               \
     hipLaunchKernelGGL((spmv_symdia_march_kernel<D_, N_, W_, O_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, \
                        (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], seglen, segs_per_xcd, (uint32_t)p->sym_front, g_symdia_dbg, (const uint8_t *)p->sym_ok.p, dg, u1, u2, u3, x, y, \
-                       shift, sigma, partials, scal)
+                       shift, sigma, partials, scal, (const uint8_t *)p->dcode.p, p->sym_shift, p->sym_shift_mode)
 #define FV_SYM(D_, N_, W_)                                                                                                                    \
     do {                                                                                                                                      \
         if (p->sym_d[0] == 1 && !(g_symdia_dbg & 8))                                                                                          \
@@ -1784,7 +1886,9 @@ extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_lau
             // slices the symmetric kernel computes; the other DIA slices (irregular ones, first / last plane, a row block's
             // boundary slices) in the sliced-DIA form
             const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - p->sym_nrest;
-            bytes = nok * (4 * 512 + 1) + dia_all / p->ndia * (p->ndia - nok) + vec + csr_part;
+            const int64_t nder = p->sym_nderived; // ... of which these re-derive the diagonal: three value streams + the shift's codes
+            bytes = (nok - nder) * (4 * 512 + 1) + nder * (3 * 512 + (p->sym_shift_mode == 1 ? 64 : 0) + 1) + dia_all / p->ndia * (p->ndia - nok) + vec +
+                    csr_part;
         } else
             bytes = dia_all + vec + csr_part;
     }

@@ -290,7 +290,11 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      the box), as one double when it has one, instead of streaming it: 7 or 8 bytes per row fewer; 0 = always stream [1]
  *  36: K2S in the z-form: between two one-iteration steps only the Jacobi-scaled residual z = M^-1 r (which is the next
  *      step's first direction) is kept, and r is taken from it as z / M^-1 where it is needed: 56 instead of 64 bytes per
- *      row; single-GPU runs, needs M^-1 > 0 on every row; 0 = keep r and z [1] */
+ *      row; needs M^-1 > 0 on every row; 0 = keep r and z [1]
+ *  37: zero row sum in the symmetric plane-marching SpMV: slices in which every row's stored diagonal is, bit for bit, minus
+ *      the sum of its six off-diagonals in assembly order (plus the folded sigma D, taken by the row's storage code) — rows
+ *      without a Dirichlet neighbour — are computed without the diagonal stream: 40 (41) instead of 48 bytes per row;
+ *      0 = always stream the diagonal [1] */
 int fv_tune(int key, int value);
 /* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event
  * between two launches is a barrier (~10 us each at 464^3), so the timed region of the bench uses 2; 0: off. */

@@ -258,8 +258,9 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
     scale = np.abs(ref).max()
     lib = fv.load()
     try:
-        ys = {}
-        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1}), ("sym march m=1", {9: 2, 10: 1, 27: 1}), ("sym march m=5", {9: 2, 10: 5}), ("sym march, plain loads", {9: 2, 28: 0}),
+        ys, forms = {}, {}
+        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1}), ("sym march m=1", {9: 2, 10: 1, 27: 1}), ("sym march m=5", {9: 2, 10: 5}), ("sym march, plain loads", {9: 2, 28: 0}),
+                            ("sym march, streamed diagonal", {9: 2, 37: 0}), ("sym march, derived diagonal again", {9: 2, 37: 1}),
                             ("march", {9: 2, 6: 1, 18: 1, 27: 0}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}),
                             ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
@@ -274,6 +275,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
             assert abs(p.dot(x, y) - x @ y) <= 1e-12 * abs(x @ y)
             assert p.spmv_form()[0] == (3 if name.startswith("sym") else 2 if name.startswith("march") else 1 if name == "slices" else 0)
             ys[name] = y
+            forms[name] = p.spmv_form()[2]
             lib.fv_tune(10, 0)
             lib.fv_tune(28, 5)
         # the DIA forms sum a row's terms in ascending column order with fused multiply-adds, absent entries as zeros: the same
@@ -281,9 +283,11 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         for name in ys:
             if name != "csr":
                 assert np.array_equal(ys[name], ys["slices"]), name
+        # zero row sum: interior rows re-derive their diagonal from the six arms (fv_tune key 37): a stream fewer, the same bits
+        assert forms["sym march"] == forms["sym march, derived diagonal again"] < forms["sym march, streamed diagonal"] - 7 * (p.n - 3 * (ns[1] - 2) * ns[2])
         # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
         heads = {}
-        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
+        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1}), ("sym march, streamed diagonal", {37: 0}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
             for k, v in knobs.items():
                 lib.fv_tune(k, v)
             st = p.new_state()
@@ -291,8 +295,12 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
             it, info, _ = p.run_fixed(st, 3600.0, 4, 1e-12)
             assert info.converged
             heads[name] = st.node_values()
+            forms[name + " folded"] = p.spmv_form()[2]
         assert np.abs(heads["march"] - heads["slices"]).max() <= 1e-9
         assert np.abs(heads["sym march"] - heads["slices"]).max() <= 1e-9
+        # with the shift folded into the diagonal the derived one adds sigma D by the row's storage code: the same bits again
+        assert np.array_equal(heads["sym march"], heads["sym march, streamed diagonal"])
+        assert forms["sym march folded"] < forms["sym march, streamed diagonal folded"] - 6 * (p.n - 3 * (ns[1] - 2) * ns[2])
     finally:
         lib.fv_tune(9, 1)
         lib.fv_tune(6, 1)
@@ -300,6 +308,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         lib.fv_tune(18, 1)
         lib.fv_tune(27, 1)
         lib.fv_tune(28, 5)
+        lib.fv_tune(37, 1)
 
 
 def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv, capfd):
