@@ -1011,7 +1011,13 @@ __device__ inline double wave_from_above(double v, double edge)
 // sym_ok = 0 and are left to the slice-by-slice kernel like the irregular ones; here their windows are simply not loaded.
 // Launch bounds: 6 waves per SIMD — the grid is sized for 6 blocks per CU anyway (see spmv_apply), and 68 registers instead
 // of 64 keep everything out of scratch.  (Tried on top: touch loads of the next step's lines one step ahead, one dword per
-// lane and stream: +19 % — more loads in flight hurt, the kernel is bound by the memory pipeline, not by latency.)
+// lane and stream: +19 % — more loads in flight hurt, the kernel is bound by the memory pipeline, not by latency.  Late in
+// round 2, a software-pipelined version: every load of a step issued unconditionally in one group, one step ahead of its
+// use, two register sets, the three edge values by vector loads: 96 registers, 5 blocks per CU, bit-identical results, 1.03-1.05 ms
+// against this kernel's 0.98 in the same process; the SQ counters say why not: here 82 % of the wave cycles are spent
+// parked in s_waitcnt and 6 % in issue stalls, there 58 % and 28 % — the vector-memory issue queue backs up.  Taking the
+// diagonal stream out (sym_ok bit 1, below) removed 15 % of the HBM bytes for 4 % of the time; not loading the in-plane
+// arms at all (fv_tune key 29) removes 27 % of the L2->L1 bytes for 3.6 %.  No single resource is the limit.)
 // D1: the first in-plane offset is 1 (consecutive cells of a grid line are consecutive rows) — the +-1 arms of x and the
 // -1 matrix value are then the neighbouring lanes' centre x / U1 value (DPP wave shift) plus one scalar load for the lane at
 // the slice's edge: three vector loads fewer per step (-6 % at 464^3, and fewer lines for the L2 to keep).
