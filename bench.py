@@ -30,7 +30,7 @@ KERNEL_NAMES = {  # fv_spmv_form id -> kernel(s) that ran
     0: "spmv_wstream_kernel<512,true,true> (wave-private CSR stream)",
     1: "spmv_dia_kernel<true,true,false> (sliced-DIA, slice by slice: x fits the last-level cache at this size)",
     2: "spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses)",
-    3: "spmv_symdia_march_kernel<true,5,true> (symmetric plane-marching: diagonal + 3 upper diagonals streamed, lower arms from the upper arrays; first/last plane by spmv_dia_kernel)",
+    3: "spmv_symdia_march_kernel<true,4,true,true> (symmetric plane-marching: 3 upper diagonals streamed, lower arms from the upper arrays, the diagonal re-derived from the six arms where the row sum is zero and streamed elsewhere; first/last plane by spmv_dia_kernel)",
 }
 
 
@@ -419,7 +419,8 @@ def roofline_block(p, prof, iters_per_step, ns):
     if os.path.exists(tfile):
         try:
             t = json.load(open(tfile)).get(str(ns))
-            if t and t.get("form") == form_id:  # measured for the kernel that ran here, not for an earlier one
+            # measured for the kernel and the storage form that ran here, not for an earlier one
+            if t and t.get("form") == form_id and abs(t.get("form_bytes", 0) - form_bytes) <= 0.01 * form_bytes:
                 roof["traffic"] = t["bytes"]
                 roof["traffic_source"] = t.get("source")
                 if roof.get("avg_launch_ms"):
