@@ -1015,7 +1015,10 @@ __device__ inline double wave_from_above(double v, double edge)
 // round 2, a software-pipelined version: every load of a step issued unconditionally in one group, one step ahead of its
 // use, two register sets, the three edge values by vector loads: 96 registers, 5 blocks per CU, bit-identical results, 1.03-1.05 ms
 // against this kernel's 0.98 in the same process; the SQ counters say why not: here 82 % of the wave cycles are spent
-// parked in s_waitcnt and 6 % in issue stalls, there 58 % and 28 % — the vector-memory issue queue backs up.  Taking the
+// parked in s_waitcnt and 6 % in issue stalls, there 58 % and 28 % — the vector-memory issue queue backs up.  (The same
+// loads in one unconditional group WITHOUT the step of lookahead, 69 registers, 6 blocks per CU: 0.981 against 0.962 ms with
+// the derived diagonal, 1.086 against 1.011 with the streamed one — staging a step's loads the way this kernel does beats
+// having them all in flight at once.)  Taking the
 // diagonal stream out (sym_ok bit 1, below) removed 15 % of the HBM bytes for 4 % of the time; not loading the in-plane
 // arms at all (fv_tune key 29) removes 27 % of the L2->L1 bytes for 3.6 %.  No single resource is the limit.)
 // D1: the first in-plane offset is 1 (consecutive cells of a grid line are consecutive rows) — the +-1 arms of x and the
