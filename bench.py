@@ -30,6 +30,7 @@ KERNEL_NAMES = {  # fv_spmv_form id -> kernel(s) that ran
     0: "spmv_wstream_kernel<512,true,true> (wave-private CSR stream)",
     1: "spmv_dia_kernel<true,true,false> (sliced-DIA, slice by slice: x fits the last-level cache at this size)",
     2: "spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses)",
+    4: "spmv_symdia_tile_kernel<true,4> (symmetric form, tiled: a block owns 1024 rows of a plane and marches through the planes; 3 upper diagonals streamed once, lower arms and the in-plane x arms through LDS, +-plane arms in registers, the diagonal re-derived from the six arms where the row sum is zero; first/last plane by spmv_dia_kernel)",
     3: "spmv_symdia_march_kernel<true,4,true,true> (symmetric plane-marching: 3 upper diagonals streamed, lower arms from the upper arrays, the diagonal re-derived from the six arms where the row sum is zero and streamed elsewhere; first/last plane by spmv_dia_kernel)",
 }
 

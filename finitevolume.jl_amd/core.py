@@ -285,7 +285,8 @@ class Problem:
         return ms.value
 
     SPMV_FORMS = {-1: "none yet", 0: "CSR wave-stream", 1: "sliced-DIA, slice by slice", 2: "sliced-DIA, plane-marching",
-                  3: "symmetric plane-marching (diagonal + 3 upper diagonals)"}
+                  3: "symmetric plane-marching (diagonal + 3 upper diagonals)",
+                  4: "symmetric, tiled traversal (diagonal + 3 upper diagonals, arms through LDS)"}
 
     def reorder_info(self):
         """fv_problem_reorder_info -> dict(reordered, mean_before, mean_after, seconds)."""

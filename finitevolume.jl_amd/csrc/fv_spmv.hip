@@ -274,6 +274,9 @@ static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune
 int g_fold_shift = 1;
 static int g_symdia = 1; // fv_tune key 27: symmetric plane-marching form where the marching kernel runs (0 off)
 static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
+static int g_tile_blocks = 2; // fv_tune key 39 (experiment): resident blocks per CU the tiled kernel's grid is sized for
+static int g_tile_segs = 0;   // fv_tune key 40 (experiment): segments of planes per tile column, 0 = chosen to fill whole rounds
+static int g_sym_tile = 1;   // fv_tune key 38: the tiled traversal of the symmetric form where the free rows are a regular box (spmv_symdia_tile_kernel)
 static int g_sym_rowsum = 1; // fv_tune key 37: 0 = the symmetric kernel always streams the diagonal (see symdia_rowsum_kernel)
 static int g_symdia_nt = 4; // fv_tune key 28: streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
@@ -365,6 +368,12 @@ extern "C" int fv_tune(int key, int value)
         g_zform = value;
     else if (key == 37 && (value == 0 || value == 1))
         g_sym_rowsum = value;
+    else if (key == 38 && (value == 0 || value == 1))
+        g_sym_tile = value;
+    else if (key == 39 && value >= 1 && value <= 4)
+        g_tile_blocks = value;
+    else if (key == 40 && value >= 0 && value <= 256)
+        g_tile_segs = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -1218,6 +1227,204 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
     }
 }
 
+// ------------------------------------------------------------------ the symmetric form, tiled (2.5-D blocking)
+// The same product from the same arrays with another traversal, for operators whose free rows form a regular box numbered
+// like regulargrid's (d1 = 1, lines of nz = d2 rows, planes of d3 rows, n a whole number of planes): a block of
+// FV_TILE_T threads owns FV_TILE_R consecutive rows of a plane (two per thread: one 16-byte access per stream, K2S's access
+// shape) and marches through a segment of planes.  Every x and matrix value the block needs is loaded once — its own rows
+// from HBM, plus the +-line halo of x (2 nz values) and the -line halo of U2 (nz values) that neighbouring blocks stream at
+// about the same time — and exchanged through LDS: the +-1 and +-line arms of x, the -1 value of U1 and the -line value of U2
+// are LDS reads, the +-plane arms of x and the -plane value of U3 stay in registers from one plane step to the next.  The
+// loads of plane p + 1 are issued before the six terms of plane p that do not need them.  Rows whose slice is not sym_ok are
+// computed and thrown away (they belong to the slice-by-slice launch, as with the marching kernel); the diagonal is derived
+// where bit 1 of the slice's flag says so.  Same terms in the same order as every other form: same bits.
+constexpr int FV_TILE_T = 512, FV_TILE_R = 1024;
+template <bool DOT, int NT>
+__global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t n, int64_t ncols, int32_t nz, int32_t d3, int32_t nplanes, int32_t seglen,
+                                                                         int32_t tiles, int32_t nsegs, const uint8_t *__restrict__ sym_ok,
+                                                                         const double *__restrict__ dg, const double *__restrict__ u1,
+                                                                         const double *__restrict__ u2, const double *__restrict__ u3,
+                                                                         const double *__restrict__ x, double *__restrict__ y,
+                                                                         const double *__restrict__ dshift, double sigma,
+                                                                         double *__restrict__ partials, const PcgScalars *__restrict__ scal,
+                                                                         const uint8_t *__restrict__ dcode, StorageTable tshift, int shift_mode)
+{
+    extern __shared__ double tile_lds[];
+    __shared__ double smem[FV_TILE_T / 64];
+    __shared__ double dtab[FV_STORAGE_CODES];
+    if (scal && scal->done)
+        return;
+    if (shift_mode && threadIdx.x < FV_STORAGE_CODES)
+        dtab[threadIdx.x] = tshift.v[threadIdx.x];
+    double *xs = tile_lds;                      // x of the centre plane at in-plane offsets [base - nz, base + R + nz)
+    double *u1s = xs + (FV_TILE_R + 2 * nz);    // U1 of the centre plane at [base - 2, base + R) (only base - 1 is used of the halo)
+    double *u2s = u1s + (FV_TILE_R + 2);        // U2 of the centre plane at [base - nz, base + R)
+    const int tid = (int)threadIdx.x;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t items = (int64_t)tiles * nsegs, per_xcd = (items + 7) / 8;
+    double dacc = 0.0;
+    // the +-line halo of x: threads [0, nz/2) take the low side, [nz/2, nz) the high side, one 16-byte access each; the -line
+    // halo of U2 goes with the low side; thread 0 also brings the one U1 value below the tile
+    const int hl = tid < (nz >> 1), hh = !hl && tid < nz;
+    for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
+        const int64_t item = (int64_t)xcd * per_xcd + j;
+        if (item >= items)
+            break;
+        const int32_t seg = (int32_t)(item / tiles), tile = (int32_t)(item % tiles);
+        const int32_t base = tile * FV_TILE_R, o = base + 2 * tid;
+        const int32_t p0 = 1 + seg * seglen, p1 = (p0 + seglen < nplanes) ? p0 + seglen : nplanes; // (nplanes: one past the last plane computed)
+        if (p0 >= p1)
+            continue;
+        const bool own = o < d3;            // this thread's two rows exist in the plane
+        const bool ownx = o < d3 + nz;      // ... or are the +line neighbours of rows that do (the plane after, in memory)
+        const int32_t hoff = hl ? base - nz + 2 * tid : base + FV_TILE_R + 2 * (tid - (nz >> 1)); // in-plane offset of this thread's halo pair
+        const int hidx = hl ? 2 * tid : FV_TILE_R + nz + 2 * (tid - (nz >> 1));                   // ... and where it goes in xs
+        auto ld2 = [&](const double *a, int64_t row, bool pred) -> double2 {
+            return pred ? *reinterpret_cast<const double2 *>(a + row) : make_double2(0.0, 0.0);
+        };
+        auto ld2nt = [&](const double *a, int64_t row, bool pred) -> double2 {
+            if (!pred)
+                return make_double2(0.0, 0.0);
+            return (NT & 1) ? make_double2(__builtin_nontemporal_load(a + row), __builtin_nontemporal_load(a + row + 1))
+                            : *reinterpret_cast<const double2 *>(a + row);
+        };
+        // ---- prologue: planes p0 - 1 (x and U3 of the own rows) and p0 (everything, and its tiles into LDS)
+        int64_t r = (int64_t)p0 * d3 + o; // the thread's first row in the centre plane
+        double2 xm = ld2(x, r - d3, own), a3m = ld2nt(u3, r - d3, own);
+        double2 xc = ld2(x, r, ownx && r + 1 < ncols), v1 = ld2nt(u1, r, own), v2 = ld2nt(u2, r, own), a3c = ld2nt(u3, r, own);
+        int fl = own ? (int)sym_ok[r >> 6] : 0;
+        double2 vd = ld2nt(dg, r, own && !(fl & 2));
+        __syncthreads(); // (the previous item's last reads of LDS)
+        {
+            const int64_t hr = (int64_t)p0 * d3 + hoff;
+            if (hl || hh)
+                *reinterpret_cast<double2 *>(xs + hidx) = ld2(x, hr, hr + 1 < ncols);
+            if (hl)
+                *reinterpret_cast<double2 *>(u2s + 2 * tid) = ld2(u2, hr, true);
+            if (tid == 0)
+                u1s[1] = u1[(int64_t)p0 * d3 + base - 1];
+            *reinterpret_cast<double2 *>(xs + nz + 2 * tid) = xc;
+            *reinterpret_cast<double2 *>(u1s + 2 + 2 * tid) = v1;
+            *reinterpret_cast<double2 *>(u2s + nz + 2 * tid) = v2;
+        }
+        __syncthreads();
+        for (int32_t p = p0; p < p1; p++, r += d3) {
+            // ---- the next plane's loads (x of the own rows is also this plane's +plane arm)
+            const bool more = p + 1 < p1;
+            const int64_t rn = r + d3;
+            const double2 xn = ld2(x, rn, ownx && rn + 1 < ncols);
+            double2 v1n = make_double2(0.0, 0.0), v2n = v1n, a3n = v1n, vdn = v1n, hx = v1n, hu2 = v1n;
+            double hu1 = 0.0;
+            int fln = 0;
+            if (more) {
+                fln = own ? (int)sym_ok[rn >> 6] : 0;
+                v1n = ld2nt(u1, rn, own);
+                v2n = ld2nt(u2, rn, own);
+                a3n = ld2nt(u3, rn, own);
+                vdn = ld2nt(dg, rn, own && !(fln & 2));
+                const int64_t hr = (int64_t)(p + 1) * d3 + hoff;
+                if (hl || hh)
+                    hx = ld2(x, hr, hr + 1 < ncols);
+                if (hl)
+                    hu2 = ld2(u2, hr, true);
+                if (tid == 0)
+                    hu1 = u1[(int64_t)(p + 1) * d3 + base - 1];
+            }
+            uint32_t cd = 0;
+            if (shift_mode == 1 && (fl & 2))
+                cd = *reinterpret_cast<const uint16_t *>(dcode + r);
+            const double2 dsv = dshift ? ld2(dshift, r, own) : make_double2(0.0, 0.0); // a separate shift vector (not folded)
+            // ---- this plane: everything but the +plane term
+            const double x1m0 = xs[nz + 2 * tid - 1], x1p1 = xs[nz + 2 * tid + 2];
+            const double2 x2m = *reinterpret_cast<const double2 *>(xs + 2 * tid), x2p = *reinterpret_cast<const double2 *>(xs + 2 * nz + 2 * tid);
+            const double v1m0 = u1s[2 + 2 * tid - 1];
+            const double2 v2m = *reinterpret_cast<const double2 *>(u2s + 2 * tid);
+            double d0 = vd.x, d1v = vd.y;
+            if (fl & 2) { // zero row sum: see spmv_symdia_march_kernel
+                double so = a3m.x + v2m.x;
+                so += v1m0;
+                so += a3c.x;
+                so += v2.x;
+                so += v1.x;
+                d0 = -so;
+                so = a3m.y + v2m.y;
+                so += v1.x;
+                so += a3c.y;
+                so += v2.y;
+                so += v1.y;
+                d1v = -so;
+                if (shift_mode) {
+                    d0 += dtab[cd & 255u];
+                    d1v += dtab[cd >> 8];
+                }
+            }
+            double s0 = 0.0, s1 = 0.0;
+            s0 += a3m.x * xm.x;
+            s1 += a3m.y * xm.y;
+            s0 += v2m.x * x2m.x;
+            s1 += v2m.y * x2m.y;
+            s0 += v1m0 * x1m0;
+            s1 += v1.x * xc.x;
+            s0 += d0 * xc.x;
+            s1 += d1v * xc.y;
+            s0 += v1.x * xc.y;
+            s1 += v1.y * x1p1;
+            s0 += v2.x * x2p.x;
+            s1 += v2.y * x2p.y;
+            // ---- the +plane term and the epilogue
+            s0 += a3c.x * xn.x;
+            s1 += a3c.y * xn.y;
+            if (dshift) {
+                s0 += sigma * dsv.x * xc.x;
+                s1 += sigma * dsv.y * xc.y;
+            }
+            if (fl & 1) {
+                if (NT & 4) {
+                    __builtin_nontemporal_store(s0, y + r);
+                    __builtin_nontemporal_store(s1, y + r + 1);
+                } else
+                    *reinterpret_cast<double2 *>(y + r) = make_double2(s0, s1);
+                if (DOT)
+                    dacc += xc.x * s0 + xc.y * s1;
+            }
+            __syncthreads(); // everybody has read this plane's tiles
+            if (more) {
+                if (hl || hh)
+                    *reinterpret_cast<double2 *>(xs + hidx) = hx;
+                if (hl)
+                    *reinterpret_cast<double2 *>(u2s + 2 * tid) = hu2;
+                if (tid == 0)
+                    u1s[1] = hu1;
+                *reinterpret_cast<double2 *>(xs + nz + 2 * tid) = xn;
+                *reinterpret_cast<double2 *>(u1s + 2 + 2 * tid) = v1n;
+                *reinterpret_cast<double2 *>(u2s + nz + 2 * tid) = v2n;
+            }
+            __syncthreads();
+            xm = xc;
+            xc = xn;
+            a3m = a3c;
+            a3c = a3n;
+            v1 = v1n;
+            v2 = v2n;
+            vd = vdn;
+            fl = fln;
+        }
+    }
+    if (DOT) {
+        dacc = wave_sum(dacc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0)
+            smem[threadIdx.x >> 6] = dacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < FV_TILE_T / 64; w++)
+                t += smem[w];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
 // per slice: are all of its stored offsets among 0, +-d1, +-d2, +-d3?  rest = it is a DIA slice but not such a one
 __global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                 int32_t d1, int32_t d2, int32_t d3, int64_t step, int64_t ncols,
@@ -1701,6 +1908,13 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
                 FV_TRY(ensure_symdia_vals(p, vals, vals_tag));
             sym = p->sym_state == 1;
         }
+        // the tiled traversal of the symmetric form where the free rows (of the operator, or of a row block) are a regular box
+        bool tile = false;
+        if (sym) {
+            const int64_t tnz = p->sym_d[1], td3 = p->sym_d[2];
+            tile = g_sym_tile && p->sym_d[0] == 1 && tnz >= 64 && tnz <= FV_TILE_T && tnz % 2 == 0 && td3 % 2 == 0 && td3 % tnz == 0 &&
+                   td3 >= FV_TILE_R + tnz && p->n % td3 == 0 && p->n / td3 >= 3;
+        }
         const bool march_pays = sym || g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
         const bool march = may_march && march_pays;
         // the lane-major copy of all seven diagonals: everything, or just the slices the symmetric kernel leaves out
@@ -1709,7 +1923,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         if (g_trace_spmv > 0) { // fv_tune key 25 / FV_TRACE_SPMV: the next N kernel choices to stderr
             g_trace_spmv--;
             fprintf(stderr, "[fvhip] sliced-DIA SpMV: %s kernel, n %lld (+%lld halo), %lld slices%s, plane stride %lld, window [%lld, %lld)\n",
-                    sym ? "symmetric plane-marching" : (march ? "plane-marching" : "slice-by-slice"), (long long)p->n, (long long)p->nhalo, (long long)dcount,
+                    sym ? (tile ? "symmetric tiled" : "symmetric plane-marching") : (march ? "plane-marching" : "slice-by-slice"), (long long)p->n, (long long)p->nhalo, (long long)dcount,
                     subset ? " (subset)" : "", (long long)p->order_stride, subset ? (long long)subset->win_lo : 0LL,
                     subset ? (long long)subset->win_hi : 0LL);
         }
@@ -1784,7 +1998,60 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         default: FV_SYM(D_, 0, W_); break;                                                                                                    \
         }                                                                                                                                     \
     } while (0)
-                if (mode == SPMV_DOT) {
+                if (tile) { // (fv_tune key 38)
+                    const int64_t tnz = p->sym_d[1], td3 = p->sym_d[2];
+                    // planes 1 .. nplanes - 1 can hold sym_ok slices; the last plane only in a row block whose +plane windows land in
+                    // its halo slots (the last block of an operator: no +plane arm, no halo entry needed)
+                    const int32_t nplanes = (int32_t)(p->n / td3) - (p->nhalo > 0 ? 0 : 1), tiles = (int32_t)((td3 + FV_TILE_R - 1) / FV_TILE_R);
+                    int resident_t = g_resident_blocks / 8 * g_tile_blocks / 8 * 8; // blocks of 512 threads per CU (4 waves per SIMD at ~120 registers: 2)
+                    if (resident_t < 8)
+                        resident_t = 8;
+                    // segments of planes per tile column: the resident blocks work through (tile, segment) items in rounds, and a
+                    // segment costs about two plane steps of start-up (its first plane of x and U3, the first tiles into LDS):
+                    // the count that minimises rounds x (planes per segment + 2)   (464^3, 210 tiles, 512 resident blocks,
+                    // ms per launch: 5 segments 0.904, 7 0.772, 10 0.830, 12 0.794, 17 0.802, 22 0.805, 44 0.824)
+                    int nsegs = 1;
+                    int64_t best = -1;
+                    for (int m = 1; m <= 64 && m <= nplanes - 1; m++) {
+                        const int64_t rounds = ((int64_t)tiles * m + resident_t - 1) / resident_t;
+                        const int64_t cost = rounds * ((nplanes - 1 + m - 1) / m + 2);
+                        if (best < 0 || cost < best) {
+                            best = cost;
+                            nsegs = m;
+                        }
+                    }
+                    if (g_tile_segs > 0 && g_tile_segs <= nplanes - 1)
+                        nsegs = g_tile_segs;
+                    const int32_t seglen_t = (nplanes - 1 + nsegs - 1) / nsegs;
+                    const int64_t items = (int64_t)tiles * nsegs;
+                    int64_t g = ((items + 7) / 8) * 8;
+                    if (g > resident_t)
+                        g = resident_t;
+                    GM = (int)g;
+                    const size_t lds = (size_t)(3 * FV_TILE_R + 3 * tnz + 2) * sizeof(double);
+                    const double *dg0 = dg + p->sym_front, *u10 = u1 + p->sym_front, *u20 = u2 + p->sym_front, *u30 = u3 + p->sym_front;
+#define FV_SYMT(D_, N_)                                                                                                                       \
+    hipLaunchKernelGGL((spmv_symdia_tile_kernel<D_, N_>), dim3(GM), dim3(FV_TILE_T), lds, ctx->stream, p->n, p->n + p->nhalo, (int32_t)tnz, (int32_t)td3, \
+                       nplanes, seglen_t, tiles, (int32_t)nsegs, (const uint8_t *)p->sym_ok.p, dg0, u10, u20, u30, x, y, shift, sigma, partials, scal, \
+                       (const uint8_t *)p->dcode.p, p->sym_shift, p->sym_shift_mode)
+                    const int nt = g_nt ? g_symdia_nt : 0;
+                    if (mode == SPMV_DOT) {
+                        if (nt == 4)
+                            FV_SYMT(true, 4);
+                        else if (nt == 5)
+                            FV_SYMT(true, 5);
+                        else
+                            FV_SYMT(true, 0);
+                    } else {
+                        if (nt == 4)
+                            FV_SYMT(false, 4);
+                        else if (nt == 5)
+                            FV_SYMT(false, 5);
+                        else
+                            FV_SYMT(false, 0);
+                    }
+#undef FV_SYMT
+                } else if (mode == SPMV_DOT) {
                     if (sh != 0)
                         FV_SYM_N(true, true);
                     else
@@ -1855,7 +2122,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 #undef FV_DIA
         FV_LAUNCH_CHECK(ctx);
         if (!subset || subset->win_hi > subset->win_lo) // (a row block reports the form of its interior pass, not of the boundary slices)
-            p->last_form = sym ? FV_SPMV_SYM_MARCH : (march ? FV_SPMV_DIA_MARCH : FV_SPMV_DIA);
+            p->last_form = sym ? (tile ? FV_SPMV_SYM_TILE : FV_SPMV_SYM_MARCH) : (march ? FV_SPMV_DIA_MARCH : FV_SPMV_DIA);
         const int GD = march ? GM + GR : GA; // partials written by the DIA part
         int GB = 0;
         if (ccount > 0) {
@@ -1891,7 +2158,7 @@ extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_lau
         const int64_t dia_all = blocks * 512 + p->ndia * meta;                // matrix side of the sliced-DIA form
         const int64_t csr_part = csr_all / ns * p->ncsr_groups;               // the CSR groups' share, by group count
         const int64_t vec = 16 * (p->ndia * 64 < n ? p->ndia * 64 : n);       // x once, y once over the DIA rows
-        if (p->last_form == FV_SPMV_SYM_MARCH) {
+        if (p->last_form == FV_SPMV_SYM_MARCH || p->last_form == FV_SPMV_SYM_TILE) {
             // slices the symmetric kernel computes; the other DIA slices (irregular ones, first / last plane, a row block's
             // boundary slices) in the sliced-DIA form
             const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - p->sym_nrest;

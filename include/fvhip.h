@@ -294,7 +294,10 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *  37: zero row sum in the symmetric plane-marching SpMV: slices in which every row's stored diagonal is, bit for bit, minus
  *      the sum of its six off-diagonals in assembly order (plus the folded sigma D, taken by the row's storage code) — rows
  *      without a Dirichlet neighbour — are computed without the diagonal stream: 40 (41) instead of 48 bytes per row;
- *      0 = always stream the diagonal [1] */
+ *      0 = always stream the diagonal [1]
+ *  38: the tiled traversal of the symmetric form (FV_SPMV_SYM_TILE) where it applies; 0 = always the plane-marching kernel [1]
+ *  39, 40: experiments on the tiled kernel's launch: resident blocks per CU its grid is sized for [2], segments of planes per
+ *      tile column (0 = chosen to fill whole rounds of the resident blocks) [0] */
 int fv_tune(int key, int value);
 /* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event
  * between two launches is a barrier (~10 us each at 464^3), so the timed region of the bench uses 2; 0: off. */
@@ -305,13 +308,17 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
  *   FV_SPMV_CSR      wave-stream CSR: 12 nnz + 20 n (SURVEY 8d's accounting)
  *   FV_SPMV_DIA      sliced-DIA, slice by slice: 8 B per stored lane-major value (zeros included) + 16 n + slice metadata
  *   FV_SPMV_DIA_MARCH  the same values, plane-marching traversal (x arms from registers)
- *   FV_SPMV_SYM_MARCH  symmetric plane-marching: 32 n (diagonal + 3 upper diagonals) + 16 n
+ *   FV_SPMV_SYM_MARCH  symmetric plane-marching: 32 n (diagonal + 3 upper diagonals; 24 n + a code byte where the diagonal is
+ *                      re-derived from the arms, fv_tune key 37) + 16 n
+ *   FV_SPMV_SYM_TILE   the same arrays, tiled traversal (blocks own 1024 rows of a plane and march through planes, arms through
+ *                      LDS): where the free rows are a regular box numbered like regulargrid's (fv_tune key 38)
  * Slices left to another form (CSR groups of an irregular part, slices the symmetric kernel hands to the slice kernel)
  * are counted in their own form, pro rata by slice count.  *form = -1 before the first SpMV. */
 #define FV_SPMV_CSR 0
 #define FV_SPMV_DIA 1
 #define FV_SPMV_DIA_MARCH 2
 #define FV_SPMV_SYM_MARCH 3
+#define FV_SPMV_SYM_TILE 4
 int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
 /* Bytes per row the most recent K2S launch (the fused vector update of a fixed-dt step in the one-iteration regime:
  * x += alpha p, r -= alpha q, the convergence sums and the next step's set-up) streams: 56 in the z-form (fv_tune key 36:

@@ -180,7 +180,7 @@ def test_synthetic_464_cubed_transient_properties(fv):
         i1, info1, _ = p.run_fixed(st, 60.0, 20, 1e-10)
         i2, info2, _ = p.run_fixed(st, 3600.0, 5, 1e-10)
         assert info1.converged and info2.converged
-        assert p.spmv_form()[0] == 3  # the symmetric plane-marching kernel
+        assert p.spmv_form()[0] == 4  # the symmetric form, tiled traversal
         its.append((i1.copy(), i2.copy()))
         draw.append(1e3 - st.free_values())
     assert (its[0][0] == 1).all() and 5 <= its[0][1].mean() <= 20, its[0]
@@ -259,8 +259,12 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
     lib = fv.load()
     try:
         ys, forms = {}, {}
-        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1}), ("sym march m=1", {9: 2, 10: 1, 27: 1}), ("sym march m=5", {9: 2, 10: 5}), ("sym march, plain loads", {9: 2, 28: 0}),
-                            ("sym march, streamed diagonal", {9: 2, 37: 0}), ("sym march, derived diagonal again", {9: 2, 37: 1}),
+        tiled_ok = ns[2] % 2 == 0  # the tiled traversal wants lines of an even number of rows
+        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1, 38: 0}), ("sym march m=1", {9: 2, 10: 1, 27: 1, 38: 0}), ("sym march m=5", {9: 2, 10: 5, 38: 0}),
+                            ("sym march, plain loads", {9: 2, 28: 0, 38: 0}),
+                            ("sym march, streamed diagonal", {9: 2, 37: 0, 38: 0}), ("sym march, derived diagonal again", {9: 2, 37: 1, 38: 0}),
+                            ("sym tiled", {9: 2, 38: 1}), ("sym tiled, streamed diagonal", {9: 2, 38: 1, 37: 0}), ("sym tiled, plain loads", {9: 2, 28: 0}),
+                            ("sym tiled, 3 segments", {9: 2, 40: 3}), ("sym tiled, 36 segments", {9: 2, 40: 36}),
                             ("march", {9: 2, 6: 1, 18: 1, 27: 0}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}),
                             ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
             for k, v in knobs.items():
@@ -268,16 +272,21 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
             lib.fv_tune(25, 1)
             y = p.spmv(x, sigma)
             trace = capfd.readouterr().err
-            assert ("symmetric plane-marching kernel" in trace) == name.startswith("sym"), (name, trace)
+            tiled = name.startswith("sym tiled") and tiled_ok
+            assert ("symmetric plane-marching kernel" in trace) == (name.startswith("sym") and not tiled), (name, trace)
+            assert ("symmetric tiled kernel" in trace) == tiled, (name, trace)
             assert (" plane-marching kernel" in trace and "symmetric" not in trace) == name.startswith("march"), (name, trace)
             assert ("slice-by-slice kernel" in trace) == (name == "slices"), (name, trace)
             assert np.abs(y - ref).max() <= 1e-13 * scale, name
             assert abs(p.dot(x, y) - x @ y) <= 1e-12 * abs(x @ y)
-            assert p.spmv_form()[0] == (3 if name.startswith("sym") else 2 if name.startswith("march") else 1 if name == "slices" else 0)
+            assert p.spmv_form()[0] == (4 if tiled else 3 if name.startswith("sym") else 2 if name.startswith("march") else 1 if name == "slices" else 0)
             ys[name] = y
             forms[name] = p.spmv_form()[2]
             lib.fv_tune(10, 0)
             lib.fv_tune(28, 5)
+            lib.fv_tune(37, 1)
+            lib.fv_tune(38, 1)
+            lib.fv_tune(40, 0)
         # the DIA forms sum a row's terms in ascending column order with fused multiply-adds, absent entries as zeros: the same
         # bits (the CSR stream rounds every product on its way through LDS, so it only agrees to rounding)
         for name in ys:
@@ -285,9 +294,10 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
                 assert np.array_equal(ys[name], ys["slices"]), name
         # zero row sum: interior rows re-derive their diagonal from the six arms (fv_tune key 37): a stream fewer, the same bits
         assert forms["sym march"] == forms["sym march, derived diagonal again"] < forms["sym march, streamed diagonal"] - 7 * (p.n - 3 * (ns[1] - 2) * ns[2])
+        assert forms["sym tiled"] == forms["sym march"] and forms["sym tiled, streamed diagonal"] == forms["sym march, streamed diagonal"]
         # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
         heads = {}
-        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1}), ("sym march, streamed diagonal", {37: 0}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
+        for name, knobs in (("sym tiled", {9: 2, 6: 1, 27: 1, 37: 1, 38: 1}), ("sym march", {38: 0}), ("sym march, streamed diagonal", {37: 0}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
             for k, v in knobs.items():
                 lib.fv_tune(k, v)
             st = p.new_state()
@@ -300,6 +310,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         assert np.abs(heads["sym march"] - heads["slices"]).max() <= 1e-9
         # with the shift folded into the diagonal the derived one adds sigma D by the row's storage code: the same bits again
         assert np.array_equal(heads["sym march"], heads["sym march, streamed diagonal"])
+        assert np.abs(heads["sym tiled"] - heads["slices"]).max() <= 1e-9  # (another grouping of the p.q partial sums: equal to rounding)
         assert forms["sym march folded"] < forms["sym march, streamed diagonal folded"] - 6 * (p.n - 3 * (ns[1] - 2) * ns[2])
     finally:
         lib.fv_tune(9, 1)
@@ -309,6 +320,8 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         lib.fv_tune(27, 1)
         lib.fv_tune(28, 5)
         lib.fv_tune(37, 1)
+        lib.fv_tune(38, 1)
+        lib.fv_tune(40, 0)
 
 
 def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv, capfd):
@@ -329,10 +342,11 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     x = rng.standard_normal(p.n)
     lib = fv.load()
     lib.fv_tune(25, 200)  # the kernel choices of the first block products go to stderr: the marching kernel must really run on a block's window
-    # 9 = 2: marching at any size; 1: the library's choice; 27: the symmetric marching kernel (default; it marches at any size)
-    for sigma, forced, sym in ((0.0, 2, 1), (1 / 60.0, 2, 1), (1 / 60.0, 2, 0), (1 / 60.0, 1, 1)):
+    # 9 = 2: marching at any size; 1: the library's choice; 27: the symmetric form (default; at any size); 38: its tiled traversal (default)
+    for sigma, forced, sym, tiled in ((0.0, 2, 1, 1), (1 / 60.0, 2, 1, 1), (1 / 60.0, 2, 1, 0), (1 / 60.0, 2, 0, 0), (1 / 60.0, 1, 1, 1)):
         lib.fv_tune(9, forced)
         lib.fv_tune(27, sym)
+        lib.fv_tune(38, tiled)
         y_global = p.spmv(x, sigma)
         for nranks in (2, 3):
             for rank in range(nranks):
@@ -345,7 +359,9 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
                 blk.close()
     lib.fv_tune(25, 0)
     lib.fv_tune(27, 1)
+    lib.fv_tune(38, 1)
     trace = capfd.readouterr().err
+    assert "SpMV: symmetric tiled kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
     assert "SpMV: symmetric plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
     assert "SpMV: plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
     assert "slice-by-slice kernel, n 1227600 (+39600 halo), 620 slices (subset)" in trace  # the boundary pass of the same block
