@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
 
 // ------------------------------------------------------------------ the symmetric form, tiled (2.5-D blocking)
 // The same product from the same arrays with another traversal, for operators whose free rows form a regular box numbered
-// like regulargrid's (d1 = 1, lines of nz = d2 rows, planes of d3 rows, n a whole number of planes): a block of
+// like regulargrid's (d1 = 1, lines of nz = d2 rows (even, 64 <= nz <= 1024), planes of d3 rows, n a whole number of planes): a block of
 // FV_TILE_T threads owns FV_TILE_R consecutive rows of a plane (two per thread: one 16-byte access per stream, K2S's access
 // shape) and marches through a segment of planes.  Every x and matrix value the block needs is loaded once — its own rows
 // from HBM, plus the +-line halo of x (2 nz values) and the -line halo of U2 (nz values) that neighbouring blocks stream at
@@ -1263,9 +1263,9 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
     const int xcd = (int)(blockIdx.x & 7);
     const int64_t items = (int64_t)tiles * nsegs, per_xcd = (items + 7) / 8;
     double dacc = 0.0;
-    // the +-line halo of x: threads [0, nz/2) take the low side, [nz/2, nz) the high side, one 16-byte access each; the -line
-    // halo of U2 goes with the low side; thread 0 also brings the one U1 value below the tile
-    const int hl = tid < (nz >> 1), hh = !hl && tid < nz;
+    // the +-line halo of x and the -line halo of U2: threads [0, nz/2) take one 16-byte pair of each; thread 0 also brings
+    // the one U1 value below the tile
+    const bool hl = tid < (nz >> 1);
     for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
         const int64_t item = (int64_t)xcd * per_xcd + j;
         if (item >= items)
@@ -1277,8 +1277,8 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
             continue;
         const bool own = o < d3;            // this thread's two rows exist in the plane
         const bool ownx = o < d3 + nz;      // ... or are the +line neighbours of rows that do (the plane after, in memory)
-        const int32_t hoff = hl ? base - nz + 2 * tid : base + FV_TILE_R + 2 * (tid - (nz >> 1)); // in-plane offset of this thread's halo pair
-        const int hidx = hl ? 2 * tid : FV_TILE_R + nz + 2 * (tid - (nz >> 1));                   // ... and where it goes in xs
+        const int32_t hofl = base - nz + 2 * tid, hofh = base + FV_TILE_R + 2 * tid; // in-plane offsets of this thread's low / high halo pair
+        const int hidl = 2 * tid, hidh = FV_TILE_R + nz + 2 * tid;                    // ... and where they go in xs
         auto ld2 = [&](const double *a, int64_t row, bool pred) -> double2 {
             return pred ? *reinterpret_cast<const double2 *>(a + row) : make_double2(0.0, 0.0);
         };
@@ -1296,11 +1296,12 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
         double2 vd = ld2nt(dg, r, own && !(fl & 2));
         __syncthreads(); // (the previous item's last reads of LDS)
         {
-            const int64_t hr = (int64_t)p0 * d3 + hoff;
-            if (hl || hh)
-                *reinterpret_cast<double2 *>(xs + hidx) = ld2(x, hr, hr + 1 < ncols);
-            if (hl)
-                *reinterpret_cast<double2 *>(u2s + 2 * tid) = ld2(u2, hr, true);
+            const int64_t hrl = (int64_t)p0 * d3 + hofl, hrh = (int64_t)p0 * d3 + hofh;
+            if (hl) {
+                *reinterpret_cast<double2 *>(xs + hidl) = ld2(x, hrl, true);
+                *reinterpret_cast<double2 *>(xs + hidh) = ld2(x, hrh, hrh + 1 < ncols);
+                *reinterpret_cast<double2 *>(u2s + 2 * tid) = ld2(u2, hrl, true);
+            }
             if (tid == 0)
                 u1s[1] = u1[(int64_t)p0 * d3 + base - 1];
             *reinterpret_cast<double2 *>(xs + nz + 2 * tid) = xc;
@@ -1313,7 +1314,7 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
             const bool more = p + 1 < p1;
             const int64_t rn = r + d3;
             const double2 xn = ld2(x, rn, ownx && rn + 1 < ncols);
-            double2 v1n = make_double2(0.0, 0.0), v2n = v1n, a3n = v1n, vdn = v1n, hx = v1n, hu2 = v1n;
+            double2 v1n = make_double2(0.0, 0.0), v2n = v1n, a3n = v1n, vdn = v1n, hxl = v1n, hxh = v1n, hu2 = v1n;
             double hu1 = 0.0;
             int fln = 0;
             if (more) {
@@ -1322,11 +1323,12 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
                 v2n = ld2nt(u2, rn, own);
                 a3n = ld2nt(u3, rn, own);
                 vdn = ld2nt(dg, rn, own && !(fln & 2));
-                const int64_t hr = (int64_t)(p + 1) * d3 + hoff;
-                if (hl || hh)
-                    hx = ld2(x, hr, hr + 1 < ncols);
-                if (hl)
-                    hu2 = ld2(u2, hr, true);
+                const int64_t hrl = (int64_t)(p + 1) * d3 + hofl, hrh = (int64_t)(p + 1) * d3 + hofh;
+                if (hl) {
+                    hxl = ld2(x, hrl, true);
+                    hxh = ld2(x, hrh, hrh + 1 < ncols);
+                    hu2 = ld2(u2, hrl, true);
+                }
                 if (tid == 0)
                     hu1 = u1[(int64_t)(p + 1) * d3 + base - 1];
             }
@@ -1389,10 +1391,11 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
             }
             __syncthreads(); // everybody has read this plane's tiles
             if (more) {
-                if (hl || hh)
-                    *reinterpret_cast<double2 *>(xs + hidx) = hx;
-                if (hl)
+                if (hl) {
+                    *reinterpret_cast<double2 *>(xs + hidl) = hxl;
+                    *reinterpret_cast<double2 *>(xs + hidh) = hxh;
                     *reinterpret_cast<double2 *>(u2s + 2 * tid) = hu2;
+                }
                 if (tid == 0)
                     u1s[1] = hu1;
                 *reinterpret_cast<double2 *>(xs + nz + 2 * tid) = xn;
@@ -1912,7 +1915,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         bool tile = false;
         if (sym) {
             const int64_t tnz = p->sym_d[1], td3 = p->sym_d[2];
-            tile = g_sym_tile && p->sym_d[0] == 1 && tnz >= 64 && tnz <= FV_TILE_T && tnz % 2 == 0 && td3 % 2 == 0 && td3 % tnz == 0 &&
+            tile = g_sym_tile && p->sym_d[0] == 1 && tnz >= 64 && tnz <= 2 * FV_TILE_T && tnz % 2 == 0 && td3 % 2 == 0 && td3 % tnz == 0 &&
                    td3 >= FV_TILE_R + tnz && p->n % td3 == 0 && p->n / td3 >= 3;
         }
         const bool march_pays = sym || g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;

@@ -232,7 +232,8 @@ def test_bench_decomposition_eight_slab_assembled_ranks(fv):
 
 # plane strides 39 600 (= 48 mod 64: centre + edge loads; lane shift -16 of the symmetric kernel), 36 100 (= 4 mod 64: 16-byte
 # windows), 36 864 (= 0 mod 64: whole-slice arms), 36 477 (odd number of rows: the last window pair straddles the end of x)
-@pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192], [41, 195, 189]])
+# ... and lines of 600 rows: the tiled kernel's halo of more than 512 values a side
+@pytest.mark.parametrize("ns", [[40, 200, 200], [40, 192, 190], [40, 194, 192], [41, 195, 189], [30, 66, 600]])
 def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd):
     """>= 2^20 unknowns with a plane stride: the symmetric plane-marching kernel (default above the size rule), the
     plane-marching sliced-DIA kernel, the slice-by-slice DIA kernel and the CSR wave-stream form against a float64 CSR
