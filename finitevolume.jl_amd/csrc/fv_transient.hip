@@ -157,6 +157,8 @@ extern "C" int fv_transient_begin(fv_problem *p, double Ss, const double *volume
     p->minv_valid = false; // D changes: cached Jacobi diagonal and folded values are stale
     p->storage_epoch++;    // ... and so is the aggregated storage term of an AMG hierarchy
     p->shifted_epoch = -1;
+    p->dia_epoch = -1; // ... and the solver's copies of a folded matrix (lane-major, symmetric), which are keyed on sigma only
+    p->sym_epoch = -1;
     DevBuf<double> dvol;
     const double *vol = nullptr;
     if (volumes) {

@@ -249,6 +249,37 @@ def test_zform_update_keeps_one_vector_between_one_iteration_steps(fv, oracle):
     assert relerr(out[1][0], out[0][0]) < 1e-12 and relerr(out[1][1], out[0][1]) < 1e-9
 
 
+def test_new_storage_term_on_the_same_assembly_reaches_every_copy_of_the_folded_matrix(fv):
+    """fv_transient_begin with another Ss on an assembled problem: the shift folded into the solver's copies of the matrix
+    (CSR values, lane-major, symmetric) and the storage codes follow — the second run equals a fresh problem's."""
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    ns = [36, 182, 186]  # free rows: 34 planes of 180 x 186 = 33 480 rows, 1.14e6 in all: the symmetric (tiled) form
+    coords, nb, aol, vol = fv.regulargrid(mins, maxs, ns)
+    N = len(vol)
+    rng = np.random.default_rng(3)
+    K = np.exp(fv.nodehycos2neighborhycos(nb, np.log(1e-5) + rng.standard_normal(N), True))
+    dn = np.nonzero((coords[0] == mins[0]) | (coords[0] == maxs[0]) | (coords[1] == mins[1]) | (coords[1] == maxs[1]))[0] + 1
+    dh = np.full(len(dn), 1.0)
+    src = np.zeros(N)
+    inner = np.setdiff1d(np.arange(1, N + 1), dn)
+    src[inner[len(inner) // 2] - 1] = -1e-3
+    u0 = np.full(N, 1.0)
+
+    def run(p, Ss):
+        st = p.transient_begin(Ss, vol, u0)
+        it, info, _ = p.run_fixed(st, 0.5, 12, rtol=1e-13)  # the same dt in every run: the copies are keyed on sigma = 1 / dt
+        assert info.converged
+        return st.node_values(), it.copy(), p.spmv_form()[0]
+
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn).assemble(K, src, dh)
+    first = run(p, 0.1)
+    second = run(p, 0.37)  # same assembly, same dt: only D changed
+    fresh = run(fv.Problem.regulargrid(mins, maxs, ns, dn).assemble(K, src, dh), 0.37)
+    assert second[2] == fresh[2] == 4
+    assert np.array_equal(second[1], fresh[1]) and np.array_equal(second[0], fresh[0])
+    assert relerr(first[0], second[0]) > 1e-9
+
+
 def test_time_dependent_getb_method(fv, oracle):
     """transient.jl:165-174: caller supplies the volume-scaled b(t)."""
     coords, nb, aol, vol, K, dn, dh = _box(fv, (8, 8, 6), sigma=0.5)
