@@ -1099,6 +1099,15 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it
     if (speculate && zf && hs->iters >= 1)
         p->z_where = p->spec_valid ? 2 : 0; // a z-form K2S ran: its p' stands for the residual, unless the K3 behind it had to go on (it wrote r)
+    if (use_spec && hs->done == 1 && hs->iters == 0) {
+        // converged at its set-up: nothing ran, so the prepared set-up (direction, sums) is still exactly the next step's — put the
+        // direction vectors back and keep it, as a burst does, instead of deriving a new one from the rounded residual
+        p->pvec.swap(p->pnext);
+        if (p->z_where)
+            p->z_where = 3 - p->z_where;
+        p->spec_valid = true;
+        p->last_iters = 1; // still the one-iteration regime, as after a chained step (the next step speculates in either mode)
+    }
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
@@ -1903,6 +1912,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1;
     if (speculate && zf && hs->iters >= 1)
         p->z_where = p->spec_valid ? 2 : 0; // as in fv_pcg_solve
+    if (use_spec && hs->done == 1 && hs->iters == 0) { // converged at its set-up: keep the prepared set-up (see fv_pcg_solve)
+        p->pvec.swap(p->pnext);
+        if (p->z_where)
+            p->z_where = 3 - p->z_where;
+        p->spec_valid = true;
+        p->last_iters = 1;
+    }
     if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;

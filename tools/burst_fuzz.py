@@ -20,6 +20,8 @@ def run(fv, nseeds=12, tight=False, verbose=True):
         ns = [int(rng.integers(12, 34)), int(rng.integers(12, 30)), int(rng.integers(8, 26))]
         if os.environ.get("FV_FUZZ_BIG"):  # > 2^20 rows with planes of > 4096 rows: sliced-DIA kernels, marching when forced (FV_TUNE 9=2)
             ns = [int(rng.integers(100, 131)), int(rng.integers(90, 120)), int(rng.integers(90, 120))]
+        if os.environ.get("FV_FUZZ_TILE"):  # planes of > 32768 rows, lines of an even number of rows: the symmetric form, tiled traversal
+            ns = [int(rng.integers(36, 50)), int(rng.integers(184, 200)), 2 * int(rng.integers(93, 105))]
         mins, maxs = bench.spacing_box(ns)
         dn, src = bench.box_setup(ns)
         if seed % 3 == 0:
