@@ -235,7 +235,8 @@ int fv_amg_info(fv_problem *p, int32_t *nlevels, int64_t *rows, int64_t *nnz, in
 /* z = M^-1 r: one cycle on host vectors over the free cells (tests: symmetry, definiteness). */
 int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_free);
 
-/* Process-wide kernel selection for A/B measurements (defaults in brackets).
+/* Process-wide kernel selection for A/B measurements (defaults in brackets).  Not synchronised: set it while no call of the
+ * library is in flight; a caller has no reason to touch it (every default is the measured best), tests and tools reset what they set.
  *   0: CSR SpMV form, 2 = wave-private CSR-stream [2], 1 = lanes-per-row;  1: unroll of the lanes-per-row form (2, 4, 8)
  *   2: plane-blocked group order [1];  3: fold sigma*D into a diagonal copy for fixed-dt runs [1]
  *   4: non-temporal matrix streams [1];  5: fuse the step set-up into the first SpMV's epilogue [0]
