@@ -306,6 +306,12 @@ class Problem:
         self.check(load().fv_update_form(self.handle, C.byref(b)))
         return b.value
 
+    def fused_form(self):
+        """(launches so far, bytes per row of its storage form) of the fused step of the one-iteration regime (fv_fused_form)."""
+        n, b = C.c_int64(), C.c_int32()
+        self.check(load().fv_fused_form(self.handle, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
     def profile(self, on=True):
         """True / 1: time K1, K2 and K3 launches; 2: the SpMV (K1) only; False: off."""
         self.check(load().fv_profile_enable(self.handle, int(on)))

@@ -1,0 +1,25 @@
+// The fused time step of the one-iteration regime (fv_fused.hip) as the PCG driver sees it.
+#pragma once
+#include "fv_internal.h"
+
+constexpr int FV_FUSED_PARTS = 4096; // per-block partial sums of one quantity (fused launch + the slice-by-slice launch behind it)
+
+// per-block partial sums a fused launch leaves for the next one (two sets, by step parity: a launch reads the previous
+// set in its first microseconds while its blocks write the other one at their end)
+struct FusedSums {
+    double *arz, *arr;       // the finished step's r.M^-1 r, r.r                 (nvec pieces)
+    double *srz, *srr, *sbb; // the next step's set-up: rho.z, rho.rho (nvec), rhs.rhs (nbb)
+    double *pq;              // z'.q' of the next step's product                 (npq)
+    int nvec, nbb, npq;
+};
+
+extern int g_fused;
+bool fv_fused_applicable(fv_problem *p, double sigma);
+int fv_fused_prepare(fv_problem *p);
+FusedSums fv_fused_sums(fv_problem *p, int parity);
+int fv_fused_enter(fv_problem *p, double sigma);
+int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
+                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums);
+// fv_spmv.hip: y = A x (values with the shift folded in) over the slices the symmetric form leaves to the slice-by-slice
+// kernel, partial x.y per block; no done-flag check
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts);

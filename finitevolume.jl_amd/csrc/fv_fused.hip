@@ -1,0 +1,678 @@
+// The fused time step of the one-iteration regime ("KF"): the vector update of step k (what K2S does: alpha, x_out, the
+// convergence sums, the next step's set-up) and the SpMV of step k + 1 (what K1 does: q' = (A + sigma D) z', partial z'.q')
+// in ONE pass over the symmetric arrays, 2-D tiles of a plane marching through the planes.
+//
+// Replaces, for fixed-dt runs whose steps converge in one PCG iteration, the K1 + K2S pair behind
+// /root/reference/src/transient.jl:60-76 (backwardeuleronestep!: rhs = b + u/dt, solve (A + I/dt) x = rhs from x0 = u) as
+// driven by fixedbackwardeulerstep! (transient.jl:130-134); semantics unchanged: the same Jacobi-PCG iteration, the same
+// stopping rule ||r|| <= rtol ||rhs||, the same fall-back to further iterations when a step does not converge in one.
+//
+// The v-form.  The residual of an implicit step's system at its start state is rho(x) = b - A x whatever the time step,
+// so across one-iteration steps  rho' = rho - alpha A z  with z = M^-1 rho the step's direction: the next direction is
+//     z' = z + alpha v ,   v = -M^-1 (A z) = -M^-1 (q - sigma D z) ,
+// and the launch that forms q = (A + sigma D) z stores v INSTEAD of q.  The SpMV of the next step needs z' on the rows
+// around a tile; with v those halo rows cost two streams and one FMA (no diagonal, no storage term, no division), which
+// is what makes the fusion pay: a row is read once (x, z, v, the three upper diagonals, one storage code byte) and written
+// once (x_out, z', v'), 73 bytes instead of the 90 of K1 + K2S.  Per own row, with d = the shifted diagonal (re-derived
+// from the six arms where the row sum is zero, streamed elsewhere) and sD = sigma D of the row:
+//     x_out = x + alpha z ;  z' = z + alpha v ;  rho' = d z'  (next step's residual at x_out) ;
+//     r = rho' - sD (x_out - x)  (this step's residual after its iteration: the convergence test) ;
+//     sums: r.M^-1 r, r.r | rho'.z', rho'.rho', |sD x_out (+ b)|^2 | z'.q'
+// A launch checks the PREVIOUS step's verdict first (all blocks reduce the same partial sums): if that step did not
+// converge in its one iteration the launch turns into the fall-back (r and the next direction of that step, done = 3)
+// exactly as pcg_chain_boundary_kernel does for the unfused chain, and the host resumes that step at iteration 2.
+//
+// Traversal: a block of TL x TW / 2 threads owns TL lines x TW columns of a plane, two consecutive columns per thread
+// (16-byte accesses).  Per plane step: loads of plane p + 2; update of plane p + 1 (needs the U1 / U2 tiles of that plane
+// for its diagonal); product of plane p from the z' tile in LDS (+-1, +-line arms), registers (+-plane arms) and the LDS
+// ring of U1 / U2 tiles; one barrier.  LDS: z' tile double-buffered, U1 / U2 in a ring of three plane slots.
+#include "fv_internal.h"
+#include "fv_device.h"
+#include "fv_spmv.h"
+#include "fv_fused.h"
+
+int g_fused = 1;       // fv_tune key 41: 0 = never use the fused step
+int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for
+int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per tile, 0 = chosen to fill whole rounds
+
+namespace {
+
+constexpr int KF_TL = 8, KF_TW = 128, KF_NT = KF_TL * KF_TW / 2; // 512 threads
+constexpr int KF_NSUM = 6;
+
+struct KfArgs {
+    // geometry: lines of nz rows, planes of d3 rows, nplanes = one past the last plane whose product this kernel forms
+    int32_t nz, L, d3, nplanes, P, seglen, tilesC, tiles, nsegs;
+    // the symmetric arrays (row 0 pointers: zero-padded in front and behind), flags per 64-row slice, storage codes
+    const double *dg, *u1, *u2, *u3;
+    const uint8_t *ok, *code;
+    StorageTable sD; // sigma x the distinct values of D
+    // vectors
+    const double *x, *z, *v;
+    double *xout, *znext, *vnext;
+    // the assembled b on its support (sparse): share of |rhs|^2
+    const int32_t *bidx;
+    const double *b;
+    int64_t bm;
+    // scalars / control
+    PcgScalars *scal;
+    FusedSums in, out;
+    int mode;        // 0: scalars of this step already in scal (set-up finalised by an earlier launch); 1: merged boundary
+    int chain_index; // index of this step in its burst
+    int force_prev_unconverged;
+    double rtol;
+    // fall-back of the previous step (mode 1): see pcg_chain_boundary_kernel
+    int64_t n;
+    double *r, *pold;
+    const double *minv, *D, *xprev;
+    double dt;
+};
+
+// all threads get the sum of v over the block; red: KF_NT / 64 doubles
+__device__ inline double kf_block_sum(double v, double *red)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < KF_NT / 64; w++)
+        t += red[w];
+    return t;
+}
+__device__ inline double kf_reduce(const double *__restrict__ part, int count, double *red)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < count; i += KF_NT)
+        v += part[i];
+    return kf_block_sum(v, red);
+}
+
+struct VRow {
+    double xn, zn, r, c, h, mv;
+};
+__device__ __forceinline__ VRow vrow(double xin, double z, double v, double d, double sD, double alpha)
+{
+    VRow o;
+    o.mv = 1.0 / d;
+    o.xn = xin + alpha * z;
+    o.zn = z + alpha * v;
+    o.c = d * o.zn;                // rho': the next system's residual at x_out
+    o.r = o.c - sD * (o.xn - xin); // the finished step's residual (increment as stored, like pcg_carry_init_kernel)
+    o.h = sD * o.xn;
+    return o;
+}
+
+__global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
+{
+    constexpr int TL = KF_TL, TW = KF_TW, NT = KF_NT, HC = TW / 2;
+    constexpr int ZS = TW + 4, U1S = TW + 2, U2S = TW; // LDS row strides: own column tc sits at 2 + tc (z', U1) so that pairs stay 16-byte aligned
+    constexpr int ZT = (TL + 2) * ZS, U1T = TL * U1S, U2T = (TL + 1) * U2S;
+    constexpr int NH = 2 * TW + 2 * TL; // threads with a halo row: line above, line below, column left, column right
+    __shared__ __align__(16) double zs[2 * ZT];
+    __shared__ __align__(16) double u1s[3 * U1T];
+    __shared__ __align__(16) double u2s[3 * U2T];
+    __shared__ double tab[FV_STORAGE_CODES];
+    __shared__ double red[NT / 64];
+    const int tid = (int)threadIdx.x;
+    PcgScalars *scal = a.scal;
+    // ---------------------------------------------------------------- scalars: every block takes the same decisions from
+    // values no block of this launch writes (the partial sums of the previous launch, scal fields written by earlier ones)
+    const int d0 = *reinterpret_cast<volatile int32_t *>(&scal->done);
+    if (d0 == 2)
+        return;
+    if (d0 == 3 && !(a.mode == 1 && *reinterpret_cast<volatile int32_t *>(&scal->chain_step) == a.chain_index - 1))
+        return; // the chain broke at an earlier step (the exception: block 0 of THIS launch has just said so)
+    double rz0;
+    bool zero_iteration;
+    if (a.mode == 1) {
+        // the previous chained step's verdict
+        const double rrn = kf_reduce(a.in.arr, a.in.nvec, red);
+        const bool converged = rrn <= scal->tol2x[(a.chain_index - 1) & 1] && !a.force_prev_unconverged;
+        if (!converged) {
+            // as pcg_chain_boundary_kernel: that step's residual without the next step's storage term, p = M^-1 r + beta p
+            const double rzn = kf_reduce(a.in.arz, a.in.nvec, red);
+            const double beta = rzn / scal->rz[0];
+            const int64_t n2 = a.n >> 1;
+            double2 *r2 = reinterpret_cast<double2 *>(a.r);
+            const double2 *m2 = reinterpret_cast<const double2 *>(a.minv);
+            double2 *p2 = reinterpret_cast<double2 *>(a.pold);
+            const double2 *xi2 = reinterpret_cast<const double2 *>(a.xprev);
+            const double2 *xo2 = reinterpret_cast<const double2 *>(a.x);
+            const double2 *D2 = reinterpret_cast<const double2 *>(a.D);
+            const double2 *z2 = reinterpret_cast<const double2 *>(a.z);
+            for (int64_t i = (int64_t)blockIdx.x * NT + tid; i < n2; i += (int64_t)gridDim.x * NT) {
+                const double2 mv = m2[i], zv = z2[i], xa = xi2[i], xb = xo2[i], dv = D2[i];
+                double2 rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+                rv.x -= dv.x * ((xb.x - xa.x) / a.dt);
+                rv.y -= dv.y * ((xb.y - xa.y) / a.dt);
+                r2[i] = rv;
+                double2 pv = p2[i];
+                pv.x = mv.x * rv.x + beta * pv.x;
+                pv.y = mv.y * rv.y + beta * pv.y;
+                p2[i] = pv;
+            }
+            if ((a.n & 1) && blockIdx.x == 0 && tid == 0) {
+                const int64_t i = a.n - 1;
+                double ri = a.z[i] / a.minv[i];
+                ri -= a.D[i] * ((a.x[i] - a.xprev[i]) / a.dt);
+                a.r[i] = ri;
+                a.pold[i] = a.minv[i] * ri + beta * a.pold[i];
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                scal->rz[1] = rzn;
+                scal->rr = rrn;
+                scal->iters = 1;
+                scal->chain_step = a.chain_index - 1;
+                __threadfence();
+                scal->done = 3;
+            }
+            return;
+        }
+        rz0 = kf_reduce(a.in.srz, a.in.nvec, red);
+        const double rr0 = kf_reduce(a.in.srr, a.in.nvec, red);
+        const double bb = kf_reduce(a.in.sbb, a.in.nbb, red);
+        const double tol2 = a.rtol * a.rtol * bb;
+        zero_iteration = rr0 <= tol2;
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->rz[0] = rz0;
+            scal->rz[1] = 0.0;
+            scal->rr = rr0;
+            scal->bnorm2 = bb;
+            scal->tol2 = tol2;
+            scal->tol2x[a.chain_index & 1] = tol2;
+            scal->iters = 0;
+            scal->done = zero_iteration ? 1 : 0;
+        }
+    } else {
+        rz0 = scal->rz[0];
+        zero_iteration = d0 == 1; // converged at its set-up (pcg_init_finalize_kernel said so)
+    }
+    double alpha = 0.0;
+    if (!zero_iteration) {
+        const double pq = kf_reduce(a.in.pq, a.in.npq, red);
+        if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
+            if (blockIdx.x == 0 && tid == 0) {
+                scal->pq = pq;
+                scal->done = 2;
+            }
+            return;
+        }
+        alpha = rz0 / pq;
+        if (blockIdx.x == 0 && tid == 0)
+            scal->pq = pq;
+    } else if (blockIdx.x == 0 && tid == 0)
+        scal->zero_mask |= 1u << a.chain_index; // the step counts 0 iterations: alpha = 0 hands the state over unchanged
+    // ---------------------------------------------------------------- the pass
+    if (tid < FV_STORAGE_CODES)
+        tab[tid] = a.sD.v[tid];
+    const int32_t nz = a.nz, d3 = a.d3;
+    const int tl = tid / HC, tc = 2 * (tid % HC);
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t items = (int64_t)a.tiles * a.nsegs, per_xcd = (items + 7) / 8;
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    const int zo = (tl + 1) * ZS + 2 + tc, u1o = tl * U1S + 2 + tc, u2o = (tl + 1) * U2S + tc; // own positions in the tiles
+    for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
+        const int64_t item = (int64_t)xcd * per_xcd + j;
+        if (item >= items)
+            break;
+        const int32_t seg = (int32_t)(item / a.tiles), tile = (int32_t)(item % a.tiles);
+        const int32_t l0 = (tile / a.tilesC) * TL, c0 = (tile % a.tilesC) * TW;
+        const int32_t p0 = 1 + seg * a.seglen, p1 = (p0 + a.seglen < a.nplanes) ? p0 + a.seglen : a.nplanes;
+        if (p0 >= p1)
+            continue;
+        // the vector part (x_out, z', the five vector sums) of the plane before the first / after the last product plane
+        // belongs to the first / last segment: planes 0 and P - 1 are nobody's product planes here (their rows are next to
+        // Dirichlet cells: the slice-by-slice launch forms their products)
+        const bool vec_first = p0 == 1, vec_last = p1 == a.nplanes && a.nplanes == a.P - 1;
+        const bool own = (l0 + tl < a.L) && (c0 + tc < nz);
+        const uint32_t o = (uint32_t)((l0 + tl) * nz + c0 + tc);
+        bool hv = false;
+        uint32_t ho = 0;
+        int hz = 0, hu = -1;
+        bool hu_is_u2 = false;
+        if (tid < TW) { // the line above the tile
+            hv = l0 >= 1 && c0 + tid < nz;
+            ho = (uint32_t)((l0 - 1) * nz + c0 + tid);
+            hz = 2 + tid;
+            hu = tid;
+            hu_is_u2 = true;
+        } else if (tid < 2 * TW) { // the line below
+            const int t = tid - TW;
+            hv = l0 + TL < a.L && c0 + t < nz;
+            ho = (uint32_t)((l0 + TL) * nz + c0 + t);
+            hz = (TL + 1) * ZS + 2 + t;
+        } else if (tid < 2 * TW + TL) { // the column to the left
+            const int t = tid - 2 * TW;
+            hv = c0 >= 1 && l0 + t < a.L;
+            ho = (uint32_t)((l0 + t) * nz + c0 - 1);
+            hz = (t + 1) * ZS + 1;
+            hu = t * U1S + 1;
+        } else if (tid < NH) { // the column to the right
+            const int t = tid - 2 * TW - TL;
+            hv = c0 + TW < nz && l0 + t < a.L;
+            ho = (uint32_t)((l0 + t) * nz + c0 + TW);
+            hz = (t + 1) * ZS + 2 + TW;
+        }
+        const bool ht = tid < NH;
+        if (!hv)
+            ho = own ? o : 0u; // (never used; keeps the address in range)
+        // one register for the halo role: z' slot | U slot << 12 | exists << 24 | has a U value << 25 | that value is U2's << 26
+        const uint32_t hdesc = (uint32_t)hz | ((uint32_t)(hu >= 0 ? hu : 0) << 12) | ((uint32_t)hv << 24) | ((uint32_t)(hu >= 0) << 25) |
+                               ((uint32_t)hu_is_u2 << 26);
+#define KF_HZ ((int)(hdesc & 4095u))
+#define KF_HU ((int)((hdesc >> 12) & 4095u))
+#define KF_HV ((hdesc >> 24) & 1u)
+#define KF_HHU ((hdesc >> 25) & 1u)
+#define KF_HU2 ((hdesc >> 26) & 1u)
+        // plane bases are uniform (scalar registers), the lane part is one 32-bit byte offset: "saddr + voffset" accesses
+        uint32_t ob = (own ? o : 0u) * 8u, hb = ho * 8u; // rows outside the plane read row 0 of it: finite, never used
+        auto PB = [&](const void *arr, int32_t pl, int esz) -> const char * {
+            return reinterpret_cast<const char *>(arr) + (uint64_t)((int64_t)pl * d3) * (uint64_t)esz;
+        };
+        auto P2 = [&](const double *arr, int32_t pl) -> double2 { return *reinterpret_cast<const double2 *>(PB(arr, pl, 8) + ob); };
+        auto P2nt = [&](const double *arr, int32_t pl) -> double2 {
+            const double *b = reinterpret_cast<const double *>(PB(arr, pl, 8) + ob);
+            return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
+        };
+        auto C2 = [&](int32_t pl) -> uint32_t { // storage codes of the thread's two rows (one value: code 0)
+            return a.code ? (uint32_t) * reinterpret_cast<const uint16_t *>(PB(a.code, pl, 1) + (ob >> 3)) : 0u;
+        };
+        auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 255u], tab[c >> 8]); }; // sigma D of the two rows
+        auto H1 = [&](const double *arr, int32_t pl) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + hb); };
+        auto ST2 = [&](double *arr, int32_t pl, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob) = val; };
+        __syncthreads(); // tab; the previous item's last LDS reads
+        // ---------------- prologue: z' of plane p0 - 1 (registers), z' of plane p0 (tile + halo), U tiles of p0 and p0 + 1
+        double2 Zm, Pc, Mc; // Mc: M^-1 of the centre plane's rows (Cc: their storage codes); Pc: the -plane and diagonal terms of their products
+        uint32_t Cc;
+        int flc;                // ... and their slice flags (bit 0: this kernel forms the product, bit 1: diagonal from the arms)
+        int zb = p0 & 1;        // half of zs that holds the centre plane's z'
+        int s0 = 0, s1 = 1, s2 = 2; // ring slots of planes p, p + 1, p + 2
+        {
+            const double2 vv = P2(a.v, p0 - 1), zz = P2(a.z, p0 - 1);
+            Zm = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
+            if (vec_first && own) { // plane 0: its vector part
+                const double2 xi = P2(a.x, 0), dd = P2(a.dg, 0), ss = SD(C2(0));
+                const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
+                ST2(a.xout, 0, make_double2(ra.xn, rb.xn));
+                ST2(a.znext, 0, Zm);
+                acc[0] += ra.r * (ra.mv * ra.r) + rb.r * (rb.mv * rb.r);
+                acc[1] += ra.r * ra.r + rb.r * rb.r;
+                acc[2] += ra.c * ra.zn + rb.c * rb.zn;
+                acc[3] += ra.c * ra.c + rb.c * rb.c;
+                acc[4] += ra.h * ra.h + rb.h * rb.h;
+            }
+        }
+        double2 Zc0;
+        {
+            const double2 xi = P2(a.x, p0), vv = P2(a.v, p0), zz = P2(a.z, p0), dd = P2(a.dg, p0);
+            // (the stored diagonal: bit for bit the derived one where bit 1 of the flag is set, symdia_rowsum_kernel)
+            Cc = C2(p0);
+            const double2 ss = SD(Cc);
+            const VRow ra = vrow(xi.x, zz.x, vv.x, own ? dd.x : 1.0, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, own ? dd.y : 1.0, ss.y, alpha);
+            Zc0 = make_double2(ra.zn, rb.zn);
+            Mc = make_double2(ra.mv, rb.mv);
+            if (own) {
+                ST2(a.xout, p0, make_double2(ra.xn, rb.xn));
+                ST2(a.znext, p0, Zc0);
+                acc[0] += ra.r * (ra.mv * ra.r) + rb.r * (rb.mv * rb.r);
+                acc[1] += ra.r * ra.r + rb.r * rb.r;
+                acc[2] += ra.c * ra.zn + rb.c * rb.zn;
+                acc[3] += ra.c * ra.c + rb.c * rb.c;
+                acc[4] += ra.h * ra.h + rb.h * rb.h;
+            }
+            const double2 A3m = P2nt(a.u3, p0 - 1);
+            Pc = make_double2(A3m.x * Zm.x + dd.x * Zc0.x, A3m.y * Zm.y + dd.y * Zc0.y);
+        }
+        flc = own ? (int)a.ok[((int64_t)p0 * d3 + o) >> 6] : 0;
+        double2 A3c = P2nt(a.u3, p0), A3n = P2nt(a.u3, p0 + 1);
+        *reinterpret_cast<double2 *>(zs + zb * ZT + zo) = Zc0;
+        *reinterpret_cast<double2 *>(u1s + s0 * U1T + u1o) = P2nt(a.u1, p0);
+        *reinterpret_cast<double2 *>(u2s + s0 * U2T + u2o) = P2nt(a.u2, p0);
+        *reinterpret_cast<double2 *>(u1s + s1 * U1T + u1o) = P2nt(a.u1, p0 + 1);
+        *reinterpret_cast<double2 *>(u2s + s1 * U2T + u2o) = P2nt(a.u2, p0 + 1);
+        if (ht) {
+            double zn = 0.0, ua = 0.0, ub = 0.0;
+            if (hv) {
+                zn = H1(a.z, p0) + alpha * H1(a.v, p0);
+                if (hu >= 0) {
+                    ua = H1(hu_is_u2 ? a.u2 : a.u1, p0);
+                    ub = H1(hu_is_u2 ? a.u2 : a.u1, p0 + 1);
+                }
+            }
+            zs[zb * ZT + hz] = zn;
+            if (hu >= 0) {
+                (hu_is_u2 ? u2s + s0 * U2T : u1s + s0 * U1T)[hu] = ua;
+                (hu_is_u2 ? u2s + s1 * U2T : u1s + s1 * U1T)[hu] = ub;
+            }
+        }
+        double2 Xa = P2nt(a.x, p0 + 1), Va = P2nt(a.v, p0 + 1), Za = P2(a.z, p0 + 1);
+        uint32_t Ca = C2(p0 + 1);
+        int fla = own ? (int)a.ok[((int64_t)(p0 + 1) * d3 + o) >> 6] : 0;
+        __syncthreads();
+        for (int32_t p = p0; p < p1; p++) {
+            // (opaque to the optimiser, or it keeps one 64-bit lane address per stream alive across the loop instead of
+            // scalar plane base + this one offset)
+            asm volatile("" : "+v"(ob), "+v"(hb));
+            // ---- own streams of plane p + 2, halo streams of plane p + 1
+            const bool more = p + 2 <= p1, inseg = p + 1 < p1;
+            const bool vec_n = inseg || vec_last; // plane p + 1's vector part is ours
+            double2 Xb = make_double2(0.0, 0.0), Vb = Xb, Zb = Xb, V1b = Xb, V2b = Xb, A3b = Xb;
+            uint32_t Cb = 0;
+            int flb = 0;
+            double hq = 0.0, hzv = 0.0, hub = 0.0;
+            if (more) {
+                Xb = P2nt(a.x, p + 2);
+                Vb = P2nt(a.v, p + 2);
+                Zb = P2(a.z, p + 2);
+                Cb = C2(p + 2);
+                V1b = P2nt(a.u1, p + 2);
+                V2b = P2nt(a.u2, p + 2);
+                A3b = P2nt(a.u3, p + 2);
+                flb = own ? (int)a.ok[((int64_t)(p + 2) * d3 + o) >> 6] : 0;
+            }
+            if (ht && KF_HV) {
+                if (inseg) {
+                    hq = H1(a.v, p + 1);
+                    hzv = H1(a.z, p + 1);
+                }
+                if (more && KF_HHU)
+                    hub = H1(KF_HU2 ? a.u2 : a.u1, p + 2);
+            }
+            // ---- update of plane p + 1
+            const double *u1n = u1s + s1 * U1T, *u2n = u2s + s1 * U2T;
+            double2 Dn;
+            const double2 Sa = SD(Ca);
+            if (fla & 2) { // zero row sum: the diagonal from the six arms, in the order the assembly added them (+ sigma D)
+                const double2 V1n = *reinterpret_cast<const double2 *>(u1n + u1o), V2n = *reinterpret_cast<const double2 *>(u2n + u2o);
+                const double v1m0n = u1n[u1o - 1];
+                const double2 V2mn = *reinterpret_cast<const double2 *>(u2n + u2o - U2S);
+                double so = A3c.x + V2mn.x;
+                so += v1m0n;
+                so += A3n.x;
+                so += V2n.x;
+                so += V1n.x;
+                Dn.x = -so + Sa.x;
+                so = A3c.y + V2mn.y;
+                so += V1n.x;
+                so += A3n.y;
+                so += V2n.y;
+                so += V1n.y;
+                Dn.y = -so + Sa.y;
+            } else
+                Dn = P2(a.dg, p + 1);
+            const VRow ua = vrow(Xa.x, Za.x, Va.x, own ? Dn.x : 1.0, Sa.x, alpha), ub = vrow(Xa.y, Za.y, Va.y, own ? Dn.y : 1.0, Sa.y, alpha);
+            const double2 Zn = make_double2(ua.zn, ub.zn);
+            const double2 Zc = *reinterpret_cast<const double2 *>(zs + zb * ZT + zo);
+            const double2 Pn = make_double2(A3c.x * Zc.x + Dn.x * Zn.x, A3c.y * Zc.y + Dn.y * Zn.y);
+            if (vec_n && own) {
+                double *xo = reinterpret_cast<double *>(const_cast<char *>(PB(a.xout, p + 1, 8)) + ob);
+                __builtin_nontemporal_store(ua.xn, xo);
+                __builtin_nontemporal_store(ub.xn, xo + 1);
+                ST2(a.znext, p + 1, Zn);
+                acc[0] += ua.r * (ua.mv * ua.r) + ub.r * (ub.mv * ub.r);
+                acc[1] += ua.r * ua.r + ub.r * ub.r;
+                acc[2] += ua.c * ua.zn + ub.c * ub.zn;
+                acc[3] += ua.c * ua.c + ub.c * ub.c;
+                acc[4] += ua.h * ua.h + ub.h * ub.h;
+            }
+            if (inseg)
+                *reinterpret_cast<double2 *>(zs + (zb ^ 1) * ZT + zo) = Zn;
+            // ---- product of plane p; stored as v' = -M^-1 (q' - sigma D z')
+            {
+                const double *zrow = zs + zb * ZT + zo, *u1c = u1s + s0 * U1T, *u2c = u2s + s0 * U2T;
+                const double x1m0 = zrow[-1], x1p1 = zrow[2];
+                const double2 x2m = *reinterpret_cast<const double2 *>(zrow - ZS), x2p = *reinterpret_cast<const double2 *>(zrow + ZS);
+                const double2 V1c = *reinterpret_cast<const double2 *>(u1c + u1o), V2c = *reinterpret_cast<const double2 *>(u2c + u2o);
+                const double v1m0 = u1c[u1o - 1];
+                const double2 V2m = *reinterpret_cast<const double2 *>(u2c + u2o - U2S);
+                double t0 = Pc.x, t1 = Pc.y;
+                t0 += V2m.x * x2m.x;
+                t1 += V2m.y * x2m.y;
+                t0 += v1m0 * x1m0;
+                t1 += V1c.x * Zc.x;
+                t0 += V1c.x * Zc.y;
+                t1 += V1c.y * x1p1;
+                t0 += V2c.x * x2p.x;
+                t1 += V2c.y * x2p.y;
+                t0 += A3c.x * Zn.x;
+                t1 += A3c.y * Zn.y;
+                if (flc & 1) {
+                    const double2 Sc = SD(Cc);
+                    ST2(a.vnext, p, make_double2(-(Mc.x * (t0 - Sc.x * Zc.x)), -(Mc.y * (t1 - Sc.y * Zc.y))));
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
+            }
+            // ---- halo z' of plane p + 1, U tiles of plane p + 2
+            if (ht && inseg)
+                zs[(zb ^ 1) * ZT + KF_HZ] = KF_HV ? hzv + alpha * hq : 0.0;
+            if (more) {
+                *reinterpret_cast<double2 *>(u1s + s2 * U1T + u1o) = V1b;
+                *reinterpret_cast<double2 *>(u2s + s2 * U2T + u2o) = V2b;
+                if (ht && KF_HHU)
+                    (KF_HU2 ? u2s + s2 * U2T : u1s + s2 * U1T)[KF_HU] = hub;
+            }
+            __syncthreads();
+            Pc = Pn;
+            Mc = make_double2(ua.mv, ub.mv);
+            Cc = Ca;
+            flc = fla;
+            A3c = A3n;
+            A3n = A3b;
+            Xa = Xb;
+            Va = Vb;
+            Za = Zb;
+            Ca = Cb;
+            fla = flb;
+            zb ^= 1;
+            const int st = s0;
+            s0 = s1;
+            s1 = s2;
+            s2 = st;
+        }
+#undef KF_HZ
+#undef KF_HU
+#undef KF_HV
+#undef KF_HHU
+#undef KF_HU2
+    }
+    // the assembled b's share of |rhs|^2 over its support: |h + b|^2 = h.h + b (2 h + b), h = sigma D x_out, with x_out of
+    // these few rows formed again from x and z
+    double sgather = 0.0;
+    if (a.bm > 0) {
+        __syncthreads();
+        for (int64_t k = (int64_t)blockIdx.x * NT + tid; k < a.bm; k += (int64_t)gridDim.x * NT) {
+            const int32_t i = a.bidx[k];
+            const double bi = a.b[i];
+            const double xn = a.x[i] + alpha * a.z[i];
+            const double sd = a.code ? tab[a.code[i]] : tab[0];
+            sgather += bi * (2.0 * (sd * xn) + bi);
+        }
+    }
+    const int G = (int)gridDim.x;
+    for (int k = 0; k < KF_NSUM; k++) {
+        const double t = kf_block_sum(acc[k], red);
+        if (tid == 0)
+            (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (a.bm > 0) {
+        const double t = kf_block_sum(sgather, red);
+        if (tid == 0)
+            a.out.sbb[G + blockIdx.x] = t;
+    }
+}
+
+// v = -M^-1 (q - sigma D z): from a product formed the classic way (entry into the fused regime, the slices the fused
+// kernel leaves to the slice-by-slice launch)
+__global__ __launch_bounds__(FV_BLOCK) void q_to_v_kernel(int64_t n, const double *__restrict__ q, const double *__restrict__ z,
+                                                           const double *__restrict__ minv, const double *__restrict__ D, double sigma,
+                                                           double *__restrict__ v)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        v[i] = -(minv[i] * (q[i] - (sigma * D[i]) * z[i]));
+}
+__global__ __launch_bounds__(FV_BLOCK) void q_to_v_slices_kernel(int64_t n, int64_t nsl, const int32_t *__restrict__ slices, const double *__restrict__ z,
+                                                                  const double *__restrict__ minv, const double *__restrict__ D, double sigma,
+                                                                  double *__restrict__ v)
+{
+    const int64_t k = ((int64_t)blockIdx.x * FV_BLOCK + threadIdx.x) >> 6;
+    if (k >= nsl)
+        return;
+    const int64_t i = ((int64_t)slices[k] << 6) + (threadIdx.x & 63);
+    if (i < n)
+        v[i] = -(minv[i] * (v[i] - (sigma * D[i]) * z[i])); // (in place: the slice-by-slice launch left q there)
+}
+
+} // namespace
+
+// Can the chained step of this problem run fused?  (The symmetric tiled form serves the operator — the classic K1 of the
+// step that enters the regime has just established that —, the shift is folded, D comes as codes, M^-1 > 0.)
+bool fv_fused_applicable(fv_problem *p, double sigma)
+{
+    if (!g_fused || p->dist || p->nhalo > 0 || p->sym_state != 1 || p->last_form != FV_SPMV_SYM_TILE)
+        return false;
+    if (p->sym_epoch != p->assemble_epoch || p->sym_tag != sigma || sigma == 0.0)
+        return false;
+    if (p->dcode_n <= 0 || p->dcode_epoch != p->storage_epoch)
+        return false;
+    const int64_t nz = p->sym_d[1], d3 = p->sym_d[2];
+    if (p->sym_d[0] != 1 || nz < 64 || nz % 2 || d3 % 2 || d3 % nz || p->n % d3 || p->n / d3 < 3)
+        return false;
+    if ((d3 / nz + 2) * (int64_t)(KF_TW + 4) >= 4096 * 64) // (the halo descriptor's 12-bit LDS slots always fit; the guard is on the grid)
+        return false;
+    return true;
+}
+
+int fv_fused_prepare(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->fz_part.p)
+        return FV_OK;
+    const size_t n = (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD;
+    FV_TRY(p->qv.alloc(ctx, n));
+    FV_TRY(p->qv2.alloc(ctx, n));
+    FV_TRY(p->qv.zero(ctx));
+    FV_TRY(p->qv2.zero(ctx));
+    FV_TRY(p->fz_part.alloc(ctx, (size_t)2 * 7 * FV_FUSED_PARTS));
+    FV_TRY(p->fz_part.zero(ctx));
+    return FV_OK;
+}
+
+FusedSums fv_fused_sums(fv_problem *p, int parity)
+{
+    FusedSums s{};
+    double *base = p->fz_part.p + (size_t)parity * 7 * FV_FUSED_PARTS;
+    s.arz = base;
+    s.arr = base + FV_FUSED_PARTS;
+    s.srz = base + 2 * FV_FUSED_PARTS;
+    s.srr = base + 3 * FV_FUSED_PARTS;
+    s.pq = base + 4 * FV_FUSED_PARTS;
+    s.sbb = base + 5 * FV_FUSED_PARTS; // two blocks of FV_FUSED_PARTS: the vector part, then the sparse-b gather
+    return s;
+}
+
+// v of the direction z (p->pvec) from its classic product q (p->q): entry into the fused regime
+int fv_fused_enter(fv_problem *p, double sigma)
+{
+    fv_ctx *ctx = p->ctx;
+    FV_TRY(fv_fused_prepare(p));
+    hipLaunchKernelGGL(q_to_v_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->q.p, (const double *)p->pvec.p,
+                       (const double *)p->minv.p, (const double *)p->D.p, sigma, p->qv.p);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+// One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
+// burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
+int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
+                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t nz = p->sym_d[1], d3 = p->sym_d[2];
+    KfArgs a{};
+    a.nz = (int32_t)nz;
+    a.d3 = (int32_t)d3;
+    a.L = (int32_t)(d3 / nz);
+    a.P = (int32_t)(p->n / d3);
+    a.nplanes = a.P - 1;
+    a.tilesC = (int32_t)((nz + KF_TW - 1) / KF_TW);
+    a.tiles = a.tilesC * (int32_t)((a.L + KF_TL - 1) / KF_TL);
+    int resident = ctx->num_cus * g_fused_blocks / 8 * 8;
+    if (resident < 8)
+        resident = 8;
+    if (resident > FV_FUSED_PARTS)
+        resident = FV_FUSED_PARTS;
+    int nsegs = 1;
+    {
+        int64_t best = -1;
+        for (int m = 1; m <= 64 && m <= a.nplanes - 1; m++) {
+            const int64_t rounds = ((int64_t)a.tiles * m + resident - 1) / resident;
+            const int64_t cost = rounds * ((a.nplanes - 1 + m - 1) / m + 3);
+            if (best < 0 || cost < best) {
+                best = cost;
+                nsegs = m;
+            }
+        }
+        if (g_fused_segs > 0 && g_fused_segs <= a.nplanes - 1)
+            nsegs = g_fused_segs;
+    }
+    a.nsegs = nsegs;
+    a.seglen = (a.nplanes - 1 + nsegs - 1) / nsegs;
+    int64_t g = (((int64_t)a.tiles * nsegs + 7) / 8) * 8;
+    if (g > resident)
+        g = resident;
+    const int GF = (int)g;
+    const double *dg = p->sym_vals.p + p->sym_front;
+    a.dg = dg;
+    a.u1 = dg + p->sym_ld;
+    a.u2 = dg + 2 * p->sym_ld;
+    a.u3 = dg + 3 * p->sym_ld;
+    a.ok = p->sym_ok.p;
+    a.code = p->dcode_n > 1 ? p->dcode.p : nullptr;
+    for (int k = 0; k < FV_STORAGE_CODES; k++)
+        a.sD.v[k] = sigma * p->dtable.v[k];
+    a.x = x;
+    a.z = p->pvec.p;
+    a.v = p->qv.p;
+    a.xout = x_next;
+    a.znext = p->pnext.p;
+    a.vnext = p->qv2.p;
+    a.bidx = bsupport > 0 ? p->bnz_idx.p : nullptr;
+    a.b = p->b.p;
+    a.bm = bsupport > 0 ? bsupport : 0;
+    a.scal = p->scal.p;
+    a.in = in;
+    FusedSums out = fv_fused_sums(p, chain_index & 1);
+    a.mode = mode;
+    a.chain_index = chain_index;
+    a.force_prev_unconverged = force_prev_unconverged ? 1 : 0;
+    a.rtol = rtol;
+    a.n = p->n;
+    a.r = p->r.p;
+    a.pold = p->pnext.p; // the previous step's direction (the host has swapped the two direction vectors for this step)
+    a.minv = p->minv.p;
+    a.D = p->D.p;
+    a.xprev = x_next;    // ... and the state that step started from
+    a.dt = dt;
+    out.nvec = GF;
+    out.nbb = a.bm > 0 ? 2 * GF : GF;
+    // (the sparse-b partials sit right behind the vector part's: sbb[GF .. 2 GF))
+    a.out = out;
+    hipLaunchKernelGGL(fused_step_kernel, dim3(GF), dim3(KF_NT), 0, ctx->stream, a);
+    FV_LAUNCH_CHECK(ctx);
+    // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
+    int GR = 0;
+    if (p->sym_nrest > 0) {
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GF, &GR));
+        hipLaunchKernelGGL(q_to_v_slices_kernel, dim3(fv_blocks(p->sym_nrest * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sym_nrest,
+                           (const int32_t *)p->sym_rest.p, (const double *)p->pnext.p, (const double *)p->minv.p, (const double *)p->D.p, sigma,
+                           p->qv2.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    out.npq = GF + GR;
+    *out_sums = out;
+    p->fused_bytes = 73;
+    return FV_OK;
+}

@@ -298,6 +298,14 @@ struct fv_problem {
     double zf_minv_sigma = -1.0;
     int64_t zf_minv_epoch = -2, zf_storage_epoch = -2;
     DevBuf<double> part_pq, part_rz, part_rr, part_bb;
+    // the fused step of the one-iteration regime (fv_fused.hip): v = -M^-1 (A z) of the direction in pvec (qv; qv2 receives the
+    // next one), its partial sums (two sets by step parity), and whether qv / the sums describe the prepared next step
+    DevBuf<double> qv, qv2, fz_part;
+    bool vready = false;
+    int vready_parity = 0;   // which set of sums the launch that left qv wrote
+    int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
+    int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
+    int64_t fused_launches = 0;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;

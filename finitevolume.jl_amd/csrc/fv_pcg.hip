@@ -18,7 +18,9 @@
 #include "fv_internal.h"
 #include "fv_device.h"
 #include "fv_spmv.h"
+#include "fv_fused.h"
 #include <cstring>
+#include <cstdlib>
 
 extern int g_carry_refresh, g_carry_speculate, g_chain_steps, g_resume_runs; // fv_transient.hip
 int g_defer_reduce = 1; // fv_tune key 22: bursts of chained steps take a step's verdict and the next step's scalars in one launch; row-block runs also merge their two all-reduces (see dist_step)
@@ -670,6 +672,15 @@ static int residual_to_r(fv_problem *p)
     return FV_OK;
 }
 
+extern "C" int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row)
+{
+    if (!p || !launches || !bytes_per_row)
+        return FV_ERR_ARG;
+    *launches = p->fused_launches;
+    *bytes_per_row = p->fused_bytes;
+    return FV_OK;
+}
+
 extern "C" int fv_update_form(fv_problem *p, int32_t *bytes_per_row)
 {
     if (!p || !bytes_per_row)
@@ -915,6 +926,32 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     bool zf = false; // this step's K2S in the z-form
     if (speculate && g_zform)
         FV_TRY(minv_positive(p, &zf));
+    // The fused step of the one-iteration regime (fv_fused.hip) where the chained step can run it; was_vready: the previous
+    // step was such a launch and has left v, the product's sums and the set-up sums of THIS step in its own arrays
+    const bool was_vready = p->vready && use_spec;
+    p->vready = false;
+    const bool fused = chained && speculate && zf && folded && sarg.D == nullptr && (bsupport >= 0 || !sys.rhs) && sys.x_next &&
+                       fv_fused_applicable(p, sigma);
+    {
+        static int trace = getenv("FV_TRACE_FUSED") ? atoi(getenv("FV_TRACE_FUSED")) : 0;
+        if (trace > 0 && sys.implicit_step) {
+            trace--;
+            fprintf(stderr, "[fvhip] step: chained %d (index %d) speculate %d use_spec %d zf %d folded %d D-stream %d b-support %lld x_next %d applicable %d last_iters %lld -> fused %d (v ready %d)\n",
+                    (int)chained, sys.chain_index, (int)speculate, (int)use_spec, (int)zf, folded ? 1 : 0, sarg.D ? 1 : 0, (long long)bsupport, sys.x_next ? 1 : 0,
+                    (int)fv_fused_applicable(p, sigma), (long long)p->last_iters, (int)fused, (int)was_vready);
+        }
+    }
+    if (chained && sys.chain_index > 0 && was_vready && !fused) {
+        fv_set_error(ctx, "internal: a burst left the fused regime in its middle");
+        return FV_ERR_STATE;
+    }
+    FusedSums fin{};
+    if (was_vready) {
+        fin = fv_fused_sums(p, p->vready_parity);
+        fin.nvec = p->vready_counts[0];
+        fin.nbb = p->vready_counts[1];
+        fin.npq = p->vready_counts[2];
+    }
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
     if (resume) {
@@ -927,6 +964,13 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         in_rz += FV_VEC_PARTIALS;
         in_rr += FV_VEC_PARTIALS;
         in_bb += FV_VEC_PARTIALS;
+        if (was_vready) { // ... a fused launch left the set-up sums in its own arrays
+            in_rz = fin.srz;
+            in_rr = fin.srr;
+            in_bb = fin.sbb;
+            Ginit = fin.nvec;
+            in_nbb = fin.nbb;
+        }
         if (!zf)
             FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
     } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
@@ -976,7 +1020,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (!resume && !use_spec)
         p->z_where = 0; // every other set-up has written r
     if (!resume)
-        if (!(chained && sys.chain_index > 0 && g_defer_reduce)) // ... unless the previous chained step's boundary launch wrote them
+        if (!(chained && sys.chain_index > 0 && (g_defer_reduce || was_vready))) // ... unless the previous chained step's boundary launch wrote them (or this step's fused launch will)
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p,
                                in_nbb, chained && sys.chain_index > 0 ? 1 : 0);
     FV_LAUNCH_CHECK(ctx);
@@ -1017,6 +1061,51 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         int32_t iters_before = 0;
         if (p->profile && polled)
             iters_before = hs->iters;
+        if (fused) {
+            const int64_t k = 0;
+            FV_TRY(fv_fused_prepare(p));
+            if (!was_vready) { // entry: the product the classic way, then v from it; the sums of this step's set-up are where K2S left them
+                int npq0 = 0;
+                FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq0));
+                FV_TRY(fv_fused_enter(p, sigma));
+                fin.arz = p->part_rz.p;
+                fin.arr = p->part_rr.p;
+                fin.srz = const_cast<double *>(in_rz);
+                fin.srr = const_cast<double *>(in_rr);
+                fin.sbb = const_cast<double *>(in_bb);
+                fin.pq = p->part_pq.p;
+                fin.nvec = Gv;
+                fin.nbb = in_nbb >= 0 ? in_nbb : Gv;
+                fin.npq = npq0;
+            }
+            const int fmode = (was_vready && sys.chain_index > 0) ? 1 : 0;
+            FusedSums fout{};
+            FV_PROF(0);
+            FV_TRY(fv_fused_step(p, x, sys.x_next, sigma, sys.dt, rtol, sys.chain_index, fmode, fin,
+                                 fmode == 1 && sys.chain_index - 1 == g_chain_test_break, folded, bsupport, &fout));
+            FV_PROF(1);
+            FV_PROF(2);
+            FV_PROF(3);
+            FV_PROF(4);
+            if (!sys.chain_more) // the burst's last step: its verdict now, so that the host's poll sees a finished state
+                hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, 0, p->r.p, (const double *)p->minv.p,
+                                   p->pvec.p, (const double *)fout.arz, (const double *)fout.arr, fout.nvec, p->scal.p, p->hist.p, p->hist_cap,
+                                   (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt, sys.chain_index,
+                                   (sys.chain_index == g_chain_test_break) ? 1 : 0, (const double *)p->pnext.p);
+            FV_PROF(5);
+            FV_LAUNCH_CHECK(ctx);
+            p->qv.swap(p->qv2);
+            p->vready = true;
+            p->vready_parity = sys.chain_index & 1;
+            p->vready_counts[0] = fout.nvec;
+            p->vready_counts[1] = fout.nbb;
+            p->vready_counts[2] = fout.npq;
+            p->fused_launches++;
+            p->last_iters = 1;
+            p->spec_valid = true;
+            p->z_where = 2;
+            return FV_OK;
+        }
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
             FV_PROF(0);
@@ -1152,6 +1241,7 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
         *zero_mask = hs->zero_mask;
     if (hs->done == 3) {
         p->spec_valid = false;
+        p->vready = false;
         p->z_where = 0; // the launch that stopped the chain wrote r
         p->last_iters = 2; // at least
         const int32_t zero = 0;

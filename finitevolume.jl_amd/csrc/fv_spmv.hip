@@ -11,6 +11,7 @@
 #include "fv_internal.h"
 #include "fv_device.h"
 #include "fv_spmv.h"
+#include "fv_fused.h"
 
 #include <cstdlib>
 
@@ -299,6 +300,7 @@ extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder;                       // fv_assembly.hip
+extern int g_fused, g_fused_blocks, g_fused_segs; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -374,6 +376,12 @@ extern "C" int fv_tune(int key, int value)
         g_tile_blocks = value;
     else if (key == 40 && value >= 0 && value <= 256)
         g_tile_segs = value;
+    else if (key == 41 && (value == 0 || value == 1))
+        g_fused = value;
+    else if (key == 42 && value >= 1 && value <= 4)
+        g_fused_blocks = value;
+    else if (key == 43 && value >= 0 && value <= 256)
+        g_fused_segs = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -2146,6 +2154,31 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
     return FV_OK;
 }
 
+
+// The slices the symmetric form leaves to the slice-by-slice kernel (first / last plane, irregular ones), on their own: the
+// fused step (fv_fused.hip) forms every other product itself.  `vals`: the value array the lane-major copy was filled from
+// (spmv_apply has done that for the same array and tag before the fused regime is entered).
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts)
+{
+    fv_ctx *ctx = p->ctx;
+    *nparts = 0;
+    if (p->sym_state != 1 || p->sym_nrest <= 0)
+        return FV_OK;
+    FV_TRY(ensure_dia_vals(p, vals, vals == p->vals.p ? 0.0 : p->shifted_sigma, !p->dist));
+    const int GR = stream_grid(p->sym_nrest);
+    const StepInitEpilogue epi{};
+    if (g_nt)
+        hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
+                           (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
+                           partials, (const PcgScalars *)nullptr, epi);
+    else
+        hipLaunchKernelGGL((spmv_dia_kernel<true, false, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
+                           (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
+                           partials, (const PcgScalars *)nullptr, epi);
+    FV_LAUNCH_CHECK(ctx);
+    *nparts = GR;
+    return FV_OK;
+}
 
 extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch)
 {

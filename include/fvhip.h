@@ -298,7 +298,9 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *      0 = always stream the diagonal [1]
  *  38: the tiled traversal of the symmetric form (FV_SPMV_SYM_TILE) where it applies; 0 = always the plane-marching kernel [1]
  *  39, 40: experiments on the tiled kernel's launch: resident blocks per CU its grid is sized for [2], segments of planes per
- *      tile column (0 = chosen to fill whole rounds of the resident blocks) [0] */
+ *      tile column (0 = chosen to fill whole rounds of the resident blocks) [0]
+ *  41: the fused step (fv_fused_form) in bursts of one-iteration steps where it applies; 0 = always K1 + K2S [1]
+ *  42, 43: experiments on its launch: resident blocks per CU [2], segments of planes per tile (0 = chosen) [0] */
 int fv_tune(int key, int value);
 /* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event
  * between two launches is a barrier (~10 us each at 464^3), so the timed region of the bench uses 2; 0: off. */
@@ -326,6 +328,12 @@ int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
  * x_in, q, M^-1, D, z in and x_out, z' out), 64 otherwise (x_in, q, M^-1, D, r in and x_out, r, p' out); 7 / 8 fewer when the
  * storage term comes as codes / one double (key 35), 8 more when a dense b' is streamed too.  0 before the first such launch. */
 int fv_update_form(fv_problem *p, int32_t *bytes_per_row);
+/* The fused step of the one-iteration regime (fv_tune key 41; replaces the K1 + K2S pair behind src/transient.jl:60-76 when a
+ * fixed-dt run's steps converge in one PCG iteration and the operator has the tiled symmetric form): launches so far on this
+ * problem and the bytes per row its storage form moves with every array touched once — x, z, v in and x_out, z', v' out (48),
+ * three upper diagonals (24), one storage code byte = 73 (+ 8 where the diagonal is streamed); 0 launches / 0 bytes when it
+ * has not run. */
+int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

@@ -1,0 +1,151 @@
+"""GPU parity of the fused step of the one-iteration regime (fv_fused.hip: the vector update of one fixed-dt step and the
+product of the next in one pass; /root/reference/src/transient.jl:60-76,130-134) through the C ABI: against the oracle's
+direct solves (1e-8 relative, the north-star bar), and against the unfused K1 + K2S chain it replaces (same iteration
+counts, heads to rounding), on boxes whose free rows take the tiled symmetric form: tile edges inside lines and planes,
+derived and streamed diagonals, a chain that breaks, steps that are converged at their set-up, runs in chunks."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _problem(fv, ns, lateral=False, seed=0, sigma=0.7, uniform_k=False):
+    """x-min / x-max planes Dirichlet (every interior row has a zero row sum: diagonal from the arms); lateral: the four
+    lateral faces instead (every slice holds a row next to a Dirichlet cell: streamed diagonal)."""
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    coords, nb, aol, vol = fv.regulargrid(mins, maxs, list(ns))
+    N = len(vol)
+    rng = np.random.default_rng(seed)
+    if uniform_k:
+        K = np.full(len(aol), 1e-5)
+    else:
+        K = np.exp(fv.nodehycos2neighborhycos(nb, np.log(1e-5) + sigma * rng.standard_normal(N), True))
+    if lateral:
+        dn = np.nonzero((coords[1] == mins[1]) | (coords[1] == maxs[1]) | (coords[2] == mins[2]) | (coords[2] == maxs[2]))[0] + 1
+    else:
+        dn = np.nonzero((coords[0] == mins[0]) | (coords[0] == maxs[0]))[0] + 1
+    dn = dn.astype(np.int64)
+    smooth = 1000.0 + 0.5 * np.sin(coords[0] / 17.0) * np.cos(coords[1] / 23.0) + 0.1 * coords[2]  # (smooth heads: one PCG iteration per small step)
+    dh = smooth[dn - 1] + 0.25
+    src = np.zeros(N)
+    inner = np.setdiff1d(np.arange(1, N + 1), dn)
+    src[inner[len(inner) // 2] - 1] = -1e-3
+    u0 = smooth + 1e-3 * rng.random(N)
+    return mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0
+
+
+def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    lib = fv.load()
+    lib.fv_tune(41, 1 if fused else 0)
+    for k, v in tune:
+        assert lib.fv_tune(k, v) == 0
+    try:
+        p = fv.Problem.create(nb, aol, len(vol), dn).assemble(K, src, dh)
+        st = p.transient_begin(Ss, vol, u0)
+        its = []
+        for dt, nsteps, rtol in schedule:
+            it, info, _ = p.run_fixed(st, dt, nsteps, rtol=rtol, maxiter=2000)
+            assert info.converged
+            its.append(it.copy())
+        out = (st.node_values(), np.concatenate(its), p.fused_form(), p.spmv_form()[0])
+        p.close()
+    finally:
+        lib.fv_tune(41, 1)
+        for k, v in tune:
+            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0}.get(k, 0))
+    return out
+
+
+# The symmetric (tiled) form wants > 2^20 rows in planes of >= 32768 rows, >= 90 % of the slices regular (the first and last plane
+# never are).  Free rows: 34 planes x 182 lines x 186 (two column tiles, the second 58 wide; 23 line tiles, the last with 6
+# lines; planes of 33 852 rows: slices straddle them); 34 x 165 x 200 (a second tile of 72 columns, a last line tile of 5); and
+# 34 x 182 x 186 again with the four lateral faces Dirichlet (every slice holds rows next to a Dirichlet cell).
+BOX, BOX2, BOX3 = (36, 182, 186), (36, 165, 200), (34, 184, 188)
+DT = 2.0**-10  # far below the diffusion time of a cell: the one-iteration regime
+
+
+@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True)])
+def test_fused_steps_against_the_unfused_chain_and_the_oracle(fv, oracle, ns, lateral):
+    case = _problem(fv, ns, lateral=lateral)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    dt, nsteps = DT, 21
+    fused = _run(fv, case, True, [(dt, nsteps, 1e-11)])
+    plain = _run(fv, case, False, [(dt, nsteps, 1e-11)])
+    assert fused[3] == 4 and plain[3] == 4  # the tiled symmetric form serves the operator
+    assert fused[2][0] >= nsteps - 4 and fused[2][1] == 73 and plain[2][0] == 0  # the fused launches ran (all but the run's first steps)
+    assert np.array_equal(fused[1], plain[1]) and (fused[1][2:] == 1).all()
+    assert relerr(fused[0], plain[0]) < 1e-12
+    # the oracle: the same steps, its CG run to 1e-14
+    ous, ots = oracle.backwardeulerintegrate(u0, (0.0, dt * nsteps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
+                                             dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
+    assert len(ous) == nsteps + 1
+    assert relerr(fused[0], ous[-1]) < 1e-8
+    print("change over the run, fused vs oracle: %.2e (unfused: %.2e)" % (relerr(fused[0] - u0, ous[-1] - u0), relerr(plain[0] - u0, ous[-1] - u0)))
+
+
+def test_fused_chain_that_breaks_falls_back_to_further_iterations(fv):
+    """fv_tune key 14 treats one chained step of every burst as not converged: the launch behind it turns into the fall-back
+    (that step's residual and next direction), the host resumes the step at its second iteration."""
+    case = _problem(fv, BOX)
+    sched = [(DT, 30, 1e-11)]
+    ref = _run(fv, case, False, sched)
+    for brk in (0, 3, 7):
+        got = _run(fv, case, True, sched, tune=((14, brk),))
+        plain = _run(fv, case, False, sched, tune=((14, brk),))
+        assert got[2][0] > 0
+        assert (got[1] >= 1).all() and (got[1] > 1).sum() >= 2 and np.array_equal(got[1] > 1, plain[1] > 1)
+        assert relerr(got[0], ref[0]) < 1e-11
+
+
+def test_fused_steps_converged_at_their_set_up_and_changing_tolerances(fv):
+    """A loose tolerance after tight steps: the steps count 0 iterations and hand the state over unchanged; a tight one
+    again: they iterate again.  Time steps that need several iterations in between leave and re-enter the fused regime."""
+    case = _problem(fv, BOX, seed=3)
+    sched = [(DT, 12, 1e-11), (DT, 20, 1e-3), (DT, 11, 1e-12), (40.0, 5, 1e-10), (DT, 19, 1e-11), (DT / 4, 9, 1e-6)]
+    fused = _run(fv, case, True, sched)
+    plain = _run(fv, case, False, sched)
+    assert fused[2][0] > 30
+    assert (fused[1][12:32] == 0).all() and (fused[1][34:43] == 1).all() and (fused[1][43:48] > 1).all()
+    assert np.array_equal(fused[1], plain[1])
+    assert relerr(fused[0], plain[0]) < 1e-11
+
+
+def test_fused_runs_in_chunks_and_burst_lengths(fv):
+    """One run of 40 steps = runs of 7 + 1 + 13 + 2 + 17 (each call goes on where the previous one stopped, fv_problem::resume),
+    whatever the burst length; all-fused runs are the same bits however they are cut."""
+    case = _problem(fv, BOX, seed=5)
+    dt, rtol = DT, 1e-11
+    whole = _run(fv, case, True, [(dt, 40, rtol)])
+    plain = _run(fv, case, False, [(dt, 40, rtol)])
+    for tune in ((), ((13, 3),), ((13, 32),)):
+        cut = _run(fv, case, True, [(dt, 7, rtol), (dt, 1, rtol), (dt, 13, rtol), (dt, 2, rtol), (dt, 17, rtol)], tune=tune)
+        assert np.array_equal(cut[1], whole[1])
+        assert relerr(cut[0], whole[0]) < 1e-12
+    assert relerr(whole[0], plain[0]) < 1e-12
+    # launch parameters that change the traversal, not the result
+    for tune in (((42, 1),), ((43, 1),), ((43, 5),)):
+        other = _run(fv, case, True, [(dt, 40, rtol)], tune=tune)
+        assert np.array_equal(other[1], whole[1]) and relerr(other[0], whole[0]) < 1e-12
+
+
+def test_fused_step_with_uniform_storage_and_profile_events(fv):
+    """One storage value (no code stream): a slab of equal cells; and the profile events of a burst are all recorded."""
+    case = list(_problem(fv, BOX, seed=7, uniform_k=True))
+    case[5] = np.full(len(case[5]), case[5].max())  # equal volumes: D takes one value
+    case = tuple(case)
+    fused = _run(fv, case, True, [(DT, 20, 1e-11)])
+    plain = _run(fv, case, False, [(DT, 20, 1e-11)])
+    assert fused[2][0] > 10 and np.array_equal(fused[1], plain[1]) and relerr(fused[0], plain[0]) < 1e-12
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    p = fv.Problem.create(nb, aol, len(vol), dn).assemble(K, src, dh)
+    st = p.transient_begin(0.1, vol, u0)
+    p.profile(1)
+    it, info, _ = p.run_fixed(st, DT, 20, rtol=1e-11)
+    prof = p.profile_get()
+    assert info.converged and prof["spmv_dot"][1] >= 18 and prof["spmv_dot"][0] > 0
+    p.close()
