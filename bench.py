@@ -261,8 +261,8 @@ def launch_ranks(n, argv):
     if rc == 0 and len(lines) != 1:
         print("bench.py: rank 0 printed %d JSON lines instead of one" % len(lines), file=sys.stderr)
         rc = 3
-    for l in lines:
-        print(l)
+    for l in lines:  # a failed run prints no headline number on stdout (a driver that parses the last JSON line must not find one)
+        print(l, file=sys.stdout if rc == 0 else sys.stderr)
     sys.stdout.flush()
     return rc
 
@@ -275,6 +275,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)  # 0.65 s of stepping: one hiccup of the box no longer decides the number
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = the median region (all are listed)")
     ap.add_argument("--ns", type=int, default=464, help="cells per dimension of the box (464 -> 9.99e7 cells)")
     ap.add_argument("--dt", type=float, default=60.0)
     ap.add_argument("--rtol", type=float, default=1e-10)
@@ -324,15 +325,22 @@ def main():
     if args.warmup > 0:
         p.run_fixed(state, args.dt, args.warmup, args.rtol, args.maxiter)
     if not args.no_profile:
-        p.profile(2)  # HIP event pairs around every K1 launch of the timed region (and nothing else: an event is a barrier)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    iters, info, dev_ms = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
-    ctx.synchronize()
-    sec = time.perf_counter() - t0
+        p.profile(2)  # HIP event pairs around every K1 / fused-step launch of the timed regions (and nothing else: an event is a barrier)
+    fused0 = p.fused_form()[0]
+    regions, iters_all = [], []
+    for rep in range(max(args.repeats, 1)):  # each region: exactly --steps steps between two synchronisations; consecutive fixed-dt
+        ctx.synchronize()                     # runs go on where the previous one stopped (fv_problem::resume)
+        t0 = time.perf_counter()
+        iters, info, dev_ms = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
+        ctx.synchronize()
+        regions.append(time.perf_counter() - t0)
+        iters_all.append(iters.copy())
+    sec = float(np.median(regions))
+    iters = np.concatenate(iters_all)
+    fused_launches = p.fused_form()[0] - fused0
     prof = p.profile_get() if not args.no_profile else None
     p.profile(False)
-    if prof is not None:  # the other kernels of the step: 16 more steps after the timed region with all event pairs on
+    if prof is not None and not fused_launches:  # the other kernels of the step: 16 more steps after the timed region with all event pairs on
         p.profile(1)
         p.run_fixed(state, args.dt, 16, args.rtol, args.maxiter)
         extra = p.profile_get()
@@ -340,7 +348,7 @@ def main():
         prof["update"], prof["pupdate"] = extra["update"], extra["pupdate"]
 
     value = p.N * args.steps / sec
-    roof, kern = roofline_block(p, prof, float(np.mean(iters)), args.ns)
+    roof, kern = roofline_block(p, prof, float(np.mean(iters)), args.ns, fused_launches, len(iters))
 
     out = {
         "metric": "DoF-updates/s (cells\u00d7steps) implicit transient; SpMV HBM GB/s vs peak",
@@ -350,6 +358,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": sec / args.steps * 1e3,
+        "repeats": {"regions": len(regions), "ms_per_step_each": [r / args.steps * 1e3 for r in regions], "value_is": "the median region",
+                    "spread": (max(regions) - min(regions)) / sec},
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
@@ -359,6 +369,9 @@ def main():
             "workload": "synthetic %d^3 box (%.3g cells), transient, fixed dt=%gs, Jacobi-PCG rtol %.0e, lateral Dirichlet + centre well (SURVEY 8d / BASELINE configs[4] on one GPU)" % (args.ns, p.N, args.dt, args.rtol),
             "cells": p.N, "unknowns": p.n, "nnz": p.nnz, "faces": p.F,
             "pcg_iters_per_step": float(np.mean(iters)), "pcg_iters_total": int(np.sum(iters)),
+            "step_form": ("fused: one launch per step does the vector update of step k and the product of step k + 1 (fv_fused.hip), %d of %d steps" % (fused_launches, len(iters)))
+                         if fused_launches else "K1 (product) + K2S (vector update and next set-up) per step",
+            "resume_runs": True, "residual_refresh_every": 128,  # consecutive run_fixed calls continue the carried residual; a fresh b - A u every 128 steps
             "last_relres": info.relres, "converged": bool(info.converged),
             "device": name, "compute_units": cus,
             "setup_s": {"grid+symbolic": t_symbolic, "assemble": t_assemble, "total": t_setup},
@@ -384,8 +397,11 @@ def main():
     print(json.dumps(out))
 
 
-def roofline_block(p, prof, iters_per_step, ns):
-    """The `roofline` object for K1, the PCG SpMV q = (A + D/dt) p with the p.q epilogue.
+def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
+    """The `roofline` object for the kernel that dominates a step.  In the one-iteration regime on an operator with the tiled
+    symmetric form that is the fused step (fused_step_kernel: vector update of step k + product of step k + 1, fv_fused_form's
+    bytes); its `spmv` sub-object then gives K1 alone (the PCG SpMV q = (A + D/dt) p with the p.q epilogue, which every other
+    regime runs), measured back to back right after the timed regions.  Otherwise the object is K1's:
     achieved / frac use the bytes one launch of the storage form that ran has to move with every array touched once
     (fv_spmv_form: e.g. 32 n of matrix + 16 n of vectors for the symmetric plane-marching form) over the HIP-event average of
     the live launches inside the timed region — a real HBM rate, never above what the hardware does.  SURVEY 8d's CSR
@@ -400,6 +416,34 @@ def roofline_block(p, prof, iters_per_step, ns):
             "algorithmic_bytes_per_launch": form_bytes,
             "bytes_model": "bytes the storage form must move, every array once (fv_spmv_form); the CSR accounting of SURVEY 8d is in effective_csr"}
     kern = {}
+    if fused_launches and prof and prof["spmv_dot"][1] > 0 and fused_launches >= 0.8 * nsteps:
+        _, fbytes_row, fbytes = p.fused_form()
+        ms, cnt = prof["spmv_dot"]
+        t = ms / cnt * 1e-3
+        k1 = dict(roof)
+        k1_ms = p.bench_spmv(1.0 / 60.0, 20)
+        k1.update(achieved=form_bytes / (k1_ms * 1e-3) / 1e9, frac=form_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, avg_launch_ms=k1_ms, launches=20,
+                  measured="20 launches back to back after the timed regions (inside the stepping loop the product is part of the fused launch)",
+                  effective_csr={"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / (k1_ms * 1e-3) / 1e9, "frac": csr_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        roof = {"bound": "hbm", "achieved": fbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "fused_step_kernel<16>: x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' "
+                          "with z'.q' of step k + 1, stored as v' = -M^-1 (q' - D z'/dt); 2-D tiles of 16 lines x 128 columns marching through the planes, "
+                          "z' tile and U1/U2 ring in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms; first/last plane's products by spmv_dia_kernel",
+                "form": "fused step, v-form (x, z, v in; x_out, z', v' out; 3 upper diagonals; storage codes): %d B per row" % fbytes_row,
+                "algorithmic_bytes_per_launch": fbytes,
+                "bytes_model": "every array once (fv_fused_form): 48 n of vectors + 1 n of storage codes + 24 B of matrix per row whose product the kernel forms (+ 8 where the diagonal is streamed); the unfused pair K1 + K2S moves 41 n + 49 n",
+                "avg_launch_ms": ms / cnt, "launches": cnt, "spmv": k1}
+        tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                tj = json.load(open(tfile)).get("fused_%d" % ns)
+                if tj and abs(tj.get("form_bytes", 0) - fbytes) <= 0.01 * fbytes:
+                    roof["traffic"] = tj["bytes"]
+                    roof["traffic_source"] = tj.get("source")
+                    roof["frac_traffic"] = tj["bytes"] / t / 1e9 / HBM_PEAK_GBS
+            except Exception:
+                pass
+        return roof, kern
     if prof and prof["spmv_dot"][1] > 0:
         ms, cnt = prof["spmv_dot"]
         t = ms / cnt * 1e-3

@@ -307,10 +307,11 @@ class Problem:
         return b.value
 
     def fused_form(self):
-        """(launches so far, bytes per row of its storage form) of the fused step of the one-iteration regime (fv_fused_form)."""
-        n, b = C.c_int64(), C.c_int32()
-        self.check(load().fv_fused_form(self.handle, C.byref(n), C.byref(b)))
-        return n.value, b.value
+        """(launches so far, bytes per row of its storage form, bytes per launch) of the fused step of the one-iteration regime
+        (fv_fused_form)."""
+        n, b, t = C.c_int64(), C.c_int32(), C.c_int64()
+        self.check(load().fv_fused_form(self.handle, C.byref(n), C.byref(b), C.byref(t)))
+        return n.value, b.value, t.value
 
     def profile(self, on=True):
         """True / 1: time K1, K2 and K3 launches; 2: the SpMV (K1) only; False: off."""

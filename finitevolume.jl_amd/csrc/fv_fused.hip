@@ -32,12 +32,15 @@
 #include "fv_fused.h"
 
 int g_fused = 1;       // fv_tune key 41: 0 = never use the fused step
-int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for
+int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for (8-line tiles)
 int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per tile, 0 = chosen to fill whole rounds
+int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
+int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
+                        // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
 
 namespace {
 
-constexpr int KF_TL = 8, KF_TW = 128, KF_NT = KF_TL * KF_TW / 2; // 512 threads
+constexpr int KF_TW = 128; // columns of a tile; lines: 8 (512 threads, two blocks per CU) or 16 (1024 threads, one)
 constexpr int KF_NSUM = 6;
 
 struct KfArgs {
@@ -57,6 +60,7 @@ struct KfArgs {
     // scalars / control
     PcgScalars *scal;
     FusedSums in, out;
+    int nt;          // streaming-hint experiment (fv_tune key 45)
     int mode;        // 0: scalars of this step already in scal (set-up finalised by an earlier launch); 1: merged boundary
     int chain_index; // index of this step in its burst
     int force_prev_unconverged;
@@ -68,7 +72,8 @@ struct KfArgs {
     double dt;
 };
 
-// all threads get the sum of v over the block; red: KF_NT / 64 doubles
+// all threads get the sum of v over the block; red: NT / 64 doubles
+template <int NT>
 __device__ inline double kf_block_sum(double v, double *red)
 {
     v = wave_sum(v);
@@ -78,16 +83,17 @@ __device__ inline double kf_block_sum(double v, double *red)
     __syncthreads();
     double t = 0.0;
 #pragma unroll
-    for (int w = 0; w < KF_NT / 64; w++)
+    for (int w = 0; w < NT / 64; w++)
         t += red[w];
     return t;
 }
+template <int NT>
 __device__ inline double kf_reduce(const double *__restrict__ part, int count, double *red)
 {
     double v = 0.0;
-    for (int i = threadIdx.x; i < count; i += KF_NT)
+    for (int i = threadIdx.x; i < count; i += NT)
         v += part[i];
-    return kf_block_sum(v, red);
+    return kf_block_sum<NT>(v, red);
 }
 
 struct VRow {
@@ -105,9 +111,10 @@ __device__ __forceinline__ VRow vrow(double xin, double z, double v, double d, d
     return o;
 }
 
-__global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
+template <int TL>
+__global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
 {
-    constexpr int TL = KF_TL, TW = KF_TW, NT = KF_NT, HC = TW / 2;
+    constexpr int TW = KF_TW, NT = TL * TW / 2, HC = TW / 2;
     constexpr int ZS = TW + 4, U1S = TW + 2, U2S = TW; // LDS row strides: own column tc sits at 2 + tc (z', U1) so that pairs stay 16-byte aligned
     constexpr int ZT = (TL + 2) * ZS, U1T = TL * U1S, U2T = (TL + 1) * U2S;
     constexpr int NH = 2 * TW + 2 * TL; // threads with a halo row: line above, line below, column left, column right
@@ -129,11 +136,11 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
     bool zero_iteration;
     if (a.mode == 1) {
         // the previous chained step's verdict
-        const double rrn = kf_reduce(a.in.arr, a.in.nvec, red);
+        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
         const bool converged = rrn <= scal->tol2x[(a.chain_index - 1) & 1] && !a.force_prev_unconverged;
         if (!converged) {
             // as pcg_chain_boundary_kernel: that step's residual without the next step's storage term, p = M^-1 r + beta p
-            const double rzn = kf_reduce(a.in.arz, a.in.nvec, red);
+            const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
             const double beta = rzn / scal->rz[0];
             const int64_t n2 = a.n >> 1;
             double2 *r2 = reinterpret_cast<double2 *>(a.r);
@@ -171,9 +178,9 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
             }
             return;
         }
-        rz0 = kf_reduce(a.in.srz, a.in.nvec, red);
-        const double rr0 = kf_reduce(a.in.srr, a.in.nvec, red);
-        const double bb = kf_reduce(a.in.sbb, a.in.nbb, red);
+        rz0 = kf_reduce<NT>(a.in.srz, a.in.nvec, red);
+        const double rr0 = kf_reduce<NT>(a.in.srr, a.in.nvec, red);
+        const double bb = kf_reduce<NT>(a.in.sbb, a.in.nbb, red);
         const double tol2 = a.rtol * a.rtol * bb;
         zero_iteration = rr0 <= tol2;
         if (blockIdx.x == 0 && tid == 0) {
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
     }
     double alpha = 0.0;
     if (!zero_iteration) {
-        const double pq = kf_reduce(a.in.pq, a.in.npq, red);
+        const double pq = kf_reduce<NT>(a.in.pq, a.in.npq, red);
         if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
             if (blockIdx.x == 0 && tid == 0) {
                 scal->pq = pq;
@@ -283,6 +290,11 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 255u], tab[c >> 8]); }; // sigma D of the two rows
         auto H1 = [&](const double *arr, int32_t pl) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + hb); };
         auto ST2 = [&](double *arr, int32_t pl, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob) = val; };
+        auto ST2nt = [&](double *arr, int32_t pl, double2 val) {
+            double *q = reinterpret_cast<double *>(const_cast<char *>(PB(arr, pl, 8)) + ob);
+            __builtin_nontemporal_store(val.x, q);
+            __builtin_nontemporal_store(val.y, q + 1);
+        };
         __syncthreads(); // tab; the previous item's last LDS reads
         // ---------------- prologue: z' of plane p0 - 1 (registers), z' of plane p0 (tile + halo), U tiles of p0 and p0 + 1
         double2 Zm, Pc, Mc; // Mc: M^-1 of the centre plane's rows (Cc: their storage codes); Pc: the -plane and diagonal terms of their products
@@ -364,13 +376,13 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
             int flb = 0;
             double hq = 0.0, hzv = 0.0, hub = 0.0;
             if (more) {
-                Xb = P2nt(a.x, p + 2);
-                Vb = P2nt(a.v, p + 2);
+                Xb = (a.nt & 4) ? P2(a.x, p + 2) : P2nt(a.x, p + 2);
+                Vb = (a.nt & 4) ? P2(a.v, p + 2) : P2nt(a.v, p + 2);
                 Zb = P2(a.z, p + 2);
                 Cb = C2(p + 2);
-                V1b = P2nt(a.u1, p + 2);
-                V2b = P2nt(a.u2, p + 2);
-                A3b = P2nt(a.u3, p + 2);
+                V1b = (a.nt & 16) ? P2(a.u1, p + 2) : P2nt(a.u1, p + 2);
+                V2b = (a.nt & 16) ? P2(a.u2, p + 2) : P2nt(a.u2, p + 2);
+                A3b = (a.nt & 16) ? P2(a.u3, p + 2) : P2nt(a.u3, p + 2);
                 flb = own ? (int)a.ok[((int64_t)(p + 2) * d3 + o) >> 6] : 0;
             }
             if (ht && KF_HV) {
@@ -409,9 +421,16 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
             const double2 Pn = make_double2(A3c.x * Zc.x + Dn.x * Zn.x, A3c.y * Zc.y + Dn.y * Zn.y);
             if (vec_n && own) {
                 double *xo = reinterpret_cast<double *>(const_cast<char *>(PB(a.xout, p + 1, 8)) + ob);
-                __builtin_nontemporal_store(ua.xn, xo);
-                __builtin_nontemporal_store(ub.xn, xo + 1);
-                ST2(a.znext, p + 1, Zn);
+                if (a.nt & 8)
+                    *reinterpret_cast<double2 *>(xo) = make_double2(ua.xn, ub.xn);
+                else {
+                    __builtin_nontemporal_store(ua.xn, xo);
+                    __builtin_nontemporal_store(ub.xn, xo + 1);
+                }
+                if (a.nt & 1)
+                    ST2nt(a.znext, p + 1, Zn);
+                else
+                    ST2(a.znext, p + 1, Zn);
                 acc[0] += ua.r * (ua.mv * ua.r) + ub.r * (ub.mv * ub.r);
                 acc[1] += ua.r * ua.r + ub.r * ub.r;
                 acc[2] += ua.c * ua.zn + ub.c * ub.zn;
@@ -441,7 +460,11 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
                 t1 += A3c.y * Zn.y;
                 if (flc & 1) {
                     const double2 Sc = SD(Cc);
-                    ST2(a.vnext, p, make_double2(-(Mc.x * (t0 - Sc.x * Zc.x)), -(Mc.y * (t1 - Sc.y * Zc.y))));
+                    const double2 vn = make_double2(-(Mc.x * (t0 - Sc.x * Zc.x)), -(Mc.y * (t1 - Sc.y * Zc.y)));
+                    if (a.nt & 2)
+                        ST2nt(a.vnext, p, vn);
+                    else
+                        ST2(a.vnext, p, vn);
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
             }
@@ -493,12 +516,12 @@ __global__ __launch_bounds__(KF_NT, 4) void fused_step_kernel(KfArgs a)
     }
     const int G = (int)gridDim.x;
     for (int k = 0; k < KF_NSUM; k++) {
-        const double t = kf_block_sum(acc[k], red);
+        const double t = kf_block_sum<NT>(acc[k], red);
         if (tid == 0)
             (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
     }
     if (a.bm > 0) {
-        const double t = kf_block_sum(sgather, red);
+        const double t = kf_block_sum<NT>(sgather, red);
         if (tid == 0)
             a.out.sbb[G + blockIdx.x] = t;
     }
@@ -597,9 +620,10 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     a.L = (int32_t)(d3 / nz);
     a.P = (int32_t)(p->n / d3);
     a.nplanes = a.P - 1;
+    const int TLr = g_fused_lines == 16 ? 16 : 8;
     a.tilesC = (int32_t)((nz + KF_TW - 1) / KF_TW);
-    a.tiles = a.tilesC * (int32_t)((a.L + KF_TL - 1) / KF_TL);
-    int resident = ctx->num_cus * g_fused_blocks / 8 * 8;
+    a.tiles = a.tilesC * (int32_t)((a.L + TLr - 1) / TLr);
+    int resident = ctx->num_cus * (TLr == 16 ? 1 : g_fused_blocks) / 8 * 8;
     if (resident < 8)
         resident = 8;
     if (resident > FV_FUSED_PARTS)
@@ -646,6 +670,7 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     a.in = in;
     FusedSums out = fv_fused_sums(p, chain_index & 1);
     a.mode = mode;
+    a.nt = g_fused_nt;
     a.chain_index = chain_index;
     a.force_prev_unconverged = force_prev_unconverged ? 1 : 0;
     a.rtol = rtol;
@@ -660,7 +685,10 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     out.nbb = a.bm > 0 ? 2 * GF : GF;
     // (the sparse-b partials sit right behind the vector part's: sbb[GF .. 2 GF))
     a.out = out;
-    hipLaunchKernelGGL(fused_step_kernel, dim3(GF), dim3(KF_NT), 0, ctx->stream, a);
+    if (TLr == 16)
+        hipLaunchKernelGGL(fused_step_kernel<16>, dim3(GF), dim3(1024), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(fused_step_kernel<8>, dim3(GF), dim3(512), 0, ctx->stream, a);
     FV_LAUNCH_CHECK(ctx);
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
@@ -673,6 +701,12 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     }
     out.npq = GF + GR;
     *out_sums = out;
-    p->fused_bytes = 73;
+    {
+        // every array once: x, z, v in and x_out, z', v' out on all rows (48) + a code byte; the three upper diagonals on the rows
+        // whose product this kernel forms (24), + the stored diagonal where it is not re-derived (8)
+        const int64_t nok = p->ndia - p->sym_nrest, nder = p->sym_nderived;
+        p->fused_bytes = nder * 2 >= nok ? 73 : 81;
+        p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + 24 * 64 * nok + 8 * 64 * (nok - nder);
+    }
     return FV_OK;
 }

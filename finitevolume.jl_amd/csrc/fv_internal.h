@@ -305,7 +305,7 @@ struct fv_problem {
     int vready_parity = 0;   // which set of sums the launch that left qv wrote
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
-    int64_t fused_launches = 0;
+    int64_t fused_launches = 0, fused_bytes_launch = 0;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;

@@ -672,12 +672,13 @@ static int residual_to_r(fv_problem *p)
     return FV_OK;
 }
 
-extern "C" int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row)
+extern "C" int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int64_t *bytes_per_launch)
 {
-    if (!p || !launches || !bytes_per_row)
+    if (!p || !launches || !bytes_per_row || !bytes_per_launch)
         return FV_ERR_ARG;
     *launches = p->fused_launches;
     *bytes_per_row = p->fused_bytes;
+    *bytes_per_launch = p->fused_bytes_launch;
     return FV_OK;
 }
 

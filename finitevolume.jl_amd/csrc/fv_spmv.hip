@@ -300,7 +300,7 @@ extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder;                       // fv_assembly.hip
-extern int g_fused, g_fused_blocks, g_fused_segs; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -382,6 +382,10 @@ extern "C" int fv_tune(int key, int value)
         g_fused_blocks = value;
     else if (key == 43 && value >= 0 && value <= 256)
         g_fused_segs = value;
+    else if (key == 44 && (value == 8 || value == 16))
+        g_fused_lines = value;
+    else if (key == 45 && value >= 0 && value <= 31)
+        g_fused_nt = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else

@@ -331,9 +331,10 @@ int fv_update_form(fv_problem *p, int32_t *bytes_per_row);
 /* The fused step of the one-iteration regime (fv_tune key 41; replaces the K1 + K2S pair behind src/transient.jl:60-76 when a
  * fixed-dt run's steps converge in one PCG iteration and the operator has the tiled symmetric form): launches so far on this
  * problem and the bytes per row its storage form moves with every array touched once — x, z, v in and x_out, z', v' out (48),
- * three upper diagonals (24), one storage code byte = 73 (+ 8 where the diagonal is streamed); 0 launches / 0 bytes when it
- * has not run. */
-int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row);
+ * three upper diagonals (24), one storage code byte = 73 (+ 8 where the diagonal is streamed); *bytes_per_launch: the same
+ * summed over the operator (rows whose product the slice-by-slice launch forms carry no matrix bytes here); 0 launches / 0
+ * bytes when it has not run. */
+int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int64_t *bytes_per_launch);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

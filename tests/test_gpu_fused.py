@@ -57,7 +57,7 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
     finally:
         lib.fv_tune(41, 1)
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0, 44: 16}.get(k, 0))
     return out
 
 
@@ -77,7 +77,7 @@ def test_fused_steps_against_the_unfused_chain_and_the_oracle(fv, oracle, ns, la
     fused = _run(fv, case, True, [(dt, nsteps, 1e-11)])
     plain = _run(fv, case, False, [(dt, nsteps, 1e-11)])
     assert fused[3] == 4 and plain[3] == 4  # the tiled symmetric form serves the operator
-    assert fused[2][0] >= nsteps - 4 and fused[2][1] == 73 and plain[2][0] == 0  # the fused launches ran (all but the run's first steps)
+    assert fused[2][0] >= nsteps - 4 and fused[2][1] == (81 if lateral else 73) and plain[2][0] == 0  # the fused launches ran (all but the run's first steps)
     assert np.array_equal(fused[1], plain[1]) and (fused[1][2:] == 1).all()
     assert relerr(fused[0], plain[0]) < 1e-12
     # the oracle: the same steps, its CG run to 1e-14
@@ -128,7 +128,7 @@ def test_fused_runs_in_chunks_and_burst_lengths(fv):
         assert relerr(cut[0], whole[0]) < 1e-12
     assert relerr(whole[0], plain[0]) < 1e-12
     # launch parameters that change the traversal, not the result
-    for tune in (((42, 1),), ((43, 1),), ((43, 5),)):
+    for tune in (((44, 8),), ((44, 8), (42, 1)), ((43, 1),), ((43, 5),), ((45, 7),)):
         other = _run(fv, case, True, [(dt, 40, rtol)], tune=tune)
         assert np.array_equal(other[1], whole[1]) and relerr(other[0], whole[0]) < 1e-12
 

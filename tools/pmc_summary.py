@@ -13,7 +13,7 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
         k = r["Kernel_Name"]
         if flt not in k:
             continue
-        agg[k.split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        agg[k.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         for c, vals in v.items():
             print("%-50s %-30s n=%3d mean=%.6g" % (k[:50], c, len(vals), sum(vals) / len(vals)))
