@@ -170,14 +170,14 @@ def other_baseline_configs(fv, ctx):
     # (reverse Cuthill-McKee inside the library, invisible at the ABI).  Second row: the same with that switched off.
     w = workloads.fractures_like(20, 500, seed=0)
     for label, mode in (("as numbered; fv_problem_create re-numbers the free cells for locality inside the library", 1),
-                        ("as numbered, the library's re-numbering switched off (fv_tune(31, 0))", 0)):
-        fv.load().fv_tune(31, mode)
+                        ("as numbered, the library's re-numbering switched off (fv_ctx_set_option(FV_OPT_REORDER, 0))", 0)):
+        ctx.set_option(1, mode)  # FV_OPT_REORDER
         try:
             t0 = time.perf_counter()
             p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], w["N"], w["dnodes"], ctx)
             t_create = time.perf_counter() - t0
         finally:
-            fv.load().fv_tune(31, 1)
+            ctx.set_option(1, 1)
         info = p.reorder_info()
         p.assemble(w["K"], np.zeros(w["N"]), w["dheads"])
         st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
@@ -297,10 +297,7 @@ def main():
     from __graft_entry__ import load_package
 
     fv = load_package()
-    for kv in os.environ.get("FV_TUNE", "").split(","):  # A/B knobs of libfvhip (fv_tune), e.g. FV_TUNE=5=0,6=0
-        if "=" in kv:
-            k, v = kv.split("=")
-            fv.load().fv_tune(int(k), int(v))
+    # (A/B knobs of libfvhip: FV_TUNE=key=value,... in the environment, read by the library itself — csrc/fv_tune.h)
     if world > 1 or os.environ.get("FV_BENCH_FORCE_DIST") == "1":  # the env var rehearses the multi-GPU driver with one rank
         from bench_dist import run_distributed
 

@@ -53,8 +53,14 @@ _i64p = C.c_void_p  # arrays are passed as raw addresses (host or device)
 _f64p = C.c_void_p
 
 # name -> (restype, argtypes): every symbol include/fvhip.h declares
+ABI_VERSION = 2  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
+FV_OPT_REORDER = 1
+# the experimenter's panel (finitevolume.jl_amd/csrc/fv_tune.h): exported, but not part of include/fvhip.h
+PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int])}
 SIGNATURES = {
     "fv_abi_version": (C.c_int, []),
+    "fv_ctx_set_option": (C.c_int, [c_ctx, C.c_int, C.c_int]),
+    "fv_ctx_get_option": (C.c_int, [c_ctx, C.c_int, P(C.c_int)]),
     "fv_ctx_create": (C.c_int, [C.c_int, P(c_ctx)]),
     "fv_ctx_destroy": (None, [c_ctx]),
     "fv_ctx_synchronize": (C.c_int, [c_ctx]),
@@ -92,7 +98,6 @@ SIGNATURES = {
     "fv_spmv": (C.c_int, [c_prob, _f64p, C.c_double, _f64p]),
     "fv_bench_spmv": (C.c_int, [c_prob, C.c_double, C.c_int32, P(C.c_double)]),
     "fv_dot": (C.c_int, [c_prob, _f64p, _f64p, P(C.c_double)]),
-    "fv_tune": (C.c_int, [C.c_int, C.c_int]),
     "fv_device_mem_info": (C.c_int, [c_ctx, P(C.c_int64), P(C.c_int64)]),
     "fv_precond_set": (C.c_int, [c_prob, C.c_int]),
     "fv_amg_configure": (C.c_int, [C.c_double, C.c_double, C.c_int, C.c_int]),
@@ -140,10 +145,13 @@ def load():
             "`make -C finitevolume.jl_amd/csrc`. There is no CPU fallback." % LIBPATH
         )
     lib = C.CDLL(LIBPATH)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(PRIVATE_SIGNATURES.items()):
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    have = lib.fv_abi_version()
+    if have != ABI_VERSION:  # a stale libfvhip.so (or a newer one): the signatures above would not match
+        raise ImportError("libfvhip.so speaks ABI version %d, this binding expects %d: rebuild it (make -C finitevolume.jl_amd/csrc)" % (have, ABI_VERSION))
     _lib = lib
     return lib
 
@@ -189,6 +197,15 @@ class Context:
 
     def synchronize(self):
         self.check(load().fv_ctx_synchronize(self.handle))
+
+    def set_option(self, option, value):
+        """fv_ctx_set_option: per-context options (FV_OPT_REORDER: 0 never / 1 auto / 2 always re-number face-list meshes)."""
+        self.check(load().fv_ctx_set_option(self.handle, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int()
+        self.check(load().fv_ctx_get_option(self.handle, int(option), C.byref(v)))
+        return v.value
 
     def mem_info(self):
         """(free, total) bytes of the device."""

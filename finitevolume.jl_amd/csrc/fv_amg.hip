@@ -1069,6 +1069,8 @@ extern "C" int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, d
     }
     FV_TRY(fv_pcg_prepare(p));
     FV_TRY(fv_free_in(p, p->tmp.p, r_free));
+    if (p->nhalo > 0) // a row block: the cycle's level-0 products read the iterate's halo slots, which must hold zeros (block-Jacobi)
+        FV_HIP(ctx, hipMemsetAsync(p->rhs.p + p->n, 0, (size_t)p->nhalo * sizeof(double), ctx->stream));
     FV_TRY(fv_amg_apply_device(p, p->tmp.p, p->rhs.p, sigma));
     return fv_free_out(p, z_free, p->rhs.p);
 }

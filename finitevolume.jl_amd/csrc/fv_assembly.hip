@@ -171,7 +171,8 @@ static int fv_reorder_free(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
     const int64_t n = p->n, F = p->F, N = p->N;
-    if (g_reorder == 0 || n < 2 || F < 1 || (g_reorder == 1 && n < 65536))
+    const int mode = ctx->opt_reorder >= 0 ? ctx->opt_reorder : g_reorder; // FV_OPT_REORDER of the context, else the process default
+    if (mode == 0 || n < 2 || F < 1 || (mode == 1 && n < 65536))
         return FV_OK;
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<int32_t> a((size_t)F), b((size_t)F), map((size_t)N);
@@ -192,13 +193,13 @@ static int fv_reorder_free(fv_problem *p)
     if (m == 0)
         return FV_OK;
     p->reorder_mean_before = sum / (double)m;
-    if (g_reorder == 1 && p->reorder_mean_before <= 2.0 * pow((double)n, 2.0 / 3.0))
+    if (mode == 1 && p->reorder_mean_before <= 2.0 * pow((double)n, 2.0 / 3.0))
         return FV_OK; // numbered like a grid (or better): nothing to gain
     std::vector<int32_t> perm((size_t)n);
     double before = 0.0, after = 0.0;
     FV_TRY(fv_host_locality_order(n, m, a.data(), b.data(), perm.data(), &before, &after));
     p->reorder_mean_after = after;
-    if (g_reorder == 1 && after * 2.0 >= before)
+    if (mode == 1 && after * 2.0 >= before)
         return FV_OK;
     FV_TRY(p->perm.alloc(ctx, (size_t)n));
     FV_TRY(p->iperm.alloc(ctx, (size_t)n));
@@ -818,8 +819,11 @@ extern "C" int fv_problem_free_rows_before(fv_problem *p, int64_t node, int64_t 
         const int64_t m = p->N - at < (int64_t)chunk.size() ? p->N - at : (int64_t)chunk.size();
         FV_HIP(ctx, hipMemcpy(chunk.data(), p->nodemap.p + at, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < m; k++)
-            if (chunk[(size_t)k] >= 0) { // the first free cell at or after `node`: its free index is the answer
-                *rows = chunk[(size_t)k];
+            if (chunk[(size_t)k] >= 0) { // the first free cell at or after `node`: its (canonical) free index is the answer
+                int32_t idx = chunk[(size_t)k];
+                if (p->reordered) // nodemap holds the internal index: callers only ever see the rank among the free nodes
+                    FV_HIP(ctx, hipMemcpy(&idx, p->iperm.p + idx, sizeof idx, hipMemcpyDeviceToHost));
+                *rows = idx;
                 return FV_OK;
             }
     }

@@ -1,6 +1,7 @@
 // Context, error reporting and the device exclusive scan used by the map and
 // CSR-pointer builders.
 #include "fv_internal.h"
+#include <cstdlib>
 
 static thread_local std::string g_err;
 
@@ -50,6 +51,31 @@ static int ctx_init(fv_ctx *ctx)
 
 extern "C" void fv_ctx_destroy(fv_ctx *ctx);
 
+extern "C" int fv_ctx_set_option(fv_ctx *ctx, int option, int value)
+{
+    if (!ctx)
+        return FV_ERR_ARG;
+    if (option == FV_OPT_REORDER && value >= 0 && value <= 2) {
+        ctx->opt_reorder = value;
+        return FV_OK;
+    }
+    fv_set_error(ctx, "fv_ctx_set_option: unknown option %d or value %d out of range", option, value);
+    return FV_ERR_ARG;
+}
+
+extern int g_reorder; // fv_assembly.hip
+extern "C" int fv_ctx_get_option(fv_ctx *ctx, int option, int *value)
+{
+    if (!ctx || !value)
+        return FV_ERR_ARG;
+    if (option == FV_OPT_REORDER) {
+        *value = ctx->opt_reorder >= 0 ? ctx->opt_reorder : g_reorder;
+        return FV_OK;
+    }
+    fv_set_error(ctx, "fv_ctx_get_option: unknown option %d", option);
+    return FV_ERR_ARG;
+}
+
 extern "C" int fv_ctx_create(int device, fv_ctx **out)
 {
     if (!out)
@@ -65,6 +91,31 @@ extern "C" int fv_ctx_create(int device, fv_ctx **out)
     if (device < 0 || device >= count) {
         fv_set_error(nullptr, "device %d out of range (have %d)", device, count);
         return FV_ERR_ARG;
+    }
+    {
+        // FV_TUNE="key=value,...": the experimenter's panel (fv_tune.h) without a call, read once per process
+        static bool env_read = false;
+        if (!env_read) {
+            env_read = true;
+            if (const char *e = getenv("FV_TUNE")) {
+                const char *s = e;
+                while (*s) {
+                    char *end = nullptr;
+                    const long k = strtol(s, &end, 10);
+                    if (end == s || *end != '=')
+                        break;
+                    s = end + 1;
+                    const long v = strtol(s, &end, 10);
+                    if (end == s)
+                        break;
+                    if (fv_tune((int)k, (int)v) != FV_OK)
+                        fprintf(stderr, "[fvhip] FV_TUNE: %ld=%ld refused\n", k, v);
+                    s = (*end == ',') ? end + 1 : end;
+                    if (*end != ',' && *end != 0)
+                        break;
+                }
+            }
+        }
     }
     fv_ctx *ctx = new fv_ctx();
     ctx->device = device;

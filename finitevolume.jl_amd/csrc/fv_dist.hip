@@ -8,7 +8,7 @@
 // columns are renumbered [local | halo] (halo = sorted remote columns) and whose
 // vectors carry nhalo extra slots.  Per SpMV a rank sends each peer the rows that
 // peer references, ascending, which is exactly the receiver's halo order.
-#include "fv_dist.h"
+#include "fv_internal.h"
 
 __global__ __launch_bounds__(FV_BLOCK) void dist_mark_remote_kernel(int64_t e0, int64_t e1, const int32_t *__restrict__ colind, int32_t lo,
                                                                      int32_t hi, int32_t *__restrict__ flag)
@@ -120,6 +120,106 @@ static int copy_slice(fv_ctx *ctx, DevBuf<double> &dst, const double *src, int64
 
 static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *bounds, fv_problem **out);
 
+// Row blocks are ranges of the CALLER's free-cell numbering (rank among the free nodes).  A problem whose free cells were
+// re-numbered for locality at creation (fv_reorder_free) keeps another numbering inside: for the time of the set-up its
+// per-row arrays are replaced by copies in the canonical order — row i = internal row perm[i], columns mapped back through
+// iperm and sorted, as fv_get_csc exports them — so a block cut from it equals the block cut from the un-numbered problem.
+__global__ __launch_bounds__(FV_BLOCK) void canon_len32_kernel(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ rowptr,
+                                                                int32_t *__restrict__ len)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        len[i] = rowptr[perm[i] + 1] - rowptr[perm[i]];
+}
+__global__ __launch_bounds__(FV_BLOCK) void canon_rows32_kernel(int64_t n, const int32_t *__restrict__ perm, const int32_t *__restrict__ iperm,
+                                                                 const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                                 const double *__restrict__ vals, const int32_t *__restrict__ start,
+                                                                 int32_t *__restrict__ colind_out, double *__restrict__ vals_out,
+                                                                 int32_t *__restrict__ diagpos_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    const int32_t r = perm[i], s0 = rowptr[r], len = rowptr[r + 1] - s0, o = start[i];
+    int32_t dp = -1;
+    for (int32_t k = 0; k < len; k++) { // insertion sort by canonical column (rows are short)
+        const int32_t c = iperm[colind[s0 + k]];
+        const double v = vals[s0 + k];
+        int32_t j = k;
+        while (j > 0 && colind_out[o + j - 1] > c) {
+            colind_out[o + j] = colind_out[o + j - 1];
+            vals_out[o + j] = vals_out[o + j - 1];
+            j--;
+        }
+        colind_out[o + j] = c;
+        vals_out[o + j] = v;
+    }
+    for (int32_t k = 0; k < len; k++)
+        if (colind_out[o + k] == (int32_t)i)
+            dp = o + k;
+    diagpos_out[i] = dp;
+}
+__global__ __launch_bounds__(FV_BLOCK) void canon_vec_kernel(int64_t n, const int32_t *__restrict__ perm, const double *__restrict__ src,
+                                                              double *__restrict__ dst)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < n)
+        dst[i] = src[perm[i]];
+}
+
+static int dist_setup_canonical(fv_problem *pg, int nranks, int rank, const int64_t *bounds, fv_problem **out)
+{
+    fv_ctx *ctx = pg->ctx;
+    const int64_t n = pg->n, nnz = pg->nnz;
+    DevBuf<int32_t> len, rowptr, colind, diagpos;
+    DevBuf<double> vals, b, diagA, D, state;
+    FV_TRY(len.alloc(ctx, (size_t)n));
+    FV_TRY(rowptr.alloc(ctx, (size_t)n + 1));
+    FV_TRY(colind.alloc(ctx, (size_t)nnz + 2));
+    FV_TRY(colind.zero(ctx));
+    FV_TRY(vals.alloc(ctx, (size_t)nnz + 2));
+    FV_TRY(vals.zero(ctx));
+    FV_TRY(diagpos.alloc(ctx, (size_t)n));
+    hipLaunchKernelGGL(canon_len32_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)pg->perm.p, (const int32_t *)pg->rowptr.p, len.p);
+    FV_LAUNCH_CHECK(ctx);
+    int64_t total = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, len.p, rowptr.p, n, &total));
+    if (total != nnz) {
+        fv_set_error(ctx, "internal: canonical view has %lld of %lld entries", (long long)total, (long long)nnz);
+        return FV_ERR_STATE;
+    }
+    hipLaunchKernelGGL(canon_rows32_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)pg->perm.p, (const int32_t *)pg->iperm.p,
+                       (const int32_t *)pg->rowptr.p, (const int32_t *)pg->colind.p, (const double *)pg->vals.p, (const int32_t *)rowptr.p, colind.p, vals.p,
+                       diagpos.p);
+    FV_LAUNCH_CHECK(ctx);
+    const size_t vn = (size_t)n + FV_VEC_PAD;
+    for (auto pr : {std::make_pair(&b, pg->b.p), std::make_pair(&diagA, pg->diagA.p), std::make_pair(&D, pg->D.p), std::make_pair(&state, pg->slots[0])}) {
+        FV_TRY(pr.first->alloc(ctx, vn));
+        FV_TRY(pr.first->zero(ctx));
+        hipLaunchKernelGGL(canon_vec_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const int32_t *)pg->perm.p, (const double *)pr.second,
+                           pr.first->p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto exchange = [&]() {
+        pg->rowptr.swap(rowptr);
+        pg->colind.swap(colind);
+        pg->vals.swap(vals);
+        pg->diagpos.swap(diagpos);
+        pg->b.swap(b);
+        pg->diagA.swap(diagA);
+        pg->D.swap(D);
+        std::swap(pg->slots[0], state.p);
+    };
+    exchange();
+    pg->reordered = false;
+    const int rc = dist_setup_impl(pg, nranks, rank, bounds, out);
+    pg->reordered = true;
+    exchange();
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
 extern "C" int fv_dist_setup(fv_problem *pg, int nranks, int rank, fv_problem **out)
 {
     return dist_setup_impl(pg, nranks, rank, nullptr, out);
@@ -150,11 +250,8 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
         fv_set_error(ctx, "fv_dist_setup: problem is already a row block");
         return FV_ERR_STATE;
     }
-    if (pg->reordered) { // row ranges are ranges of the caller's free-cell numbering; a re-numbered problem has another one inside
-        fv_set_error(ctx, "fv_dist_setup: the problem's free cells were re-numbered for locality at creation; create it with fv_tune(31, 0) "
-                          "to cut row blocks in the caller's numbering");
-        return FV_ERR_STATE;
-    }
+    if (pg->reordered) // row ranges are ranges of the caller's free-cell numbering: cut the block from a canonical view
+        return dist_setup_canonical(pg, nranks, rank, bounds, out);
     const int64_t n = pg->n;
     fv_dist *d = new fv_dist();
     d->nranks = nranks;

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "fvhip.h"
+#include "fv_tune.h"
 
 constexpr int FV_BLOCK = 256;        // 4 waves of 64
 constexpr int FV_MAX_PARTIALS = 2048; // 8 blocks/CU x 256 CUs: one partial per block (SpMV kernels: all blocks resident)
@@ -38,6 +39,7 @@ struct fv_ctx {
     int local_group_id = 0;
     int nranks = 1, rank = 0;
     int64_t n_allreduce = 0, n_halo = 0; // collectives issued through this context (fv_comm_stats)
+    int opt_reorder = -1; // FV_OPT_REORDER of this context; -1: the process-wide default (fv_tune key 31)
 };
 
 void fv_set_error(fv_ctx *ctx, const char *fmt, ...);

@@ -114,11 +114,15 @@ def partial_problem(neighbors, areasoverlengths, N, dirichletnodes, nranks, rank
 
     sel, bounds = rank_faces(neighbors, N, dirichletnodes, nranks, rank, bounds)
     n1, n2 = _split_neighbors(neighbors)
-    load().fv_tune(31, 0)  # row blocks are ranges of the caller's free-cell numbering: no locality re-numbering inside
+    from ._lib import default_context
+
+    ctx = ctx or default_context()
+    before = ctx.get_option(_lib.FV_OPT_REORDER)
+    ctx.set_option(_lib.FV_OPT_REORDER, 0)  # a partial operator: a re-numbering computed from a rank's own faces would only cost time
     try:
         p = Problem.create(_np.stack([n1[sel], n2[sel]], axis=1), _np.asarray(areasoverlengths, dtype=_np.float64)[sel], N, dirichletnodes, ctx)
     finally:
-        load().fv_tune(31, 1)
+        ctx.set_option(_lib.FV_OPT_REORDER, before)
     return p, bounds, sel
 
 

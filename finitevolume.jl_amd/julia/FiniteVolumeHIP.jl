@@ -19,6 +19,11 @@ import LinearAlgebra
 import SparseArrays
 
 const libfvhip = get(ENV, "FVHIP_LIB", joinpath(@__DIR__, "..", "libfvhip.so"))
+const FVHIP_ABI_VERSION = 2   # of include/fvhip.h this shim was written against
+function __init__()
+	have = ccall((:fv_abi_version, libfvhip), Cint, ())
+	have == FVHIP_ABI_VERSION || error("libfvhip.so speaks ABI version $have, FiniteVolumeHIP.jl expects $FVHIP_ABI_VERSION: rebuild it (make -C finitevolume.jl_amd/csrc)")
+end
 
 struct SolveInfo            # fv_solve_info
 	converged::Int32
@@ -410,14 +415,16 @@ function backwardeulerintegrate(u0, A, getb::Function, dt0, t0, tfinal; stepper!
 		first = Float64[u0...]
 		rhs = similar(first)
 	end
-	us = Any[first]
-	ts = [t0]
-	dt = min(dt0, tfinal - t0)
-	while ts[end] < tfinal
-		solution, laststeptime, increasestepsize = stepper!(rhs, A, getb, us[end], ts[end], dt, linearsolver, atol, callback)
-		push!(us, solution)
-		push!(ts, ts[end] + dt)
-		dt = increasestepsize ? min(tfinal - ts[end], 2 * laststeptime) : min(tfinal - ts[end], laststeptime)
+	# the outer loop of transient.jl:141-152: the recorded time advances by the REQUESTED step (also when the stepper
+	# sub-stepped); the next request is what the stepper reports it took, doubled if it asks for it, clipped to tfinal
+	us, ts = Any[first], [t0]
+	now, request = t0, min(dt0, tfinal - t0)
+	while now < tfinal
+		state, taken, grow = stepper!(rhs, A, getb, us[end], now, request, linearsolver, atol, callback)
+		now += request
+		push!(us, state)
+		push!(ts, now)
+		request = min(tfinal - now, (grow ? 2 : 1) * taken)
 	end
 	if device && history == :host
 		result = map(freevalues, us)
@@ -587,13 +594,13 @@ function getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss::Number, v
 		uo, ue = uobs(t), u(t)
 		return sum(sigma(i, t)^2 * (ue[freenodei2nodei[i]] - uo[freenodei2nodei[i]])^2 for i in obsfreenodes)
 	end
-	function dgdu(u, t)
-		uo, ue = uobs(t), u(t)
-		result = zeros(nfree)
-		for i in obsfreenodes
-			result[i] = 2 * sigma(i, t)^2 * (ue[freenodei2nodei[i]] - uo[freenodei2nodei[i]])
-		end
-		return result
+	obsnodes = [freenodei2nodei[i] for i in obsfreenodes]   # the observed free unknowns as node indices
+	function dgdu(u, t)   # transientadjointutils.jl:13-21: d/du of the weighted misfit, non-zero on the observed unknowns only
+		misfit = u(t)[obsnodes] .- uobs(t)[obsnodes]
+		weights = [sigma(i, t)^2 for i in obsfreenodes]
+		gradient = zeros(nfree)
+		gradient[obsfreenodes] .= 2 .* weights .* misfit
+		return gradient
 	end
 	splitp(p) = (p[1:nK], p[nK + 1:nK + N], p[nK + N + 1:nK + N + nd])
 	function dfdp(u, t, p)

@@ -198,17 +198,15 @@ def _integrate_generic(u0, A, b_or_getb, dt0, t0, tfinal, stepper=adaptivebackwa
             first = A.problem.new_state().set_free(af64(u0))
         rhs = None
         us = [first]
-    ts = [t0]
-    dt = min(dt0, tfinal - t0)
-    while ts[-1] < tfinal:
-        solution, laststeptime, increasestepsize = stepper(rhs, A, getb, us[-1], ts[-1], dt, linearsolver, atol, callback)
-        us.append(solution)
-        ts.append(ts[-1] + dt)
-        if increasestepsize:
-            newdt = min(tfinal - ts[-1], 2 * laststeptime)
-        else:
-            newdt = min(tfinal - ts[-1], laststeptime)
-        dt = newdt
+    # the outer loop of transient.jl:141-152: the recorded time advances by the REQUESTED step (also when the stepper
+    # sub-stepped), the next request is what the stepper reports it took — doubled if it asks for it — clipped to tfinal
+    now, request, ts = t0, min(dt0, tfinal - t0), [t0]
+    while now < tfinal:
+        state, taken, grow = stepper(rhs, A, getb, us[-1], now, request, linearsolver, atol, callback)
+        now += request
+        us.append(state)
+        ts.append(now)
+        request = min(tfinal - now, (2 if grow else 1) * taken)
     if not host_path and _history == "host":
         us = [u.free_values() for u in us]
     return us, ts

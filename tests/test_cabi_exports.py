@@ -26,7 +26,11 @@ def test_every_declared_symbol_is_exported_and_bound(fv):
         assert hasattr(lib, name), "libfvhip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "python binding lacks %s" % name
     assert set(_lib.SIGNATURES) == set(declared)
-    assert fv.load().fv_abi_version() == 1
+    assert fv.load().fv_abi_version() == _lib.ABI_VERSION == 2
+    hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
+    assert "#define FVHIP_ABI_VERSION 2" in hdr
+    # the experimenter's panel is exported for the tools, but it is not part of the public header
+    assert "fv_tune" not in declared and hasattr(lib, "fv_tune") and set(_lib.PRIVATE_SIGNATURES) == {"fv_tune"}
 
 
 def test_product_never_imports_the_oracle():
@@ -134,3 +138,20 @@ def test_julia_shim_defines_the_reference_call_surface_with_its_positional_ariti
         assert got == lead, (name, got)
     for kw in ("stepper!", "linearsolver", "atol", "callback", "dt0", "keep"):
         assert re.search(r"[;,]\s*[^)]*\b" + re.escape(kw) + r"\s*=", src), "keyword %s missing" % kw
+
+
+def test_julia_package_wrapper_has_the_reference_name_and_uuid():
+    """`import FiniteVolume` in the reference's tests and examples must resolve to the shim without an edited line: a package
+    directory with the reference's name and UUID (tests/golden/reference_api.json records them) whose module includes the shim
+    and binds its names."""
+    import json
+
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_api.json")))
+    pkg = os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolume")
+    toml = open(os.path.join(pkg, "Project.toml")).read()
+    assert 'name = "FiniteVolume"' in toml and ('uuid = "%s"' % api["_package"]["uuid"]) in toml
+    src = open(os.path.join(pkg, "src", "FiniteVolume.jl")).read()
+    assert re.search(r"^module FiniteVolume\s*$", src, flags=re.M) and "FiniteVolumeHIP.jl" in src and "@eval const $name = FiniteVolumeHIP.$name" in src
+    assert os.path.exists(os.path.normpath(os.path.join(pkg, "src", "..", "..", "FiniteVolumeHIP.jl")))
+    shim = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
+    assert "FVHIP_ABI_VERSION = 2" in shim and ":fv_abi_version" in shim

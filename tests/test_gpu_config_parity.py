@@ -1,0 +1,150 @@
+"""GPU parity with the CPU oracle AT the sizes BASELINE.json names: heads of the HIP path against the
+oracle's own solves of the same inputs, <= 1e-8 relative (north_star's bar), for configs[2] (216^3 transient: 5 steps at
+dt = 60 s, 3 at dt = 3600 s), configs[1] (256^3 steady, homogeneous and a sigma = 1 field) and configs[3] (5M-cell irregular
+mesh, 3 transient steps).  The oracle follows /root/reference/src/FiniteVolume.jl:75-139 (assembleA / assembleb),
+src/transient.jl:7-22,60-76,130-174 (scalebyvolume!, backwardeuleronestep!, fixedbackwardeulerstep!, backwardeulerintegrate)
+with IterativeSolvers' cg at 1e-13 .. 1e-14 as the linear solver.
+
+Transient steps: the oracle integrates from the same u0, every step its own CG solve from the previous state — an
+independent run.  Steady 256^3: a cold CG of 1.7e7 unknowns on one host core takes tens of minutes, so the oracle's CG is
+started FROM the device's heads and run to its own tolerance: if the reference algorithm, given those heads, moves them by
+less than 1e-8 before it declares convergence at 1e-13, the heads are its solution to that accuracy; the oracle's
+independently assembled system also confirms the residual."""
+import time
+
+import numpy as np
+import pytest
+
+import bench
+from tests import workloads
+
+pytestmark = pytest.mark.gpu
+HEAD_RTOL = 1e-8
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+def _oracle_transient(o, n1, n2, aol, vol, K, src, dn, dh, Ss, u0, schedule, tol=1e-13, logk=False):
+    """The reference's fixed-dt integration on the oracle; schedule = [(dt, steps), ...]; returns the final heads (all nodes)."""
+    freenode, n2f = o.getfreenodes(len(vol), dn)
+    f2n = o.freenodei2nodei(n2f)
+    A = o.assembleA(n1, n2, aol, K, src, dn, dh, None, logk)
+    b = o.assembleb(n1, n2, aol, K, src, dn, dh, None, logk)
+    o.scalebyvolume_A(A, Ss * vol, f2n)
+    b = o.scalebyvolume_b(b, Ss * vol, f2n)
+    u = np.ascontiguousarray(u0[freenode])
+    iters = []
+
+    def solver(Am, rhs, x0):
+        x, ch = o.cg(Am, rhs, x0=x0, tol=tol, maxiter=20000)
+        assert ch.isconverged
+        iters.append(ch.iters)
+        return x
+
+    t = 0.0
+    for dt, steps in schedule:
+        us, ts = o.backwardeulerintegrate_generic(u, A, b, dt, t, t + dt * steps, stepper=o.fixedbackwardeulerstep, linearsolver=solver)
+        assert len(us) == steps + 1
+        u, t = us[-1], ts[-1]
+    head, _, _ = o.freenodes2nodes(u, src, dn, dh)
+    return head, iters
+
+
+def test_watertable_like_216_cubed_heads_vs_oracle(fv, oracle):
+    """configs[2] at full size: 5 steps of dt = 60 s (one PCG iteration each: the fused step) and 3 of dt = 3600 s (several)."""
+    o = oracle
+    ns = [216, 216, 216]
+    mins, maxs = [0.0, 0.0, 0.0], [1000.0, 1000.0, 100.0]
+    dn, src = bench.box_setup(ns)
+    dh = np.full(len(dn), 1e3)
+    t0 = time.perf_counter()
+    _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
+    u0 = np.full(len(vol), 1e3)
+    sched = [(60.0, 5), (3600.0, 3)]
+    ohead, oit = _oracle_transient(o, n1, n2, aol, vol, np.full(len(aol), 1e-5), src, dn, dh, 0.1, u0, sched, tol=1e-14)
+    t_oracle = time.perf_counter() - t0
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    p.assemble(np.array([1e-5]), src, dh)
+    st = p.transient_begin(0.1, None, u0)
+    its = []
+    for dt, steps in sched:
+        it, info, _ = p.run_fixed(st, dt, steps, rtol=1e-13, maxiter=5000)
+        assert info.converged
+        its.append(it.copy())
+    head = st.node_values()
+    draw, odraw = 1e3 - head, 1e3 - ohead
+    print("216^3: oracle %.1f s (CG iterations %s), device PCG iterations %s, drawdown max %.3e, heads rel %.2e, drawdown rel %.2e" %
+          (t_oracle, oit, [i.tolist() for i in its], odraw.max(), relerr(head, ohead), relerr(draw, odraw)))
+    assert relerr(head, ohead) < HEAD_RTOL
+    assert odraw.max() > 1e-4 and relerr(draw, odraw) < 1e-6  # ... and the drawdown itself, not only the 1e3 level of the heads
+    p.close()
+
+
+@pytest.mark.parametrize("sigma", [0.0, 1.0])
+def test_box_model_256_cubed_steady_heads_vs_oracle(fv, oracle, sigma):
+    """configs[1] at full size: one steady solve, homogeneous and with a sigma = 1 log-conductivity field."""
+    o = oracle
+    ns = [256, 256, 256]
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    dn, dh = workloads.box_model_dirichlet(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    src = np.zeros(p.N)
+    t0 = time.perf_counter()
+    _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
+    if sigma == 0.0:
+        Kf, logk = np.full(len(aol), 1e-5), False
+        p.assemble(np.array([1e-5]), src, dh)
+    else:
+        node_logk = np.log(1e-5) + sigma * workloads.smooth_gaussian_field(ns, seed=0)
+        Kf, logk = o.nodehycos2neighborhycos(n1, n2, node_logk, True), True
+        p.assemble(fv.nodehycos2neighborhycos((n1, n2), node_logk, True), src, dh, None, True)
+    A = o.assembleA(n1, n2, aol, Kf, src, dn, dh, None, logk)
+    b = o.assembleb(n1, n2, aol, Kf, src, dn, dh, None, logk)
+    del n1, n2
+    t_asm = time.perf_counter() - t0
+    p.set_preconditioner("amg")
+    head, res, ch = p.solve_steady(None, 1e-13, 2000, want_resnorm=False)
+    assert ch.isconverged
+    # the oracle's own system: residual of the device's free-cell solution, then the reference's CG from there to 1e-13
+    r = b - A.matvec(res)
+    t1 = time.perf_counter()
+    x, och = o.cg(A, b, x0=res, tol=1e-13, maxiter=60)
+    t_cg = time.perf_counter() - t1
+    moved = relerr(x, res)
+    print("256^3 sigma=%g: device AMG-PCG %d iterations; oracle assembly %.1f s, residual of the device heads in the oracle's system %.2e, "
+          "oracle CG from them: %d iterations to 1e-13 (%.1f s), heads moved by %.2e relative" %
+          (sigma, ch.iters, t_asm, np.linalg.norm(r) / np.linalg.norm(b), och.iters, t_cg, moved))
+    assert np.linalg.norm(r) / np.linalg.norm(b) < 1e-11
+    assert och.isconverged and moved < HEAD_RTOL
+    ohead, _, _ = o.freenodes2nodes(x, src, dn, dh)
+    assert relerr(head, ohead) < HEAD_RTOL
+    if sigma == 0.0:  # and the closed form: the discrete solution is linear in x
+        xs = np.repeat(np.linspace(mins[0], maxs[0], ns[0]), ns[1] * ns[2])
+        assert np.abs(ohead - (1.0 - (xs - mins[0]) / (maxs[0] - mins[0]))).max() < 1e-8
+    p.close()
+
+
+def test_fractures_like_5M_transient_heads_vs_oracle(fv, oracle):
+    """configs[3] at full size: the 5M-cell irregular mesh as numbered (the library re-numbers it inside), 3 implicit steps."""
+    o = oracle
+    w = workloads.fractures_like(20, 500, seed=0)
+    N = w["N"]
+    src = np.zeros(N)
+    u0 = np.full(N, 1.5e6)
+    t0 = time.perf_counter()
+    ohead, oit = _oracle_transient(o, w["node1"], w["node2"], w["aol"], w["volumes"], w["K"], src, w["dnodes"], w["dheads"], 1e-9, u0, [(1.0, 3)], tol=1e-13)
+    t_oracle = time.perf_counter() - t0
+    p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], N, w["dnodes"])
+    p.assemble(w["K"], src, w["dheads"])
+    st = p.transient_begin(1e-9, w["volumes"], u0)
+    it, info, _ = p.run_fixed(st, 1.0, 3, rtol=1e-13, maxiter=5000)
+    assert info.converged
+    head = st.node_values()
+    change, ochange = head - u0, ohead - u0
+    print("fractures-like 5M: oracle %.1f s (CG iterations %s), device PCG iterations %s, re-numbered %s, heads rel %.2e, change rel %.2e (max |change| %.3e)" %
+          (t_oracle, oit, it.tolist(), p.reorder_info()["reordered"], relerr(head, ohead), relerr(change, ochange), np.abs(ochange).max()))
+    assert relerr(head, ohead) < HEAD_RTOL
+    assert relerr(change, ochange) < 1e-6
+    p.close()

@@ -5,6 +5,8 @@ oracle's, every free-indexed vector in the caller's numbering, heads as before â
 import math
 import os
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -96,10 +98,28 @@ def test_the_numbering_really_changed_and_vectors_cross_in_the_callers_order(fv,
     ib, _, _ = q.run_fixed(sq, 50.0, 12, 1e-13, 5000)
     ha, hb = st.node_values(), sq.node_values()
     assert np.abs(ha - hb).max() <= 1e-9 * np.abs(hb).max()
-    with pytest.raises(fv.FVError, match="re-numbered for locality"):
-        from fvamd import dist
+    # row blocks are ranges of the CALLER's numbering: cut from the re-numbered problem (through a canonical view of its
+    # rows, fv_dist_setup) they are the blocks of the un-numbered one â€” plan, block products with injected halos, state
+    from fvamd import dist
 
-        dist.RowBlock(p, 2, 0)
+    for nranks in (2, 3):
+        for rank in range(nranks):
+            ba, bb = dist.RowBlock(p, nranks, rank), dist.RowBlock(q, nranks, rank)
+            pa, pb = ba.plan(), bb.plan()
+            assert (ba.lo, ba.hi, ba.nnz, ba.nhalo, ba.nsend) == (bb.lo, bb.hi, bb.nnz, bb.nhalo, bb.nsend)
+            for key in pa:
+                assert np.array_equal(pa[key], pb[key]), key
+            xl, hl = rng.standard_normal(ba.nloc), rng.standard_normal(ba.nhalo)
+            assert np.array_equal(ba.spmv_halo(xl, hl, 0.02), bb.spmv_halo(xl, hl, 0.02))
+            assert np.abs(ba.state() - bb.state()).max() <= 1e-9 * np.abs(bb.state()).max()  # (the two 12-step runs above)
+            ba.close()
+            bb.close()
+    # ... and the first free row at or after a node is a rank among the free nodes whatever the numbering inside
+    for node in (0, 1, 17, 1000, 2105, 2106):
+        ra, rb = C.c_int64(), C.c_int64()
+        p.check(forced.fv_problem_free_rows_before(p.handle, node, C.byref(ra)))
+        q.check(forced.fv_problem_free_rows_before(q.handle, node, C.byref(rb)))
+        assert ra.value == rb.value == int(ofree[:node].sum())
 
 
 def test_fractures_like_mesh_is_renumbered_by_the_library_and_runs_faster(fv):
