@@ -21,5 +21,7 @@ int fv_fused_enter(fv_problem *p, double sigma);
 int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
                   bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums);
 // fv_spmv.hip: y = A x (values with the shift folded in) over the slices the symmetric form leaves to the slice-by-slice
-// kernel, partial x.y per block; no done-flag check
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts);
+// kernel, partial x.y per block; use_done: a no-op once the solve's done flag is set
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done = false);
+bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded);
+int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq);

@@ -34,6 +34,7 @@
 int g_fused = 1;       // fv_tune key 41: 0 = never use the fused step
 int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for (8-line tiles)
 int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per tile, 0 = chosen to fill whole rounds
+int g_fused_iter = 1;   // fv_tune key 46: the many-iteration loop through the fused kernel too (direction update + product in one pass, z kept instead of r)
 int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
 int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
                         // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
@@ -65,6 +66,8 @@ struct KfArgs {
     int chain_index; // index of this step in its burst
     int force_prev_unconverged;
     double rtol;
+    double *hist;     // MODE 1: residual history (may be null) and its capacity; chain_index = the iteration the vector pass finished
+    int64_t hist_cap;
     // fall-back of the previous step (mode 1): see pcg_chain_boundary_kernel
     int64_t n;
     double *r, *pold;
@@ -111,7 +114,11 @@ __device__ __forceinline__ VRow vrow(double xin, double z, double v, double d, d
     return o;
 }
 
-template <int TL>
+// MODE 0: the fused step.  MODE 1: one pass of the many-iteration regime — the direction update of PCG iteration `it` and its
+// product: p' = z + beta p (z = M^-1 r, kept instead of r between the passes), q = (A + sigma D) p', partial p'.q; the scalar
+// work of K3 (beta, the convergence verdict, the residual history) in the prologue.  Same traversal, same halo trick (a halo
+// row is z + beta p: two streams, one FMA); no x, no storage term, no vector sums.  a.z = z, a.v = p (old), a.znext = p', a.vnext = q.
+template <int TL, int MODE>
 __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
 {
     constexpr int TW = KF_TW, NT = TL * TW / 2, HC = TW / 2;
@@ -127,6 +134,28 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     PcgScalars *scal = a.scal;
     // ---------------------------------------------------------------- scalars: every block takes the same decisions from
     // values no block of this launch writes (the partial sums of the previous launch, scal fields written by earlier ones)
+    double alpha = 0.0;
+    if (MODE == 1) {
+        if (*reinterpret_cast<volatile int32_t *>(&scal->done))
+            return;
+        // K3's scalars (pcg_pupdate_kernel): beta from the sums the vector pass left, the verdict on the iteration that pass finished
+        const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
+        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
+        const bool converged = rrn <= scal->tol2;
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->rz[(a.chain_index + 1) & 1] = rzn;
+            scal->rr = rrn;
+            scal->iters = a.chain_index + 1;
+            if (a.hist && a.chain_index < a.hist_cap)
+                a.hist[a.chain_index] = sqrt(rrn);
+            if (converged)
+                scal->done = 1;
+        }
+        if (converged)
+            return;
+        alpha = rzn / scal->rz[a.chain_index & 1]; // (beta: it plays alpha's part in z + alpha v)
+    }
+    if (MODE == 0) {
     const int d0 = *reinterpret_cast<volatile int32_t *>(&scal->done);
     if (d0 == 2)
         return;
@@ -197,7 +226,6 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         rz0 = scal->rz[0];
         zero_iteration = d0 == 1; // converged at its set-up (pcg_init_finalize_kernel said so)
     }
-    double alpha = 0.0;
     if (!zero_iteration) {
         const double pq = kf_reduce<NT>(a.in.pq, a.in.npq, red);
         if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
@@ -212,6 +240,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             scal->pq = pq;
     } else if (blockIdx.x == 0 && tid == 0)
         scal->zero_mask |= 1u << a.chain_index; // the step counts 0 iterations: alpha = 0 hands the state over unchanged
+    }
     // ---------------------------------------------------------------- the pass
     if (tid < FV_STORAGE_CODES)
         tab[tid] = a.sD.v[tid];
@@ -305,7 +334,9 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         {
             const double2 vv = P2(a.v, p0 - 1), zz = P2(a.z, p0 - 1);
             Zm = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
-            if (vec_first && own) { // plane 0: its vector part
+            if (MODE == 1 && vec_first && own)
+                ST2(a.znext, 0, Zm);
+            if (MODE == 0 && vec_first && own) { // plane 0: its vector part
                 const double2 xi = P2(a.x, 0), dd = P2(a.dg, 0), ss = SD(C2(0));
                 const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
                 ST2(a.xout, 0, make_double2(ra.xn, rb.xn));
@@ -319,14 +350,16 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         }
         double2 Zc0;
         {
-            const double2 xi = P2(a.x, p0), vv = P2(a.v, p0), zz = P2(a.z, p0), dd = P2(a.dg, p0);
+            const double2 xi = MODE == 0 ? P2(a.x, p0) : make_double2(0.0, 0.0), vv = P2(a.v, p0), zz = P2(a.z, p0), dd = P2(a.dg, p0);
             // (the stored diagonal: bit for bit the derived one where bit 1 of the flag is set, symdia_rowsum_kernel)
             Cc = C2(p0);
             const double2 ss = SD(Cc);
             const VRow ra = vrow(xi.x, zz.x, vv.x, own ? dd.x : 1.0, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, own ? dd.y : 1.0, ss.y, alpha);
             Zc0 = make_double2(ra.zn, rb.zn);
             Mc = make_double2(ra.mv, rb.mv);
-            if (own) {
+            if (MODE == 1 && own)
+                ST2(a.znext, p0, Zc0);
+            if (MODE == 0 && own) {
                 ST2(a.xout, p0, make_double2(ra.xn, rb.xn));
                 ST2(a.znext, p0, Zc0);
                 acc[0] += ra.r * (ra.mv * ra.r) + rb.r * (rb.mv * rb.r);
@@ -360,7 +393,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 (hu_is_u2 ? u2s + s1 * U2T : u1s + s1 * U1T)[hu] = ub;
             }
         }
-        double2 Xa = P2nt(a.x, p0 + 1), Va = P2nt(a.v, p0 + 1), Za = P2(a.z, p0 + 1);
+        double2 Xa = MODE == 0 ? P2nt(a.x, p0 + 1) : make_double2(0.0, 0.0), Va = P2nt(a.v, p0 + 1), Za = P2(a.z, p0 + 1);
         uint32_t Ca = C2(p0 + 1);
         int fla = own ? (int)a.ok[((int64_t)(p0 + 1) * d3 + o) >> 6] : 0;
         __syncthreads();
@@ -376,7 +409,8 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             int flb = 0;
             double hq = 0.0, hzv = 0.0, hub = 0.0;
             if (more) {
-                Xb = (a.nt & 4) ? P2(a.x, p + 2) : P2nt(a.x, p + 2);
+                if (MODE == 0)
+                    Xb = (a.nt & 4) ? P2(a.x, p + 2) : P2nt(a.x, p + 2);
                 Vb = (a.nt & 4) ? P2(a.v, p + 2) : P2nt(a.v, p + 2);
                 Zb = P2(a.z, p + 2);
                 Cb = C2(p + 2);
@@ -419,7 +453,9 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             const double2 Zn = make_double2(ua.zn, ub.zn);
             const double2 Zc = *reinterpret_cast<const double2 *>(zs + zb * ZT + zo);
             const double2 Pn = make_double2(A3c.x * Zc.x + Dn.x * Zn.x, A3c.y * Zc.y + Dn.y * Zn.y);
-            if (vec_n && own) {
+            if (MODE == 1 && vec_n && own)
+                ST2(a.znext, p + 1, Zn);
+            if (MODE == 0 && vec_n && own) {
                 double *xo = reinterpret_cast<double *>(const_cast<char *>(PB(a.xout, p + 1, 8)) + ob);
                 if (a.nt & 8)
                     *reinterpret_cast<double2 *>(xo) = make_double2(ua.xn, ub.xn);
@@ -458,7 +494,11 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 t1 += V2c.y * x2p.y;
                 t0 += A3c.x * Zn.x;
                 t1 += A3c.y * Zn.y;
-                if (flc & 1) {
+                if (MODE == 1 && (flc & 1)) {
+                    ST2nt(a.vnext, p, make_double2(t0, t1)); // q itself: the vector pass reads it once
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
+                if (MODE == 0 && (flc & 1)) {
                     const double2 Sc = SD(Cc);
                     const double2 vn = make_double2(-(Mc.x * (t0 - Sc.x * Zc.x)), -(Mc.y * (t1 - Sc.y * Zc.y)));
                     if (a.nt & 2)
@@ -504,7 +544,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     // the assembled b's share of |rhs|^2 over its support: |h + b|^2 = h.h + b (2 h + b), h = sigma D x_out, with x_out of
     // these few rows formed again from x and z
     double sgather = 0.0;
-    if (a.bm > 0) {
+    if (MODE == 0 && a.bm > 0) {
         __syncthreads();
         for (int64_t k = (int64_t)blockIdx.x * NT + tid; k < a.bm; k += (int64_t)gridDim.x * NT) {
             const int32_t i = a.bidx[k];
@@ -515,12 +555,12 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         }
     }
     const int G = (int)gridDim.x;
-    for (int k = 0; k < KF_NSUM; k++) {
+    for (int k = MODE == 1 ? KF_NSUM - 1 : 0; k < KF_NSUM; k++) {
         const double t = kf_block_sum<NT>(acc[k], red);
         if (tid == 0)
             (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
     }
-    if (a.bm > 0) {
+    if (MODE == 0 && a.bm > 0) {
         const double t = kf_block_sum<NT>(sgather, red);
         if (tid == 0)
             a.out.sbb[G + blockIdx.x] = t;
@@ -607,14 +647,11 @@ int fv_fused_enter(fv_problem *p, double sigma)
     return FV_OK;
 }
 
-// One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
-// burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
-int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
-                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
+// geometry, grid and the symmetric arrays of a launch; returns the grid size
+static int kf_setup(fv_problem *p, KfArgs &a)
 {
     fv_ctx *ctx = p->ctx;
     const int64_t nz = p->sym_d[1], d3 = p->sym_d[2];
-    KfArgs a{};
     a.nz = (int32_t)nz;
     a.d3 = (int32_t)d3;
     a.L = (int32_t)(d3 / nz);
@@ -654,6 +691,18 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     a.u2 = dg + 2 * p->sym_ld;
     a.u3 = dg + 3 * p->sym_ld;
     a.ok = p->sym_ok.p;
+    return GF;
+}
+
+// One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
+// burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
+int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
+                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
+{
+    fv_ctx *ctx = p->ctx;
+    KfArgs a{};
+    const int GF = kf_setup(p, a);
+    const int TLr = g_fused_lines == 16 ? 16 : 8;
     a.code = p->dcode_n > 1 ? p->dcode.p : nullptr;
     for (int k = 0; k < FV_STORAGE_CODES; k++)
         a.sD.v[k] = sigma * p->dtable.v[k];
@@ -686,9 +735,9 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     // (the sparse-b partials sit right behind the vector part's: sbb[GF .. 2 GF))
     a.out = out;
     if (TLr == 16)
-        hipLaunchKernelGGL(fused_step_kernel<16>, dim3(GF), dim3(1024), 0, ctx->stream, a);
+        hipLaunchKernelGGL((fused_step_kernel<16, 0>), dim3(GF), dim3(1024), 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(fused_step_kernel<8>, dim3(GF), dim3(512), 0, ctx->stream, a);
+        hipLaunchKernelGGL((fused_step_kernel<8, 0>), dim3(GF), dim3(512), 0, ctx->stream, a);
     FV_LAUNCH_CHECK(ctx);
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
@@ -708,5 +757,61 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
         p->fused_bytes = nder * 2 >= nok ? 73 : 81;
         p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + 24 * 64 * nok + 8 * 64 * (nok - nder);
     }
+    return FV_OK;
+}
+
+// Can the many-iteration loop run its passes through the fused kernel (MODE 1)?  The tiled symmetric form serves the
+// operator with the shift folded into its copy (or no shift at all).
+bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded)
+{
+    if (!g_fused || !g_fused_iter || p->dist || p->nhalo > 0 || p->sym_state != 1 || p->last_form != FV_SPMV_SYM_TILE)
+        return false;
+    if (p->sym_epoch != p->assemble_epoch || p->sym_tag != (folded ? sigma : 0.0) || (sigma != 0.0 && !folded))
+        return false;
+    const int64_t nz = p->sym_d[1], d3 = p->sym_d[2];
+    return p->sym_d[0] == 1 && nz >= 64 && nz % 2 == 0 && d3 % 2 == 0 && d3 % nz == 0 && p->n % d3 == 0 && p->n / d3 >= 3;
+}
+
+// One pass of the many-iteration regime: the scalars of K3 for iteration `it` (from the sums the vector pass left in
+// part_rz / part_rr), p' = z + beta p into p->pnext (z = p->r, which holds M^-1 r between the passes; p = p->pvec), q = (A + sigma D) p'
+// into p->q, partial p'.q into part_pq (*npq pieces, the slice-by-slice launch's behind the kernel's).
+int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq)
+{
+    fv_ctx *ctx = p->ctx;
+    KfArgs a{};
+    const int GF = kf_setup(p, a);
+    const int TLr = g_fused_lines == 16 ? 16 : 8;
+    a.code = nullptr;
+    for (int k = 0; k < FV_STORAGE_CODES; k++)
+        a.sD.v[k] = 0.0;
+    // the diagonal of a slice that re-derives it carries the folded shift by the row's storage code (sym_shift, as in K1)
+    if (p->sym_shift_mode) {
+        a.sD = p->sym_shift;
+        a.code = p->sym_shift_mode == 1 ? p->dcode.p : nullptr;
+    }
+    a.z = p->r.p;
+    a.v = p->pvec.p;
+    a.znext = p->pnext.p;
+    a.vnext = p->q.p;
+    a.scal = p->scal.p;
+    a.in = FusedSums{};
+    a.in.arz = const_cast<double *>(part_rz);
+    a.in.arr = const_cast<double *>(part_rr);
+    a.in.nvec = nvec;
+    a.out = FusedSums{};
+    a.out.pq = p->part_pq.p;
+    a.chain_index = it;
+    a.hist = p->hist.p;
+    a.hist_cap = p->hist_cap;
+    a.n = p->n;
+    if (TLr == 16)
+        hipLaunchKernelGGL((fused_step_kernel<16, 1>), dim3(GF), dim3(1024), 0, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((fused_step_kernel<8, 1>), dim3(GF), dim3(512), 0, ctx->stream, a);
+    FV_LAUNCH_CHECK(ctx);
+    int GR = 0;
+    if (p->sym_nrest > 0)
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GF, &GR, true));
+    *npq = GF + GR;
     return FV_OK;
 }

@@ -243,6 +243,92 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_kernel(int64_t n, int it,
     }
 }
 
+// K2 of the many-iteration loop when its passes run through the fused kernel (fv_fused_iteration): between the passes the
+// residual is kept Jacobi-scaled, z = M^-1 r, in the array r (the direction update p' = z + beta p and the halo rows of the
+// next product then need z and p only); the residual itself is z / M^-1 here, as in K2S's z-form.  r_is_z = 0: the array
+// still holds r (the first iteration after a set-up).  x += alpha p; r' = r - alpha q; the array receives z' = M^-1 r'.
+template <bool SPLIT>
+__global__ __launch_bounds__(FV_BLOCK) void pcg_update_z_kernel(int64_t n, int it, int r_is_z, const double *xin, double *x, double *__restrict__ r,
+                                                                 const double *__restrict__ pv, const double *__restrict__ q,
+                                                                 const double *__restrict__ minv, const double *__restrict__ part_pq,
+                                                                 int npq, PcgScalars *__restrict__ scal, double *__restrict__ part_rz,
+                                                                 double *__restrict__ part_rr)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    const double pq = reduce_partials(part_pq, npq, smem);
+    if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->pq = pq;
+            scal->done = 2;
+        }
+        return;
+    }
+    const double alpha = scal->rz[it & 1] / pq;
+    double arz = 0.0, arr = 0.0;
+    const int64_t n2 = n >> 1;
+    double2 *x2 = reinterpret_cast<double2 *>(x);
+    const double2 *xi2 = SPLIT ? reinterpret_cast<const double2 *>(xin) : x2;
+    double2 *r2 = reinterpret_cast<double2 *>(r);
+    const double2 *p2 = reinterpret_cast<const double2 *>(pv);
+    const double2 *q2 = reinterpret_cast<const double2 *>(q);
+    const double2 *m2 = reinterpret_cast<const double2 *>(minv);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        double2 xv = xi2[i], rv = r2[i];
+        const double2 pvv = p2[i], qv = nt_load2(q2 + i), mv = m2[i];
+        if (r_is_z)
+            rv = make_double2(rv.x / mv.x, rv.y / mv.y);
+        xv.x += alpha * pvv.x;
+        xv.y += alpha * pvv.y;
+        rv.x -= alpha * qv.x;
+        rv.y -= alpha * qv.y;
+        const double2 zv = make_double2(mv.x * rv.x, mv.y * rv.y);
+        x2[i] = xv;
+        r2[i] = zv;
+        arz += rv.x * zv.x + rv.y * zv.y;
+        arr += rv.x * rv.x + rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double xi = (SPLIT ? xin[i] : x[i]) + alpha * pv[i];
+        const double ri = (r_is_z ? r[i] / minv[i] : r[i]) - alpha * q[i];
+        x[i] = xi;
+        r[i] = minv[i] * ri;
+        arz += ri * (minv[i] * ri);
+        arr += ri * ri;
+    }
+    const double t0 = block_sum(arz, smem);
+    const double t1 = block_sum(arr, smem);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+        if (blockIdx.x == 0)
+            scal->pq = pq;
+    }
+}
+
+// K3's scalars alone (the verdict on iteration `it`), for the end of a chunk of that loop: the next pass's prologue would
+// take it, but the host polls first.  The pass that follows repeats the same values.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_verdict_kernel(int it, const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nparts,
+                                                                PcgScalars *__restrict__ scal, double *__restrict__ hist, int64_t hist_cap)
+{
+    __shared__ double smem[4];
+    if (scal->done)
+        return;
+    const double rzn = reduce_partials(part_rz, nparts, smem);
+    const double rrn = reduce_partials(part_rr, nparts, smem);
+    if (threadIdx.x == 0) {
+        scal->rz[(it + 1) & 1] = rzn;
+        scal->rr = rrn;
+        scal->iters = it + 1;
+        if (hist && it < hist_cap)
+            hist[it] = sqrt(rrn);
+        if (rrn <= scal->tol2)
+            scal->done = 1;
+    }
+}
+
 // the sparse assembled b of K2S: its support (rows next to a Dirichlet cell or with a source) and where the gather
 // blocks leave their partial sums; nblocks = 0: b' is streamed by the vector blocks (or there is none)
 struct SparseRhs {
@@ -665,7 +751,7 @@ static int residual_to_r(fv_problem *p)
     if (p->z_where == 0)
         return FV_OK;
     fv_ctx *ctx = p->ctx;
-    const double *z = p->z_where == 1 ? p->pvec.p : p->pnext.p;
+    const double *z = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : p->r.p; // (4: in r itself, the many-iteration loop's z-form)
     hipLaunchKernelGGL(unscale_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, z, (const double *)p->minv.p, p->r.p);
     FV_LAUNCH_CHECK(ctx);
     p->z_where = 0;
@@ -871,6 +957,8 @@ int fv_pcg_prepare(fv_problem *p)
     return FV_OK;
 }
 
+static inline int fv_step_precond_of(const fv_problem *p, const PcgSystem &sys) { return sys.implicit_step ? fv_step_precond(p) : p->precond; }
+
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it)
 {
     fv_ctx *ctx = p->ctx;
@@ -960,7 +1048,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     } else if (use_spec) {
         in_nbb = Gv + p->spec_extra_bb;
         p->pvec.swap(p->pnext);
-        if (p->z_where)
+        if (p->z_where == 1 || p->z_where == 2)
             p->z_where = 3 - p->z_where; // the scaled residual a z-form K2S left moves with its vector
         in_rz += FV_VEC_PARTIALS;
         in_rr += FV_VEC_PARTIALS;
@@ -975,7 +1063,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         if (!zf)
             FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
     } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
-        const double *zsrc = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : nullptr;
+        const double *zsrc = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : p->z_where == 4 ? p->r.p : nullptr;
         hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
                            (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
                            p->part_bb.p, zsrc);
@@ -1057,6 +1145,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
 #define FV_PROF(idx)                                                                                            \
     if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
+    int zloop = 0, zr_is_z = 0; // the many-iteration loop through the fused kernel: 0 no, 1 to be decided after the first product, 2 yes
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         int32_t iters_before = 0;
@@ -1109,11 +1198,42 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         }
         for (int64_t k = 0; k < m; k++) {
             const int iter = (int)(it + k);
+            // The many-iteration loop through the fused kernel: the direction update of K3 and the product in one pass, the
+            // residual kept as z = M^-1 r in the array r between the passes (pcg_update_z_kernel).  Entered at a solve's first
+            // iteration (the set-up left r and p = M^-1 r; the classic K1 forms that product and establishes the storage form).
+            if (iter == 0 && !resume && !speculate && !chained && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && !p->dist)
+                zloop = 1; // (decided for good once the first product has shown the form: see below)
             FV_PROF(0);
             int npq = 0;
-            FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
+            if (zloop == 2) {
+                FV_TRY(fv_fused_iteration(p, iter - 1, folded, p->part_rz.p, p->part_rr.p, Gv, &npq));
+                p->pvec.swap(p->pnext);
+            } else
+                FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
             FV_PROF(1);
             FV_PROF(2);
+            if (zloop == 1) {
+                zloop = fv_fused_iteration_applicable(p, sigma, folded != nullptr) ? 2 : 0;
+                if (zloop == 2 && !p->pnext.p) // the pass writes the new direction beside the old one (halo rows of other tiles still read it)
+                    FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+            }
+            if (zloop == 2) {
+                if (iter == 0 && sys.x_next)
+                    hipLaunchKernelGGL(pcg_update_z_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)x, sys.x_next,
+                                       p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
+                else
+                    hipLaunchKernelGGL(pcg_update_z_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)nullptr,
+                                       sys.x_next ? sys.x_next : x, p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p,
+                                       p->part_rz.p, p->part_rr.p);
+                zr_is_z = 1;
+                FV_PROF(3);
+                FV_PROF(4);
+                if (k == m - 1) // the chunk's last iteration: its verdict now, for the host's poll (the next pass would take it otherwise)
+                    hipLaunchKernelGGL(pcg_verdict_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, iter, (const double *)p->part_rz.p,
+                                       (const double *)p->part_rr.p, Gv, p->scal.p, p->hist.p, p->hist_cap);
+                FV_PROF(5);
+                continue;
+            }
             const bool spec = iter == 0 && speculate;
             if (spec) {
                 hipLaunchKernelGGL(k2s_kernel(zf), dim3(Gv + Gx), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)x, sys.x_next, p->r.p,
@@ -1186,6 +1306,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
+    if (zloop == 2 && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)
+        p->z_where = 4; // the array r holds M^-1 r (residual_to_r / the next step's carried set-up take it from there)
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it
     if (speculate && zf && hs->iters >= 1)
         p->z_where = p->spec_valid ? 2 : 0; // a z-form K2S ran: its p' stands for the residual, unless the K3 behind it had to go on (it wrote r)
@@ -1193,7 +1315,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         // converged at its set-up: nothing ran, so the prepared set-up (direction, sums) is still exactly the next step's — put the
         // direction vectors back and keep it, as a burst does, instead of deriving a new one from the rounded residual
         p->pvec.swap(p->pnext);
-        if (p->z_where)
+        if (p->z_where == 1 || p->z_where == 2)
             p->z_where = 3 - p->z_where;
         p->spec_valid = true;
         p->last_iters = 1; // still the one-iteration regime, as after a chained step (the next step speculates in either mode)
@@ -2005,7 +2127,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         p->z_where = p->spec_valid ? 2 : 0; // as in fv_pcg_solve
     if (use_spec && hs->done == 1 && hs->iters == 0) { // converged at its set-up: keep the prepared set-up (see fv_pcg_solve)
         p->pvec.swap(p->pnext);
-        if (p->z_where)
+        if (p->z_where == 1 || p->z_where == 2)
             p->z_where = 3 - p->z_where;
         p->spec_valid = true;
         p->last_iters = 1;

@@ -300,7 +300,7 @@ extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder;                       // fv_assembly.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -386,6 +386,8 @@ extern "C" int fv_tune(int key, int value)
         g_fused_lines = value;
     else if (key == 45 && value >= 0 && value <= 31)
         g_fused_nt = value;
+    else if (key == 46 && (value == 0 || value == 1))
+        g_fused_iter = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -2162,7 +2164,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 // The slices the symmetric form leaves to the slice-by-slice kernel (first / last plane, irregular ones), on their own: the
 // fused step (fv_fused.hip) forms every other product itself.  `vals`: the value array the lane-major copy was filled from
 // (spmv_apply has done that for the same array and tag before the fused regime is entered).
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts)
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done)
 {
     fv_ctx *ctx = p->ctx;
     *nparts = 0;
@@ -2174,11 +2176,11 @@ int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, 
     if (g_nt)
         hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
                            (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
-                           partials, (const PcgScalars *)nullptr, epi);
+                           partials, use_done ? (const PcgScalars *)p->scal.p : (const PcgScalars *)nullptr, epi);
     else
         hipLaunchKernelGGL((spmv_dia_kernel<true, false, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
                            (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
-                           partials, (const PcgScalars *)nullptr, epi);
+                           partials, use_done ? (const PcgScalars *)p->scal.p : (const PcgScalars *)nullptr, epi);
     FV_LAUNCH_CHECK(ctx);
     *nparts = GR;
     return FV_OK;
