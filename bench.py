@@ -490,17 +490,20 @@ def multi_iteration_block(p, args):
     del st
     form_id, form_name, form_bytes = p.spmv_form()
     nit = int(np.sum(iters))
-    per_it_bytes = form_bytes + 88 * p.n
+    loop = p.loop_form()  # 113: direction update + product in one pass of the fused kernel (57) and the z-form vector update (56)
+    per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
-           "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes, "bytes_model": "K1 storage form (%s) + 88 n for K2 + K3" % form_name,
+           "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
+           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (57 n: z, p in, p', q out, 3 upper diagonals, storage codes) + z-form vector update (56 n)" if loop
+                           else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
-    for k, bytes_ in (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n)):
+    for k, bytes_ in ((("spmv_dot", 57 * p.n), ("update", 56 * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]
         if kc:
-            out["kernels"][k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
+            out["kernels"]["fused_pass" if (loop and k == "spmv_dot") else k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
     return out
 
 

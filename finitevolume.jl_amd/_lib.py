@@ -107,6 +107,7 @@ SIGNATURES = {
     "fv_profile_get": (C.c_int, [c_prob, C.c_int, P(C.c_double), P(C.c_int64)]),
     "fv_spmv_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64)]),
     "fv_update_form": (C.c_int, [c_prob, P(C.c_int32)]),
+    "fv_loop_form": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_fused_form": (C.c_int, [c_prob, P(C.c_int64), P(C.c_int32), P(C.c_int64)]),
     "fv_problem_reorder_info": (C.c_int, [c_prob, P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double)]),
     "fv_comm_unique_id": (C.c_int, [C.c_char_p]),

@@ -306,6 +306,13 @@ class Problem:
         self.check(load().fv_update_form(self.handle, C.byref(b)))
         return b.value
 
+    def loop_form(self):
+        """Bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (113),
+        0 for the K1 + K2 + K3 loop (fv_loop_form)."""
+        b = C.c_int32()
+        self.check(load().fv_loop_form(self.handle, C.byref(b)))
+        return b.value
+
     def fused_form(self):
         """(launches so far, bytes per row of its storage form, bytes per launch) of the fused step of the one-iteration regime
         (fv_fused_form)."""

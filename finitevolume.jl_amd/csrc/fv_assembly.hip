@@ -92,6 +92,7 @@ int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes)
 }
 
 // ------------------------------------------------------------------ locality re-numbering of the free cells
+int g_reorder_device = 1; // fv_tune key 47: the re-numbering is computed on the device (0: by the host routine, one core)
 int g_reorder = 1; // fv_tune key 31: 0 never, 1 when the mesh is numbered badly and the re-numbering helps, 2 always (tests)
 
 __global__ __launch_bounds__(FV_BLOCK) void apply_perm_kernel(int64_t N, const int32_t *__restrict__ perm, int32_t *__restrict__ nodemap,
@@ -175,6 +176,25 @@ static int fv_reorder_free(fv_problem *p)
     if (mode == 0 || n < 2 || F < 1 || (mode == 1 && n < 65536))
         return FV_OK;
     const auto t0 = std::chrono::steady_clock::now();
+    if (g_reorder_device) { // the same order, built in HBM (fv_reorder.hip); the host routine below stays as the reference and the fall-back
+        DevBuf<int32_t> dperm;
+        FV_TRY(dperm.alloc(ctx, (size_t)n));
+        bool adopted = false, handled = false;
+        FV_TRY(fv_device_locality_order(p, mode, dperm.p, &adopted, &handled, &p->reorder_mean_before, &p->reorder_mean_after));
+        if (handled) {
+            if (!adopted)
+                return FV_OK;
+            FV_TRY(p->iperm.alloc(ctx, (size_t)n));
+            p->perm.swap(dperm);
+            hipLaunchKernelGGL(apply_perm_kernel, dim3(fv_blocks(N)), dim3(FV_BLOCK), 0, ctx->stream, N, (const int32_t *)p->perm.p, p->nodemap.p, p->f2n.p,
+                               p->iperm.p);
+            FV_LAUNCH_CHECK(ctx);
+            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            p->reordered = true;
+            p->reorder_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            return FV_OK;
+        }
+    }
     std::vector<int32_t> a((size_t)F), b((size_t)F), map((size_t)N);
     FV_HIP(ctx, hipMemcpy(a.data(), p->node1.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
     FV_HIP(ctx, hipMemcpy(b.data(), p->node2.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));

@@ -308,6 +308,7 @@ struct fv_problem {
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
     int64_t fused_launches = 0, fused_bytes_launch = 0;
+    int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;
@@ -356,6 +357,8 @@ int fv_gather_free(fv_problem *p, const double *unodes_dev, double *ufree_dev); 
 // side in the problem's internal one (the same unless p->reordered).  count vectors of n doubles, one after the other.
 int fv_free_in(fv_problem *p, double *dst_dev, const double *src_host_or_dev, int64_t count = 1);
 int fv_free_out(fv_problem *p, double *dst_host_or_dev, const double *src_dev, int64_t count = 1);
+// fv_reorder.hip: the same order on the device; *handled = false: graph not suited to it, run the host routine
+int fv_device_locality_order(fv_problem *p, int want, int32_t *perm_dev, bool *adopted, bool *handled, double *mean_before, double *mean_after);
 // fv_host.cpp
 int fv_host_locality_order(int64_t n, int64_t m, const int32_t *ea, const int32_t *eb, int32_t *perm, double *mean_before, double *mean_after);
 

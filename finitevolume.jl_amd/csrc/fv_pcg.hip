@@ -768,6 +768,14 @@ extern "C" int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_pe
     return FV_OK;
 }
 
+extern "C" int fv_loop_form(fv_problem *p, int32_t *bytes_per_row)
+{
+    if (!p || !bytes_per_row)
+        return FV_ERR_ARG;
+    *bytes_per_row = p->loop_bytes;
+    return FV_OK;
+}
+
 extern "C" int fv_update_form(fv_problem *p, int32_t *bytes_per_row)
 {
     if (!p || !bytes_per_row)
@@ -1306,6 +1314,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
+    p->loop_bytes = zloop == 2 ? 113 : 0;
     if (zloop == 2 && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)
         p->z_where = 4; // the array r holds M^-1 r (residual_to_r / the next step's carried set-up take it from there)
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it

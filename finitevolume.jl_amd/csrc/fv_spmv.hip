@@ -299,7 +299,8 @@ static void set_resident_blocks(const fv_ctx *ctx)
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
-extern int g_reorder;                       // fv_assembly.hip
+extern int g_reorder, g_reorder_device;     // fv_assembly.hip
+extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
@@ -388,6 +389,10 @@ extern "C" int fv_tune(int key, int value)
         g_fused_nt = value;
     else if (key == 46 && (value == 0 || value == 1))
         g_fused_iter = value;
+    else if (key == 47 && (value == 0 || value == 1))
+        g_reorder_device = value;
+    else if (key == 48 && value >= 0 && value <= 64)
+        g_reorder_blocks = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else

@@ -73,6 +73,8 @@ extern "C" {
  *  41: the fused step (fv_fused_form) in bursts of one-iteration steps where it applies; 0 = always K1 + K2S [1]
  *  42, 43: experiments on its launch: resident blocks per CU for 8-line tiles [2], segments of planes per tile (0 = chosen) [0]
  *  44: lines per tile of the fused step: 16 (blocks of 1024 threads, one per CU) or 8 (512 threads, two per CU) [16]
+ *  46: the many-iteration PCG loop through the fused kernel too (fv_loop_form) [1]
+ *  47: the locality re-numbering of FV_OPT_REORDER computed on the device (fv_reorder.hip) [1]; 0 = by the host routine
  *  45: streaming-hint experiments on the fused step (bit 0: z' stored non-temporally, 1: v' too, 2: x / v plain loads, 3: x_out
  *      plain store, 4: matrix plain loads) [0] */
 int fv_tune(int key, int value);

@@ -276,6 +276,11 @@ int fv_update_form(fv_problem *p, int32_t *bytes_per_row);
  * summed over the operator (rows whose product the slice-by-slice launch forms carry no matrix bytes here); 0 launches / 0
  * bytes when it has not run. */
 int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int64_t *bytes_per_launch);
+/* The PCG loop of the most recent solve with several iterations (cg! of src/transient.jl:52 / src/FiniteVolume.jl:161): 0 = K1 + K2 +
+ * K3 per iteration (the SpMV form's bytes + 88 per row); 113 = the direction update and the product as one pass of the fused kernel
+ * (z = M^-1 r and p in, p' and q out, three upper diagonals, a code byte: 57) + the vector update in the z-form (x, z, p, q, M^-1 in,
+ * x, z out: 56). */
+int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

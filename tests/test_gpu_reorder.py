@@ -152,3 +152,60 @@ def test_fractures_like_mesh_is_renumbered_by_the_library_and_runs_faster(fv):
     print("fractures-like 5M: re-numbered %.4f s (SpMV %.3f ms), as numbered %.4f s (SpMV %.3f ms); %r" % (res[1]["sec"], res[1]["spmv_ms"], res[0]["sec"], res[0]["spmv_ms"], res[1]["info"]))
     assert np.abs(res[1]["head"] - res[0]["head"]).max() <= 1e-8 * np.abs(res[0]["head"]).max()
     assert res[1]["sec"] * 1.4 <= res[0]["sec"]
+
+
+def test_device_renumbering_is_the_host_routine_s_order(fv, forced):
+    """fv_reorder.hip builds the reverse Cuthill-McKee order level by level on the device; it must be the order of the host
+    routine it replaces (fv_tune key 47 = 0), cell for cell: the mean |i - j| over the faces after the re-numbering — an exact
+    rational of integers on both sides — is compared on a shuffled fourfractures mesh, on multigraphs with repeated faces,
+    self-loops, isolated cells and several components, and on the 5M-cell mesh (where the time is printed)."""
+    d = np.load(os.path.join(GOLDEN, "fourfractures.npz"))
+    rng = np.random.default_rng(9)
+    cases = []
+    shuffle = rng.permutation(2106)
+    rank = np.empty(2106, np.int64)
+    rank[shuffle] = np.arange(2106)
+    cases.append((np.stack([rank[d["node1"] - 1] + 1, rank[d["node2"] - 1] + 1], 1), 2106, rank[d["dirichletnodes"] - 1] + 1))
+    for seed in range(6):
+        r = np.random.default_rng(100 + seed)
+        N = int(r.integers(50, 4000))
+        parts = []
+        for lo, hi in ((1, N // 3), (N // 3 + 5, 2 * N // 3), (2 * N // 3 + 3, N)):  # three components and a few cells nobody touches
+            m = 3 * (hi - lo)
+            parts.append(np.stack([r.integers(lo, hi + 1, m), r.integers(lo, hi + 1, m)], 1))
+        nb = np.concatenate(parts)
+        nb = np.concatenate([nb, nb[: len(nb) // 10]])  # repeated faces (and self-loops from the random draw)
+        r.shuffle(nb)
+        dn = np.unique(r.integers(1, N + 1, max(1, N // 40)))
+        cases.append((nb, N, dn))
+    lib = forced
+    for nb, N, dn in cases:
+        got = {}
+        for dev in (1, 0):
+            assert lib.fv_tune(47, dev) == 0
+            try:
+                p = fv.Problem.create(nb, np.ones(len(nb)), N, dn.astype(np.int64))
+                got[dev] = p.reorder_info()
+                p.close()
+            finally:
+                lib.fv_tune(47, 1)
+        assert got[1]["reordered"] and got[0]["reordered"]
+        assert got[1]["mean_before"] == got[0]["mean_before"] and got[1]["mean_after"] == got[0]["mean_after"], (N, got)
+    lib.fv_tune(31, 1)
+    w = workloads.fractures_like(20, 500, seed=0)
+    got = {}
+    for dev in (1, 0):
+        assert lib.fv_tune(47, dev) == 0
+        try:
+            import time
+
+            t0 = time.perf_counter()
+            p = fv.Problem.create((w["node1"], w["node2"]), w["aol"], w["N"], w["dnodes"])
+            got[dev] = dict(p.reorder_info(), create_s=time.perf_counter() - t0)
+            p.close()
+        finally:
+            lib.fv_tune(47, 1)
+    print("fractures-like 5M: fv_problem_create %.3f s with the device re-numbering (%.3f s of it), %.3f s with the host routine (%.3f s)" %
+          (got[1]["create_s"], got[1]["seconds"], got[0]["create_s"], got[0]["seconds"]))
+    assert got[1]["reordered"] and got[1]["mean_after"] == got[0]["mean_after"]
+    assert got[1]["seconds"] < 0.5 * got[0]["seconds"]
