@@ -34,6 +34,7 @@
 int g_fused = 1;       // fv_tune key 41: 0 = never use the fused step
 int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for (8-line tiles)
 int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per tile, 0 = chosen to fill whole rounds
+int g_fused_codes = 1;  // fv_tune key 49: the matrix as 16-bit codes per row where its diagonals take few distinct values (0: always the doubles)
 int g_fused_iter = 1;   // fv_tune key 46: the many-iteration loop through the fused kernel too (direction update + product in one pass, z kept instead of r)
 int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
 int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
@@ -50,6 +51,8 @@ struct KfArgs {
     // the symmetric arrays (row 0 pointers: zero-padded in front and behind), flags per 64-row slice, storage codes
     const double *dg, *u1, *u2, *u3;
     const uint8_t *ok, *code;
+    const uint16_t *mcode; // CODED: per row, codes of U1 | U2 << 5 | U3 << 10 into mt
+    MatrixTables mt;
     StorageTable sD; // sigma x the distinct values of D
     // vectors
     const double *x, *z, *v;
@@ -118,7 +121,10 @@ __device__ __forceinline__ VRow vrow(double xin, double z, double v, double d, d
 // product: p' = z + beta p (z = M^-1 r, kept instead of r between the passes), q = (A + sigma D) p', partial p'.q; the scalar
 // work of K3 (beta, the convergence verdict, the residual history) in the prologue.  Same traversal, same halo trick (a halo
 // row is z + beta p: two streams, one FMA); no x, no storage term, no vector sums.  a.z = z, a.v = p (old), a.znext = p', a.vnext = q.
-template <int TL, int MODE>
+// CODED: the three upper diagonals come as one 16-bit word per row — three 5-bit codes into tables of their distinct values
+// (a homogeneous conductivity on a regular grid: a handful of values per direction; fv_matrix_codes) — instead of three doubles:
+// 2 instead of 24 bytes of matrix per row, the same doubles out of the tables, so nothing else changes.
+template <int TL, int MODE, bool CODED>
 __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
 {
     constexpr int TW = KF_TW, NT = TL * TW / 2, HC = TW / 2;
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     __shared__ __align__(16) double u1s[3 * U1T];
     __shared__ __align__(16) double u2s[3 * U2T];
     __shared__ double tab[FV_STORAGE_CODES];
+    __shared__ double mtab[CODED ? 3 * FV_MATRIX_CODES : 1];
     __shared__ double red[NT / 64];
     const int tid = (int)threadIdx.x;
     PcgScalars *scal = a.scal;
@@ -244,6 +251,8 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     // ---------------------------------------------------------------- the pass
     if (tid < FV_STORAGE_CODES)
         tab[tid] = a.sD.v[tid];
+    if (CODED && tid < 3 * FV_MATRIX_CODES)
+        mtab[tid] = a.mt.v[tid];
     const int32_t nz = a.nz, d3 = a.d3;
     const int tl = tid / HC, tc = 2 * (tid % HC);
     const int xcd = (int)(blockIdx.x & 7);
@@ -318,6 +327,23 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         };
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 255u], tab[c >> 8]); }; // sigma D of the two rows
         auto H1 = [&](const double *arr, int32_t pl) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + hb); };
+        // the matrix values of the thread's two rows of plane pl: which = 0, 1, 2 for U1, U2, U3 (as doubles, or out of the tables)
+        auto MW = [&](int32_t pl) -> uint32_t { return *reinterpret_cast<const uint32_t *>(PB(a.mcode, pl, 2) + (ob >> 2)); };
+        auto MV = [&](uint32_t w, int which) -> double2 {
+            return make_double2(mtab[which * FV_MATRIX_CODES + ((w >> (5 * which)) & 31u)], mtab[which * FV_MATRIX_CODES + ((w >> (16 + 5 * which)) & 31u)]);
+        };
+        auto MU = [&](const double *arr, int which, int32_t pl, bool plain) -> double2 {
+            if (CODED)
+                return MV(MW(pl), which);
+            return plain ? P2(arr, pl) : P2nt(arr, pl);
+        };
+        auto MH = [&](bool u2, int32_t pl) -> double { // a halo row's U2 (line above) or U1 (column to the left)
+            if (CODED) {
+                const uint32_t w = *reinterpret_cast<const uint16_t *>(PB(a.mcode, pl, 2) + (hb >> 2));
+                return mtab[(u2 ? 1 : 0) * FV_MATRIX_CODES + ((w >> (u2 ? 5 : 0)) & 31u)];
+            }
+            return H1(u2 ? a.u2 : a.u1, pl);
+        };
         auto ST2 = [&](double *arr, int32_t pl, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob) = val; };
         auto ST2nt = [&](double *arr, int32_t pl, double2 val) {
             double *q = reinterpret_cast<double *>(const_cast<char *>(PB(arr, pl, 8)) + ob);
@@ -368,23 +394,24 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 acc[3] += ra.c * ra.c + rb.c * rb.c;
                 acc[4] += ra.h * ra.h + rb.h * rb.h;
             }
-            const double2 A3m = P2nt(a.u3, p0 - 1);
+            const double2 A3m = MU(a.u3, 2, p0 - 1, false);
             Pc = make_double2(A3m.x * Zm.x + dd.x * Zc0.x, A3m.y * Zm.y + dd.y * Zc0.y);
         }
         flc = own ? (int)a.ok[((int64_t)p0 * d3 + o) >> 6] : 0;
-        double2 A3c = P2nt(a.u3, p0), A3n = P2nt(a.u3, p0 + 1);
+        const uint32_t w0 = CODED ? MW(p0) : 0u, w1 = CODED ? MW(p0 + 1) : 0u;
+        double2 A3c = CODED ? MV(w0, 2) : P2nt(a.u3, p0), A3n = CODED ? MV(w1, 2) : P2nt(a.u3, p0 + 1);
         *reinterpret_cast<double2 *>(zs + zb * ZT + zo) = Zc0;
-        *reinterpret_cast<double2 *>(u1s + s0 * U1T + u1o) = P2nt(a.u1, p0);
-        *reinterpret_cast<double2 *>(u2s + s0 * U2T + u2o) = P2nt(a.u2, p0);
-        *reinterpret_cast<double2 *>(u1s + s1 * U1T + u1o) = P2nt(a.u1, p0 + 1);
-        *reinterpret_cast<double2 *>(u2s + s1 * U2T + u2o) = P2nt(a.u2, p0 + 1);
+        *reinterpret_cast<double2 *>(u1s + s0 * U1T + u1o) = CODED ? MV(w0, 0) : P2nt(a.u1, p0);
+        *reinterpret_cast<double2 *>(u2s + s0 * U2T + u2o) = CODED ? MV(w0, 1) : P2nt(a.u2, p0);
+        *reinterpret_cast<double2 *>(u1s + s1 * U1T + u1o) = CODED ? MV(w1, 0) : P2nt(a.u1, p0 + 1);
+        *reinterpret_cast<double2 *>(u2s + s1 * U2T + u2o) = CODED ? MV(w1, 1) : P2nt(a.u2, p0 + 1);
         if (ht) {
             double zn = 0.0, ua = 0.0, ub = 0.0;
             if (hv) {
                 zn = H1(a.z, p0) + alpha * H1(a.v, p0);
                 if (hu >= 0) {
-                    ua = H1(hu_is_u2 ? a.u2 : a.u1, p0);
-                    ub = H1(hu_is_u2 ? a.u2 : a.u1, p0 + 1);
+                    ua = MH(hu_is_u2, p0);
+                    ub = MH(hu_is_u2, p0 + 1);
                 }
             }
             zs[zb * ZT + hz] = zn;
@@ -405,7 +432,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             const bool more = p + 2 <= p1, inseg = p + 1 < p1;
             const bool vec_n = inseg || vec_last; // plane p + 1's vector part is ours
             double2 Xb = make_double2(0.0, 0.0), Vb = Xb, Zb = Xb, V1b = Xb, V2b = Xb, A3b = Xb;
-            uint32_t Cb = 0;
+            uint32_t Cb = 0, Wb = 0; // (CODED: the matrix word of plane p + 2, decoded when it is needed)
             int flb = 0;
             double hq = 0.0, hzv = 0.0, hub = 0.0;
             if (more) {
@@ -414,9 +441,13 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 Vb = (a.nt & 4) ? P2(a.v, p + 2) : P2nt(a.v, p + 2);
                 Zb = P2(a.z, p + 2);
                 Cb = C2(p + 2);
-                V1b = (a.nt & 16) ? P2(a.u1, p + 2) : P2nt(a.u1, p + 2);
-                V2b = (a.nt & 16) ? P2(a.u2, p + 2) : P2nt(a.u2, p + 2);
-                A3b = (a.nt & 16) ? P2(a.u3, p + 2) : P2nt(a.u3, p + 2);
+                if (CODED)
+                    Wb = MW(p + 2);
+                else {
+                    V1b = (a.nt & 16) ? P2(a.u1, p + 2) : P2nt(a.u1, p + 2);
+                    V2b = (a.nt & 16) ? P2(a.u2, p + 2) : P2nt(a.u2, p + 2);
+                    A3b = (a.nt & 16) ? P2(a.u3, p + 2) : P2nt(a.u3, p + 2);
+                }
                 flb = own ? (int)a.ok[((int64_t)(p + 2) * d3 + o) >> 6] : 0;
             }
             if (ht && KF_HV) {
@@ -425,7 +456,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                     hzv = H1(a.z, p + 1);
                 }
                 if (more && KF_HHU)
-                    hub = H1(KF_HU2 ? a.u2 : a.u1, p + 2);
+                    hub = MH(KF_HU2 != 0, p + 2);
             }
             // ---- update of plane p + 1
             const double *u1n = u1s + s1 * U1T, *u2n = u2s + s1 * U2T;
@@ -512,6 +543,11 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             if (ht && inseg)
                 zs[(zb ^ 1) * ZT + KF_HZ] = KF_HV ? hzv + alpha * hq : 0.0;
             if (more) {
+                if (CODED) {
+                    V1b = MV(Wb, 0);
+                    V2b = MV(Wb, 1);
+                    A3b = MV(Wb, 2);
+                }
                 *reinterpret_cast<double2 *>(u1s + s2 * U1T + u1o) = V1b;
                 *reinterpret_cast<double2 *>(u2s + s2 * U2T + u2o) = V2b;
                 if (ht && KF_HHU)
@@ -694,6 +730,16 @@ static int kf_setup(fv_problem *p, KfArgs &a)
     return GF;
 }
 
+// the matrix as codes where the symmetric copy has them (fv_matrix_codes, fv_spmv.hip) and the switch is on
+static bool kf_codes(fv_problem *p, KfArgs &a)
+{
+    if (!g_fused_codes || p->sym_mcode_n <= 0 || !p->sym_mcode.p)
+        return false;
+    a.mcode = p->sym_mcode.p;
+    a.mt = p->sym_mtab;
+    return true;
+}
+
 // One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
 // burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
 int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
@@ -734,10 +780,18 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     out.nbb = a.bm > 0 ? 2 * GF : GF;
     // (the sparse-b partials sit right behind the vector part's: sbb[GF .. 2 GF))
     a.out = out;
-    if (TLr == 16)
-        hipLaunchKernelGGL((fused_step_kernel<16, 0>), dim3(GF), dim3(1024), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((fused_step_kernel<8, 0>), dim3(GF), dim3(512), 0, ctx->stream, a);
+    const bool coded = kf_codes(p, a);
+    if (TLr == 16) {
+        if (coded)
+            hipLaunchKernelGGL((fused_step_kernel<16, 0, true>), dim3(GF), dim3(1024), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((fused_step_kernel<16, 0, false>), dim3(GF), dim3(1024), 0, ctx->stream, a);
+    } else {
+        if (coded)
+            hipLaunchKernelGGL((fused_step_kernel<8, 0, true>), dim3(GF), dim3(512), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((fused_step_kernel<8, 0, false>), dim3(GF), dim3(512), 0, ctx->stream, a);
+    }
     FV_LAUNCH_CHECK(ctx);
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
@@ -754,8 +808,9 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
         // every array once: x, z, v in and x_out, z', v' out on all rows (48) + a code byte; the three upper diagonals on the rows
         // whose product this kernel forms (24), + the stored diagonal where it is not re-derived (8)
         const int64_t nok = p->ndia - p->sym_nrest, nder = p->sym_nderived;
-        p->fused_bytes = nder * 2 >= nok ? 73 : 81;
-        p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + 24 * 64 * nok + 8 * 64 * (nok - nder);
+        const int mb = coded ? 2 : 24;
+        p->fused_bytes = (nder * 2 >= nok ? 73 : 81) - 24 + mb;
+        p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + mb * 64 * nok + 8 * 64 * (nok - nder);
     }
     return FV_OK;
 }
@@ -804,10 +859,19 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     a.hist = p->hist.p;
     a.hist_cap = p->hist_cap;
     a.n = p->n;
-    if (TLr == 16)
-        hipLaunchKernelGGL((fused_step_kernel<16, 1>), dim3(GF), dim3(1024), 0, ctx->stream, a);
-    else
-        hipLaunchKernelGGL((fused_step_kernel<8, 1>), dim3(GF), dim3(512), 0, ctx->stream, a);
+    const bool coded = kf_codes(p, a);
+    if (TLr == 16) {
+        if (coded)
+            hipLaunchKernelGGL((fused_step_kernel<16, 1, true>), dim3(GF), dim3(1024), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((fused_step_kernel<16, 1, false>), dim3(GF), dim3(1024), 0, ctx->stream, a);
+    } else {
+        if (coded)
+            hipLaunchKernelGGL((fused_step_kernel<8, 1, true>), dim3(GF), dim3(512), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((fused_step_kernel<8, 1, false>), dim3(GF), dim3(512), 0, ctx->stream, a);
+    }
+    p->loop_bytes = coded ? 91 : 113;
     FV_LAUNCH_CHECK(ctx);
     int GR = 0;
     if (p->sym_nrest > 0)

@@ -163,6 +163,11 @@ constexpr int FV_STORAGE_CODES = 16;
 struct StorageTable {
     double v[FV_STORAGE_CODES];
 };
+// the three upper diagonals of the symmetric copy as 5-bit codes per row (fv_matrix_codes): tables of their distinct values
+constexpr int FV_MATRIX_CODES = 32;
+struct MatrixTables {
+    double v[3 * FV_MATRIX_CODES];
+};
 struct StorageArg {
     const double *D;
     const uint8_t *code;
@@ -229,6 +234,13 @@ struct fv_problem {
     int sym_rowsum_switch = -1;   // fv_tune key 37 as it was when the flags were set
     int sym_shift_mode = 0;       // 0: the derived diagonal carries no shift; 1: + sym_shift.v[code of the row]; 2: + sym_shift.v[0]
     StorageTable sym_shift = {};  // sigma x the distinct values of D, for the sigma folded into the copy
+    // ... and, where each of the three upper diagonals takes at most FV_MATRIX_CODES distinct values (a homogeneous conductivity on a
+    // regular grid), one 16-bit word per row: U1 | U2 << 5 | U3 << 10 as codes into sym_mtab.  sym_mcode_n: 0 not applicable, > 0 built
+    // (for the copy's current epoch and tag), -1 not looked at yet
+    DevBuf<uint16_t> sym_mcode;
+    MatrixTables sym_mtab = {};
+    int sym_mcode_n = -1;
+    int64_t sym_mcode_epoch = -1;
     int last_form = -1; // FV_SPMV_* of the most recent spmv_apply (fv_spmv_form)
     int sym_state = -1; // -1 not looked at yet, 0 not applicable (no such structure, or not symmetric), 1 built
 

@@ -1266,7 +1266,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 // this step's verdict and, if it converged, the next chained step's scalars from the set-up K2S left
                 const BoundarySums bs{p->part_rz.p, p->part_rr.p, p->part_rz.p + FV_VEC_PARTIALS, p->part_rr.p + FV_VEC_PARTIALS,
                                       p->part_bb.p + FV_VEC_PARTIALS, Gv, Gv, Gv + Gs};
-                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
+                // (every block takes the verdict from the same sums; only a chain that breaks — rare — has vector work here, so the
+                // grid is small: 2048 blocks re-reducing five arrays cost 14 us per step on the 5M-cell mesh, 128 cost 4)
+                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv < 128 ? Gv : 128), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
                                    p->pvec.p, bs, rtol, p->scal.p, (const double *)x, (const double *)sys.x_next, (const double *)p->D.p, sys.dt,
                                    sys.chain_index, (sys.chain_index == g_chain_test_break) ? 1 : 0, zf ? (const double *)p->pnext.p : nullptr);
             } else if (spec)
@@ -1314,7 +1316,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
-    p->loop_bytes = zloop == 2 ? 113 : 0;
+    if (zloop != 2)
+        p->loop_bytes = 0; // (else what fv_fused_iteration reported: 113, or 91 with the matrix as codes)
     if (zloop == 2 && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)
         p->z_where = 4; // the array r holds M^-1 r (residual_to_r / the next step's carried set-up take it from there)
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it

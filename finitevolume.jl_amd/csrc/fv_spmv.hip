@@ -14,6 +14,7 @@
 #include "fv_fused.h"
 
 #include <cstdlib>
+#include <cstring>
 
 // ------------------------------------------------------------------ SpMV
 // LPR lanes cooperate on one row (8 for the 7-point stencil: a wave64 covers 8
@@ -301,7 +302,7 @@ extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -393,6 +394,8 @@ extern "C" int fv_tune(int key, int value)
         g_reorder_device = value;
     else if (key == 48 && value >= 0 && value <= 64)
         g_reorder_blocks = value;
+    else if (key == 49 && (value == 0 || value == 1))
+        g_fused_codes = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -1621,6 +1624,89 @@ static int build_symdia(fv_problem *p)
     return FV_OK;
 }
 
+
+// The three upper diagonals as codes (fv_internal.h: sym_mcode): on a regular grid with one conductivity each of them takes a
+// handful of values (the conductance of an interior face, of a face on the box's faces / edges, 0 where the arm is absent), and
+// the kernels that stream them (the fused step, fv_fused.hip) can read one 16-bit word per row instead of three doubles.
+// Built like the storage codes (fv_storage_form): every pass codes the rows whose value is in the table, one row that is not
+// offers its value as the next entry; more than FV_MATRIX_CODES distinct values in any of the three: no codes.
+__global__ __launch_bounds__(FV_BLOCK) void matrix_code_kernel(int64_t n, const double *__restrict__ v, MatrixTables tab, int which, int ntab,
+                                                                uint16_t *__restrict__ code, int32_t *__restrict__ claim, double *__restrict__ offered)
+{
+    bool offered_one = false;
+    const unsigned shift = 5u * (unsigned)which;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK) {
+        const long long bits = __double_as_longlong(v[i]);
+        int c = -1;
+        for (int k = 0; k < ntab; k++)
+            if (__double_as_longlong(tab.v[which * FV_MATRIX_CODES + k]) == bits)
+                c = k;
+        if (c >= 0)
+            code[i] = (uint16_t)((code[i] & ~(31u << shift)) | ((unsigned)c << shift));
+        else if (!offered_one) {
+            offered_one = true; // one try per thread: whoever gets the claim decides the next table entry
+            if (*reinterpret_cast<volatile int32_t *>(claim) == 0 && atomicCAS(claim, 0, 1) == 0)
+                *offered = v[i];
+        }
+    }
+}
+
+static int build_matrix_codes(fv_problem *p)
+{
+    fv_ctx *ctx = p->ctx;
+    p->sym_mcode_n = 0;
+    const int64_t n = p->n;
+    const double *dg = p->sym_vals.p + p->sym_front;
+    // two samples first: a heterogeneous field shows more than FV_MATRIX_CODES values at once
+    const size_t m = (size_t)(n < 4096 ? n : 4096);
+    for (int which = 0; which < 3; which++) {
+        const double *u = dg + (which + 1) * p->sym_ld;
+        std::vector<double> h(2 * m);
+        FV_TRY(fv_copy(ctx, h.data(), u + ((size_t)n - m) / 3, m * sizeof(double)));
+        FV_TRY(fv_copy(ctx, h.data() + m, u + ((size_t)n - m) / 2, m * sizeof(double)));
+        std::vector<uint64_t> bits(2 * m);
+        memcpy(bits.data(), h.data(), 2 * m * sizeof(double));
+        std::sort(bits.begin(), bits.end());
+        if (std::unique(bits.begin(), bits.end()) - bits.begin() > FV_MATRIX_CODES)
+            return FV_OK;
+    }
+    FV_TRY(p->sym_mcode.alloc(ctx, (size_t)n + 64));
+    FV_TRY(p->sym_mcode.zero(ctx));
+    DevBuf<int32_t> claim;
+    DevBuf<double> offered;
+    FV_TRY(claim.alloc(ctx, 1));
+    FV_TRY(offered.alloc(ctx, 1));
+    int64_t g = (n + FV_BLOCK - 1) / FV_BLOCK;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    for (int which = 0; which < 3; which++) {
+        const double *u = dg + (which + 1) * p->sym_ld;
+        int ntab = 0;
+        bool ok = false;
+        for (;;) {
+            FV_TRY(claim.zero(ctx));
+            hipLaunchKernelGGL(matrix_code_kernel, dim3((unsigned)g), dim3(FV_BLOCK), 0, ctx->stream, n, u, p->sym_mtab, which, ntab, p->sym_mcode.p, claim.p,
+                               offered.p);
+            FV_LAUNCH_CHECK(ctx);
+            int32_t hc = 0;
+            FV_TRY(fv_copy(ctx, &hc, claim.p, sizeof hc));
+            if (!hc) { // every row has its code
+                ok = true;
+                break;
+            }
+            if (ntab == FV_MATRIX_CODES)
+                break; // too many distinct values
+            FV_TRY(fv_copy(ctx, &p->sym_mtab.v[which * FV_MATRIX_CODES + ntab], offered.p, sizeof(double)));
+            ntab++;
+        }
+        if (!ok) {
+            p->sym_mcode.release();
+            return FV_OK;
+        }
+        p->sym_mcode_n += ntab > 0 ? ntab : 1;
+    }
+    return FV_OK;
+}
+
 static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
 {
     fv_ctx *ctx = p->ctx;
@@ -1683,6 +1769,10 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
         FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
         p->sym_nderived = h;
         p->sym_shift_mode = h > 0 ? mode : 0;
+    }
+    if (p->sym_mcode_epoch != p->assemble_epoch) { // (the upper diagonals do not depend on the folded shift)
+        FV_TRY(build_matrix_codes(p));
+        p->sym_mcode_epoch = p->assemble_epoch;
     }
     p->sym_epoch = p->assemble_epoch;
     p->sym_tag = src_tag;

@@ -57,7 +57,7 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
     finally:
         lib.fv_tune(41, 1)
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0, 44: 16, 46: 1}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0, 44: 16, 46: 1, 49: 1}.get(k, 0))
     return out
 
 
@@ -190,3 +190,21 @@ def test_many_iteration_loop_through_the_fused_kernel(fv, oracle):
     assert out[1][3] == 4 and len(out[1][0]) == 150
     assert np.allclose(out[1][0], out[0][0], rtol=1e-6, atol=0) and abs(out[1][2] - out[0][2]) <= max(3, out[0][2] // 50)
     assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6 * np.abs(out[0][1]).max()  # both are rtol 1e-10 solves
+
+
+def test_matrix_as_codes_gives_the_same_bits(fv):
+    """fv_tune key 49: with one conductivity on a regular grid each upper diagonal of the operator takes a handful of values and
+    the fused kernel reads one 16-bit word of codes per row instead of three doubles — the same doubles out of the tables: heads
+    and iteration counts bit for bit those of the run that streams the matrix, in the one-iteration regime and in the
+    many-iteration loop; a heterogeneous field keeps the doubles."""
+    case = _problem(fv, BOX, seed=13, uniform_k=True)
+    sched = [(DT, 17, 1e-11), (40.0, 4, 1e-12), (DT, 10, 1e-11)]
+    coded = _run(fv, case, True, sched)
+    plain = _run(fv, case, True, sched, tune=((49, 0),))
+    assert coded[2][0] > 15 and plain[2][0] == coded[2][0]
+    assert coded[2][2] < 0.75 * plain[2][2]  # bytes per launch of the storage form: 2 instead of 24 of matrix per row
+    assert np.array_equal(coded[1], plain[1]) and np.array_equal(coded[0], plain[0])
+    hetero = _problem(fv, BOX, seed=13)
+    a = _run(fv, hetero, True, [(DT, 12, 1e-11)])
+    b = _run(fv, hetero, True, [(DT, 12, 1e-11)], tune=((49, 0),))
+    assert a[2][2] == b[2][2] and np.array_equal(a[0], b[0])
