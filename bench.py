@@ -283,6 +283,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of BASELINE.json's other single-GPU configurations")
     ap.add_argument("--no-multi-iteration", action="store_true", help="skip the second measured block (dt = 1 h, ~10 PCG iterations per step)")
+    ap.add_argument("--no-hetero", action="store_true", help="skip the same workload with a heterogeneous conductivity (the matrix then streams as doubles: 73 B per row)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     args = ap.parse_args()
 
@@ -385,6 +386,12 @@ def main():
             out["config"]["multi_iteration"] = "failed: %r" % (e,)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
+    if not args.no_hetero:
+        p.close()
+        try:
+            out["config"]["heterogeneous_K"] = hetero_block(fv, ctx, args)
+        except Exception as e:
+            out["config"]["heterogeneous_K"] = "failed: %r" % (e,)
     if not args.no_other_configs:
         p.close()  # 45 GB back before the next problems
         try:
@@ -392,6 +399,49 @@ def main():
         except Exception as e:
             out["config"]["other_baseline_configs"] = "failed: %r" % (e,)
     print(json.dumps(out))
+
+
+def hetero_block(fv, ctx, args):
+    """The headline workload with a smooth heterogeneous conductivity (sigma = 1 in log K) instead of one value: SURVEY 8d names both
+    for the 10^8-cell configuration.  The operator's diagonals then take as many values as there are faces, so the fused step
+    streams them as doubles (73 B per row) where the homogeneous headline reads 16-bit codes (51)."""
+    ns = [args.ns] * 3
+    mins, maxs = spacing_box(ns)
+    dn, src = box_setup(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+    # a smooth log-conductivity of unit variance, evaluated per face from the cell the face list reaches it in (regulargrid emits
+    # up to three faces per cell, cell by cell: face f belongs to cell ~ f / 3): sigma = 1 without the 5 GB of face ends on the host
+    n1, n2, n3 = ns
+    K = np.empty(p.F)
+    for lo in range(0, p.F, 1 << 24):  # (in pieces: 3e8 faces)
+        hi = min(lo + (1 << 24), p.F)
+        cell = (np.arange(lo, hi, dtype=np.float64) * (p.N / p.F)).astype(np.int64)
+        i3 = cell % n3
+        i2 = (cell // n3) % n2
+        i1 = cell // (n3 * n2)
+        g = (np.sin(2 * np.pi * i1 / 97.0) + np.sin(2 * np.pi * i2 / 61.0) + np.sin(2 * np.pi * i3 / 43.0)) / np.sqrt(1.5)
+        K[lo:hi] = 1e-5 * np.exp(g)
+        del cell, i1, i2, i3, g
+    p.assemble(K, src, np.full(len(dn), 1e3))
+    del K
+    st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    p.run_fixed(st, args.dt, max(args.warmup, 3), args.rtol, args.maxiter)
+    f0 = p.fused_form()[0]
+    secs = []
+    for rep in range(3):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        iters, info, _ = p.run_fixed(st, args.dt, args.steps, args.rtol, args.maxiter)
+        ctx.synchronize()
+        secs.append(time.perf_counter() - t0)
+    sec = float(np.median(secs))
+    launches, brow, bl = p.fused_form()
+    out = {"workload": "same %d^3 box, K = 1e-5 exp(g) per face with g a smooth field of unit variance (sums of sines of the cell indices), %d steps x 3 regions" % (args.ns, args.steps),
+           "dof_updates_per_s": p.N * args.steps / sec, "ms_per_step": sec / args.steps * 1e3, "ms_per_step_each": [s / args.steps * 1e3 for s in secs],
+           "pcg_iters_per_step": float(iters.mean()), "converged": bool(info.converged), "last_relres": info.relres,
+           "fused_launches": launches - f0, "bytes_per_row": brow, "GB/s": bl / (sec / args.steps) / 1e9 if launches > f0 else None}
+    p.close()
+    return out
 
 
 def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
@@ -423,12 +473,12 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
                   measured="20 launches back to back after the timed regions (inside the stepping loop the product is part of the fused launch)",
                   effective_csr={"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / (k1_ms * 1e-3) / 1e9, "frac": csr_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         roof = {"bound": "hbm", "achieved": fbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "fused_step_kernel<16>: x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' "
+                "kernel": "fused_step_kernel<16, 0, %s>: x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' " % ("true" if fbytes_row < 60 else "false") +
                           "with z'.q' of step k + 1, stored as v' = -M^-1 (q' - D z'/dt); 2-D tiles of 16 lines x 128 columns marching through the planes, "
                           "z' tile and U1/U2 ring in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms; first/last plane's products by spmv_dia_kernel",
-                "form": "fused step, v-form (x, z, v in; x_out, z', v' out; 3 upper diagonals; storage codes): %d B per row" % fbytes_row,
+                "form": "fused step, v-form (x, z, v in; x_out, z', v' out; 3 upper diagonals%s; storage codes): %d B per row" % (" as one 16-bit word of codes per row (one conductivity: each diagonal takes a handful of values)" if fbytes_row < 60 else "", fbytes_row),
                 "algorithmic_bytes_per_launch": fbytes,
-                "bytes_model": "every array once (fv_fused_form): 48 n of vectors + 1 n of storage codes + 24 B of matrix per row whose product the kernel forms (+ 8 where the diagonal is streamed); the unfused pair K1 + K2S moves 41 n + 49 n",
+                "bytes_model": "every array once (fv_fused_form): 48 n of vectors + 1 n of storage codes + 24 B of matrix per row whose product the kernel forms (2 B where the matrix comes as codes; + 8 where the diagonal is streamed); the unfused pair K1 + K2S moves 41 n + 49 n",
                 "avg_launch_ms": ms / cnt, "launches": cnt, "spmv": k1}
         tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tfile):
@@ -496,11 +546,11 @@ def multi_iteration_block(p, args):
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
-           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (57 n: z, p in, p', q out, 3 upper diagonals, storage codes) + z-form vector update (56 n)" if loop
+           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (%d n: z, p in, p', q out, the 3 upper diagonals%s, storage codes) + z-form vector update (56 n)" % (loop - 56, " as 16-bit codes" if loop < 100 else "") if loop
                            else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
-    for k, bytes_ in ((("spmv_dot", 57 * p.n), ("update", 56 * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
+    for k, bytes_ in ((("spmv_dot", (loop - 56) * p.n), ("update", 56 * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]
         if kc:
             out["kernels"]["fused_pass" if (loop and k == "spmv_dot") else k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}

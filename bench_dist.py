@@ -12,6 +12,34 @@ import time
 import numpy as np
 
 
+class Watchdog:
+    """A rank stuck in a collective (a peer died, a link is down) never comes back from the library call: after `seconds`
+    without a sign of life this thread says where the rank was and ends the PROCESS with a non-zero code, so that the launcher
+    (bench.py's own, or torch.distributed.run) takes the other ranks down.  Nothing is re-executed: the process just exits."""
+
+    def __init__(self, rank, seconds):
+        import threading
+
+        self.rank, self.seconds, self.stage = rank, seconds, "start"
+        self._beat = time.monotonic()
+        self._stop = threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def beat(self, stage):
+        self.stage, self._beat = stage, time.monotonic()
+
+    def _run(self):
+        while not self._stop.wait(1.0):
+            if time.monotonic() - self._beat > self.seconds:
+                print("bench_dist: rank %d made no progress for %.0f s in stage '%s' (a collective that never completes?); exiting with code 4" %
+                      (self.rank, self.seconds, self.stage), file=sys.stderr, flush=True)
+                os._exit(4)
+
+    def stop(self):
+        self._stop.set()
+
+
 def run_distributed(fv, args, world, rank):
     import torch
     import torch.distributed as dist
@@ -19,6 +47,7 @@ def run_distributed(fv, args, world, rank):
     import bench
     from fvamd import dist as fvdist
 
+    dog = Watchdog(rank, float(os.environ.get("FV_BENCH_COLLECTIVE_TIMEOUT", "300")))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if "FV_BENCH_DEVICE" in os.environ:  # rehearsal on a one-GPU box: several ranks on the same device
         local_rank = int(os.environ["FV_BENCH_DEVICE"])
@@ -40,6 +69,7 @@ def run_distributed(fv, args, world, rank):
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)
 
+    dog.beat("communicator up, building the problem")
     ns = [args.ns] * 3
     mins, maxs = bench.spacing_box(ns)
     dn, src = bench.box_setup(ns)
@@ -60,8 +90,10 @@ def run_distributed(fv, args, world, rank):
     t_setup = time.perf_counter() - t_setup
 
     prob = fv.Problem(blk.handle, ctx)  # a view of the block for the profiling entry points; the block owns the handle
+    dog.beat("warm-up steps")
     if args.warmup > 0:
         blk.run_fixed(args.dt, args.warmup, args.rtol, args.maxiter)
+    dog.beat("timed region")
     if not args.no_profile:
         prob.profile(1)
     ctx.synchronize()
@@ -71,8 +103,23 @@ def run_distributed(fv, args, world, rank):
     ctx.synchronize()
     dist.barrier()
     sec = time.perf_counter() - t0
+    sec_own = sec  # this rank's own clock over the timed region (the headline takes the max over ranks)
     prof = prob.profile_get() if not args.no_profile else None
     prob.profile(False)
+    dog.beat("diagnosis pass")
+    # where a step's time goes on this rank (events around the collectives, the halo wait and the two SpMV passes): 16 more
+    # steps AFTER the timed region, since every event is a barrier between two launches
+    diag = None
+    if not args.no_profile:
+        fvdist.comm_diag(ctx, True)
+        blk.run_fixed(args.dt, 16, args.rtol, args.maxiter)
+        ctx.synchronize()
+        raw = fvdist.comm_diag_get(ctx)
+        fvdist.comm_diag(ctx, False)
+        diag = {k + "_ms_per_step": v[0] / 16 for k, v in raw.items()}
+        diag.update({k + "_per_step": v[1] / 16 for k, v in raw.items()})
+    dist.barrier()
+    dog.beat("gathering")
     tmax = torch.tensor([sec], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     sec = float(tmax[0])
@@ -91,7 +138,8 @@ def run_distributed(fv, args, world, rank):
     ach = form_bytes / (ms * 1e-3) / 1e9
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(rank=rank, rows=blk.nloc, nnz=blk.nnz, halo=blk.nhalo, send=blk.nsend, spmv_ms_in_loop=ms_inloop,
-                                          spmv_ms_back_to_back=ms_b2b, spmv_gbs=ach, update_ms_in_loop=ms_k2, device_ms=dev_ms))
+                                          spmv_ms_back_to_back=ms_b2b, spmv_gbs=ach, update_ms_in_loop=ms_k2, device_ms=dev_ms,
+                                          wall_s_own=sec_own, diagnosis=diag))
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = bench.cpu_baseline(args.dt, args.rtol)  # the other ranks wait at the barrier below
@@ -114,6 +162,7 @@ def run_distributed(fv, args, world, rank):
                 "cells": N, "unknowns": n_total, "nnz": int(sum(g["nnz"] for g in gathered)), "assembly": assembly,
                 "pcg_iters_per_step": float(np.mean(iters)), "last_relres": info.relres, "converged": bool(info.converged),
                 "device": name, "setup_s": t_setup, "per_rank": gathered,
+                "per_rank_diagnosis": "ms per step in 16 extra steps with HIP events around every all-reduce (allreduce), the halo exchange on the second stream (halo_exchange), the compute stream's wait for it (halo_wait) and the interior / boundary SpMV passes; a rank that waits for a slower one shows it in allreduce and halo_wait",
             },
             "roofline": {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / bench.HBM_PEAK_GBS,
                          "traffic": None, "kernel": "PCG SpMV of rank 0's row block: pack + interior pass || halo exchange + boundary pass (%s), per GPU" % prob_form,
@@ -125,6 +174,8 @@ def run_distributed(fv, args, world, rank):
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
+    dog.beat("closing")
     dist.barrier()
     blk.close()
     dist.destroy_process_group()
+    dog.stop()

@@ -114,6 +114,8 @@ SIGNATURES = {
     "fv_comm_init": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p]),
     "fv_comm_destroy": (C.c_int, [c_ctx]),
     "fv_comm_selftest": (C.c_int, [c_ctx, C.c_int64, P(C.c_int)]),
+    "fv_comm_diag": (C.c_int, [c_ctx, C.c_int]),
+    "fv_comm_diag_get": (C.c_int, [c_ctx, P(C.c_double), P(C.c_int64)]),
     "fv_comm_init_local": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
     "fv_param_gradient_integral": (C.c_int, [c_prob, C.c_int64, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),

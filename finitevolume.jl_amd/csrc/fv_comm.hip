@@ -194,11 +194,80 @@ extern "C" int fv_comm_destroy(fv_ctx *ctx)
 // every peer's contribution straight into the halo slots (recv_base, grouped by
 // owner).  One grouped ncclSend/ncclRecv batch on `stream`; over xGMI these are
 // point-to-point transfers between the two neighbouring slabs of a structured grid.
+// ------------------------------------------------------------------ diagnostics of a distributed step
+// Where does a step's time go on a rank that waits for others?  With fv_comm_diag(ctx, 1) every all-reduce, every halo
+// exchange, the compute stream's wait for the halo and the two SpMV passes of a row block are bracketed by HIP events on the
+// stream they run on; fv_comm_diag_get sums them.  An event between two launches is a barrier (~10 us each at 10^8 cells): for
+// a diagnosis pass after the timed region, not for the timed region itself.
+constexpr size_t FV_DIAG_MAX_EVENTS = 1 << 14;
+int fv_diag_mark(fv_ctx *ctx, int cat, hipStream_t stream)
+{
+    if (!ctx->diag || cat < 0 || cat >= 5 || ctx->diag_ev[cat].size() >= FV_DIAG_MAX_EVENTS)
+        return FV_OK;
+    hipEvent_t e;
+    FV_HIP(ctx, hipEventCreate(&e));
+    ctx->diag_ev[cat].push_back(e);
+    FV_HIP(ctx, hipEventRecord(e, stream));
+    return FV_OK;
+}
+
+static int diag_harvest(fv_ctx *ctx)
+{
+    for (int cat = 0; cat < 5; cat++) {
+        std::vector<hipEvent_t> &v = ctx->diag_ev[cat];
+        for (size_t k = 0; k + 1 < v.size(); k += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(v[k + 1]) == hipSuccess && hipEventElapsedTime(&ms, v[k], v[k + 1]) == hipSuccess) {
+                ctx->diag_ms[cat] += ms;
+                ctx->diag_n[cat]++;
+            }
+        }
+        for (hipEvent_t e : v)
+            (void)hipEventDestroy(e);
+        v.clear();
+    }
+    return FV_OK;
+}
+
+extern "C" int fv_comm_diag(fv_ctx *ctx, int enable)
+{
+    if (!ctx)
+        return FV_ERR_ARG;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(diag_harvest(ctx));
+    if (enable)
+        for (int cat = 0; cat < 5; cat++) {
+            ctx->diag_ms[cat] = 0.0;
+            ctx->diag_n[cat] = 0;
+        }
+    ctx->diag = enable != 0;
+    return FV_OK;
+}
+
+extern "C" int fv_comm_diag_get(fv_ctx *ctx, double total_ms[5], int64_t counts[5])
+{
+    if (!ctx || !total_ms || !counts)
+        return FV_ERR_ARG;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(diag_harvest(ctx));
+    for (int cat = 0; cat < 5; cat++) {
+        total_ms[cat] = ctx->diag_ms[cat];
+        counts[cat] = ctx->diag_n[cat];
+    }
+    return FV_OK;
+}
+
 int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream)
 {
     ctx->n_halo++;
     if (d->nranks <= 1)
         return FV_OK;
+    FV_TRY(fv_diag_mark(ctx, 1, stream));
+    struct MarkEnd { // the closing event, on every way out
+        fv_ctx *c;
+        hipStream_t s;
+        ~MarkEnd() { (void)fv_diag_mark(c, 1, s); }
+    } mark_end{ctx, stream};
     if (ctx->local_group && ctx->nranks == d->nranks && ctx->rank == d->rank)
         return local_halo_exchange(ctx, d, sendbuf, recv_base, stream);
     if (!ctx->comm || ctx->nranks != d->nranks || ctx->rank != d->rank) {
@@ -287,12 +356,18 @@ int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count,
     ctx->n_allreduce++; // counted also for one rank (where nothing is sent): the call pattern is what tests look at
     if (d->nranks <= 1 && !(g_comm_single_rank_collectives && ctx->comm && ctx->nranks == 1))
         return FV_OK;
-    if (ctx->local_group && ctx->nranks == d->nranks)
-        return local_allreduce(ctx, d, buf, count, stream);
+    if (ctx->local_group && ctx->nranks == d->nranks) {
+        FV_TRY(fv_diag_mark(ctx, 0, stream));
+        const int rc = local_allreduce(ctx, d, buf, count, stream);
+        FV_TRY(fv_diag_mark(ctx, 0, stream));
+        return rc;
+    }
     if (!ctx->comm || ctx->nranks != d->nranks) {
         fv_set_error(ctx, "distributed problem (%d ranks) without a matching communicator: call fv_comm_init first", d->nranks);
         return FV_ERR_COMM;
     }
+    FV_TRY(fv_diag_mark(ctx, 0, stream));
     FV_NCCL(ctx, ncclAllReduce(buf, buf, (size_t)count, ncclDouble, ncclSum, (ncclComm_t)ctx->comm, stream));
+    FV_TRY(fv_diag_mark(ctx, 0, stream));
     return FV_OK;
 }

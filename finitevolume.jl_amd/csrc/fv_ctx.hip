@@ -136,6 +136,9 @@ extern "C" void fv_ctx_destroy(fv_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     fv_comm_destroy(ctx);
+    for (auto &v : ctx->diag_ev)
+        for (hipEvent_t e : v)
+            (void)hipEventDestroy(e);
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -40,6 +40,12 @@ struct fv_ctx {
     int nranks = 1, rank = 0;
     int64_t n_allreduce = 0, n_halo = 0; // collectives issued through this context (fv_comm_stats)
     int opt_reorder = -1; // FV_OPT_REORDER of this context; -1: the process-wide default (fv_tune key 31)
+    // fv_comm_diag: HIP event pairs around the pieces of a distributed step — [0] all-reduces, [1] the halo exchange on the second
+    // stream, [2] the compute stream's stall at the wait for the halo, [3] interior SpMV pass, [4] boundary pass
+    bool diag = false;
+    std::vector<hipEvent_t> diag_ev[5]; // pairs, in order of recording
+    double diag_ms[5] = {0, 0, 0, 0, 0};
+    int64_t diag_n[5] = {0, 0, 0, 0, 0};
 };
 
 void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
@@ -436,6 +442,8 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
 
 // y = (A_local + sigma D) x with the row block's own columns only: the caller keeps x's halo slots at zero (fv_pcg.hip)
 int fv_dist_local_spmv(fv_problem *p, double *x_with_zero_halo, double *y, double sigma, bool fold, bool want_dot = false);
+// diagnostics (fv_comm_diag): record an event of category `cat` on `stream` (a pair = two consecutive calls)
+int fv_diag_mark(fv_ctx *ctx, int cat, hipStream_t stream);
 // ---- fv_comm.hip (RCCL); all are no-ops for a single rank
 int fv_comm_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *sendbuf, double *recv_base, hipStream_t stream);
 int fv_comm_allreduce_sum(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream);

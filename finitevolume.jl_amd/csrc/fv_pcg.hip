@@ -1506,7 +1506,9 @@ static int dist_exchange_wait(fv_problem *p)
 {
     if (p->dist->nranks <= 1)
         return FV_OK;
+    FV_TRY(fv_diag_mark(p->ctx, 2, p->ctx->stream)); // (diagnosis: how long the compute stream stalls here)
     FV_HIP(p->ctx, hipStreamWaitEvent(p->ctx->stream, p->ctx->ev_halo, 0));
+    FV_TRY(fv_diag_mark(p->ctx, 2, p->ctx->stream));
     return FV_OK;
 }
 
@@ -1607,11 +1609,16 @@ static int dist_spmv(fv_problem *p, double *xext, double *y, double sigma, const
     int na = 0, nb = 0;
     if (!skip_exchange)
         FV_TRY(dist_exchange_begin(p, xext));
+    FV_TRY(fv_diag_mark(ctx, 3, ctx->stream));
     FV_TRY(spmv_apply(p, xext, y, sigma, folded, mode, want_dot ? p->part_pq.p : nullptr, nullptr, use_done, &na, &interior));
+    FV_TRY(fv_diag_mark(ctx, 3, ctx->stream));
     if (!skip_exchange)
         FV_TRY(dist_exchange_wait(p));
-    if (d->n_bnd > 0)
+    if (d->n_bnd > 0) {
+        FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
         FV_TRY(spmv_apply(p, xext, y, sigma, folded, mode, want_dot ? p->part_pq.p + na : nullptr, nullptr, use_done, &nb, &boundary));
+        FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
+    }
     if (want_dot && npq_out)
         *npq_out = na + nb;
     else if (want_dot) {

@@ -38,6 +38,20 @@ def comm_stats(ctx, reset=False):
     return a.value, h.value
 
 
+def comm_diag(ctx, enable=True):
+    """fv_comm_diag: bracket the collectives, the halo wait and the two SpMV passes of a row block with HIP events."""
+    ctx.check(load().fv_comm_diag(ctx.handle, int(bool(enable))))
+
+
+def comm_diag_get(ctx):
+    """-> {name: (total ms, pairs)} for allreduce, halo_exchange, halo_wait, interior_spmv, boundary_spmv (fv_comm_diag_get)."""
+    ms = (C.c_double * 5)()
+    cnt = (C.c_int64 * 5)()
+    ctx.check(load().fv_comm_diag_get(ctx.handle, ms, cnt))
+    names = ("allreduce", "halo_exchange", "halo_wait", "interior_spmv", "boundary_spmv")
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(names)}
+
+
 def comm_init_local(ctx, nranks, rank, group_id=0):
     """Loopback transport: `nranks` threads of this process, one context each on the same device (rehearsals/tests)."""
     ctx.check(load().fv_comm_init_local(ctx.handle, int(nranks), int(rank), int(group_id)))

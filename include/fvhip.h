@@ -291,6 +291,13 @@ int fv_comm_destroy(fv_ctx *ctx);
  * reset != 0 zeroes the counters.  For tests of the collective pattern: two all-reduces per PCG iteration in the classic
  * form, one in the one-reduction form (fv_tune key 34), one per step in the one-iteration regime. */
 int fv_comm_stats(fv_ctx *ctx, int64_t *allreduces, int64_t *halo_exchanges, int reset);
+/* Where a distributed step's time goes on this rank: enable = 1 brackets, from now on, every all-reduce [0], every halo exchange
+ * (on the second stream) [1], the compute stream's wait for the halo [2] and the interior [3] / boundary [4] SpMV passes of a row
+ * block with HIP events and zeroes the sums; fv_comm_diag_get returns milliseconds and pair counts per category so far.  A rank
+ * that waits for a slower one shows it in [0] and [2].  An event between two launches is a barrier: run a few steps with it
+ * after the timed region, not inside it.  enable = 0 stops recording (the sums stay readable). */
+int fv_comm_diag(fv_ctx *ctx, int enable);
+int fv_comm_diag_get(fv_ctx *ctx, double total_ms[5], int64_t counts[5]);
 /* Health check of the RCCL transport, to run once after fv_comm_init on every rank: a ring of ncclSend/ncclRecv (the halo
  * exchange's call pattern, on the halo stream) and an ncclAllReduce of `count` doubles; *ok = 1 when the data arrived. */
 int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok);
