@@ -2063,7 +2063,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
                 // step's scalars
                 FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 6, ctx->stream));
                 const BoundarySums bs{red + 1, red + 2, red + 3, red + 4, red + 5, 1, 1, 1};
-                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
+                hipLaunchKernelGGL(pcg_chain_boundary_kernel, dim3(Gv < 128 ? Gv : 128), dim3(FV_BLOCK), 0, ctx->stream, n, p->r.p, (const double *)p->minv.p,
                                    p->pnext.p, bs, rtol, p->scal.p, carry_prev, (const double *)u, (const double *)p->D.p, dt,
                                    chain_index - 1, (chain_index - 1 == g_chain_test_break) ? 1 : 0, prev_z);
                 FV_LAUNCH_CHECK(ctx);

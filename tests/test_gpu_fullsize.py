@@ -466,7 +466,7 @@ def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
     import os as _os
 
     root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
-    common = [sys.executable, _os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs",
+    common = [sys.executable, _os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs",
               "--no-multi-iteration", "--no-hetero"]
     env = {k: v for k, v in _os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
 
@@ -480,7 +480,7 @@ def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
     plain = run({"FV_TUNE": "41=0"})
     blocks = run({"FV_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"})
     print("one rank through the row-block driver %.3f ms per step, the plain loop (K1 + K2S) %.3f" % (blocks["ms_per_step"], plain["ms_per_step"]))
-    assert blocks["n_gpus"] == 1 and abs(blocks["value"] / plain["value"] - 1.0) < 0.05
+    assert blocks["n_gpus"] == 1 and abs(blocks["value"] / plain["value"] - 1.0) < 0.06
     d = blocks["config"]["per_rank"][0]["diagnosis"]
     # (one rank: nothing travels — no all-reduce is issued, no halo is waited for —, the passes are timed)
     assert d["interior_spmv_per_step"] >= 1 and d["interior_spmv_ms_per_step"] > 0 and d["halo_wait_ms_per_step"] == 0.0 and d["allreduce_ms_per_step"] == 0.0

@@ -1098,10 +1098,15 @@ def _run_ranks_in_threads(fv, nranks, group_id, make_problem, schedule, rtol, by
             blk = dist.RowBlock(p, nranks, rank, bounds)
             p.close()
             its = []
+            dist.comm_diag(ctx, True)  # (events around the collectives and passes: must not change a bit of the result)
             for dt, nsteps in schedule:
                 it, info, _ = blk.run_fixed(dt, nsteps, rtol)
                 assert info.converged
                 its.append(it.copy())
+            diag = dist.comm_diag_get(ctx)
+            dist.comm_diag(ctx, False)
+            assert diag["allreduce"][1] > 0 and diag["halo_exchange"][1] == diag["halo_wait"][1] > 0 and diag["interior_spmv"][1] > 0, diag
+            assert all(ms >= 0.0 for ms, _ in diag.values())
             out[rank] = (blk.lo, blk.hi, blk.state(), np.concatenate(its))
             blk.close()
             fv.load().fv_comm_destroy(ctx.handle)
