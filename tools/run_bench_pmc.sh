@@ -3,7 +3,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
-ARGS="--steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-other-configs --no-multi-iteration"
+ARGS="--steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-other-configs --no-multi-iteration --no-hetero"
 rm -rf $O/bpmc_rd $O/bpmc_wr $O/bpmc_sq
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/bpmc_rd -- python3 $R/bench.py $ARGS > $O/bpmc_rd.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/bpmc_wr -- python3 $R/bench.py $ARGS > $O/bpmc_wr.log 2>&1
