@@ -119,6 +119,7 @@ SIGNATURES = {
     "fv_comm_init_local": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
     "fv_param_gradient_integral": (C.c_int, [c_prob, C.c_int64, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+    "fv_param_jacobian_apply": (C.c_int, [c_prob, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     "fv_dist_setup_bounds": (C.c_int, [c_prob, C.c_int, C.c_int, _i64p, P(c_prob)]),
     "fv_problem_create_regulargrid_slab": (C.c_int, [c_ctx, _f64p, _f64p, _i64p, C.c_int64, _i64p, C.c_int64, C.c_int64, P(c_prob)]),
     "fv_problem_free_rows_before": (C.c_int, [c_prob, C.c_int64, P(C.c_int64)]),

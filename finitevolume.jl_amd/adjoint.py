@@ -102,7 +102,7 @@ def gradientintegrate(lambdac_or_lambda0, du0dp, dgdp, dfdp_or_integral, tspan, 
 
         def dfdp_lambda(t):
             M = dfdp(t)
-            if not hasattr(M, "tocsr"):  # dense array; scipy sparse matrices multiply as they are
+            if not hasattr(M, "tocsr") and not isinstance(M, DeviceJacobian):  # dense array; scipy sparse matrices and device Jacobians multiply as they are
                 M = np.asarray(M)
             return np.asarray(M @ np.asarray(lambdac(t))).ravel()
 
@@ -164,8 +164,34 @@ def _parameter_jacobians(ueval_free, neighbors, areasoverlengths, conductivities
     return M, freenode, n2f
 
 
+class DeviceJacobian:
+    """dfdp(u, t, p) of transientadjointutils.jl:23-30 — the (np x nfree) matrix (b_p - A_px)' scaled by the storage term — held
+    as what it does: `J @ lam` is computed on the device (fv_param_jacobian_apply: one thread per face) and summed over the faces
+    of each parameter on the host, without forming the matrix.  What gradientintegrate needs of it (`dfdp(t) * lambdac(t)`,
+    transient.jl:208-219)."""
+
+    def __init__(self, problem, ueval_free, maps, scale, logtransformconductivity):
+        self.problem, self.ueval, self.maps, self.scale, self.log = problem, ueval_free, maps, scale, logtransformconductivity
+        self.shape = (maps["np"], len(ueval_free))
+
+    def __matmul__(self, lam):
+        mp = self.maps
+        w = af64(lam) * self.scale  # the reference's scaling by the FREE index (see getadjointfunctions)
+        face_k, face_dir, row_src = self.problem.param_jacobian_apply(self.ueval, w, False, self.log)
+        out = np.zeros(mp["np"])
+        out[: mp["nK"]] = np.bincount(mp["m"], weights=face_k, minlength=mp["nK"])
+        out[mp["nK"] + mp["free_nodes0"]] = row_src
+        for sel, pos in mp["dir_terms"]:
+            out[mp["nK"] + mp["N"] :] += np.bincount(pos, weights=face_dir[sel], minlength=mp["ndir"])
+        return out
+
+    dot = __matmul__
+
+
 def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, **kwargs):
-    """transientadjointutils.jl:1-55 -> g, dgdu, dfdp, dgdp, du0dp, G."""
+    """transientadjointutils.jl:1-55 -> g, dgdu, dfdp, dgdp, du0dp, G.  device=True (keyword): dfdp(u, t, p) returns a
+    DeviceJacobian — its product with lambda runs on the GPU — instead of a scipy matrix."""
+    on_device = bool(kwargs.pop("device", False))
     import scipy.sparse as sp
     from scipy.integrate import quad
 
@@ -193,7 +219,34 @@ def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neigh
         p = af64(p)
         return p[:nK], p[nK : nK + N], p[nK + N : nK + N + ndir]
 
+    device_state = {}
+
+    def dfdp_device(u, t, p):
+        from .core import Problem, _metaindex_array, _split_neighbors, getnodei2dirichleti
+
+        pK, ps, pd = split(p)
+        key = (pK.tobytes(), pd.tobytes())
+        if device_state.get("key") != key:  # one problem per parameter vector: the conductances and heads live on the device
+            if "problem" in device_state:
+                device_state["problem"].close()
+            n1, n2 = _split_neighbors(neighbors)
+            F = len(n1)
+            mi = _metaindex_array(metaindex, F)
+            n2d = getnodei2dirichleti(np.zeros(N), dirichletnodes)
+            a, b = n1 - 1, n2 - 1
+            dir_terms = []
+            for fr, di in ((a, b), (b, a)):
+                sel = freenodes[fr] & ~freenodes[di]
+                dir_terms.append((sel, n2d[di[sel]] - 1))
+            device_state.update(key=key, problem=Problem.create(neighbors, areasoverlengths, N, dirichletnodes).assemble(pK, np.zeros(N), pd, metaindex, logtransformconductivity),
+                                maps=dict(np=nK + N + ndir, nK=nK, N=N, ndir=ndir, m=(mi - 1) if mi is not None else np.arange(F),
+                                          free_nodes0=np.nonzero(freenodes)[0], dir_terms=dir_terms))
+        ueval = np.ascontiguousarray(np.asarray(u(t))[freenodes])
+        return DeviceJacobian(device_state["problem"], ueval, device_state["maps"], 1.0 / vols[:nfree], logtransformconductivity)
+
     def dfdp(u, t, p):
+        if on_device:
+            return dfdp_device(u, t, p)
         pK, ps, pd = split(p)
         ueval = np.asarray(u(t))[freenodes]
         M, _, _ = _parameter_jacobians(ueval, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, logtransformconductivity)

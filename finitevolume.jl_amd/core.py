@@ -354,6 +354,17 @@ class Problem:
                                                      int(bool(logtransformconductivity)), ptr(fk), ptr(fd), ptr(rs)))
         return fk, fd, rs
 
+    def param_jacobian_apply(self, x_free, lam_free, scale_by_storage=False, logtransformconductivity=False):
+        """fv_param_jacobian_apply: (b_p - A_p u)' w at one time -> per-face K terms, per-face Dirichlet-head terms, per-free-row
+        source terms (the action of the pointwise dfdp(u, t, p)' on w)."""
+        x, lam = af64(x_free), af64(lam_free)
+        if x.shape != (self.n,) or lam.shape != (self.n,):
+            raise FVError(_lib.FV_ERR_ARG, "x_free and lam_free must have n entries")
+        fk, fd, rs = np.empty(self.F), np.empty(self.F), np.empty(self.n)
+        self.check(load().fv_param_jacobian_apply(self.handle, ptr(x), ptr(lam), int(bool(scale_by_storage)), int(bool(logtransformconductivity)),
+                                                  ptr(fk), ptr(fd), ptr(rs)))
+        return fk, fd, rs
+
     def new_state(self):
         s = C.c_int32()
         self.check(load().fv_state_alloc(self.handle, C.byref(s)))

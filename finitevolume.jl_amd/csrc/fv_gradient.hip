@@ -93,7 +93,87 @@ __global__ __launch_bounds__(FV_BLOCK) void gradient_row_kernel(int64_t n, int k
     row_src[f] = accumulate ? row_src[f] + acc : acc;
 }
 
+// The same terms at ONE time: (b_p - A_p u)' w per face / free row — the action of the pointwise Jacobian dfdp(u, t, p)' on a vector
+// (transientadjointutils.jl:23-30: assembleb_p - assembleA_px, scaled by the storage term), for callers that run their own
+// quadrature over dfdp(t) * lambda(t) (transient.jl:208-219).
+__global__ __launch_bounds__(FV_BLOCK) void jacobian_face_kernel(int64_t F, const double *__restrict__ X, const double *__restrict__ L,
+                                                                  const double *__restrict__ D, const int32_t *__restrict__ node1,
+                                                                  const int32_t *__restrict__ node2, const int32_t *__restrict__ nodemap,
+                                                                  const double *__restrict__ cond, const double *__restrict__ aol,
+                                                                  const double *__restrict__ dheads, int logtransform, double *__restrict__ face_k,
+                                                                  double *__restrict__ face_dir)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= F)
+        return;
+    const int32_t na = node1[i], nb = node2[i];
+    const int32_t a = nodemap[na], b = nodemap[nb];
+    double gk = 0.0, gd = 0.0;
+    if (na != nb && (a >= 0 || b >= 0)) {
+        const double c = cond[i];
+        const double dc = logtransform ? c : aol[i];
+        if (a >= 0 && b >= 0) {
+            const double sa = D ? 1.0 / D[a] : 1.0, sb = D ? 1.0 / D[b] : 1.0;
+            gk = -dc * ((X[a] - X[b]) * (L[a] * sa - L[b] * sb));
+        } else {
+            const int32_t f = a >= 0 ? a : b;
+            const double H = dheads[-(a >= 0 ? b : a) - 1];
+            const double w = L[f] * (D ? 1.0 / D[f] : 1.0);
+            gk = dc * ((H - X[f]) * w);
+            gd = c * w;
+        }
+    }
+    face_k[i] = gk;
+    face_dir[i] = gd;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void jacobian_row_kernel(int64_t n, const double *__restrict__ L, const double *__restrict__ D,
+                                                                 double *__restrict__ row_src)
+{
+    const int64_t f = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (f < n)
+        row_src[f] = L[f] * (D ? 1.0 / D[f] : 1.0);
+}
+
 } // namespace
+
+extern "C" int fv_param_jacobian_apply(fv_problem *p, const double *x_free, const double *lam_free, int scale_by_storage, int logtransform,
+                                       double *face_k, double *face_dir, double *row_src)
+{
+    if (!p || !x_free || !lam_free || !face_k || !face_dir || !row_src)
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    if (!p->assembled || p->from_csc || p->dist) {
+        fv_set_error(ctx, "fv_param_jacobian_apply: needs a mesh problem after fv_assemble (not a CSC import or a row block)");
+        return FV_ERR_STATE;
+    }
+    if (scale_by_storage && !p->transient_ready) {
+        fv_set_error(ctx, "fv_param_jacobian_apply: the D^-1 scaling needs fv_transient_begin (Ss, volumes)");
+        return FV_ERR_STATE;
+    }
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    const int64_t n = p->n, F = p->F;
+    DevBuf<double> X, L, gk, gd, gs;
+    FV_TRY(X.alloc(ctx, (size_t)n));
+    FV_TRY(L.alloc(ctx, (size_t)n));
+    FV_TRY(gk.alloc(ctx, (size_t)F));
+    FV_TRY(gd.alloc(ctx, (size_t)F));
+    FV_TRY(gs.alloc(ctx, (size_t)n));
+    FV_TRY(fv_free_in(p, X.p, x_free)); // (the caller's numbering of the free cells)
+    FV_TRY(fv_free_in(p, L.p, lam_free));
+    const double *D = scale_by_storage ? p->D.p : nullptr;
+    if (F > 0)
+        hipLaunchKernelGGL(jacobian_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, (const double *)X.p, (const double *)L.p, D,
+                           (const int32_t *)p->node1.p, (const int32_t *)p->node2.p, (const int32_t *)p->nodemap.p, (const double *)p->cond.p,
+                           (const double *)p->aol.p, (const double *)p->dheads.p, logtransform ? 1 : 0, gk.p, gd.p);
+    if (n > 0)
+        hipLaunchKernelGGL(jacobian_row_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)L.p, D, gs.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipMemcpyAsync(face_k, gk.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipMemcpyAsync(face_dir, gd.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return fv_free_out(p, row_src, gs.p);
+}
 
 extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const double *ts, const double *x_knots, const double *lam_knots,
                                           int scale_by_storage, int logtransform, double *face_k, double *face_dir, double *row_src)

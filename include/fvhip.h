@@ -203,6 +203,11 @@ int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfi
  * Uses the conductances and heads of the last fv_assemble; scale_by_storage needs fv_transient_begin. */
 int fv_param_gradient_integral(fv_problem *p, int64_t nt, const double *ts, const double *x_knots, const double *lam_knots,
                                int scale_by_storage, int logtransform, double *face_k, double *face_dir, double *row_src);
+/* The same per-face / per-row terms at ONE time: the action of the pointwise parameter Jacobian dfdp(u, t, p)' = (b_p - A_p u)' D^-1
+ * (src/transientadjointutils.jl:23-30: assembleb_p - assembleA_px, then scalebyvolume!) on a free-indexed vector lam, for callers that
+ * hand dfdp(t) * lambda(t) to their own quadrature (src/transient.jl:208-219).  x_free, lam_free: n doubles each; outputs as above. */
+int fv_param_jacobian_apply(fv_problem *p, const double *x_free, const double *lam_free, int scale_by_storage, int logtransform,
+                            double *face_k, double *face_dir, double *row_src);
 
 /* ---------------------------------------------------------------- kernel-level entry points (parity tests, roofline) */
 /* y = (A + sigma*D) x on n free unknowns */

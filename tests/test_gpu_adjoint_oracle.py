@@ -75,3 +75,16 @@ def test_adjoint_functions_and_gradient_integrals_match_the_oracle(fv, oracle, o
     odG = oa.gradientintegrate(olam, odu0dp, lambda t: odgdp(ouc, t, p0), lambda t: odfdp(ouc, t, p0), c["tspan"], knots=ts_i)
     dG = fv.gradientintegrate(lambdas[0], du0dp, lambda t: dgdp(uc, t, p0), got, c["tspan"])
     assert np.abs(dG - odG).max() <= 1e-10 * np.abs(odG).max()
+    # the POINTWISE Jacobian on the device (getadjointfunctions(..., device=True): dfdp(u, t, p) as a DeviceJacobian whose product
+    # with a vector is fv_param_jacobian_apply) against the oracle's dfdp matrix applied to the same vectors
+    _, _, dfdp_dev, _, _, _ = fv.getadjointfunctions(sigma, obsfree, uobs, c["u0"], c["tspan"], *mesh_fv, c["K"], *rest, device=True, **kw)
+    rng = np.random.default_rng(4)
+    for t in (0.0, 1.234e4, 4.0e4):
+        J, oM = dfdp_dev(uc, t, p0), odfdp(ouc, t, p0)
+        assert J.shape == oM.shape
+        for vec in (np.asarray(olam(t)), rng.standard_normal(oM.shape[1])):
+            assert np.abs(J @ vec - oM @ vec).max() <= 1e-12 * np.abs(oM @ vec).max()
+    # ... and through gradientintegrate's own quadrature of dfdp(t) * lambdac(t)
+    lamc = fv.getcontinuoussolution(lambdas, ts_l)
+    dG2 = fv.gradientintegrate(lamc, du0dp, lambda t: dgdp(uc, t, p0), lambda t: dfdp_dev(uc, t, p0), c["tspan"])
+    assert np.abs(dG2 - odG).max() <= 1e-6 * np.abs(odG).max()  # (adaptive Gauss-Kronrod on the host against the oracle's exact pieces)

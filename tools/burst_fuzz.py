@@ -44,8 +44,12 @@ def run(fv, nseeds=12, tight=False, verbose=True):
             out[name] = (st.free_values(), np.concatenate(its))
             p.close()
         ref = out["polled"]
+        # where the fused step runs (tile-sized boxes) a burst does its steps by another kernel than a polled step: same
+        # iteration counts, states to rounding (FV_FUZZ_RTOL, default 1e-11 of the heads); elsewhere bit for bit
+        loose = float(os.environ.get("FV_FUZZ_RTOL", "1e-11")) if os.environ.get("FV_FUZZ_TILE") else 0.0
         for name, (state, its) in out.items():
-            if not (np.array_equal(state, ref[0]) and np.array_equal(its, ref[1])):
+            same = np.array_equal(state, ref[0]) if loose == 0.0 else np.abs(state - ref[0]).max() <= loose * np.abs(ref[0]).max()
+            if not (same and np.array_equal(its, ref[1])):
                 bad += 1
                 d = np.nonzero(its != ref[1])[0]
                 print("seed %d %s: MISMATCH max |diff| %.3e, first differing step %s, schedule %s" % (seed, name, np.abs(state - ref[0]).max(), d[:3], schedule), flush=True)
