@@ -232,8 +232,8 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * than 50 iterations, the V-cycle from the next step on (large time steps). */
 #define FV_PRECOND_AUTO 2
 int fv_precond_set(fv_problem *p, int kind);
-/* theta: strength threshold of the matching (0.25); omega: Jacobi damping of the smoother (2/3); passes: pairwise
- * passes per level (3 -> aggregates of ~8-10); rounds: handshake rounds per pass (6).  Process-wide. */
+/* theta: strength threshold of the matching (0.10); omega: Jacobi damping of the smoother (0.85); passes: pairwise
+ * passes per level (3 -> aggregates of ~8-10); rounds: handshake rounds per pass (10).  Process-wide. */
 int fv_amg_configure(double theta, double omega, int passes, int rounds);
 /* Builds the hierarchy if needed; rows[l], nnz[l] for l < min(*nlevels, cap). */
 int fv_amg_info(fv_problem *p, int32_t *nlevels, int64_t *rows, int64_t *nnz, int32_t cap);
