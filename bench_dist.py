@@ -98,12 +98,15 @@ def run_distributed(fv, args, world, rank):
         prob.profile(2)  # event pairs around the block SpMV only, as in the single-GPU loop (every event is a barrier between two launches)
     ctx.synchronize()
     dist.barrier()
+    fused_before = blk.fused_form()[0]
     t0 = time.perf_counter()
     iters, info, dev_ms = blk.run_fixed(args.dt, args.steps, args.rtol, args.maxiter)
     ctx.synchronize()
     dist.barrier()
     sec = time.perf_counter() - t0
     sec_own = sec  # this rank's own clock over the timed region (the headline takes the max over ranks)
+    fused_launches, fused_row_bytes, fused_bytes = blk.fused_form()
+    fused_launches -= fused_before
     prof = prob.profile_get() if not args.no_profile else None
     prob.profile(False)
     if prof is not None:  # the vector pass: 16 more steps with all event pairs on
@@ -140,10 +143,15 @@ def run_distributed(fv, args, world, rank):
     finally:
         prob.handle = None
     ms = ms_inloop if ms_inloop else ms_b2b
-    ach = form_bytes / (ms * 1e-3) / 1e9
+    # the one-iteration regime on blocks of whole planes runs the fused step (fv_fused.hip): the event pairs then bracket the
+    # whole step on the block — send-row pack, fused launch || halo exchange, boundary products, their conversion
+    fused = bool(ms_inloop) and fused_launches >= 0.8 * args.steps
+    step_bytes = fused_bytes if fused else form_bytes
+    ach = step_bytes / (ms * 1e-3) / 1e9
     gathered = [None] * world
     dist.all_gather_object(gathered, dict(rank=rank, rows=blk.nloc, nnz=blk.nnz, halo=blk.nhalo, send=blk.nsend, spmv_ms_in_loop=ms_inloop,
                                           spmv_ms_back_to_back=ms_b2b, spmv_gbs=ach, update_ms_in_loop=ms_k2, device_ms=dev_ms,
+                                          fused_launches=fused_launches, fused_bytes_per_row=fused_row_bytes if fused else None,
                                           wall_s_own=sec_own, diagnosis=diag))
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -164,14 +172,17 @@ def run_distributed(fv, args, world, rank):
             "data": "synthetic",
             "config": {
                 "workload": "synthetic %d^3 box (%.3g cells), transient, fixed dt=%gs, Jacobi-PCG rtol %.0e, contiguous row blocks (x-slabs) over %d GPUs, RCCL halo exchange + one merged 6-double all-reduce per one-iteration step (two per PCG iteration otherwise)" % (args.ns, N, args.dt, args.rtol, world),
+                "step_form": "fused step on every row block (fv_fused.hip)" if fused else "K1 + K2S per step",
                 "cells": N, "unknowns": n_total, "nnz": int(sum(g["nnz"] for g in gathered)), "assembly": assembly,
                 "pcg_iters_per_step": float(np.mean(iters)), "last_relres": info.relres, "converged": bool(info.converged),
                 "device": name, "setup_s": t_setup, "per_rank": gathered,
                 "per_rank_diagnosis": "ms per step in 16 extra steps with HIP events around every all-reduce (allreduce), the halo exchange on the second stream (halo_exchange), the compute stream's wait for it (halo_wait) and the interior / boundary SpMV passes; a rank that waits for a slower one shows it in allreduce and halo_wait",
             },
             "roofline": {"bound": "hbm", "achieved": ach, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / bench.HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "PCG SpMV of rank 0's row block: pack + interior pass || halo exchange + boundary pass (%s), per GPU" % prob_form,
-                         "algorithmic_bytes_per_launch": form_bytes, "avg_launch_ms": ms,
+                         "traffic": None,
+                         "kernel": ("fused step of rank 0's row block: z' of the send rows -> halo exchange || fused_step_kernel (vector update of step k + product of step k + 1 on the interior window) -> boundary products + v-form conversion, per GPU"
+                                    if fused else "PCG SpMV of rank 0's row block: pack + interior pass || halo exchange + boundary pass (%s), per GPU" % prob_form),
+                         "algorithmic_bytes_per_launch": step_bytes, "avg_launch_ms": ms,
                          "timing": "HIP events around every live launch set inside the timed region (includes the wait for the halo)" if ms_inloop else "back-to-back launches after the timed region",
                          "effective_csr": {"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / (ms * 1e-3) / 1e9, "frac": csr_bytes / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS,
                                            "note": "SURVEY 8d CSR accounting 12 nnz + 20 n; the storage form moves fewer bytes, so this can exceed the hardware rate"}},

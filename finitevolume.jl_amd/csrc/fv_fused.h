@@ -13,13 +13,17 @@ struct FusedSums {
     int nvec, nbb, npq;
 };
 
-extern int g_fused;
+extern int g_fused, g_fused_dist, g_fused_dist_spare;
 bool fv_fused_applicable(fv_problem *p, double sigma);
 int fv_fused_prepare(fv_problem *p);
 FusedSums fv_fused_sums(fv_problem *p, int parity);
 int fv_fused_enter(fv_problem *p, double sigma);
 int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
-                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums);
+                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums, const double *red = nullptr);
+// row blocks (red: the six all-reduced sums, see fused_step_kernel): the z' the neighbours need into the send buffer
+// before the launch; the boundary groups' classic products (left in p->qv2) into the v-form after it
+int fv_fused_pack(fv_problem *p, const double *red, int mode, int chain_index, bool force_prev_unconverged, double rtol);
+int fv_fused_convert_groups(fv_problem *p, const int32_t *groups, int64_t count, double sigma);
 // fv_spmv.hip: y = A x (values with the shift folded in) over the slices the symmetric form leaves to the slice-by-slice
 // kernel, partial x.y per block; use_done: a no-op once the solve's done flag is set
 int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done = false);

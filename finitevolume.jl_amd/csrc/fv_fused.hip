@@ -37,6 +37,8 @@ int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per t
 int g_fused_codes = 1;  // fv_tune key 49: the matrix as 16-bit codes per row where its diagonals take few distinct values (0: always the doubles)
 int g_fused_iter = 1;   // fv_tune key 46: the many-iteration loop through the fused kernel too (direction update + product in one pass, z kept instead of r)
 int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
+int g_fused_dist_spare = 1; // fv_tune key 51: CUs per XCD a row block's fused launch leaves to the halo exchange
+int g_fused_dist = 1;  // fv_tune key 50: the fused step on row blocks too (0: row blocks keep the K1 + K2S pair)
 int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
                         // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
 
@@ -69,6 +71,8 @@ struct KfArgs {
     int chain_index; // index of this step in its burst
     int force_prev_unconverged;
     double rtol;
+    const double *red; // row blocks: the six sums all-reduced over the ranks — [0] z.q, [1] r.M^-1 r, [2] r.r of the previous step, [3..5] this
+                       // step's rho.z, rho.rho, rhs.rhs — instead of the previous launch's partial sums (null: single GPU)
     double *hist;     // MODE 1: residual history (may be null) and its capacity; chain_index = the iteration the vector pass finished
     int64_t hist_cap;
     // fall-back of the previous step (mode 1): see pcg_chain_boundary_kernel
@@ -170,13 +174,15 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         return; // the chain broke at an earlier step (the exception: block 0 of THIS launch has just said so)
     double rz0;
     bool zero_iteration;
+    // a sum of the previous launch: its partial pieces, or (row blocks) the value all-reduced over the ranks
+    auto total = [&](int which, const double *part, int count) -> double { return a.red ? a.red[which] : kf_reduce<NT>(part, count, red); };
     if (a.mode == 1) {
         // the previous chained step's verdict
-        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
+        const double rrn = total(2, a.in.arr, a.in.nvec);
         const bool converged = rrn <= scal->tol2x[(a.chain_index - 1) & 1] && !a.force_prev_unconverged;
         if (!converged) {
             // as pcg_chain_boundary_kernel: that step's residual without the next step's storage term, p = M^-1 r + beta p
-            const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
+            const double rzn = total(1, a.in.arz, a.in.nvec);
             const double beta = rzn / scal->rz[0];
             const int64_t n2 = a.n >> 1;
             double2 *r2 = reinterpret_cast<double2 *>(a.r);
@@ -214,9 +220,9 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             }
             return;
         }
-        rz0 = kf_reduce<NT>(a.in.srz, a.in.nvec, red);
-        const double rr0 = kf_reduce<NT>(a.in.srr, a.in.nvec, red);
-        const double bb = kf_reduce<NT>(a.in.sbb, a.in.nbb, red);
+        rz0 = total(3, a.in.srz, a.in.nvec);
+        const double rr0 = total(4, a.in.srr, a.in.nvec);
+        const double bb = total(5, a.in.sbb, a.in.nbb);
         const double tol2 = a.rtol * a.rtol * bb;
         zero_iteration = rr0 <= tol2;
         if (blockIdx.x == 0 && tid == 0) {
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         zero_iteration = d0 == 1; // converged at its set-up (pcg_init_finalize_kernel said so)
     }
     if (!zero_iteration) {
-        const double pq = kf_reduce<NT>(a.in.pq, a.in.npq, red);
+        const double pq = total(0, a.in.pq, a.in.npq);
         if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
             if (blockIdx.x == 0 && tid == 0) {
                 scal->pq = pq;
@@ -624,18 +630,68 @@ __global__ __launch_bounds__(FV_BLOCK) void q_to_v_slices_kernel(int64_t n, int6
         v[i] = -(minv[i] * (v[i] - (sigma * D[i]) * z[i])); // (in place: the slice-by-slice launch left q there)
 }
 
+// Row blocks: z' = z + alpha v of the rows the neighbouring ranks need, straight into the send buffer BEFORE the fused
+// launch, so that the halo exchange travels while that launch runs (a v-form halo row costs two loads and one FMA here
+// as well).  Every thread takes the launch's own decisions from the same all-reduced sums (fused_step_kernel's prologue
+// with a.red): whenever the launch will stop short of its pass, nothing is packed (the exchange then ships stale, finite
+// values nobody uses).
+__global__ __launch_bounds__(FV_BLOCK) void fused_pack_kernel(int64_t nsend, const int32_t *__restrict__ idx, const double *__restrict__ z,
+                                                               const double *__restrict__ v, const double *__restrict__ red,
+                                                               const PcgScalars *__restrict__ scal, int mode, int chain_index, int force_prev_unconverged,
+                                                               double rtol, double *__restrict__ buf)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= nsend)
+        return;
+    const int d0 = *reinterpret_cast<const volatile int32_t *>(&scal->done);
+    if (d0 == 2 || d0 == 3)
+        return;
+    double rz0;
+    bool zero_iteration;
+    if (mode == 1) {
+        const bool converged = red[2] <= scal->tol2x[(chain_index - 1) & 1] && !force_prev_unconverged;
+        if (!converged)
+            return;
+        rz0 = red[3];
+        const double tol2 = rtol * rtol * red[5];
+        zero_iteration = red[4] <= tol2;
+    } else {
+        rz0 = scal->rz[0];
+        zero_iteration = d0 == 1;
+    }
+    double alpha = 0.0;
+    if (!zero_iteration) {
+        const double pq = red[0];
+        if (!(pq > 0.0))
+            return;
+        alpha = rz0 / pq;
+    }
+    const int32_t r = idx[i];
+    buf[i] = z[r] + alpha * v[r];
+}
+
 } // namespace
 
 // Can the chained step of this problem run fused?  (The symmetric tiled form serves the operator — the classic K1 of the
 // step that enters the regime has just established that —, the shift is folded, D comes as codes, M^-1 > 0.)
 bool fv_fused_applicable(fv_problem *p, double sigma)
 {
-    if (!g_fused || p->dist || p->nhalo > 0 || p->sym_state != 1 || p->last_form != FV_SPMV_SYM_TILE)
+    if (!g_fused || (!p->dist && p->nhalo > 0) || p->sym_state != 1 || p->last_form != FV_SPMV_SYM_TILE)
         return false;
     if (p->sym_epoch != p->assemble_epoch || p->sym_tag != sigma || sigma == 0.0)
         return false;
     if (p->dcode_n <= 0 || p->dcode_epoch != p->storage_epoch)
         return false;
+    if (p->dist) {
+        // a row block: whole planes, the symmetric form on its interior window, every other interior slice and the boundary
+        // slices by the slice-by-slice / CSR launches behind the fused one (their partial sums must fit behind its own)
+        const fv_dist *d = p->dist;
+        if (!g_fused_dist || !d->split_built || d->int_hi <= d->int_lo || d->n_int_csr > 0)
+            return false;
+        auto grid_bound = [](int64_t groups) -> int64_t { return groups > 0 ? (groups / 4 + 16 < FV_MAX_PARTIALS ? groups / 4 + 16 : FV_MAX_PARTIALS) : 0; };
+        if (2 * (int64_t)p->ctx->num_cus + grid_bound(p->sym_nrest) + grid_bound(d->n_bnd_dia) + grid_bound(d->n_bnd_csr) > FV_FUSED_PARTS)
+            return false;
+    }
     const int64_t nz = p->sym_d[1], d3 = p->sym_d[2];
     if (p->sym_d[0] != 1 || nz < 64 || nz % 2 || d3 % 2 || d3 % nz || p->n % d3 || p->n / d3 < 3)
         return false;
@@ -697,6 +753,10 @@ static int kf_setup(fv_problem *p, KfArgs &a)
     a.tilesC = (int32_t)((nz + KF_TW - 1) / KF_TW);
     a.tiles = a.tilesC * (int32_t)((a.L + TLr - 1) / TLr);
     int resident = ctx->num_cus * (TLr == 16 ? 1 : g_fused_blocks) / 8 * 8;
+    // a row block's launch runs while the halo exchange is in flight: its blocks fill their CUs (registers, LDS), so one CU
+    // per XCD is left to the transport's kernel — or that kernel, enqueued first, would push a block into a second round
+    if (p->dist && p->dist->nranks > 1 && resident >= 64)
+        resident -= 8 * g_fused_dist_spare;
     if (resident < 8)
         resident = 8;
     if (resident > FV_FUSED_PARTS)
@@ -743,10 +803,11 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
 // One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
 // burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
 int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
-                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
+                  bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums, const double *red)
 {
     fv_ctx *ctx = p->ctx;
     KfArgs a{};
+    a.red = red;
     const int GF = kf_setup(p, a);
     const int TLr = g_fused_lines == 16 ? 16 : 8;
     a.code = p->dcode_n > 1 ? p->dcode.p : nullptr;
@@ -807,11 +868,39 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     {
         // every array once: x, z, v in and x_out, z', v' out on all rows (48) + a code byte; the three upper diagonals on the rows
         // whose product this kernel forms (24), + the stored diagonal where it is not re-derived (8)
-        const int64_t nok = p->ndia - p->sym_nrest, nder = p->sym_nderived;
+        const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - p->sym_nrest, nder = p->sym_nderived;
         const int mb = coded ? 2 : 24;
         p->fused_bytes = (nder * 2 >= nok ? 73 : 81) - 24 + mb;
         p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + mb * 64 * nok + 8 * 64 * (nok - nder);
     }
+    return FV_OK;
+}
+
+// Row blocks: the send buffer of the halo exchange of z' (p->pnext), formed from z (p->pvec), v (p->qv) and the all-reduced
+// sums in `red` before the fused launch of the same step (fused_pack_kernel).
+int fv_fused_pack(fv_problem *p, const double *red, int mode, int chain_index, bool force_prev_unconverged, double rtol)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    if (!d || d->nsend <= 0)
+        return FV_OK;
+    hipLaunchKernelGGL(fused_pack_kernel, dim3(fv_blocks(d->nsend)), dim3(FV_BLOCK), 0, ctx->stream, d->nsend, (const int32_t *)d->send_idx.p,
+                       (const double *)p->pvec.p, (const double *)p->qv.p, red, (const PcgScalars *)p->scal.p, mode, chain_index,
+                       force_prev_unconverged ? 1 : 0, rtol, d->sendbuf.p);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+// Row blocks: the products of the listed 64-row groups (boundary slices), left as q' in the NEW v array (p->qv2) by the
+// classic launches, into v' = -M^-1 (q' - sigma D z') with z' = p->pnext.
+int fv_fused_convert_groups(fv_problem *p, const int32_t *groups, int64_t count, double sigma)
+{
+    fv_ctx *ctx = p->ctx;
+    if (count <= 0)
+        return FV_OK;
+    hipLaunchKernelGGL(q_to_v_slices_kernel, dim3(fv_blocks(count * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, count, groups, (const double *)p->pnext.p,
+                       (const double *)p->minv.p, (const double *)p->D.p, sigma, p->qv2.p);
+    FV_LAUNCH_CHECK(ctx);
     return FV_OK;
 }
 

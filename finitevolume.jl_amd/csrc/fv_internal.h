@@ -322,6 +322,7 @@ struct fv_problem {
     // next one), its partial sums (two sets by step parity), and whether qv / the sums describe the prepared next step
     DevBuf<double> qv, qv2, fz_part;
     bool vready = false;
+    bool burst_fused = false; // row blocks: what the current burst's first step decided for the whole burst
     int vready_parity = 0;   // which set of sums the launch that left qv wrote
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)

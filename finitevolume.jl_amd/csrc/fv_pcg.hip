@@ -1484,13 +1484,14 @@ __global__ __launch_bounds__(FV_BLOCK) void dist_pack_kernel(int64_t nsend, cons
         buf[i] = x[idx[i]];
 }
 
-static int dist_exchange_begin(fv_problem *p, double *xext)
+// packed: the send buffer has been filled by the caller (the fused step forms the values it ships, fv_fused_pack)
+static int dist_exchange_begin(fv_problem *p, double *xext, bool packed = false)
 {
     fv_ctx *ctx = p->ctx;
     fv_dist *d = p->dist;
     if (d->nranks <= 1)
         return FV_OK;
-    if (d->nsend > 0) {
+    if (d->nsend > 0 && !packed) {
         hipLaunchKernelGGL(dist_pack_kernel, dim3(fv_blocks(d->nsend)), dim3(FV_BLOCK), 0, ctx->stream, d->nsend, d->send_idx.p, xext,
                            d->sendbuf.p);
         FV_LAUNCH_CHECK(ctx);
@@ -1876,6 +1877,23 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     bool zf = false; // this step's K2S in the z-form (each rank decides for its own rows: the arithmetic is per row)
     if (speculate && g_zform)
         FV_TRY(minv_positive(p, &zf));
+    // The fused step (fv_fused.hip) on the row block, decided at a burst's first step for the whole burst; was_vready: the
+    // previous step was such a launch (its v, its six local sums are in the fused step's own arrays)
+    const bool was_vready = p->vready && use_spec;
+    p->vready = false;
+    bool fused = false;
+    if (chained && speculate && zf && folded && sarg.D == nullptr && bsupport >= 0 && x_next && carry_prev) {
+        if (chain_index == 0) {
+            if (!d->split_built)
+                FV_TRY(dist_build_split(p));
+            p->burst_fused = fv_fused_applicable(p, sigma);
+        }
+        fused = p->burst_fused;
+    }
+    if (chained && chain_index > 0 && was_vready != fused) {
+        fv_set_error(ctx, "internal: a burst changed between the fused step and the K1 + K2S pair in its middle");
+        return FV_ERR_STATE;
+    }
     const double *prev_z = nullptr; // use_spec: where the previous step's z-form K2S left its p' (nullptr: it wrote r)
     const bool defer_in = chained && chain_index > 0 && g_defer_reduce && speculate && carry_prev;   // red[1..5]: the previous step's local sums
     const bool defer_out = chained && !last_in_burst && g_defer_reduce && speculate; // leave this step's sums to the next one
@@ -1889,7 +1907,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
         if (!zf)
             FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
         prev_z = p->z_where == 1 ? p->pvec.p : nullptr;
-        if (!defer_in) {
+        if (!defer_in && !(fused && chain_index > 0)) { // (a fused launch past a burst's first takes its scalars from the merged collective itself)
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)(red + 3),
                                (const double *)(red + 4), (const double *)(red + 5), 1, rtol, p->scal.p, -1, chained && chain_index > 0 ? 1 : 0);
             FV_LAUNCH_CHECK(ctx);
@@ -2035,6 +2053,101 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
 #define FV_PROF(idx)                                                                                            \
     if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
+    if (fused && !resume && maxiter > 0) {
+        // ---- the fused step on a row block.  Per step ONE 6-double collective (the previous launch's local sums: z.q, that
+        // step's r.M^-1 r and r.r, this step's set-up scalars), then: z' of the rows the neighbours need straight into the send
+        // buffer (two loads and an FMA per row: the v-form), the halo exchange of z' on its way while the fused launch runs
+        // over the block (vector part of all rows, products of the interior window), then the boundary groups' products from
+        // the halo and their conversion to the v-form.  The launch's prologue takes verdict, alpha and the fall-back from the
+        // all-reduced sums, so every rank takes the same decisions.
+        const int64_t k = 0;
+        FV_TRY(fv_fused_prepare(p));
+        FusedSums fin{};
+        int fmode = 0;
+        FV_PROF(0);
+        if (!was_vready) { // entry: the product the classic way, v from it
+            FV_TRY(dist_spmv(p, p->pvec.p, p->q.p, sig_mv, folded, true, true));
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red, 1, ctx->stream));
+            FV_TRY(fv_fused_enter(p, sigma));
+        } else {
+            fin = fv_fused_sums(p, p->vready_parity);
+            fin.nvec = p->vready_counts[0];
+            fin.nbb = p->vready_counts[1];
+            fin.npq = p->vready_counts[2];
+            SumSet six{};
+            six.a[0] = fin.pq;
+            six.extra[0] = fin.npq - fin.nvec;
+            six.a[1] = fin.arz;
+            six.a[2] = fin.arr;
+            six.a[3] = fin.srz;
+            six.a[4] = fin.srr;
+            six.a[5] = fin.sbb;
+            six.extra[5] = fin.nbb - fin.nvec;
+            // (a burst's first step: the five vector sums were all-reduced and judged at the end of the previous burst)
+            const int nsum = chain_index > 0 ? 6 : 1;
+            hipLaunchKernelGGL(final_sum_multi_kernel, dim3(nsum), dim3(FV_BLOCK), 0, ctx->stream, six, fin.nvec, red);
+            FV_LAUNCH_CHECK(ctx);
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red, nsum, ctx->stream));
+            fmode = chain_index > 0 ? 1 : 0;
+        }
+        const bool force_prev = fmode == 1 && chain_index - 1 == g_chain_test_break;
+        FV_TRY(fv_fused_pack(p, red, fmode, chain_index, force_prev, rtol));
+        FV_TRY(dist_exchange_begin(p, p->pnext.p, true));
+        FusedSums fout{};
+        FV_TRY(fv_diag_mark(ctx, 3, ctx->stream));
+        FV_TRY(fv_fused_step(p, u, x_next, sigma, dt, rtol, chain_index, fmode, fin, force_prev, folded, bsupport, &fout, red));
+        FV_TRY(fv_diag_mark(ctx, 3, ctx->stream));
+        FV_TRY(dist_exchange_wait(p));
+        if (d->n_bnd > 0) {
+            GroupSubset boundary;
+            boundary.dia = d->bnd_dia.p;
+            boundary.ndia = d->n_bnd_dia;
+            boundary.csr = d->bnd_csr.p;
+            boundary.ncsr = d->n_bnd_csr;
+            int nb = 0;
+            FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
+            FV_TRY(spmv_apply(p, p->pnext.p, p->qv2.p, sig_mv, folded, SPMV_DOT, fout.pq + fout.npq, nullptr, false, &nb, &boundary));
+            FV_TRY(fv_fused_convert_groups(p, d->bnd_dia.p, d->n_bnd_dia, sigma));
+            FV_TRY(fv_fused_convert_groups(p, d->bnd_csr.p, d->n_bnd_csr, sigma));
+            FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
+            fout.npq += nb;
+            if (fout.npq > FV_FUSED_PARTS) {
+                fv_set_error(ctx, "internal: %d partial sums of the fused step's product on a row block", fout.npq);
+                return FV_ERR_STATE;
+            }
+        }
+        FV_PROF(1);
+        FV_PROF(2);
+        FV_PROF(3);
+        if (last_in_burst) { // its five vector sums and its verdict now, so that the host's poll sees a finished state
+            SumSet five{};
+            five.a[0] = fout.arz;
+            five.a[1] = fout.arr;
+            five.a[2] = fout.srz;
+            five.a[3] = fout.srr;
+            five.a[4] = fout.sbb;
+            five.extra[4] = fout.nbb - fout.nvec;
+            hipLaunchKernelGGL(final_sum_multi_kernel, dim3(5), dim3(FV_BLOCK), 0, ctx->stream, five, fout.nvec, red + 1);
+            FV_LAUNCH_CHECK(ctx);
+            FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 5, ctx->stream));
+            hipLaunchKernelGGL(pcg_pupdate_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, 0, p->r.p, (const double *)p->minv.p, p->pvec.p,
+                               (const double *)(red + 1), (const double *)(red + 2), 1, p->scal.p, (double *)nullptr, (int64_t)0, (const double *)u,
+                               (const double *)x_next, (const double *)p->D.p, dt, chain_index, (chain_index == g_chain_test_break) ? 1 : 0,
+                               (const double *)p->pnext.p);
+            FV_LAUNCH_CHECK(ctx);
+        }
+        p->qv.swap(p->qv2);
+        p->vready = true;
+        p->vready_parity = chain_index & 1;
+        p->vready_counts[0] = fout.nvec;
+        p->vready_counts[1] = fout.nbb;
+        p->vready_counts[2] = fout.npq;
+        p->fused_launches++;
+        p->last_iters = 1;
+        p->spec_valid = true;
+        p->z_where = 2;
+        return FV_OK;
+    }
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         for (int64_t k = 0; k < m; k++) {

@@ -302,7 +302,7 @@ extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -396,6 +396,10 @@ extern "C" int fv_tune(int key, int value)
         g_reorder_blocks = value;
     else if (key == 49 && (value == 0 || value == 1))
         g_fused_codes = value;
+    else if (key == 50 && (value == 0 || value == 1))
+        g_fused_dist = value;
+    else if (key == 51 && value >= 0 && value <= 4)
+        g_fused_dist_spare = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -1600,8 +1604,11 @@ static int build_symdia(fv_problem *p)
     int sh = (int)(d3 % 64);
     if (sh > 32)
         sh -= 64; // signed lane shift of the march (spmv_apply computes the same)
+    // (the column limit is the block's own rows, not its halo slots: the last plane of the last row block — whose +plane
+    // windows would land in the halo slots — goes to the slice-by-slice kernel like the last plane of a whole operator, so
+    // that "planes 1 .. P - 2" is the symmetric form's range everywhere; the fused step relies on it)
     hipLaunchKernelGGL(symdia_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const uint8_t *)p->sl_noff.p,
-                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n + p->nhalo, win_lo, win_hi, p->sym_ok.p, restflag.p);
+                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n, win_lo, win_hi, p->sym_ok.p, restflag.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY(p->sym_rest.alloc(ctx, (size_t)ns));
     FV_TRY(fv_compact_flags(ctx, restflag.p, ns, p->sym_rest.p, &p->sym_nrest));

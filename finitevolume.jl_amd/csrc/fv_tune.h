@@ -78,6 +78,8 @@ extern "C" {
  *  48: experiment: blocks of the device re-numbering's walk (0 = an eighth of the CUs, at most 32) [0]
  *  49: the fused kernel reads the three upper diagonals as one 16-bit word of codes per row where each takes at most 32 distinct
  *      values (a homogeneous conductivity on a regular grid): 2 instead of 24 bytes of matrix per row; 0 = always the doubles [1]
+ *  50: the fused step on row blocks (fv_dist_run_fixed) too; 0 = row blocks keep the K1 + K2S pair [1]
+ *  51: CUs per XCD a row block's fused launch leaves to the halo exchange's kernel [1]
  *  45: streaming-hint experiments on the fused step (bit 0: z' stored non-temporally, 1: v' too, 2: x / v plain loads, 3: x_out
  *      plain store, 4: matrix plain loads) [0] */
 int fv_tune(int key, int value);

@@ -177,6 +177,12 @@ class RowBlock:
         self.ctx.check(load().fv_dist_run_fixed(self.handle, float(dt), int(nsteps), float(rtol), int(maxiter), ptr(iters), C.byref(info), C.byref(ms)))
         return iters[: int(nsteps)], info, ms.value
 
+    def fused_form(self):
+        """(launches so far, bytes per row, bytes per launch) of the fused step on this block (fv_fused_form)."""
+        n, b, t = C.c_int64(), C.c_int32(), C.c_int64()
+        self.ctx.check(load().fv_fused_form(self.handle, C.byref(n), C.byref(b), C.byref(t)))
+        return n.value, b.value, t.value
+
     def set_preconditioner(self, kind):
         """"jacobi" (default) or "amg": block-Jacobi with the aggregation-AMG V-cycle of the rank's diagonal block as the
         block solver (no communication inside the preconditioner).  Every rank must make the same choice."""

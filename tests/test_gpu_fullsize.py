@@ -466,7 +466,7 @@ def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
     import os as _os
 
     root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
-    common = [sys.executable, _os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--no-other-configs",
+    common = [sys.executable, _os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "64", "--warmup", "8", "--no-cpu-baseline", "--no-other-configs",
               "--no-multi-iteration", "--no-hetero"]
     env = {k: v for k, v in _os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
 
@@ -478,9 +478,18 @@ def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
         return json.loads(lines[0])
 
     plain = run({"FV_TUNE": "41=0"})
-    blocks = run({"FV_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"})
+    blocks = run({"FV_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611", "FV_TUNE": "50=0"})
     print("one rank through the row-block driver %.3f ms per step, the plain loop (K1 + K2S) %.3f" % (blocks["ms_per_step"], plain["ms_per_step"]))
     assert blocks["n_gpus"] == 1 and abs(blocks["value"] / plain["value"] - 1.0) < 0.06
+    assert blocks["config"]["step_form"].startswith("K1 + K2S")
+    # ... and with the fused step on both sides (the default): the block's launch takes its sums from the reduction launch
+    # in front of it instead of reducing them in its prologue, nothing else differs at one rank
+    plain_f = run({})
+    blocks_f = run({"FV_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29612"})
+    print("fused step: row-block driver %.3f ms per step, the plain loop %.3f" % (blocks_f["ms_per_step"], plain_f["ms_per_step"]))
+    assert blocks_f["config"]["step_form"].startswith("fused step") and blocks_f["config"]["per_rank"][0]["fused_launches"] >= 50
+    assert abs(blocks_f["value"] / plain_f["value"] - 1.0) < 0.06 and blocks_f["value"] > 1.3 * blocks["value"]
+    assert blocks_f["roofline"]["kernel"].startswith("fused step") and 0.4 < blocks_f["roofline"]["frac"] < 0.8
     d = blocks["config"]["per_rank"][0]["diagnosis"]
     # (one rank: nothing travels — no all-reduce is issued, no halo is waited for —, the passes are timed)
     assert d["interior_spmv_per_step"] >= 1 and d["interior_spmv_ms_per_step"] > 0 and d["halo_wait_ms_per_step"] == 0.0 and d["allreduce_ms_per_step"] == 0.0

@@ -208,3 +208,116 @@ def test_matrix_as_codes_gives_the_same_bits(fv):
     a = _run(fv, hetero, True, [(DT, 12, 1e-11)])
     b = _run(fv, hetero, True, [(DT, 12, 1e-11)], tune=((49, 0),))
     assert a[2][2] == b[2][2] and np.array_equal(a[0], b[0])
+
+
+# ------------------------------------------------------------------ the fused step on row blocks (loopback transport)
+def _run_row_blocks(fv, case, nranks, group_id, schedule, planes_per_rank, Ss=0.1, tune=()):
+    """One host thread per rank (own context on device 0, fv_comm_init_local), whole planes per rank: the row-block driver
+    with the fused step inside its bursts.  -> per rank (lo, hi, state, iterations, fused form)."""
+    import threading
+
+    from fvamd import dist
+
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    lib = fv.load()
+    for k, v in tune:
+        assert lib.fv_tune(k, v) == 0
+    out, errors = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = fv.Context(0)
+            dist.comm_init_local(ctx, nranks, rank, group_id)
+            p = fv.Problem.create(nb, aol, len(vol), dn, ctx).assemble(K, src, dh)
+            p.transient_begin(Ss, vol, u0)
+            d3 = p.n // sum(planes_per_rank)
+            assert d3 * sum(planes_per_rank) == p.n
+            bounds = np.concatenate([[0], np.cumsum(planes_per_rank)]) * d3
+            blk = dist.RowBlock(p, nranks, rank, bounds)
+            p.close()
+            its = []
+            for dt, nsteps, rtol in schedule:
+                it, info, _ = blk.run_fixed(dt, nsteps, rtol, maxiter=2000)
+                assert info.converged
+                its.append(it.copy())
+            out[rank] = (blk.lo, blk.hi, blk.state(), np.concatenate(its), blk.fused_form())
+            blk.close()
+            lib.fv_comm_destroy(ctx.handle)
+        except BaseException as e:  # noqa: BLE001  (a failing rank would leave the others waiting at a barrier)
+            errors.append((rank, repr(e)))
+
+    try:
+        threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+    finally:
+        for k, v in tune:
+            lib.fv_tune(k, {14: -1, 13: 8, 44: 16, 49: 1, 50: 1, 51: 1}.get(k, 0))
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank did not finish (deadlock in the protocol?)"
+    return out
+
+
+def _gather(out, n):
+    got = np.empty(n)
+    for lo, hi, state, _, _ in out:
+        got[lo:hi] = state
+    return got
+
+
+# two blocks of 34 planes, three of 34 / 36 / 34 (each > 2^20 rows: the tiled symmetric form serves a block's interior window)
+@pytest.mark.parametrize("planes", [(34, 34), (34, 36, 34)])
+def test_fused_steps_on_row_blocks_against_one_gpu(fv, planes):
+    """fv_dist_run_fixed with the fused step in its bursts (per step: one 6-double collective, z' of the send rows formed
+    from z and v before the launch, the boundary groups' products after the halo): same iteration counts on every rank as
+    the single-GPU fused run, heads to rounding; the unfused row-block run (fv_tune 50 = 0) agrees as well."""
+    ns = (sum(planes) + 2, 182, 186)
+    case = _problem(fv, ns)
+    sched = [(DT, 21, 1e-11), (1.0, 2, 1e-11), (DT, 12, 1e-11)]
+    one = _run(fv, case, True, sched)
+    free = np.ones(len(case[5]), bool)
+    free[case[7] - 1] = False
+    want = one[0][free]
+    nranks = len(planes)
+    res = _run_row_blocks(fv, case, nranks, 7000 + nranks, sched, planes)
+    for lo, hi, state, its, form in res:
+        assert np.array_equal(its, one[1]), (its, one[1])
+        assert form[0] >= 21 + 12 - 10 and form[1] == 73, form  # the fused launches ran on every rank
+    assert relerr(_gather(res, len(want)), want) < 1e-12
+    plain = _run_row_blocks(fv, case, nranks, 7100 + nranks, sched, planes, tune=((50, 0),))
+    assert all(r[4][0] == 0 for r in plain) and all(np.array_equal(r[3], one[1]) for r in plain)
+    assert relerr(_gather(plain, len(want)), want) < 1e-12
+    print("row blocks, fused vs unfused run: %.2e; vs one GPU: %.2e" % (relerr(_gather(res, len(want)), _gather(plain, len(want))), relerr(_gather(res, len(want)), want)))
+
+
+def test_fused_row_block_chain_that_breaks_and_steps_converged_at_their_set_up(fv):
+    """The injected break (fv_tune 14) at a burst's first, a middle and its last step, on every rank at the same place; a loose
+    tolerance after tight steps (zero-iteration steps: alpha = 0 on every rank); uniform conductivity: the matrix as codes."""
+    planes = (34, 34)
+    ns = (sum(planes) + 2, 182, 186)
+    case = _problem(fv, ns, seed=2)
+    sched = [(DT, 30, 1e-11)]
+    ref = _run_row_blocks(fv, case, 2, 7200, sched, planes, tune=((50, 0),))
+    want = _gather(ref, ref[-1][1])
+    for brk in (0, 3, 7):
+        got = _run_row_blocks(fv, case, 2, 7210 + brk, sched, planes, tune=((14, brk),))
+        plain = _run_row_blocks(fv, case, 2, 7220 + brk, sched, planes, tune=((14, brk), (50, 0)))
+        for g, q in zip(got, plain):
+            assert g[4][0] > 0 and q[4][0] == 0
+            assert (g[3] >= 1).all() and (g[3] > 1).sum() >= 2 and np.array_equal(g[3] > 1, q[3] > 1), (brk, g[3], q[3])
+            assert np.array_equal(g[3], got[0][3])
+        assert relerr(_gather(got, len(want)), want) < 1e-11
+    sched2 = [(DT, 12, 1e-11), (DT, 20, 1e-3), (DT, 10, 1e-12)]
+    a = _run_row_blocks(fv, case, 2, 7300, sched2, planes)
+    b = _run_row_blocks(fv, case, 2, 7301, sched2, planes, tune=((50, 0),))
+    for x, y in zip(a, b):
+        assert np.array_equal(x[3], y[3]) and (x[3][12:32] == 0).sum() >= 15 and x[4][0] > 0
+    assert relerr(_gather(a, len(want)), _gather(b, len(want))) < 1e-12
+    cu = _problem(fv, ns, seed=2, uniform_k=True)
+    c = _run_row_blocks(fv, cu, 2, 7310, sched, planes)
+    d = _run_row_blocks(fv, cu, 2, 7311, sched, planes, tune=((50, 0),))
+    assert all(r[4][1] == 51 for r in c), [r[4] for r in c]  # 73 - 24 + 2: the three upper diagonals as one 16-bit word
+    assert all(np.array_equal(x[3], y[3]) for x, y in zip(c, d))
+    assert relerr(_gather(c, len(want)), _gather(d, len(want))) < 1e-12
