@@ -44,6 +44,8 @@ struct AmgLevel {
     DevBuf<int32_t> memptr, mem; // nc+1 / members of every aggregate, ascending
     // cycle workspace
     DevBuf<double> x, b, t;
+    // K-cycle workspace (levels solved by two flexible-CG steps, amg_kcycle): v1 = A c1, r1, c2, v2 = A c2, partial sums
+    DevBuf<double> kv1, kr1, kc2, kv2, kpart;
 };
 
 } // namespace
@@ -57,6 +59,7 @@ struct fv_amg {
     double sigma = NAN;       // the sigma dinv / inv were built for
     int64_t epoch = -1;       // assemble_epoch of the hierarchy
     int64_t storage_epoch = -1; // which fv_transient_begin the aggregated D belongs to
+    bool kcycle = false;      // this application of the cycle may use the K-cycle (the PCG loop around it is flexible); fv_amg_apply keeps the linear V-cycle
     bool fold = false;        // level-0 SpMVs use the folded value array (fixed-dt runs), as the PCG around them
     DevBuf<double> z;         // preconditioned residual of the PCG
     DevBuf<int32_t> loc_rowptr, loc_colind; // row blocks: the rank's diagonal block as the level-0 structure
@@ -75,10 +78,12 @@ void fv_amg_free(fv_amg *a) { delete a; }
 // 0.85, rounds 6 -> 10: 148 -> 97 PCG iterations, solve 0.25 -> 0.13 s at the same set-up time and operator complexity.
 static double g_theta = 0.10; // a coupling is strong when -a_ij >= theta * max_k(-a_ik)
 static double g_omega = 0.85; // Jacobi damping of the smoother
-static int g_passes = 3;      // pairwise passes per level
+static int g_passes = 2;      // pairwise passes per level (aggregates of ~4: the K-cycle keeps the extra levels near their two-grid rate)
 static int g_rounds = 10;     // handshake rounds per pass
 static int g_coarse_max = 1024;
 static int g_coarse_sweeps = 12; // Jacobi sweeps on a coarsest level too large for the dense inverse
+int g_amg_stream = 65536;       // fv_tune key 53: coarse levels with at least this many rows use the wave-stream CSR kernel (0: never)
+int g_amg_kcycle = 2;            // fv_tune key 52: coarse levels 1 .. g_amg_kcycle are solved by two flexible-CG steps preconditioned by the cycle below them (K-cycle)
 
 extern "C" int fv_amg_configure(double theta, double omega, int passes, int rounds)
 {
@@ -365,19 +370,25 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_smooth_kernel(int64_t n, const d
 // the last smoothing pass of the top level, with the PCG's r.z folded in (b is r, x is z): one partial per block
 __global__ __launch_bounds__(FV_BLOCK) void amg_smooth_dot_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ b,
                                                                    const double *__restrict__ t, double omega, double *__restrict__ x,
-                                                                   double *__restrict__ part)
+                                                                   double *__restrict__ part, const double *__restrict__ q, double *__restrict__ part_q)
 {
     __shared__ double smem[4];
-    double acc = 0.0;
+    double acc = 0.0, accq = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
         const double bi = b[i];
         const double xi = x[i] + omega * dinv[i] * (bi - t[i]);
         x[i] = xi;
         acc += bi * xi;
+        if (q)
+            accq += q[i] * xi; // flexible PCG (a K-cycle is not a fixed linear operator): z_new.q for beta = -alpha z_new.q / (r.z)_old
     }
     const double s = block_sum(acc, smem);
-    if (threadIdx.x == 0)
+    const double sq = q ? block_sum(accq, smem) : 0.0;
+    if (threadIdx.x == 0) {
         part[blockIdx.x] = s;
+        if (q)
+            part_q[blockIdx.x] = sq;
+    }
 }
 
 // b_c[I] = sum over the members of (b - t): 8 lanes per aggregate (aggregates of a high-conductivity region can have
@@ -412,6 +423,88 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_prolong_kernel(int64_t n, const 
         if (a >= 0)
             x[i] += xc[a];
     }
+}
+
+// ------------------------------------------------------------------ K-cycle (Notay's AGMG): a coarse system A_l e = b is solved by
+// two steps of flexible CG preconditioned by the cycle of level l instead of by one application of that cycle:
+//   c1 = cycle(b), v1 = A c1, rho1 = c1.v1, alpha1 = c1.b, r1 = b - (alpha1 / rho1) v1,
+//   c2 = cycle(r1), v2 = A c2, gamma = c2.v1, beta = c2.v2, alpha2 = c2.r1, rho2 = beta - gamma^2 / rho1,
+//   e = (alpha1 / rho1 - gamma alpha2 / (rho1 rho2)) c1 + (alpha2 / rho2) c2.
+// Unsmoothed aggregation loses a factor per level in a V-cycle; the K-cycle keeps every level near its two-grid rate.  All scalars
+// stay on the device: the dot kernels leave per-block partials, the consumers reduce them in their first microseconds.
+constexpr int AMG_KG = 256; // blocks (= partial sums per quantity) of the K-cycle's vector kernels
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_kdot2_kernel(int64_t n, const double *__restrict__ c1, const double *__restrict__ v1,
+                                                              const double *__restrict__ b, double *__restrict__ part)
+{
+    __shared__ double smem[4];
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK) {
+        const double c = c1[i];
+        s0 += c * v1[i];
+        s1 += c * b[i];
+    }
+    const double t0 = block_sum(s0, smem);
+    const double t1 = block_sum(s1, smem);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = t0;
+        part[AMG_KG + blockIdx.x] = t1;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_kres_kernel(int64_t n, const double *__restrict__ b, const double *__restrict__ v1,
+                                                             const double *__restrict__ part, int nparts, double *__restrict__ r1)
+{
+    __shared__ double smem[4];
+    const double rho1 = reduce_partials(part, nparts, smem);
+    const double alpha1 = reduce_partials(part + AMG_KG, nparts, smem);
+    const double f = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK)
+        r1[i] = b[i] - f * v1[i];
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_kdot3_kernel(int64_t n, const double *__restrict__ c2, const double *__restrict__ v1,
+                                                              const double *__restrict__ v2, const double *__restrict__ r1, double *__restrict__ part)
+{
+    __shared__ double smem[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK) {
+        const double c = c2[i];
+        s0 += c * v1[i];
+        s1 += c * v2[i];
+        s2 += c * r1[i];
+    }
+    const double t0 = block_sum(s0, smem);
+    const double t1 = block_sum(s1, smem);
+    const double t2 = block_sum(s2, smem);
+    if (threadIdx.x == 0) {
+        part[2 * AMG_KG + blockIdx.x] = t0;
+        part[3 * AMG_KG + blockIdx.x] = t1;
+        part[4 * AMG_KG + blockIdx.x] = t2;
+    }
+}
+
+// x holds c1 on entry, the level's correction on exit
+__global__ __launch_bounds__(FV_BLOCK) void amg_kcomb_kernel(int64_t n, const double *__restrict__ c2, const double *__restrict__ part, int nparts,
+                                                              double *__restrict__ x)
+{
+    __shared__ double smem[4];
+    const double rho1 = reduce_partials(part, nparts, smem);
+    const double alpha1 = reduce_partials(part + AMG_KG, nparts, smem);
+    const double gamma = reduce_partials(part + 2 * AMG_KG, nparts, smem);
+    const double beta = reduce_partials(part + 3 * AMG_KG, nparts, smem);
+    const double alpha2 = reduce_partials(part + 4 * AMG_KG, nparts, smem);
+    double f1 = 1.0, f2 = 0.0; // breakdown of the first step (rho1 <= 0: c1 = 0 or an indefinite cycle): the plain cycle's c1
+    if (rho1 > 0.0) {
+        const double rho2 = beta - gamma * gamma / rho1;
+        f1 = alpha1 / rho1;
+        if (rho2 > 0.0) {
+            f1 -= gamma * alpha2 / (rho1 * rho2);
+            f2 = alpha2 / rho2;
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK)
+        x[i] = f1 * x[i] + f2 * c2[i];
 }
 
 // ------------------------------------------------------------------ coarsest level: explicit inverse by Gauss-Jordan
@@ -478,6 +571,10 @@ static int amg_level_spmv(fv_ctx *ctx, const AmgLevel *L, const double *x, doubl
 {
     const double *D = (sigma != 0.0) ? L->D : nullptr;
     const double avg = L->n > 0 ? (double)L->nnz / (double)L->n : 0.0;
+    // large levels: the library's wave-private CSR stream (fv_spmv.hip: contiguous 16-byte loads of values and columns per wave, row
+    // sums out of the wave's LDS tile) — 64 rows x 16 entries per pass; a level of a few thousand rows is launch-bound either way
+    if (g_amg_stream && L->o_vals.p && L->n >= g_amg_stream && avg <= 14.0)
+        return fv_csr_stream_spmv(ctx, L->n, L->rowptr, L->colind, L->vals, x, y, D, sigma);
     if (avg > 12.0)
         hipLaunchKernelGGL(amg_spmv_kernel<16>, dim3(fv_blocks(L->n, FV_BLOCK / 16)), dim3(FV_BLOCK), 0, ctx->stream, L->n, L->rowptr, L->colind,
                            L->vals, x, y, D, sigma);
@@ -579,8 +676,10 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
     hipLaunchKernelGGL(amg_heads_kernel, dim3(fv_blocks(nnz)), dim3(FV_BLOCK), 0, ctx->stream, nnz, (const uint64_t *)key2.p, unc * unc, head.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY(fv_exclusive_scan_i32(ctx, head.p, pos.p, nnz, nnz_c));
-    FV_TRY(colind_c.alloc(ctx, (size_t)*nnz_c));
-    FV_TRY(vals_c.alloc(ctx, (size_t)*nnz_c));
+    FV_TRY(colind_c.alloc(ctx, (size_t)*nnz_c + 2)); // (+ two zero entries: the wave-stream kernel reads pairs)
+    FV_TRY(vals_c.alloc(ctx, (size_t)*nnz_c + 2));
+    FV_HIP(ctx, hipMemsetAsync(colind_c.p + *nnz_c, 0, 2 * sizeof(int32_t), ctx->stream));
+    FV_HIP(ctx, hipMemsetAsync(vals_c.p + *nnz_c, 0, 2 * sizeof(double), ctx->stream));
     FV_TRY(rowcnt.alloc(ctx, (size_t)nc + 1));
     FV_TRY(rowcnt.zero(ctx));
     hipLaunchKernelGGL(amg_runs_kernel, dim3(fv_blocks(nnz)), dim3(FV_BLOCK), 0, ctx->stream, nnz, (const uint64_t *)key2.p, (const double *)val2.p,
@@ -636,7 +735,7 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_local_fill_kernel(int64_t n, con
         }
 }
 
-static int amg_build(fv_problem *p)
+static int amg_build_pooled(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
     const double t_start = amg_now();
@@ -772,6 +871,15 @@ static int amg_build(fv_problem *p)
     return FV_OK;
 }
 
+// the set-up's scratch arrays (sort buffers, flags, scans: hundreds of them, shrinking level by level) come out of a pool
+static int amg_build(fv_problem *p)
+{
+    fv_pool_begin();
+    const int rc = amg_build_pooled(p);
+    fv_pool_end();
+    return rc;
+}
+
 // Jacobi diagonals of every level and the coarsest inverse for this sigma
 static int amg_set_sigma(fv_problem *p, double sigma)
 {
@@ -827,9 +935,42 @@ static int amg_top_spmv(fv_problem *p, const double *x, double *t, double sigma)
     return fv_spmv_launch(p, x, t, sigma, nullptr, p->amg->fold);
 }
 
+static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part, const double *dot_q, double *dot_part_q);
+
+// x_l ~ A_l^-1 b_l by two flexible-CG steps preconditioned by the cycle of level l (l >= 1, not the coarsest)
+static int amg_kcycle(fv_problem *p, size_t l, const double *b, double *x, double sigma)
+{
+    fv_ctx *ctx = p->ctx;
+    AmgLevel *L = p->amg->lev[l];
+    if (!L->kpart.p) {
+        FV_TRY(L->kv1.alloc(ctx, (size_t)L->n));
+        FV_TRY(L->kr1.alloc(ctx, (size_t)L->n));
+        FV_TRY(L->kc2.alloc(ctx, (size_t)L->n));
+        FV_TRY(L->kv2.alloc(ctx, (size_t)L->n));
+        FV_TRY(L->kpart.alloc(ctx, (size_t)5 * AMG_KG));
+    }
+    const unsigned nb = fv_blocks(L->n);
+    const int G = nb < (unsigned)AMG_KG ? (int)nb : AMG_KG;
+    const dim3 g(G), blk(FV_BLOCK);
+    FV_TRY(amg_cycle(p, l, b, x, sigma, nullptr, nullptr, nullptr)); // c1
+    FV_TRY(amg_level_spmv(ctx, L, x, L->kv1.p, sigma));
+    hipLaunchKernelGGL(amg_kdot2_kernel, g, blk, 0, ctx->stream, L->n, (const double *)x, (const double *)L->kv1.p, b, L->kpart.p);
+    hipLaunchKernelGGL(amg_kres_kernel, g, blk, 0, ctx->stream, L->n, b, (const double *)L->kv1.p, (const double *)L->kpart.p, G, L->kr1.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(amg_cycle(p, l, L->kr1.p, L->kc2.p, sigma, nullptr, nullptr, nullptr)); // c2
+    FV_TRY(amg_level_spmv(ctx, L, L->kc2.p, L->kv2.p, sigma));
+    hipLaunchKernelGGL(amg_kdot3_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->kc2.p, (const double *)L->kv1.p, (const double *)L->kv2.p,
+                       (const double *)L->kr1.p, L->kpart.p);
+    hipLaunchKernelGGL(amg_kcomb_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->kc2.p, (const double *)L->kpart.p, G, x);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
 // x_l = V(b_l) on level l (x, b: the level's vectors; level 0: the caller's)
 // dot_part (top level only): per-block partials of b.x, i.e. the PCG's r.z, written by the last smoothing pass
-static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part = nullptr)
+// dot_q / dot_part_q (with dot_part): also the partials of x.dot_q (flexible PCG: z.q)
+static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part = nullptr, const double *dot_q = nullptr,
+                     double *dot_part_q = nullptr)
 {
     fv_ctx *ctx = p->ctx;
     fv_amg *a = p->amg;
@@ -863,7 +1004,10 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     hipLaunchKernelGGL(amg_restrict_kernel, dim3(fv_blocks(C->n, FV_BLOCK / 8)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
                        (const int32_t *)L->mem.p, b, (const double *)L->t.p, C->b.p);
     FV_LAUNCH_CHECK(ctx);
-    FV_TRY(amg_cycle(p, l + 1, C->b.p, C->x.p, sigma));
+    if (a->kcycle && (int)(l + 1) <= g_amg_kcycle && l + 2 < a->lev.size())
+        FV_TRY(amg_kcycle(p, l + 1, C->b.p, C->x.p, sigma));
+    else
+        FV_TRY(amg_cycle(p, l + 1, C->b.p, C->x.p, sigma));
     hipLaunchKernelGGL(amg_prolong_kernel, g, blk, 0, ctx->stream, L->n, (const int32_t *)L->agg.p, (const double *)C->x.p, x);
     FV_LAUNCH_CHECK(ctx);
     if (l == 0)
@@ -872,7 +1016,7 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
         FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
     if (dot_part)
         hipLaunchKernelGGL(amg_smooth_dot_kernel, dim3(vec_grid(L->n)), blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b,
-                           (const double *)L->t.p, g_omega, x, dot_part);
+                           (const double *)L->t.p, g_omega, x, dot_part, dot_q, dot_part_q);
     else
         hipLaunchKernelGGL(amg_smooth_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, (const double *)L->t.p, g_omega, x);
     FV_LAUNCH_CHECK(ctx);
@@ -883,6 +1027,7 @@ int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma)
 {
     FV_TRY(fv_amg_prepare(p, sigma));
     p->amg->fold = false;
+    p->amg->kcycle = false;
     return amg_cycle(p, 0, r, z, sigma);
 }
 
@@ -962,14 +1107,19 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_pcg_check_kernel(int it, const d
     }
 }
 
-// beta = r.z / (r.z)_old ; p = z + beta p
+// beta = r.z / (r.z)_old ; p = z + beta p.  part_zq (flexible PCG, for a preconditioner that is not a fixed linear operator):
+// beta = z.(r - r_old) / (r.z)_old with r_old = r + alpha q, i.e. -alpha z.q / (r.z)_old — the same number when z = M r exactly.
 __global__ __launch_bounds__(FV_BLOCK) void amg_pcg_direction_kernel(int64_t n, int it, const double *__restrict__ z, double *__restrict__ pv,
                                                                       const double *__restrict__ part_rz, int nparts,
-                                                                      PcgScalars *__restrict__ scal)
+                                                                      PcgScalars *__restrict__ scal, const double *__restrict__ part_zq)
 {
     __shared__ double smem[4];
     const double rzn = reduce_partials(part_rz, nparts, smem);
-    const double beta = rzn / scal->rz[it & 1];
+    double beta = rzn / scal->rz[it & 1];
+    if (part_zq) {
+        const double zq = reduce_partials(part_zq, nparts, smem);
+        beta = -zq / scal->pq; // (alpha = (r.z)_old / p.q)
+    }
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
         pv[i] = z[i] + beta * pv[i];
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -989,6 +1139,8 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
     if (hs->done || maxiter <= 0)
         return FV_OK;
     const bool fused_dot = a->lev.size() > 1; // a single-level "hierarchy" (tiny problem) ends in the dense solve, not in a smoothing pass
+    a->kcycle = g_amg_kcycle > 0 && a->lev.size() > 2 && !p->dist;
+    const bool flexible = a->kcycle && fused_dot;
     FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
     if (!fused_dot)
         hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p, p->part_rz.p);
@@ -1007,12 +1159,12 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done)
             break;
-        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
+        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr, flexible ? (const double *)p->q.p : nullptr, p->part_bb.p));
         if (!fused_dot)
             hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p,
                                p->part_rz.p);
         hipLaunchKernelGGL(amg_pcg_direction_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, (const double *)a->z.p, p->pvec.p,
-                           (const double *)p->part_rz.p, Gv, p->scal.p);
+                           (const double *)p->part_rz.p, Gv, p->scal.p, flexible ? (const double *)p->part_bb.p : nullptr);
         FV_LAUNCH_CHECK(ctx);
     }
     return FV_OK;

@@ -323,3 +323,60 @@ int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, 
     }
     return FV_OK;
 }
+
+// ------------------------------------------------------------------ scratch pool of a set-up phase (see fv_internal.h)
+#include <map>
+#include <unordered_map>
+namespace {
+struct DevPool {
+    int depth = 0;
+    std::multimap<size_t, void *> idle;          // released blocks by capacity
+    std::unordered_map<void *, size_t> capacity; // blocks handed out while the pool is on
+};
+thread_local DevPool t_pool;
+} // namespace
+
+hipError_t fv_dev_malloc(void **p, size_t bytes)
+{
+    DevPool &pool = t_pool;
+    if (pool.depth > 0) {
+        auto it = pool.idle.lower_bound(bytes);
+        if (it != pool.idle.end() && it->first <= 4 * bytes + ((size_t)1 << 20)) {
+            *p = it->second;
+            pool.capacity[*p] = it->first;
+            pool.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    const hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && pool.depth > 0)
+        pool.capacity[*p] = bytes;
+    return e;
+}
+
+void fv_dev_free(void *p)
+{
+    DevPool &pool = t_pool;
+    if (pool.depth > 0) {
+        auto it = pool.capacity.find(p);
+        if (it != pool.capacity.end()) {
+            pool.idle.emplace(it->second, p);
+            pool.capacity.erase(it);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void fv_pool_begin() { t_pool.depth++; }
+
+void fv_pool_end()
+{
+    DevPool &pool = t_pool;
+    if (pool.depth <= 0 || --pool.depth > 0)
+        return;
+    for (auto &kv : pool.idle)
+        (void)hipFree(kv.second);
+    pool.idle.clear();
+    pool.capacity.clear(); // (blocks still in use are their owners' from here on)
+}

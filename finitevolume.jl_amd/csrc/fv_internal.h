@@ -49,6 +49,9 @@ struct fv_ctx {
 };
 
 void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
+// fv_spmv.hip: the wave-stream CSR SpMV on caller-owned arrays (two padding entries behind vals / colind)
+int fv_csr_stream_spmv(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *x, double *y,
+                       const double *D, double sigma);
 
 #define FV_HIP(ctx, call)                                                                                       \
     do {                                                                                                        \
@@ -74,6 +77,15 @@ void fv_set_error(fv_ctx *ctx, const char *fmt, ...);
 extern int g_alloc_skew_bytes;
 extern int g_alloc_skew_count;
 
+// Device allocations of DevBuf go through these two (fv_ctx.hip).  Between fv_pool_begin / fv_pool_end on the calling thread a
+// released block is kept and handed to a later request it fits (a set-up phase such as the AMG hierarchy allocates and frees
+// hundreds of scratch arrays of shrinking size: hipMalloc / hipFree — a device-wide synchronisation each — cost more than its
+// kernels); everything such a phase does runs on the context's one stream, which orders the re-use.
+hipError_t fv_dev_malloc(void **p, size_t bytes);
+void fv_dev_free(void *p);
+void fv_pool_begin();
+void fv_pool_end();
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -86,7 +98,7 @@ struct DevBuf {
     void release()
     {
         if (base)
-            (void)hipFree(base);
+            fv_dev_free(base);
         p = nullptr;
         base = nullptr;
         n = 0;
@@ -99,7 +111,7 @@ struct DevBuf {
         size_t skew = 0;
         if (g_alloc_skew_bytes > 0 && count * sizeof(T) >= ((size_t)1 << 22)) // arrays of 4 MiB and more
             skew = (size_t)(g_alloc_skew_count++ % 16) * (size_t)g_alloc_skew_bytes;
-        hipError_t e = hipMalloc(&base, count * sizeof(T) + skew);
+        hipError_t e = fv_dev_malloc(&base, count * sizeof(T) + skew);
         if (e != hipSuccess) {
             p = nullptr;
             base = nullptr;

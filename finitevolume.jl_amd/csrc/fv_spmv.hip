@@ -302,6 +302,7 @@ extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
+extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
 extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
@@ -396,6 +397,10 @@ extern "C" int fv_tune(int key, int value)
         g_reorder_blocks = value;
     else if (key == 49 && (value == 0 || value == 1))
         g_fused_codes = value;
+    else if (key == 52 && value >= 0 && value <= 8)
+        g_amg_kcycle = value;
+    else if (key == 53 && value >= 0)
+        g_amg_stream = value;
     else if (key == 50 && (value == 0 || value == 1))
         g_fused_dist = value;
     else if (key == 51 && value >= 0 && value <= 4)
@@ -1915,6 +1920,20 @@ static int stream_grid(int64_t npos)
     if (g > g_resident_blocks)
         g = g_resident_blocks;
     return (int)g;
+}
+
+// y = (A + sigma D) x for a CSR the library did not build itself (the AMG's coarse levels): the wave-stream kernel over all 64-row
+// groups in their natural order, 1024 entries per group and pass.  vals / colind must carry two padding entries past nnz.
+int fv_csr_stream_spmv(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *x, double *y,
+                       const double *D, double sigma)
+{
+    set_resident_blocks(ctx);
+    const int64_t npos = (n + 63) >> 6;
+    const int G = stream_grid(npos);
+    hipLaunchKernelGGL((spmv_wstream_kernel<1024, false, false>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, n, rowptr, colind, vals, x, y, D, sigma,
+                       (double *)nullptr, (const PcgScalars *)nullptr, (const int32_t *)nullptr, npos);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
 }
 
 // One launch of the CSR wave-stream kernel over `npos` 64-row groups (all of them in `order`, or the listed ones).

@@ -220,8 +220,10 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * roofline figures of bench.py).  kernel: 0 = SpMV+dot, 1 = x/r update, 2 = p update. */
 /* ---------------------------------------------------------------- preconditioner of the PCG
  * FV_PRECOND_JACOBI (default): diagonal scaling fused into the PCG's vector kernels.
- * FV_PRECOND_AMG: one V(1,1) cycle of an aggregation-based algebraic multigrid per iteration — the role
- * AlgebraicMultigrid.ruge_stuben + aspreconditioner play at FiniteVolume.jl:159-161 (solvediffusion).  The hierarchy
+ * FV_PRECOND_AMG: one cycle of an aggregation-based algebraic multigrid per iteration — the role
+ * AlgebraicMultigrid.ruge_stuben + aspreconditioner play at FiniteVolume.jl:159-161 (solvediffusion).  Inside the library's
+ * own PCG loop the first two coarse levels are solved by two flexible-CG steps each (K-cycle; the PCG around it is then the
+ * flexible variant); fv_amg_apply and row blocks apply the plain V(1,1) cycle, a fixed symmetric operator.  The hierarchy
  * is built on the device at the first solve after fv_assemble (and again after the next fv_assemble /
  * fv_transient_begin); it carries the storage term, so shifted solves (implicit steps) can use it as well.
  * Not available for row blocks of a distributed run. */
@@ -233,7 +235,7 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
 #define FV_PRECOND_AUTO 2
 int fv_precond_set(fv_problem *p, int kind);
 /* theta: strength threshold of the matching (0.10); omega: Jacobi damping of the smoother (0.85); passes: pairwise
- * passes per level (3 -> aggregates of ~8-10); rounds: handshake rounds per pass (10).  Process-wide. */
+ * passes per level (2 -> aggregates of ~4-5); rounds: handshake rounds per pass (10).  Process-wide. */
 int fv_amg_configure(double theta, double omega, int passes, int rounds);
 /* Builds the hierarchy if needed; rows[l], nnz[l] for l < min(*nlevels, cap). */
 int fv_amg_info(fv_problem *p, int32_t *nlevels, int64_t *rows, int64_t *nnz, int32_t cap);

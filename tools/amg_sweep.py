@@ -28,7 +28,14 @@ del n1, n2
 configs = [(0.25, 2 / 3, 3, 6), (0.25, 2 / 3, 2, 6), (0.25, 0.8, 3, 6), (0.25, 0.9, 3, 6), (0.25, 0.8, 2, 6), (0.1, 2 / 3, 3, 6), (0.5, 2 / 3, 3, 6), (0.25, 2 / 3, 4, 6)]
 if os.environ.get("FV_AMG_SWEEP") == "2":
     configs = [(th, om, 3, 6) for th in (0.0, 0.05, 0.1, 0.15) for om in (2 / 3, 0.85, 1.0)] + [(0.1, 0.85, 3, 10), (0.05, 0.85, 2, 6)]
-for theta, omega, passes, rounds in configs:
+if os.environ.get("FV_AMG_SWEEP") == "3":  # the K-cycle (fv_tune 52: levels 1 .. k by two flexible-CG steps)
+    configs = [(0.1, 0.85, 3, 10, k) for k in (0, 1, 2, 3)] + [(0.1, 0.85, 2, 10, k) for k in (0, 1, 2, 3, 5)] + [(0.05, 0.85, 2, 10, 3), (0.1, 0.7, 3, 10, 2), (0.1, 1.0, 3, 10, 2)]
+if os.environ.get("FV_AMG_SWEEP") == "4":  # handshake rounds / threshold under the K-cycle
+    configs = [(0.1, 0.85, 2, r, 2) for r in (3, 4, 6, 8, 10)] + [(th, 0.85, 2, 6, 2) for th in (0.05, 0.2, 0.3)] + [(0.1, om, 2, 6, 2) for om in (0.7, 1.0)]
+for cfg in configs:
+    theta, omega, passes, rounds = cfg[:4]
+    kc = cfg[4] if len(cfg) > 4 else 0
+    lib.fv_tune(52, kc)
     lib.fv_amg_configure(theta, omega, passes, rounds)
     p.assemble(Kf, np.zeros(p.N), dh, None, True)  # (a new assembly epoch: the hierarchy is rebuilt with the new parameters)
     p.set_preconditioner("amg")
@@ -41,7 +48,7 @@ for theta, omega, passes, rounds in configs:
     head, res, ch = p.solve_steady(None, 1e-8, 600, want_head=False, want_resnorm=False)
     p.ctx.synchronize()
     t_solve = time.perf_counter() - t0
-    print("theta %.2f omega %.2f passes %d rounds %d: rows %s complexity %.2f set-up %.3f s, %d iterations (%s) %.3f s -> %.2f ms per iteration" %
-          (theta, omega, passes, rounds, rows.tolist(), nnz.sum() / nnz[0], t_setup, ch.iters, "converged" if ch.isconverged else "NOT converged", t_solve,
+    print("theta %.2f omega %.2f passes %d rounds %d K-levels %d: rows %s complexity %.2f set-up %.3f s, %d iterations (%s) %.3f s -> %.2f ms per iteration" %
+          (theta, omega, passes, rounds, kc, rows.tolist(), nnz.sum() / nnz[0], t_setup, ch.iters, "converged" if ch.isconverged else "NOT converged", t_solve,
            t_solve / max(ch.iters, 1) * 1e3), flush=True)
 lib.fv_amg_configure(0.10, 0.85, 3, 10)

@@ -4,6 +4,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 rm -rf $O/aprof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/aprof -- python3 $R/tools/amg_box.py 256 3.0 0 > $O/aprof.log 2>&1
+FV_AMG_VERBOSE=1 python3 $R/tools/amg_box.py 256 3.0 0 > $O/aprof_verbose.log 2>&1
 cd $R
 python - <<PY
 import csv, glob
