@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6290 GB/s is the measured copy ceiling
 KERNEL_NAMES = {  # fv_spmv_form id -> kernel(s) that ran
+    5: "spmv_sell_kernel<true> (SELL-64: per 64-row group lane-major blocks of 64 values + 64 sixteen-bit column offsets, the diagonal first; one wave per group)",
     0: "spmv_wstream_kernel<512,true,true> (wave-private CSR stream)",
     1: "spmv_dia_kernel<true,true,false> (sliced-DIA, slice by slice: x fits the last-level cache at this size)",
     2: "spmv_dia_march_kernel<true,true,true> (plane-marching sliced-DIA, 16-byte window accesses)",

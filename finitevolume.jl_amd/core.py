@@ -286,7 +286,8 @@ class Problem:
 
     SPMV_FORMS = {-1: "none yet", 0: "CSR wave-stream", 1: "sliced-DIA, slice by slice", 2: "sliced-DIA, plane-marching",
                   3: "symmetric plane-marching (diagonal + 3 upper diagonals)",
-                  4: "symmetric, tiled traversal (diagonal + 3 upper diagonals, arms through LDS)"}
+                  4: "symmetric, tiled traversal (diagonal + 3 upper diagonals, arms through LDS)",
+                  5: "SELL-64, 16-bit column offsets (irregular meshes after the locality re-numbering)"}
 
     def reorder_info(self):
         """fv_problem_reorder_info -> dict(reordered, mean_before, mean_after, seconds)."""

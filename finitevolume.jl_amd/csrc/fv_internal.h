@@ -234,6 +234,15 @@ struct fv_problem {
     DevBuf<int32_t> dia_list_ord; // the DIA slices in traversal order (plane-blocked), when the operator has a plane stride
     DevBuf<double> dia_vals;
     int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
+    // SELL-64 copy of the 64-row groups the CSR kernel would serve (irregular meshes after the locality re-numbering): per group
+    // `width` lane-major blocks of 64 values + 64 sixteen-bit column offsets relative to the row, the diagonal first (fv_spmv.hip)
+    DevBuf<double> sell_vals;
+    DevBuf<int16_t> sell_dcol;
+    DevBuf<int32_t> sell_ptr, sell_list, sell_rest; // first block of every group; groups in the form / CSR groups that are not
+    DevBuf<uint8_t> sell_w;
+    int64_t sell_n = 0, sell_nrest = 0, sell_blocks = 0, sell_vals_epoch = -1;
+    double sell_tag = 0.0;
+    int sell_state = -1; // -1 not looked at, 0 not usable, 1 built
     double dia_tag = 0.0;
     bool dia_built = false;
     bool dia_partial = false; // dia_vals holds only the slices of sym_rest (the symmetric marching kernel does the others)

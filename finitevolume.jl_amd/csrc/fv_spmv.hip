@@ -256,6 +256,150 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
     }
 }
 
+// ------------------------------------------------------------------ SELL-64 with 16-bit column offsets (irregular meshes)
+// After the locality re-numbering (fv_reorder.hip) every neighbour of a DFN cell sits within a few thousand rows, so a column is
+// row + a 16-bit offset, and rows of a 64-row group have about the same length: group g stores width(g) blocks of 64 values and
+// 64 offsets, block k holding entry k of every row (lane-major: a wave's load of a block is one contiguous 512 + 128 bytes), the
+// diagonal as entry 0, zeros behind a row's last entry.  No row pointers, no 32-bit columns, no staging of products in LDS:
+// 10 bytes per stored entry instead of 12 + the row pointer, and the fused step (fv_fused.hip) reads the same arrays.
+constexpr int SELL_MAX_W = 32;
+
+// width of every listed group (0: not representable — a row longer than SELL_MAX_W, a column further than 32767 rows away, a
+// row without a diagonal entry); one wave per group
+__global__ __launch_bounds__(FV_BLOCK) void sell_width_kernel(int64_t n, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ rowptr,
+                                                               const int32_t *__restrict__ colind, int32_t *__restrict__ width, int32_t *__restrict__ good,
+                                                               int32_t *__restrict__ bad)
+{
+    const int64_t k = ((int64_t)blockIdx.x * FV_BLOCK + threadIdx.x) >> 6;
+    if (k >= count)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = list ? list[k] : k, row = (g << 6) + lane;
+    int len = 0;
+    bool ok = true;
+    if (row < n) {
+        const int32_t s = rowptr[row], e = rowptr[row + 1];
+        len = e - s;
+        bool diag = false;
+        for (int32_t j = s; j < e; j++) {
+            const int64_t d = (int64_t)colind[j] - row;
+            ok = ok && d >= -32767 && d <= 32767;
+            diag = diag || d == 0;
+        }
+        ok = ok && diag && len <= SELL_MAX_W;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(len, off, 64);
+        len = o > len ? o : len;
+    }
+    const bool all_ok = __all(ok);
+    if (lane == 0) {
+        width[g] = all_ok ? len : 0;
+        good[k] = all_ok ? 1 : 0;
+        bad[k] = all_ok ? 0 : 1;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void sell_fill_kernel(int64_t n, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ptr,
+                                                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                              const double *__restrict__ vals, double *__restrict__ sv, int16_t *__restrict__ sd,
+                                                              uint8_t *__restrict__ w8)
+{
+    const int64_t k = ((int64_t)blockIdx.x * FV_BLOCK + threadIdx.x) >> 6;
+    if (k >= count)
+        return;
+    const int lane = threadIdx.x & 63;
+    const int64_t g = list[k], row = (g << 6) + lane;
+    const int64_t base = (int64_t)ptr[g] * 64 + lane;
+    const int w = ptr[g + 1] - ptr[g];
+    if (lane == 0)
+        w8[g] = (uint8_t)w;
+    int filled = 1;
+    double dv = 0.0;
+    if (row < n) {
+        for (int32_t j = rowptr[row], e = rowptr[row + 1]; j < e; j++) {
+            const int32_t d = colind[j] - (int32_t)row;
+            if (d == 0)
+                dv += vals[j];
+            else {
+                sv[base + (int64_t)filled * 64] = vals[j];
+                sd[base + (int64_t)filled * 64] = (int16_t)d;
+                filled++;
+            }
+        }
+    }
+    sv[base] = dv; // the diagonal first
+    sd[base] = 0;
+    for (; filled < w; filled++) {
+        sv[base + (int64_t)filled * 64] = 0.0;
+        sd[base + (int64_t)filled * 64] = 0;
+    }
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void sell_gather_kernel(int64_t m, const int32_t *__restrict__ idx, const int32_t *__restrict__ list,
+                                                                int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < m)
+        out[i] = list[idx[i]];
+}
+
+// y = (A + sigma D) x over the listed groups, one wave per group and pass, every XCD a contiguous share of the list
+template <bool DOT>
+__global__ __launch_bounds__(FV_BLOCK) void spmv_sell_kernel(int64_t n, int64_t count, const int32_t *__restrict__ list, const int32_t *__restrict__ ptr,
+                                                              const uint8_t *__restrict__ w8, const double *__restrict__ sv,
+                                                              const int16_t *__restrict__ sd, const double *__restrict__ x, double *__restrict__ y,
+                                                              const double *__restrict__ shift, double sigma, double *__restrict__ partials,
+                                                              const PcgScalars *__restrict__ scal)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double smem[4];
+    if (scal && scal->done)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t per_xcd = (count + 7) >> 3;
+    const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xend = (xbase + per_xcd < count) ? xbase + per_xcd : count;
+    double dacc = 0.0;
+    for (int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave; pos < xend; pos += pstride) {
+        const int64_t g = list[pos], row = (g << 6) + lane;
+        const int w = w8[g];
+        const bool live = row < n;
+        const double *v = sv + (int64_t)ptr[g] * 64 + lane;
+        const int16_t *d = sd + (int64_t)ptr[g] * 64 + lane;
+        const double *xr = x + (live ? row : 0); // (lanes past the last row: zeros times x[0])
+        double sum = 0.0;
+        int k = 0;
+        for (; k + 4 <= w; k += 4) {
+            const double a0 = __builtin_nontemporal_load(v + (k + 0) * 64), a1 = __builtin_nontemporal_load(v + (k + 1) * 64);
+            const double a2 = __builtin_nontemporal_load(v + (k + 2) * 64), a3 = __builtin_nontemporal_load(v + (k + 3) * 64);
+            const int d0 = __builtin_nontemporal_load(d + (k + 0) * 64), d1 = __builtin_nontemporal_load(d + (k + 1) * 64);
+            const int d2 = __builtin_nontemporal_load(d + (k + 2) * 64), d3 = __builtin_nontemporal_load(d + (k + 3) * 64);
+            sum += a0 * xr[d0];
+            sum += a1 * xr[d1];
+            sum += a2 * xr[d2];
+            sum += a3 * xr[d3];
+        }
+        for (; k < w; k++)
+            sum += __builtin_nontemporal_load(v + k * 64) * xr[(int)__builtin_nontemporal_load(d + k * 64)];
+        if (live) {
+            const double xi = xr[0];
+            if (shift)
+                sum += sigma * shift[row] * xi;
+            __builtin_nontemporal_store(sum, y + row);
+            if (DOT)
+                dacc += xi * sum;
+        }
+    }
+    if (DOT) {
+        const double t = block_sum(dacc, smem);
+        if (threadIdx.x == 0)
+            partials[blockIdx.x] = t;
+    }
+}
+
 // Tuning knobs (fv_tune) for in-process A/B: 0 = SpMV form (1 lanes-per-row, 2 wave stream),
 // 1 = unroll of the lanes-per-row form, 2 = use the plane-blocked traversal order (0/1),
 // 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1),
@@ -266,6 +410,7 @@ static int g_use_order = 1;
 static int g_nt = 1;
 int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 int g_use_dia = 1;
+static int g_sell = 1; // fv_tune key 54: SELL-64 with 16-bit column offsets for the groups the CSR kernel would serve (0: always the CSR wave-stream)
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
 static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
@@ -401,6 +546,8 @@ extern "C" int fv_tune(int key, int value)
         g_amg_kcycle = value;
     else if (key == 53 && value >= 0)
         g_amg_stream = value;
+    else if (key == 54 && (value == 0 || value == 1))
+        g_sell = value;
     else if (key == 50 && (value == 0 || value == 1))
         g_fused_dist = value;
     else if (key == 51 && value >= 0 && value <= 4)
@@ -1922,6 +2069,124 @@ static int stream_grid(int64_t npos)
     return (int)g;
 }
 
+static int launch_wstream(fv_problem *p, int G, const double *vals, const double *x, double *y, const double *shift, double sigma,
+                          int mode, double *partials, const PcgScalars *scal, const int32_t *order, int64_t npos, const StepInitEpilogue &epi);
+// The SELL copy of the groups the CSR kernel would serve (`list` / `count`: p->csr_list, or all groups of a pure-CSR operator):
+// structure once per problem (the symbolic phase fixed the pattern), values per assembly and folded shift.
+static int ensure_sell(fv_problem *p, const int32_t *list, int64_t count, const double *vals, double tag)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->sell_state == 0 || !g_sell)
+        return FV_OK;
+    const int64_t ns = (p->n + 63) >> 6;
+    if (p->sell_state < 0) {
+        p->sell_state = 0;
+        if (count < 1024 || p->n >= (int64_t)0x7fffffff - 64) // small operators are launch-bound either way
+            return FV_OK;
+        fv_pool_begin();
+        int rc = FV_OK;
+        do {
+            DevBuf<int32_t> width, good, bad;
+            if ((rc = width.alloc(ctx, (size_t)ns + 1)) || (rc = width.zero(ctx)) || (rc = good.alloc(ctx, (size_t)count)) || (rc = bad.alloc(ctx, (size_t)count)))
+                break;
+            hipLaunchKernelGGL(sell_width_kernel, dim3(fv_blocks(count * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, count, list,
+                               (const int32_t *)p->rowptr.p, (const int32_t *)p->colind.p, width.p, good.p, bad.p);
+            if ((rc = p->sell_ptr.alloc(ctx, (size_t)ns + 1)) || (rc = fv_exclusive_scan_i32(ctx, width.p, p->sell_ptr.p, ns, &p->sell_blocks)))
+                break;
+            if ((rc = p->sell_list.alloc(ctx, (size_t)count)) || (rc = p->sell_rest.alloc(ctx, (size_t)count)))
+                break;
+            // positions in `list` -> group numbers
+            DevBuf<int32_t> pos;
+            if ((rc = pos.alloc(ctx, (size_t)count)))
+                break;
+            if ((rc = fv_compact_flags(ctx, good.p, count, pos.p, &p->sell_n)))
+                break;
+            if (p->sell_n > 0) {
+                if (list)
+                    hipLaunchKernelGGL(sell_gather_kernel, dim3(fv_blocks(p->sell_n)), dim3(FV_BLOCK), 0, ctx->stream, p->sell_n, (const int32_t *)pos.p, list,
+                                       p->sell_list.p);
+                else
+                    rc = fv_copy(ctx, p->sell_list.p, pos.p, (size_t)p->sell_n * sizeof(int32_t));
+            }
+            if (rc || (rc = fv_compact_flags(ctx, bad.p, count, pos.p, &p->sell_nrest)))
+                break;
+            if (p->sell_nrest > 0) {
+                if (list)
+                    hipLaunchKernelGGL(sell_gather_kernel, dim3(fv_blocks(p->sell_nrest)), dim3(FV_BLOCK), 0, ctx->stream, p->sell_nrest, (const int32_t *)pos.p,
+                                       list, p->sell_rest.p);
+                else
+                    rc = fv_copy(ctx, p->sell_rest.p, pos.p, (size_t)p->sell_nrest * sizeof(int32_t));
+            }
+            if (rc)
+                break;
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                rc = FV_ERR_HIP;
+                break;
+            }
+        } while (0);
+        fv_pool_end();
+        FV_TRY(rc);
+        // worth it when nearly every group fits and the padding stays small (10 B per stored entry against 12 per real one)
+        int64_t nnz_groups = p->nnz; // (an upper bound when some groups are DIA slices)
+        if (p->sell_n * 10 < count * 9 || p->sell_blocks * 64 * 10 > nnz_groups * 12 + 4 * p->n) {
+            p->sell_ptr.release();
+            p->sell_list.release();
+            p->sell_rest.release();
+            return FV_OK;
+        }
+        FV_TRY(p->sell_vals.alloc(ctx, (size_t)p->sell_blocks * 64 + 64));
+        FV_TRY(p->sell_dcol.alloc(ctx, (size_t)p->sell_blocks * 64 + 64));
+        FV_TRY(p->sell_w.alloc(ctx, (size_t)ns));
+        FV_HIP(ctx, hipMemsetAsync(p->sell_w.p, 0, (size_t)ns, ctx->stream));
+        p->sell_vals_epoch = -1;
+        p->sell_state = 1;
+    }
+    if (p->sell_vals_epoch != p->assemble_epoch || p->sell_tag != tag) {
+        hipLaunchKernelGGL(sell_fill_kernel, dim3(fv_blocks(p->sell_n * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sell_n, (const int32_t *)p->sell_list.p,
+                           (const int32_t *)p->sell_ptr.p, (const int32_t *)p->rowptr.p, (const int32_t *)p->colind.p, vals, p->sell_vals.p, p->sell_dcol.p,
+                           p->sell_w.p);
+        FV_LAUNCH_CHECK(ctx);
+        p->sell_vals_epoch = p->assemble_epoch;
+        p->sell_tag = tag;
+    }
+    return FV_OK;
+}
+
+// The groups the CSR kernel would serve, through the SELL form where it was built (SPMV_PLAIN / SPMV_DOT; not for subsets of a
+// row block); *nparts: partial sums written from `partials` on
+static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, const double *x, double *y, const double *shift, double sigma, int mode,
+                            double *partials, const PcgScalars *scal, const int32_t *list, int64_t count, const StepInitEpilogue &epi, int *nparts, bool *used_sell)
+{
+    fv_ctx *ctx = p->ctx;
+    *used_sell = false;
+    if (mode != SPMV_INIT && !p->dist && p->nhalo == 0)
+        FV_TRY(ensure_sell(p, list == p->group_order.p ? nullptr : list, count, vals, vals_tag));
+    if (mode == SPMV_INIT || p->sell_state != 1 || p->dist || p->nhalo > 0) {
+        const int G = stream_grid(count);
+        FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, list, count, epi));
+        *nparts = G;
+        return FV_OK;
+    }
+    const int GS = stream_grid(p->sell_n);
+    if (mode == SPMV_DOT)
+        hipLaunchKernelGGL((spmv_sell_kernel<true>), dim3(GS), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sell_n, (const int32_t *)p->sell_list.p,
+                           (const int32_t *)p->sell_ptr.p, (const uint8_t *)p->sell_w.p, (const double *)p->sell_vals.p, (const int16_t *)p->sell_dcol.p, x, y,
+                           shift, sigma, partials, scal);
+    else
+        hipLaunchKernelGGL((spmv_sell_kernel<false>), dim3(GS), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sell_n, (const int32_t *)p->sell_list.p,
+                           (const int32_t *)p->sell_ptr.p, (const uint8_t *)p->sell_w.p, (const double *)p->sell_vals.p, (const int16_t *)p->sell_dcol.p, x, y,
+                           shift, sigma, partials, scal);
+    FV_LAUNCH_CHECK(ctx);
+    int GR = 0;
+    if (p->sell_nrest > 0) {
+        GR = stream_grid(p->sell_nrest);
+        FV_TRY(launch_wstream(p, GR, vals, x, y, shift, sigma, mode, partials ? partials + GS : nullptr, scal, p->sell_rest.p, p->sell_nrest, epi));
+    }
+    *nparts = GS + GR;
+    *used_sell = true;
+    return FV_OK;
+}
+
 // y = (A + sigma D) x for a CSR the library did not build itself (the AMG's coarse levels): the wave-stream kernel over all 64-row
 // groups in their natural order, 1024 entries per group and pass.  vals / colind must carry two padding entries past nnz.
 int fv_csr_stream_spmv(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *x, double *y,
@@ -2264,18 +2529,24 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         const int GD = march ? GM + GR : GA; // partials written by the DIA part
         int GB = 0;
         if (ccount > 0) {
-            GB = stream_grid(ccount);
-            FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GD : nullptr, scal, clist, ccount,
-                                  offset_epilogue(epi, GD)));
+            bool sell = false;
+            if (subset) {
+                GB = stream_grid(ccount);
+                FV_TRY(launch_wstream(p, GB, vals, x, y, shift, sigma, mode, partials ? partials + GD : nullptr, scal, clist, ccount,
+                                      offset_epilogue(epi, GD)));
+            } else
+                FV_TRY(launch_irregular(p, vals, vals_tag, x, y, shift, sigma, mode, partials ? partials + GD : nullptr, scal, clist, ccount,
+                                        offset_epilogue(epi, GD), &GB, &sell));
         }
         if (nparts)
             *nparts = GD + GB;
         return FV_OK;
     }
-    const int G = stream_grid(ngroups);
+    int G = 0;
     const int32_t *order = (g_use_order && p->group_order.p) ? p->group_order.p : nullptr;
-    p->last_form = FV_SPMV_CSR;
-    FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, order, ngroups, epi));
+    bool sell = false;
+    FV_TRY(launch_irregular(p, vals, vals_override ? p->shifted_sigma : 0.0, x, y, shift, sigma, mode, partials, scal, order, ngroups, epi, &G, &sell));
+    p->last_form = sell ? FV_SPMV_SELL : FV_SPMV_CSR;
     if (nparts)
         *nparts = G;
     return FV_OK;
@@ -2331,6 +2602,8 @@ extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_lau
         } else
             bytes = dia_all + vec + csr_part;
     }
+    if (p->last_form == FV_SPMV_SELL && ns > 0)
+        bytes = p->sell_blocks * 64 * 10 + 5 * p->sell_n + 16 * n + csr_all / ns * p->sell_nrest;
     *bytes_per_launch = bytes;
     return FV_OK;
 }

@@ -83,6 +83,7 @@ extern "C" {
  *  52: AMG K-cycle: the coarse levels 1 .. value are solved by two flexible-CG steps preconditioned by the cycle below them, the PCG
  *      around the cycle becomes flexible [see fv_amg.hip for the default]; 0 = V-cycle
  *  53: AMG coarse levels with at least this many rows run the wave-stream CSR kernel [65536]; 0 = always the lanes-per-row kernel
+ *  54: SELL-64 with 16-bit column offsets (FV_SPMV_SELL) for the 64-row groups the CSR wave-stream kernel would serve [1]
  *  45: streaming-hint experiments on the fused step (bit 0: z' stored non-temporally, 1: v' too, 2: x / v plain loads, 3: x_out
  *      plain store, 4: matrix plain loads) [0] */
 int fv_tune(int key, int value);

@@ -263,6 +263,9 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
  *                      re-derived from the arms, fv_tune key 37) + 16 n
  *   FV_SPMV_SYM_TILE   the same arrays, tiled traversal (blocks own 1024 rows of a plane and march through planes, arms through
  *                      LDS): where the free rows are a regular box numbered like regulargrid's (fv_tune key 38)
+ *   FV_SPMV_SELL     SELL-64 with 16-bit column offsets (irregular meshes whose locality re-numbering keeps every neighbour
+ *                    within 32767 rows): 10 B per stored entry (64 x the longest row of each 64-row group; the diagonal first)
+ *                    + 16 n + 5 B per group; groups that do not fit (rows of more than 32 entries, a far neighbour) stay CSR
  * Slices left to another form (CSR groups of an irregular part, slices the symmetric kernel hands to the slice kernel)
  * are counted in their own form, pro rata by slice count.  *form = -1 before the first SpMV. */
 #define FV_SPMV_CSR 0
@@ -270,6 +273,7 @@ int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64_t *launche
 #define FV_SPMV_DIA_MARCH 2
 #define FV_SPMV_SYM_MARCH 3
 #define FV_SPMV_SYM_TILE 4
+#define FV_SPMV_SELL 5
 int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_launch);
 /* Bytes per row the most recent K2S launch (the fused vector update of a fixed-dt step in the one-iteration regime:
  * x += alpha p, r -= alpha q, the convergence sums and the next step's set-up) streams: 56 in the z-form (fv_tune key 36:
