@@ -13,7 +13,11 @@ struct FusedSums {
     int nvec, nbb, npq;
 };
 
-extern int g_fused, g_fused_dist, g_fused_dist_spare;
+extern int g_fused, g_fused_dist, g_fused_dist_spare, g_fused_sell;
+// fv_spmv.hip: the SELL form's grid, and the classic product (with partial x.y) of the groups outside it
+int fv_sell_grid(fv_problem *p);
+int fv_spmv_sell_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts);
+bool fv_fused_streams_storage(fv_problem *p);
 bool fv_fused_applicable(fv_problem *p, double sigma);
 int fv_fused_prepare(fv_problem *p);
 FusedSums fv_fused_sums(fv_problem *p, int parity);

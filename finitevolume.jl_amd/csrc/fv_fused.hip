@@ -38,6 +38,8 @@ int g_fused_codes = 1;  // fv_tune key 49: the matrix as 16-bit codes per row wh
 int g_fused_iter = 1;   // fv_tune key 46: the many-iteration loop through the fused kernel too (direction update + product in one pass, z kept instead of r)
 int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
 int g_fused_dist_spare = 1; // fv_tune key 51: CUs per XCD a row block's fused launch leaves to the halo exchange
+int g_fused_sell_blocks = 4; // fv_tune key 56 (experiment): resident blocks per CU the SELL step's grid is sized for
+int g_fused_sell = 1;  // fv_tune key 55: the fused step on the SELL form (irregular meshes) too
 int g_fused_dist = 1;  // fv_tune key 50: the fused step on row blocks too (0: row blocks keep the K1 + K2S pair)
 int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
                         // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
@@ -121,57 +123,21 @@ __device__ __forceinline__ VRow vrow(double xin, double z, double v, double d, d
     return o;
 }
 
-// MODE 0: the fused step.  MODE 1: one pass of the many-iteration regime — the direction update of PCG iteration `it` and its
-// product: p' = z + beta p (z = M^-1 r, kept instead of r between the passes), q = (A + sigma D) p', partial p'.q; the scalar
-// work of K3 (beta, the convergence verdict, the residual history) in the prologue.  Same traversal, same halo trick (a halo
-// row is z + beta p: two streams, one FMA); no x, no storage term, no vector sums.  a.z = z, a.v = p (old), a.znext = p', a.vnext = q.
-// CODED: the three upper diagonals come as one 16-bit word per row — three 5-bit codes into tables of their distinct values
-// (a homogeneous conductivity on a regular grid: a handful of values per direction; fv_matrix_codes) — instead of three doubles:
-// 2 instead of 24 bytes of matrix per row, the same doubles out of the tables, so nothing else changes.
-template <int TL, int MODE, bool CODED>
-__global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
+// The scalar part of a fused step (MODE 0), shared by the tiled kernel and the SELL kernel: every block takes the same decisions
+// from values no block of this launch writes (the partial sums of the previous launch or the all-reduced sums of a row block, scal
+// fields written by earlier launches) — the previous chained step's verdict and, if it did not converge, its fall-back (that
+// step's residual and next direction, done = 3); this step's set-up scalars, zero-iteration steps, breakdown; alpha.
+// false: the launch stops here.  red: NT / 64 doubles of LDS.
+template <int NT>
+__device__ __forceinline__ bool kf_step_prologue(const KfArgs &a, double *red, double &alpha)
 {
-    constexpr int TW = KF_TW, NT = TL * TW / 2, HC = TW / 2;
-    constexpr int ZS = TW + 4, U1S = TW + 2, U2S = TW; // LDS row strides: own column tc sits at 2 + tc (z', U1) so that pairs stay 16-byte aligned
-    constexpr int ZT = (TL + 2) * ZS, U1T = TL * U1S, U2T = (TL + 1) * U2S;
-    constexpr int NH = 2 * TW + 2 * TL; // threads with a halo row: line above, line below, column left, column right
-    __shared__ __align__(16) double zs[2 * ZT];
-    __shared__ __align__(16) double u1s[3 * U1T];
-    __shared__ __align__(16) double u2s[3 * U2T];
-    __shared__ double tab[FV_STORAGE_CODES];
-    __shared__ double mtab[CODED ? 3 * FV_MATRIX_CODES : 1];
-    __shared__ double red[NT / 64];
     const int tid = (int)threadIdx.x;
     PcgScalars *scal = a.scal;
-    // ---------------------------------------------------------------- scalars: every block takes the same decisions from
-    // values no block of this launch writes (the partial sums of the previous launch, scal fields written by earlier ones)
-    double alpha = 0.0;
-    if (MODE == 1) {
-        if (*reinterpret_cast<volatile int32_t *>(&scal->done))
-            return;
-        // K3's scalars (pcg_pupdate_kernel): beta from the sums the vector pass left, the verdict on the iteration that pass finished
-        const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
-        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
-        const bool converged = rrn <= scal->tol2;
-        if (blockIdx.x == 0 && tid == 0) {
-            scal->rz[(a.chain_index + 1) & 1] = rzn;
-            scal->rr = rrn;
-            scal->iters = a.chain_index + 1;
-            if (a.hist && a.chain_index < a.hist_cap)
-                a.hist[a.chain_index] = sqrt(rrn);
-            if (converged)
-                scal->done = 1;
-        }
-        if (converged)
-            return;
-        alpha = rzn / scal->rz[a.chain_index & 1]; // (beta: it plays alpha's part in z + alpha v)
-    }
-    if (MODE == 0) {
     const int d0 = *reinterpret_cast<volatile int32_t *>(&scal->done);
     if (d0 == 2)
-        return;
+        return false;
     if (d0 == 3 && !(a.mode == 1 && *reinterpret_cast<volatile int32_t *>(&scal->chain_step) == a.chain_index - 1))
-        return; // the chain broke at an earlier step (the exception: block 0 of THIS launch has just said so)
+        return false; // the chain broke at an earlier step (the exception: block 0 of THIS launch has just said so)
     double rz0;
     bool zero_iteration;
     // a sum of the previous launch: its partial pieces, or (row blocks) the value all-reduced over the ranks
@@ -218,7 +184,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 __threadfence();
                 scal->done = 3;
             }
-            return;
+            return false;
         }
         rz0 = total(3, a.in.srz, a.in.nvec);
         const double rr0 = total(4, a.in.srr, a.in.nvec);
@@ -246,13 +212,64 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 scal->pq = pq;
                 scal->done = 2;
             }
-            return;
+            return false;
         }
         alpha = rz0 / pq;
         if (blockIdx.x == 0 && tid == 0)
             scal->pq = pq;
     } else if (blockIdx.x == 0 && tid == 0)
         scal->zero_mask |= 1u << a.chain_index; // the step counts 0 iterations: alpha = 0 hands the state over unchanged
+    return true;
+}
+
+// MODE 0: the fused step.  MODE 1: one pass of the many-iteration regime — the direction update of PCG iteration `it` and its
+// product: p' = z + beta p (z = M^-1 r, kept instead of r between the passes), q = (A + sigma D) p', partial p'.q; the scalar
+// work of K3 (beta, the convergence verdict, the residual history) in the prologue.  Same traversal, same halo trick (a halo
+// row is z + beta p: two streams, one FMA); no x, no storage term, no vector sums.  a.z = z, a.v = p (old), a.znext = p', a.vnext = q.
+// CODED: the three upper diagonals come as one 16-bit word per row — three 5-bit codes into tables of their distinct values
+// (a homogeneous conductivity on a regular grid: a handful of values per direction; fv_matrix_codes) — instead of three doubles:
+// 2 instead of 24 bytes of matrix per row, the same doubles out of the tables, so nothing else changes.
+template <int TL, int MODE, bool CODED>
+__global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
+{
+    constexpr int TW = KF_TW, NT = TL * TW / 2, HC = TW / 2;
+    constexpr int ZS = TW + 4, U1S = TW + 2, U2S = TW; // LDS row strides: own column tc sits at 2 + tc (z', U1) so that pairs stay 16-byte aligned
+    constexpr int ZT = (TL + 2) * ZS, U1T = TL * U1S, U2T = (TL + 1) * U2S;
+    constexpr int NH = 2 * TW + 2 * TL; // threads with a halo row: line above, line below, column left, column right
+    __shared__ __align__(16) double zs[2 * ZT];
+    __shared__ __align__(16) double u1s[3 * U1T];
+    __shared__ __align__(16) double u2s[3 * U2T];
+    __shared__ double tab[FV_STORAGE_CODES];
+    __shared__ double mtab[CODED ? 3 * FV_MATRIX_CODES : 1];
+    __shared__ double red[NT / 64];
+    const int tid = (int)threadIdx.x;
+    PcgScalars *scal = a.scal;
+    // ---------------------------------------------------------------- scalars: every block takes the same decisions from
+    // values no block of this launch writes (the partial sums of the previous launch, scal fields written by earlier ones)
+    double alpha = 0.0;
+    if (MODE == 1) {
+        if (*reinterpret_cast<volatile int32_t *>(&scal->done))
+            return;
+        // K3's scalars (pcg_pupdate_kernel): beta from the sums the vector pass left, the verdict on the iteration that pass finished
+        const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
+        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
+        const bool converged = rrn <= scal->tol2;
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->rz[(a.chain_index + 1) & 1] = rzn;
+            scal->rr = rrn;
+            scal->iters = a.chain_index + 1;
+            if (a.hist && a.chain_index < a.hist_cap)
+                a.hist[a.chain_index] = sqrt(rrn);
+            if (converged)
+                scal->done = 1;
+        }
+        if (converged)
+            return;
+        alpha = rzn / scal->rz[a.chain_index & 1]; // (beta: it plays alpha's part in z + alpha v)
+    }
+    if (MODE == 0) {
+        if (!kf_step_prologue<NT>(a, red, alpha))
+            return;
     }
     // ---------------------------------------------------------------- the pass
     if (tid < FV_STORAGE_CODES)
@@ -609,6 +626,124 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     }
 }
 
+// ------------------------------------------------------------------ the fused step on the SELL form (irregular meshes)
+// The same step (kf_step_prologue, vrow, the same six sums) for operators stored as SELL-64 with 16-bit column offsets
+// (fv_spmv.hip): one wave per 64-row group, a lane per row.  A neighbour's z' is z + alpha v of that row — two gathers that hit the
+// cache lines the re-numbering keeps close — so a row streams x, z, v, its matrix blocks and sigma D (a code byte where the
+// storage term takes few values) in and x_out, z', v' out: 74 + 56 = 130 B per row against 89 + 49 for the SpMV + K2S pair.
+struct KsArgs {
+    int64_t count;
+    const int32_t *list, *ptr;
+    const uint8_t *w8;
+    const double *sv;
+    const int16_t *sd;
+    const double *D; // the storage term as a stream (null: codes / one value through a.code and a.sD)
+    double sigma;
+    // the groups that stay with the CSR kernel: their vector part is this kernel's, their products follow (fv_spmv_sell_rest)
+    const int32_t *rest;
+    int64_t nrest;
+    const double *diagA; // ... whose shifted diagonal is diagA + sigma D, as the Jacobi preconditioner formed it
+};
+
+__global__ __launch_bounds__(FV_BLOCK) void fused_sell_step_kernel(KfArgs a, KsArgs s)
+{
+    constexpr int NT = FV_BLOCK, WPB = FV_BLOCK / 64;
+    __shared__ double red[NT / 64];
+    __shared__ double tab[FV_STORAGE_CODES];
+    const int tid = (int)threadIdx.x;
+    double alpha = 0.0;
+    if (!kf_step_prologue<NT>(a, red, alpha))
+        return;
+    if (tid < FV_STORAGE_CODES)
+        tab[tid] = a.sD.v[tid];
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t per_xcd = (s.count + 7) >> 3;
+    const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xend = (xbase + per_xcd < s.count) ? xbase + per_xcd : s.count;
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    for (int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave; pos < xend; pos += pstride) {
+        const int64_t g = s.list[pos], row = (g << 6) + lane;
+        const int w = s.w8[g];
+        const bool live = row < a.n;
+        const int64_t r0 = live ? row : 0;
+        const double *mv = s.sv + (int64_t)s.ptr[g] * 64 + lane;
+        const int16_t *md = s.sd + (int64_t)s.ptr[g] * 64 + lane;
+        const double *zr = a.z + r0, *vr = a.v + r0;
+        const double xi = __builtin_nontemporal_load(a.x + r0), zi = zr[0], vi = vr[0];
+        const double sD = s.D ? s.sigma * __builtin_nontemporal_load(s.D + r0) : (a.code ? tab[a.code[r0]] : tab[0]);
+        const double d = live ? __builtin_nontemporal_load(mv) : 1.0; // the (shifted) diagonal first
+        double sum = 0.0;
+        int k = 1;
+        // (three entries at a time, loads first: written out by hand — a generic predicated loop over the entries, also with two or
+        // four groups per wave and pass, measured 0.17-0.19 ms per step on the 5M-cell mesh against 0.136; six at a time: no gain)
+        for (; k + 3 <= w; k += 3) {
+            const double a0 = __builtin_nontemporal_load(mv + (k + 0) * 64), a1 = __builtin_nontemporal_load(mv + (k + 1) * 64);
+            const double a2 = __builtin_nontemporal_load(mv + (k + 2) * 64);
+            const int d0 = __builtin_nontemporal_load(md + (k + 0) * 64), d1 = __builtin_nontemporal_load(md + (k + 1) * 64);
+            const int d2 = __builtin_nontemporal_load(md + (k + 2) * 64);
+            const double z0 = zr[d0] + alpha * vr[d0], z1 = zr[d1] + alpha * vr[d1], z2 = zr[d2] + alpha * vr[d2];
+            sum += a0 * z0;
+            sum += a1 * z1;
+            sum += a2 * z2;
+        }
+        for (; k < w; k++) {
+            const int dk = __builtin_nontemporal_load(md + k * 64);
+            sum += __builtin_nontemporal_load(mv + k * 64) * (zr[dk] + alpha * vr[dk]);
+        }
+        if (live) {
+            const VRow o = vrow(xi, zi, vi, d, sD, alpha);
+            const double q = d * o.zn + sum;
+            __builtin_nontemporal_store(o.xn, a.xout + row);
+            a.znext[row] = o.zn;
+            a.vnext[row] = -(o.mv * (q - sD * o.zn));
+            acc[0] += o.r * (o.mv * o.r);
+            acc[1] += o.r * o.r;
+            acc[2] += o.c * o.zn;
+            acc[3] += o.c * o.c;
+            acc[4] += o.h * o.h;
+            acc[5] += o.zn * q;
+        }
+    }
+    for (int64_t pos = (int64_t)blockIdx.x * WPB + wave; pos < s.nrest; pos += (int64_t)gridDim.x * WPB) {
+        const int64_t row = ((int64_t)s.rest[pos] << 6) + lane;
+        if (row < a.n) {
+            const double sD = a.D[row] * s.sigma;
+            const VRow o = vrow(a.x[row], a.z[row], a.v[row], s.diagA[row] + sD, sD, alpha);
+            a.xout[row] = o.xn;
+            a.znext[row] = o.zn;
+            acc[0] += o.r * (o.mv * o.r);
+            acc[1] += o.r * o.r;
+            acc[2] += o.c * o.zn;
+            acc[3] += o.c * o.c;
+            acc[4] += o.h * o.h;
+        }
+    }
+    // the assembled b's share of |rhs|^2 over its support (as in the tiled kernel)
+    double sgather = 0.0;
+    if (a.bm > 0) {
+        for (int64_t k = (int64_t)blockIdx.x * NT + tid; k < a.bm; k += (int64_t)gridDim.x * NT) {
+            const int32_t i = a.bidx[k];
+            const double bi = a.b[i];
+            const double xn = a.x[i] + alpha * a.z[i];
+            const double sd = s.D ? s.sigma * s.D[i] : (a.code ? tab[a.code[i]] : tab[0]);
+            sgather += bi * (2.0 * (sd * xn) + bi);
+        }
+    }
+    const int G = (int)gridDim.x;
+    for (int k = 0; k < KF_NSUM; k++) {
+        const double t = kf_block_sum<NT>(acc[k], red);
+        if (tid == 0)
+            (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (a.bm > 0) {
+        const double t = kf_block_sum<NT>(sgather, red);
+        if (tid == 0)
+            a.out.sbb[G + blockIdx.x] = t;
+    }
+}
+
 // v = -M^-1 (q - sigma D z): from a product formed the classic way (entry into the fused regime, the slices the fused
 // kernel leaves to the slice-by-slice launch)
 __global__ __launch_bounds__(FV_BLOCK) void q_to_v_kernel(int64_t n, const double *__restrict__ q, const double *__restrict__ z,
@@ -674,8 +809,15 @@ __global__ __launch_bounds__(FV_BLOCK) void fused_pack_kernel(int64_t nsend, con
 
 // Can the chained step of this problem run fused?  (The symmetric tiled form serves the operator — the classic K1 of the
 // step that enters the regime has just established that —, the shift is folded, D comes as codes, M^-1 > 0.)
+// ... on the SELL form (irregular meshes): the classic K1 has just run in that form with the shift folded
+static bool kf_sell(const fv_problem *p) { return p->sell_state == 1 && p->last_form == FV_SPMV_SELL; }
+bool fv_fused_streams_storage(fv_problem *p) { return kf_sell(p); } // (the SELL kernel takes sigma D as a stream where there are no codes)
+
 bool fv_fused_applicable(fv_problem *p, double sigma)
 {
+    if (g_fused && g_fused_sell && kf_sell(p))
+        return !p->dist && p->nhalo == 0 && sigma != 0.0 && p->sell_vals_epoch == p->assemble_epoch && p->sell_tag == sigma &&
+               fv_sell_grid(p) <= FV_FUSED_PARTS / 2;
     if (!g_fused || (!p->dist && p->nhalo > 0) || p->sym_state != 1 || p->last_form != FV_SPMV_SYM_TILE)
         return false;
     if (p->sym_epoch != p->assemble_epoch || p->sym_tag != sigma || sigma == 0.0)
@@ -800,12 +942,84 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
     return true;
 }
 
+// the SELL variant of fv_fused_step (same contract)
+static int fused_sell_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode,
+                           const FusedSums &in, bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
+{
+    fv_ctx *ctx = p->ctx;
+    KfArgs a{};
+    KsArgs s{};
+    const bool coded = p->dcode_n > 0 && p->dcode_epoch == p->storage_epoch;
+    a.code = coded && p->dcode_n > 1 ? p->dcode.p : nullptr;
+    for (int k = 0; k < FV_STORAGE_CODES; k++)
+        a.sD.v[k] = coded ? sigma * p->dtable.v[k] : 0.0;
+    a.x = x;
+    a.z = p->pvec.p;
+    a.v = p->qv.p;
+    a.xout = x_next;
+    a.znext = p->pnext.p;
+    a.vnext = p->qv2.p;
+    a.bidx = bsupport > 0 ? p->bnz_idx.p : nullptr;
+    a.b = p->b.p;
+    a.bm = bsupport > 0 ? bsupport : 0;
+    a.scal = p->scal.p;
+    a.in = in;
+    a.mode = mode;
+    a.chain_index = chain_index;
+    a.force_prev_unconverged = force_prev_unconverged ? 1 : 0;
+    a.rtol = rtol;
+    a.n = p->n;
+    a.r = p->r.p;
+    a.pold = p->pnext.p;
+    a.minv = p->minv.p;
+    a.D = p->D.p;
+    a.xprev = x_next;
+    a.dt = dt;
+    // (78 registers: six waves per SIMD at most, and four blocks per CU measure best — 5M-cell mesh, ms per step at 8 / 6 / 5 / 4 / 3 / 2: 0.161 / 0.146 / 0.142 / 0.136 / 0.142 / 0.174; a grid beyond the resident blocks runs a second, thin round of its static shares)
+    int G = fv_sell_grid(p);
+    const int resident = p->ctx->num_cus * g_fused_sell_blocks / 8 * 8;
+    if (G > resident && resident >= 8)
+        G = resident;
+    FusedSums out = fv_fused_sums(p, chain_index & 1);
+    out.nvec = G;
+    out.nbb = a.bm > 0 ? 2 * G : G;
+    a.out = out;
+    s.count = p->sell_n;
+    s.list = p->sell_list.p;
+    s.ptr = p->sell_ptr.p;
+    s.w8 = p->sell_w.p;
+    s.sv = p->sell_vals.p;
+    s.sd = p->sell_dcol.p;
+    s.D = coded ? nullptr : p->D.p;
+    s.sigma = sigma;
+    s.rest = p->sell_rest.p;
+    s.nrest = p->sell_nrest;
+    s.diagA = p->diagA.p;
+    hipLaunchKernelGGL(fused_sell_step_kernel, dim3(G), dim3(FV_BLOCK), 0, ctx->stream, a, s);
+    FV_LAUNCH_CHECK(ctx);
+    int GR = 0;
+    if (p->sell_nrest > 0) { // the groups outside the form: classic product of z' into v', then the v-form
+        FV_TRY(fv_spmv_sell_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + G, &GR));
+        hipLaunchKernelGGL(q_to_v_slices_kernel, dim3(fv_blocks(p->sell_nrest * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sell_nrest,
+                           (const int32_t *)p->sell_rest.p, (const double *)p->pnext.p, (const double *)p->minv.p, (const double *)p->D.p, sigma, p->qv2.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    out.npq = G + GR;
+    *out_sums = out;
+    const int64_t matrix = p->sell_blocks * 640 + 5 * p->sell_n, stor = coded ? (a.code ? 1 : 0) : 8;
+    p->fused_bytes_launch = (48 + stor) * p->n + matrix;
+    p->fused_bytes = (int32_t)(p->fused_bytes_launch / (p->n > 0 ? p->n : 1));
+    return FV_OK;
+}
+
 // One fused launch (+ the slice-by-slice launch for the slices the symmetric form leaves out): step `chain_index` of a
 // burst.  x -> x_next, p->pvec (z) -> p->pnext (z'), p->qv (v) -> p->qv2 (v'); sums of parity `chain_index & 1`.
 int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode, const FusedSums &in,
                   bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums, const double *red)
 {
     fv_ctx *ctx = p->ctx;
+    if (kf_sell(p))
+        return fused_sell_step(p, x, x_next, sigma, dt, rtol, chain_index, mode, in, force_prev_unconverged, folded, bsupport, out_sums);
     KfArgs a{};
     a.red = red;
     const int GF = kf_setup(p, a);

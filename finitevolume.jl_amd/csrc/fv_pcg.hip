@@ -1027,8 +1027,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     // step was such a launch and has left v, the product's sums and the set-up sums of THIS step in its own arrays
     const bool was_vready = p->vready && use_spec;
     p->vready = false;
-    const bool fused = chained && speculate && zf && folded && sarg.D == nullptr && (bsupport >= 0 || !sys.rhs) && sys.x_next &&
-                       fv_fused_applicable(p, sigma);
+    const bool fused = chained && speculate && zf && folded && (sarg.D == nullptr || fv_fused_streams_storage(p)) && (bsupport >= 0 || !sys.rhs) &&
+                       sys.x_next && fv_fused_applicable(p, sigma);
     {
         static int trace = getenv("FV_TRACE_FUSED") ? atoi(getenv("FV_TRACE_FUSED")) : 0;
         if (trace > 0 && sys.implicit_step) {

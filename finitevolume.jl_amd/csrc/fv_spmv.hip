@@ -448,7 +448,7 @@ extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zf
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare, g_fused_sell, g_fused_sell_blocks; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -548,6 +548,10 @@ extern "C" int fv_tune(int key, int value)
         g_amg_stream = value;
     else if (key == 54 && (value == 0 || value == 1))
         g_sell = value;
+    else if (key == 55 && (value == 0 || value == 1))
+        g_fused_sell = value;
+    else if (key == 56 && value >= 1 && value <= 8)
+        g_fused_sell_blocks = value;
     else if (key == 50 && (value == 0 || value == 1))
         g_fused_dist = value;
     else if (key == 51 && value >= 0 && value <= 4)
@@ -2184,6 +2188,24 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
     }
     *nparts = GS + GR;
     *used_sell = true;
+    return FV_OK;
+}
+
+int fv_sell_grid(fv_problem *p)
+{
+    set_resident_blocks(p->ctx);
+    return stream_grid(p->sell_n);
+}
+
+// the groups outside the SELL form through the CSR kernel, with partial x.y (the fused step's products of those groups)
+int fv_spmv_sell_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts)
+{
+    *nparts = 0;
+    if (p->sell_state != 1 || p->sell_nrest <= 0)
+        return FV_OK;
+    const int GR = stream_grid(p->sell_nrest);
+    FV_TRY(launch_wstream(p, GR, vals, x, y, nullptr, 0.0, SPMV_DOT, partials, nullptr, p->sell_rest.p, p->sell_nrest, StepInitEpilogue{}));
+    *nparts = GR;
     return FV_OK;
 }
 

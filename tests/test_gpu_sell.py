@@ -109,3 +109,55 @@ def test_sell_fixed_dt_runs_and_steady_solve_match_the_csr_path(fv, hubs, far):
     assert np.array_equal(out[1][1], out[0][1]), (out[1][1], out[0][1])
     assert relerr(out[1][0], out[0][0]) < 1e-12
     assert abs(out[1][4] - out[0][4]) <= 2 and relerr(out[1][3], out[0][3]) < 1e-8
+
+
+@pytest.mark.parametrize("hubs,far,uniform_vol", [(0, 0, False), (5, 50, False), (0, 0, True)])
+def test_fused_step_on_the_sell_form_against_the_unfused_pair_and_the_csr_path(fv, oracle, hubs, far, uniform_vol):
+    """fused_sell_step_kernel in the bursts of a fixed-dt run (fv_tune 55): same iteration counts as the SpMV + K2S pair on the same
+    form and on the CSR form, heads to rounding; the storage term as a stream (arbitrary cell volumes) and as codes (one volume);
+    groups outside the form take the classic product + conversion; an injected chain break falls back to further iterations; the
+    oracle's direct solves for the same steps."""
+    w = _mesh(nfrac=3, m=300, hubs=hubs, far=far)
+    if uniform_vol:
+        w = dict(w, volumes=np.full(w["N"], 3e-3))
+    lib = fv.load()
+    sched = [(1.0, 26, 1e-12), (1e4, 2, 1e-12), (1.0, 11, 1e-12)]
+
+    def run(tune):
+        for k, v in tune:
+            assert lib.fv_tune(k, v) == 0
+        try:
+            p = _problem(fv, w)
+            st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
+            its = [p.run_fixed(st, dt, k, rtol=rtol, maxiter=5000)[0].copy() for dt, k, rtol in sched]
+            out = (st.node_values(), np.concatenate(its), p.fused_form(), p.spmv_form()[0])
+            p.close()
+        finally:
+            for k, v in tune:
+                lib.fv_tune(k, {14: -1}.get(k, 1))
+        return out
+
+    fused = run(())
+    pair = run(((55, 0),))
+    csr = run(((54, 0),))
+    assert fused[3] == 5 and pair[3] == 5 and csr[3] == 0
+    assert fused[2][0] >= 20 and pair[2][0] == 0 and csr[2][0] == 0, (fused[2], pair[2], csr[2])
+    per_row = fused[2][1]
+    assert (115 <= per_row <= 126) if uniform_vol else (122 <= per_row <= 134), fused[2]
+    assert np.array_equal(fused[1], pair[1]) and np.array_equal(fused[1], csr[1]), (fused[1], pair[1], csr[1])
+    assert relerr(fused[0], pair[0]) < 1e-12 and relerr(fused[0], csr[0]) < 1e-12
+    for brk in (0, 4):
+        b = run(((14, brk),))
+        c = run(((14, brk), (55, 0)))
+        assert b[2][0] > 0 and (b[1] > 1).sum() >= 2 and np.array_equal(b[1] > 1, c[1] > 1), (brk, b[1], c[1])
+        assert relerr(b[0], fused[0]) < 1e-11
+    # the oracle: the first 8 steps with its own CG at 1e-14
+    u0 = np.full(w["N"], 1.5e6)
+    ous, _ = oracle.backwardeulerintegrate(u0, (0.0, 8.0), 1e-9, w["volumes"], w["node1"], w["node2"], w["aol"], w["K"], np.zeros(w["N"]), w["dnodes"], w["dheads"],
+                                           stepper=oracle.fixedbackwardeulerstep, dt0=1.0, linearsolver=oracle.tightcgsolver(1e-14))
+    p = _problem(fv, w)
+    st = p.transient_begin(1e-9, w["volumes"], u0)
+    p.run_fixed(st, 1.0, 8, rtol=1e-12, maxiter=5000)
+    assert relerr(st.node_values(), ous[-1]) < 1e-8
+    print("fused step on SELL: %d B per row; change over 8 steps vs oracle %.2e" % (per_row, relerr(st.node_values() - u0, ous[-1] - u0)))
+    p.close()
