@@ -696,8 +696,15 @@ __global__ __launch_bounds__(FV_BLOCK) void fused_sell_step_kernel(KfArgs a, KsA
             const VRow o = vrow(xi, zi, vi, d, sD, alpha);
             const double q = d * o.zn + sum;
             __builtin_nontemporal_store(o.xn, a.xout + row);
-            a.znext[row] = o.zn;
-            a.vnext[row] = -(o.mv * (q - sD * o.zn));
+            const double vn = -(o.mv * (q - sD * o.zn));
+            if (a.nt & 1)
+                __builtin_nontemporal_store(o.zn, a.znext + row);
+            else
+                a.znext[row] = o.zn;
+            if (a.nt & 2)
+                __builtin_nontemporal_store(vn, a.vnext + row);
+            else
+                a.vnext[row] = vn;
             acc[0] += o.r * (o.mv * o.r);
             acc[1] += o.r * o.r;
             acc[2] += o.c * o.zn;
@@ -965,6 +972,7 @@ static int fused_sell_step(fv_problem *p, const double *x, double *x_next, doubl
     a.scal = p->scal.p;
     a.in = in;
     a.mode = mode;
+    a.nt = g_fused_nt;
     a.chain_index = chain_index;
     a.force_prev_unconverged = force_prev_unconverged ? 1 : 0;
     a.rtol = rtol;

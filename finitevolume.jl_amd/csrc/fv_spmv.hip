@@ -410,6 +410,7 @@ static int g_use_order = 1;
 static int g_nt = 1;
 int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 int g_use_dia = 1;
+static int g_sell_blocks = 8; // fv_tune key 58 (experiment): resident blocks per CU the SELL SpMV's grid is sized for
 static int g_sell = 1; // fv_tune key 54: SELL-64 with 16-bit column offsets for the groups the CSR kernel would serve (0: always the CSR wave-stream)
 static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
 static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
@@ -550,6 +551,8 @@ extern "C" int fv_tune(int key, int value)
         g_sell = value;
     else if (key == 55 && (value == 0 || value == 1))
         g_fused_sell = value;
+    else if (key == 58 && value >= 1 && value <= 8)
+        g_sell_blocks = value;
     else if (key == 56 && value >= 1 && value <= 8)
         g_fused_sell_blocks = value;
     else if (key == 50 && (value == 0 || value == 1))
@@ -2171,7 +2174,9 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
         *nparts = G;
         return FV_OK;
     }
-    const int GS = stream_grid(p->sell_n);
+    int GS = stream_grid(p->sell_n);
+    if (g_sell_blocks < 8 && GS > ctx->num_cus * g_sell_blocks)
+        GS = ctx->num_cus * g_sell_blocks / 8 * 8;
     if (mode == SPMV_DOT)
         hipLaunchKernelGGL((spmv_sell_kernel<true>), dim3(GS), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sell_n, (const int32_t *)p->sell_list.p,
                            (const int32_t *)p->sell_ptr.p, (const uint8_t *)p->sell_w.p, (const double *)p->sell_vals.p, (const int16_t *)p->sell_dcol.p, x, y,

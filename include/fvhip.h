@@ -285,7 +285,9 @@ int fv_update_form(fv_problem *p, int32_t *bytes_per_row);
  * problem and the bytes per row its storage form moves with every array touched once — x, z, v in and x_out, z', v' out (48),
  * three upper diagonals (24), one storage code byte = 73 (+ 8 where the diagonal is streamed); *bytes_per_launch: the same
  * summed over the operator (rows whose product the slice-by-slice launch forms carry no matrix bytes here); 0 launches / 0
- * bytes when it has not run. */
+ * bytes when it has not run.  Where the matrix comes as 16-bit codes: 51.  On the SELL form of an irregular mesh (FV_SPMV_SELL):
+ * 48 + the storage term (8 as a stream, 1 as codes) + 10 per stored entry, ~129 on a DFN mesh.  On row blocks the same launch runs
+ * inside fv_dist_run_fixed's bursts. */
 int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int64_t *bytes_per_launch);
 /* The PCG loop of the most recent solve with several iterations (cg! of src/transient.jl:52 / src/FiniteVolume.jl:161): 0 = K1 + K2 +
  * K3 per iteration (the SpMV form's bytes + 88 per row); 113 = the direction update and the product as one pass of the fused kernel
