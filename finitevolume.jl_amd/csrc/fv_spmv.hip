@@ -2651,9 +2651,15 @@ __global__ __launch_bounds__(FV_BLOCK) void fold_shift_kernel(int64_t n, const i
     if (r >= n)
         return;
     const int32_t dp = diagpos[r];
-    if (dp >= 0)
-        vals_shifted[dp] += sigma * D[r];
-    else
+    // product and sum rounded separately, not fused (HIP's __dmul_rn is a plain product the compiler would contract as well): the
+    // symmetric kernels re-derive this double bit for bit as -(sum of the arms) + round(sigma D) from a table of the few distinct
+    // products (symdia_rowsum_kernel); a fused multiply-add here agrees with that only by luck — never, for most rows, when the
+    // conductivity varies, and the diagonal was then streamed (81 instead of 73 B per row in the fused step)
+    if (dp >= 0) {
+#pragma clang fp contract(off)
+        const double s = sigma * D[r];
+        vals_shifted[dp] = vals_shifted[dp] + s;
+    } else
         *missing = 1;
 }
 
