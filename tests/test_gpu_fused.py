@@ -321,3 +321,29 @@ def test_fused_row_block_chain_that_breaks_and_steps_converged_at_their_set_up(f
     assert all(r[4][1] == 51 for r in c), [r[4] for r in c]  # 73 - 24 + 2: the three upper diagonals as one 16-bit word
     assert all(np.array_equal(x[3], y[3]) for x, y in zip(c, d))
     assert relerr(_gather(c, len(want)), _gather(d, len(want))) < 1e-12
+
+
+def test_time_steps_that_are_not_powers_of_two_keep_the_derived_diagonal(fv):
+    """The shifted diagonal is re-derived bit for bit as -(sum of the arms) + round(D / dt) only if the fold formed it with two
+    roundings as well (not one FMA): with a heterogeneous conductivity and dt = 1e-3 (1 / dt inexact) every slice away from the
+    Dirichlet planes must still do without the diagonal stream — 73 B per row in the fused step, 41 in K1 — and agree with the run
+    that streams it (fv_tune 37 = 0)."""
+    case = _problem(fv, BOX, seed=5)
+    sched = [(1.0e-3, 24, 1e-11), (3.0e-3, 10, 1e-11)]
+    a = _run(fv, case, True, sched)
+    n_free = len(case[5]) - len(case[7])
+    assert a[2][0] >= 20 and a[2][1] == 73, a[2]
+    lib = fv.load()
+    lib.fv_tune(37, 0)
+    try:
+        b = _run(fv, case, True, sched)
+    finally:
+        lib.fv_tune(37, 1)
+    assert b[2][1] == 81 and np.array_equal(a[1], b[1])
+    assert relerr(a[0], b[0]) < 1e-13
+    p = fv.Problem.create(case[3], case[4], len(case[5]), case[7]).assemble(case[6], case[9], case[8])
+    st = p.transient_begin(0.1, case[5], case[10])
+    p.run_fixed(st, 1.0e-3, 4, rtol=1e-11, maxiter=100)
+    form = p.spmv_form()
+    assert form[0] == 4 and form[2] < 43 * n_free, form  # 24 (three upper diagonals) + 1 (storage code) + 16 (x, y) per row
+    p.close()
