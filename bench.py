@@ -444,22 +444,24 @@ def hetero_block(fv, ctx, args):
     # ... and at a time step short enough for this field's stiffest cells to converge in one PCG iteration: the regime of the
     # headline, where the fused step streams the matrix as doubles
     if out["pcg_iters_per_step"] > 1.0:
-        dt1 = args.dt / 8.0
-        p.run_fixed(st, dt1, max(args.warmup, 8), args.rtol, args.maxiter)
+        dt1, n1s = args.dt / 8.0, min(args.steps, 20)  # (few steps from the initial state again: hundreds of them at this dt end below the tolerance, 0 iterations)
+        st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+        p.run_fixed(st, dt1, 8, args.rtol, args.maxiter)
         f1 = p.fused_form()[0]
-        secs1 = []
+        secs1, its1 = [], []
         for rep in range(3):
             ctx.synchronize()
             t0 = time.perf_counter()
-            it1, info1, _ = p.run_fixed(st, dt1, args.steps, args.rtol, args.maxiter)
+            it1, info1, _ = p.run_fixed(st, dt1, n1s, args.rtol, args.maxiter)
             ctx.synchronize()
             secs1.append(time.perf_counter() - t0)
+            its1.append(float(it1.mean()))
         sec1 = float(np.median(secs1))
         l1, brow1, bl1 = p.fused_form()
-        out["one_iteration_regime"] = {"dt": dt1, "dof_updates_per_s": p.N * args.steps / sec1, "ms_per_step": sec1 / args.steps * 1e3,
-                                       "ms_per_step_each": [s / args.steps * 1e3 for s in secs1], "pcg_iters_per_step": float(it1.mean()),
+        out["one_iteration_regime"] = {"dt": dt1, "steps": n1s, "dof_updates_per_s": p.N * n1s / sec1, "ms_per_step": sec1 / n1s * 1e3,
+                                       "ms_per_step_each": [s / n1s * 1e3 for s in secs1], "pcg_iters_per_step": float(np.mean(its1)),
                                        "converged": bool(info1.converged), "fused_launches": l1 - f1, "bytes_per_row": brow1,
-                                       "GB/s": bl1 / (sec1 / args.steps) / 1e9 if l1 - f1 >= 0.8 * 3 * args.steps else None}
+                                       "GB/s": bl1 / (sec1 / n1s) / 1e9 if l1 - f1 >= 0.8 * 3 * n1s else None}
     p.close()
     return out
 
