@@ -1023,11 +1023,13 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     return FV_OK;
 }
 
-int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma)
+// kcycle: the caller's PCG is flexible (row blocks: dist_amg_loop); fv_amg_apply keeps the fixed linear V-cycle
+bool fv_amg_kcycle_available(fv_problem *p) { return g_amg_kcycle > 0; }
+int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma, bool kcycle)
 {
     FV_TRY(fv_amg_prepare(p, sigma));
     p->amg->fold = false;
-    p->amg->kcycle = false;
+    p->amg->kcycle = kcycle && g_amg_kcycle > 0 && p->amg->lev.size() > 2;
     return amg_cycle(p, 0, r, z, sigma);
 }
 
@@ -1139,7 +1141,7 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
     if (hs->done || maxiter <= 0)
         return FV_OK;
     const bool fused_dot = a->lev.size() > 1; // a single-level "hierarchy" (tiny problem) ends in the dense solve, not in a smoothing pass
-    a->kcycle = g_amg_kcycle > 0 && a->lev.size() > 2 && !p->dist;
+    a->kcycle = g_amg_kcycle > 0 && a->lev.size() > 2;
     const bool flexible = a->kcycle && fused_dot;
     FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
     if (!fused_dot)

@@ -458,7 +458,8 @@ inline int fv_step_precond(const fv_problem *p)
 
 // ---- fv_amg.hip
 int fv_amg_prepare(fv_problem *p, double sigma);
-int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma);
+int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma, bool kcycle = false);
+bool fv_amg_kcycle_available(fv_problem *p);
 // runs the V-cycle-preconditioned CG from the set-up left in the workspace (r, scal); x is updated in place
 int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t maxiter, PcgScalars *hs);
 

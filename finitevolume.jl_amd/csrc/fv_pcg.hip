@@ -1666,12 +1666,14 @@ int fv_dist_local_spmv(fv_problem *p, double *x, double *y, double sigma, bool f
 // z = V_local(r) on every rank's diagonal block (fv_amg.hip; no communication), the PCG around it as on one GPU with its
 // three sums all-reduced: p.q, r.r (the stopping test, before the next V-cycle is spent) and r.z.
 __global__ __launch_bounds__(FV_BLOCK) void dist_amg_direction_kernel(int64_t n, int first, const double *__restrict__ z, double *__restrict__ pv,
-                                                                       const double *__restrict__ rz_new, int it, PcgScalars *__restrict__ scal)
+                                                                       const double *__restrict__ rz_new, int it, PcgScalars *__restrict__ scal,
+                                                                       const double *__restrict__ zq, const double *__restrict__ pq)
 {
     if (scal->done)
         return;
     const double rzn = *rz_new;
-    const double beta = first ? 0.0 : rzn / scal->rz[it & 1];
+    // zq / pq (the K-cycle is not a fixed linear operator: flexible PCG): beta = z.(r - r_old) / (r.z)_old = -z.q / p.q
+    const double beta = first ? 0.0 : (zq ? -*zq / *pq : rzn / scal->rz[it & 1]);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
         pv[i] = first ? z[i] : z[i] + beta * pv[i];
     if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1706,14 +1708,22 @@ static int dist_amg_loop(fv_problem *p, double *x, double sigma, double sig_mv, 
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (hs->done || maxiter <= 0)
         return FV_OK;
+    // the rank's cycle as a K-cycle (fv_amg.hip; its inner products are the rank's own: block-Jacobi stays communication-free):
+    // the PCG around it is then the flexible variant, z.q travelling with r.z in the same collective
+    const bool flexible = fv_amg_kcycle_available(p);
     auto precondition = [&](int first, int it) -> int {
-        FV_TRY(fv_amg_apply_device(p, p->r.p, z, sigma));
+        FV_TRY(fv_amg_apply_device(p, p->r.p, z, sigma, flexible));
         hipLaunchKernelGGL(dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)z, p->part_rz.p);
-        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 1);
+        hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_rz.p, Gv, red + 4);
+        if (flexible && !first) {
+            hipLaunchKernelGGL(dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->q.p, (const double *)z, p->part_bb.p);
+            hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (const double *)p->part_bb.p, Gv, red + 5);
+        }
         FV_LAUNCH_CHECK(ctx);
-        FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 1, 1, ctx->stream));
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 4, (flexible && !first) ? 2 : 1, ctx->stream));
         hipLaunchKernelGGL(dist_amg_direction_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, first, (const double *)z, p->pvec.p,
-                           (const double *)(red + 1), it, p->scal.p);
+                           (const double *)(red + 4), it, p->scal.p, (flexible && !first) ? (const double *)(red + 5) : (const double *)nullptr,
+                           (const double *)red);
         FV_LAUNCH_CHECK(ctx);
         return FV_OK;
     };

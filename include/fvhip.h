@@ -223,7 +223,7 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * FV_PRECOND_AMG: one cycle of an aggregation-based algebraic multigrid per iteration — the role
  * AlgebraicMultigrid.ruge_stuben + aspreconditioner play at FiniteVolume.jl:159-161 (solvediffusion).  Inside the library's
  * own PCG loop the first two coarse levels are solved by two flexible-CG steps each (K-cycle; the PCG around it is then the
- * flexible variant); fv_amg_apply and row blocks apply the plain V(1,1) cycle, a fixed symmetric operator.  The hierarchy
+ * flexible variant), on row blocks with the rank's own inner products; fv_amg_apply applies the plain V(1,1) cycle, a fixed symmetric operator.  The hierarchy
  * is built on the device at the first solve after fv_assemble (and again after the next fv_assemble /
  * fv_transient_begin); it carries the storage term, so shifted solves (implicit steps) can use it as well.
  * Not available for row blocks of a distributed run. */
