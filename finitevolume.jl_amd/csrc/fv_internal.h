@@ -170,6 +170,7 @@ struct fv_dist {
     int64_t n_int_dia = 0, n_int_csr = 0, n_bnd_dia = 0, n_bnd_csr = 0;
     int64_t int_lo = 0, int_hi = 0; // the interior groups as a slice range [lo, hi) when they are contiguous (else empty)
     bool split_built = false;
+    int fused_agreed = -1; // per fv_dist_run_fixed call: -1 not yet asked, 1 every rank can run the fused step, 0 at least one cannot
 };
 
 struct fv_amg; // fv_amg.hip

@@ -1892,11 +1892,32 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     const bool was_vready = p->vready && use_spec;
     p->vready = false;
     bool fused = false;
-    if (chained && speculate && zf && folded && sarg.D == nullptr && bsupport >= 0 && x_next && carry_prev) {
+    if (chained && speculate && x_next && carry_prev) { // (these four are the same on every rank)
         if (chain_index == 0) {
             if (!d->split_built)
                 FV_TRY(dist_build_split(p));
-            p->burst_fused = fv_fused_applicable(p, sigma);
+            // what this rank could do — its rows' M^-1, its storage codes, its block's shape — and what ALL ranks can: the fused
+            // step and the K1 + K2S pair issue their collectives and halo exchanges in different orders, so the ranks must not
+            // mix them.  Agreed once per fv_dist_run_fixed call (one 1-double all-reduce and a host read-back).
+            const bool local = zf && folded && sarg.D == nullptr && bsupport >= 0 && fv_fused_applicable(p, sigma);
+            if (d->fused_agreed < 0) {
+                bool all = local;
+                if (d->nranks > 1) {
+                    double *h = reinterpret_cast<double *>(static_cast<char *>(ctx->pinned) + 2048);
+                    h[0] = local ? 0.0 : 1.0;
+                    FV_HIP(ctx, hipMemcpyAsync(red + 7, h, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+                    FV_TRY(fv_comm_allreduce_sum(ctx, d, red + 7, 1, ctx->stream));
+                    FV_HIP(ctx, hipMemcpyAsync(h, red + 7, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                    all = h[0] == 0.0;
+                }
+                d->fused_agreed = all ? 1 : 0;
+            }
+            if (d->fused_agreed == 1 && !local) {
+                fv_set_error(ctx, "internal: the ranks agreed on the fused step at the start of this run and this rank can no longer run it");
+                return FV_ERR_STATE;
+            }
+            p->burst_fused = d->fused_agreed == 1;
         }
         fused = p->burst_fused;
     }
@@ -2302,6 +2323,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     FV_HIP(ctx, hipEventRecord(e0, ctx->stream));
     fv_solve_info inf = {};
     int rc = FV_OK;
+    p->dist->fused_agreed = -1; // (the ranks agree on the fused step at this call's first burst: dist_step)
     // ping-pong state + residual carry-over, as in fv_transient_run_fixed (identical decisions on every rank:
     // they depend only on the step index and on the all-reduced iteration count)
     const int64_t refresh = g_carry_refresh;

@@ -347,3 +347,21 @@ def test_time_steps_that_are_not_powers_of_two_keep_the_derived_diagonal(fv):
     form = p.spmv_form()
     assert form[0] == 4 and form[2] < 43 * n_free, form  # 24 (three upper diagonals) + 1 (storage code) + 16 (x, y) per row
     p.close()
+
+
+def test_ranks_agree_on_the_fused_step_before_they_use_it(fv):
+    """A block of two planes cannot run the fused step, its neighbour of 34 planes could: the two forms issue their collectives
+    and halo exchanges in different orders, so the ranks agree at the start of every fv_dist_run_fixed call (one all-reduce) and
+    both keep K1 + K2S — no launch of the fused kernel anywhere, no hang, the single-GPU heads."""
+    planes = (34, 2)
+    ns = (sum(planes) + 2, 182, 186)
+    case = _problem(fv, ns, seed=4)
+    sched = [(DT, 19, 1e-11), (DT, 6, 1e-11)]
+    one = _run(fv, case, True, sched)
+    free = np.ones(len(case[5]), bool)
+    free[case[7] - 1] = False
+    want = one[0][free]
+    res = _run_row_blocks(fv, case, 2, 7400, sched, planes)
+    assert all(r[4][0] == 0 for r in res), [r[4] for r in res]
+    assert all(np.array_equal(r[3], one[1]) for r in res)
+    assert relerr(_gather(res, len(want)), want) < 1e-12
