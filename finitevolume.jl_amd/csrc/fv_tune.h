@@ -81,11 +81,12 @@ extern "C" {
  *  50: the fused step on row blocks (fv_dist_run_fixed) too; 0 = row blocks keep the K1 + K2S pair [1]
  *  51: CUs per XCD a row block's fused launch leaves to the halo exchange's kernel [1]
  *  52: AMG K-cycle: the coarse levels 1 .. value are solved by two flexible-CG steps preconditioned by the cycle below them, the PCG
- *      around the cycle becomes flexible [see fv_amg.hip for the default]; 0 = V-cycle
+ *      around the cycle becomes flexible [2]; 0 = V-cycle
  *  53: AMG coarse levels with at least this many rows run the wave-stream CSR kernel [65536]; 0 = always the lanes-per-row kernel
  *  54: SELL-64 with 16-bit column offsets (FV_SPMV_SELL) for the 64-row groups the CSR wave-stream kernel would serve [1]
  *  55: the fused step on the SELL form (irregular meshes) [1]
  *  56: experiment: resident blocks per CU the SELL step's grid is sized for [4]
+ *  58: experiment: resident blocks per CU the SELL SpMV's grid is sized for [8]
  *  45: streaming-hint experiments on the fused step (bit 0: z' stored non-temporally, 1: v' too, 2: x / v plain loads, 3: x_out
  *      plain store, 4: matrix plain loads) [0] */
 int fv_tune(int key, int value);
