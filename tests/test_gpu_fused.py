@@ -365,3 +365,28 @@ def test_ranks_agree_on_the_fused_step_before_they_use_it(fv):
     assert all(r[4][0] == 0 for r in res), [r[4] for r in res]
     assert all(np.array_equal(r[3], one[1]) for r in res)
     assert relerr(_gather(res, len(want)), want) < 1e-12
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_fused_row_blocks_on_random_schedules_against_the_unfused_driver(fv, seed):
+    """Differential fuzz of the row-block driver with the fused step: random sequences of (dt, steps, rtol) — one-iteration runs,
+    runs with several iterations per step, loose tolerances (zero-iteration steps), short and long calls, an injected chain break
+    on some seeds — with fv_tune 50 on and off: the same iteration counts on every rank, heads to rounding."""
+    rng = np.random.default_rng(4200 + seed)
+    planes = (34, 34) if seed % 2 == 0 else (34, 35, 34)
+    ns = (sum(planes) + 2, 182, 186)
+    case = _problem(fv, ns, seed=10 + seed)
+    sched = []
+    for _ in range(int(rng.integers(3, 6))):
+        dt = float(rng.choice([DT, DT, 3 * DT, 0.7e-3, 1.0]))
+        sched.append((dt, int(rng.integers(1, 26)), float(rng.choice([1e-11, 1e-11, 1e-9, 1e-3]))))
+    tune = ((14, int(rng.integers(0, 8))),) if seed >= 2 else ()
+    nranks = len(planes)
+    a = _run_row_blocks(fv, case, nranks, 7500 + 10 * seed, sched, planes, tune=tune)
+    b = _run_row_blocks(fv, case, nranks, 7501 + 10 * seed, sched, planes, tune=tune + ((50, 0),))
+    n = a[-1][1]
+    for x, y in zip(a, b):
+        assert np.array_equal(x[3], y[3]), (sched, tune, x[3], y[3])
+        assert y[4][0] == 0
+    assert relerr(_gather(a, n), _gather(b, n)) < 1e-11, (sched, tune)
+    assert any(x[4][0] > 0 for x in a) or all(dt >= 1.0 or k < 4 for dt, k, _ in sched), (sched, [x[4] for x in a])
