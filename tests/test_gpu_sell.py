@@ -161,3 +161,33 @@ def test_fused_step_on_the_sell_form_against_the_unfused_pair_and_the_csr_path(f
     assert relerr(st.node_values(), ous[-1]) < 1e-8
     print("fused step on SELL: %d B per row; change over 8 steps vs oracle %.2e" % (per_row, relerr(st.node_values() - u0, ous[-1] - u0)))
     p.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fused_sell_step_on_random_schedules_against_the_unfused_pair(fv, seed):
+    """Differential fuzz: random sequences of (dt, steps, rtol) on a fractures-like mesh with hub rows and far ties, an injected
+    chain break on some seeds, the fused step on the SELL form on and off (fv_tune 55): same iteration counts, heads to rounding."""
+    rng = np.random.default_rng(900 + seed)
+    w = _mesh(nfrac=3, m=280, seed=20 + seed, hubs=int(rng.integers(0, 4)), far=int(rng.integers(0, 60)))
+    lib = fv.load()
+    sched = [(float(rng.choice([1.0, 1.0, 3.0, 0.25, 1e4])), int(rng.integers(1, 24)), float(rng.choice([1e-12, 1e-12, 1e-9, 1e-4]))) for _ in range(int(rng.integers(3, 6)))]
+    tune = ((14, int(rng.integers(0, 8))),) if seed % 2 else ()
+
+    def run(extra):
+        for k, v in tune + extra:
+            assert lib.fv_tune(k, v) == 0
+        try:
+            p = _problem(fv, w)
+            st = p.transient_begin(1e-9, w["volumes"], np.full(w["N"], 1.5e6))
+            its = [p.run_fixed(st, dt, k, rtol=rtol, maxiter=5000)[0].copy() for dt, k, rtol in sched]
+            out = (st.node_values(), np.concatenate(its), p.fused_form()[0])
+            p.close()
+        finally:
+            for k, v in tune + extra:
+                lib.fv_tune(k, {14: -1}.get(k, 1))
+        return out
+
+    a, b = run(()), run(((55, 0),))
+    assert b[2] == 0
+    assert np.array_equal(a[1], b[1]), (sched, tune, a[1], b[1])
+    assert relerr(a[0], b[0]) < 1e-11, (sched, tune)
