@@ -75,7 +75,7 @@ extern "C" {
  *  44: lines per tile of the fused step: 16 (blocks of 1024 threads, one per CU) or 8 (512 threads, two per CU) [16]
  *  46: the many-iteration PCG loop through the fused kernel too (fv_loop_form) [1]
  *  47: the locality re-numbering of FV_OPT_REORDER computed on the device (fv_reorder.hip) [1]; 0 = by the host routine
- *  48: experiment: blocks of the device re-numbering's walk (0 = an eighth of the CUs, at most 32) [0]
+ *  48: experiment: blocks of the device re-numbering's walk (0 = a sixteenth of the CUs, at most 16) [0]
  *  49: the fused kernel reads the three upper diagonals as one 16-bit word of codes per row where each takes at most 32 distinct
  *      values (a homogeneous conductivity on a regular grid): 2 instead of 24 bytes of matrix per row; 0 = always the doubles [1]
  *  50: the fused step on row blocks (fv_dist_run_fixed) too; 0 = row blocks keep the K1 + K2S pair [1]
