@@ -562,17 +562,18 @@ def multi_iteration_block(p, args):
     del st
     form_id, form_name, form_bytes = p.spmv_form()
     nit = int(np.sum(iters))
-    loop = p.loop_form()  # 113: direction update + product in one pass of the fused kernel (57) and the z-form vector update (56)
+    loop = p.loop_form()  # 113: direction update + product in one pass of the fused kernel (57) and the z-form vector update (56);
+    upd = 49 if loop in (84, 106) else 56  # 91 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
     per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
-           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (%d n: z, p in, p', q out, the 3 upper diagonals%s, storage codes) + z-form vector update (56 n)" % (loop - 56, " as 16-bit codes" if loop < 100 else "") if loop
+           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (%d n: z, p in, p', q out, the 3 upper diagonals%s, storage codes) + z-form vector update (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 50 else "", upd, ": M^-1 as a code byte" if upd == 49 else "") if loop
                            else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
-    for k, bytes_ in ((("spmv_dot", (loop - 56) * p.n), ("update", 56 * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
+    for k, bytes_ in ((("spmv_dot", (loop - upd) * p.n), ("update", upd * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]
         if kc:
             out["kernels"]["fused_pass" if (loop and k == "spmv_dot") else k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}

@@ -336,6 +336,14 @@ struct fv_problem {
     // z-form K2S (fv_pcg.hip): where the residual of the state between two steps lives: 0 = in r; 1 / 2 = Jacobi-scaled in
     // pvec / pnext (r = that vector / M^-1, r itself stale)
     int z_where = 0;
+    // M^-1 as one-byte codes (fv_minv_codes) and whether the most recent many-iteration loop used them
+    DevBuf<uint8_t> mvcode;
+    StorageTable mvtable{};
+    int mvcode_n = 0;
+    int64_t mvcode_epoch = -1, mvcode_sepoch = -1;
+    double mvcode_sigma = 0.0;
+    const double *mvcode_ptr = nullptr;
+    bool loop_minv_coded = false;
     bool zf_minv_ok = false; // M^-1 > 0 on every row, for (zf_minv_sigma, zf_minv_epoch, zf_storage_epoch)
     double zf_minv_sigma = -1.0;
     int64_t zf_minv_epoch = -2, zf_storage_epoch = -2;

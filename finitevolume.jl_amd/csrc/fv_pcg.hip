@@ -252,12 +252,15 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_z_kernel(int64_t n, int i
                                                                  const double *__restrict__ pv, const double *__restrict__ q,
                                                                  const double *__restrict__ minv, const double *__restrict__ part_pq,
                                                                  int npq, PcgScalars *__restrict__ scal, double *__restrict__ part_rz,
-                                                                 double *__restrict__ part_rr)
+                                                                 double *__restrict__ part_rr, const uint8_t *__restrict__ mcode, StorageTable mtab)
 {
     __shared__ double smem[4];
+    __shared__ double mvtab[FV_STORAGE_CODES]; // mcode: M^-1 as one-byte codes into its few distinct values (fv_minv_codes) instead of its stream
     if (scal->done)
         return;
-    const double pq = reduce_partials(part_pq, npq, smem);
+    if (mcode && threadIdx.x < FV_STORAGE_CODES)
+        mvtab[threadIdx.x] = mtab.v[threadIdx.x];
+    const double pq = reduce_partials(part_pq, npq, smem); // (its barriers publish mvtab)
     if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             scal->pq = pq;
@@ -276,7 +279,13 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_z_kernel(int64_t n, int i
     const double2 *m2 = reinterpret_cast<const double2 *>(minv);
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
         double2 xv = xi2[i], rv = r2[i];
-        const double2 pvv = p2[i], qv = nt_load2(q2 + i), mv = m2[i];
+        const double2 pvv = p2[i], qv = nt_load2(q2 + i);
+        double2 mv;
+        if (mcode) {
+            const uint32_t c = reinterpret_cast<const uint16_t *>(mcode)[i];
+            mv = make_double2(mvtab[c & 255u], mvtab[c >> 8]);
+        } else
+            mv = m2[i];
         if (r_is_z)
             rv = make_double2(rv.x / mv.x, rv.y / mv.y);
         xv.x += alpha * pvv.x;
@@ -706,6 +715,64 @@ int fv_storage_form(fv_problem *p, StorageArg *out, int *bytes_saved, bool ignor
     return FV_OK;
 }
 
+// M^-1 (the Jacobi diagonal's reciprocal) as one-byte codes where it takes few distinct values — a homogeneous conductivity on a
+// regular grid: the interior rows share one diagonal, the rows on faces / edges / next to Dirichlet cells a handful more — for the
+// vector pass of the many-iteration loop (pcg_update_z_kernel): 1 instead of 8 bytes per row, the same doubles out of the table.
+// Built like the storage codes (fv_storage_form), for the M^-1 of (minv_sigma, minv_epoch, storage_epoch).
+int g_minv_codes = 1; // fv_tune key 59
+static int fv_minv_codes(fv_problem *p, const uint8_t **code, StorageTable *tab)
+{
+    fv_ctx *ctx = p->ctx;
+    *code = nullptr;
+    if (!g_minv_codes || !p->minv.p || p->n < 2)
+        return FV_OK;
+    if (!(p->mvcode_epoch == p->minv_epoch && p->mvcode_sigma == p->minv_sigma && p->mvcode_sepoch == p->storage_epoch && p->mvcode_ptr == p->minv.p)) {
+        p->mvcode_n = 0;
+        const size_t m = (size_t)(p->n < 2048 ? p->n : 2048);
+        std::vector<double> h(2 * m);
+        FV_TRY(fv_copy(ctx, h.data(), p->minv.p, m * sizeof(double)));
+        FV_TRY(fv_copy(ctx, h.data() + m, p->minv.p + ((size_t)p->n - m) / 2, m * sizeof(double)));
+        std::vector<uint64_t> bits(2 * m);
+        memcpy(bits.data(), h.data(), 2 * m * sizeof(double));
+        std::sort(bits.begin(), bits.end());
+        if (std::unique(bits.begin(), bits.end()) - bits.begin() <= FV_STORAGE_CODES) {
+            if (!p->mvcode.p || p->mvcode.n < (size_t)p->n + 16)
+                FV_TRY(p->mvcode.alloc(ctx, (size_t)p->n + 16));
+            FV_TRY(p->mvcode.zero(ctx));
+            DevBuf<int32_t> claim;
+            DevBuf<double> offered;
+            FV_TRY(claim.alloc(ctx, 1));
+            FV_TRY(offered.alloc(ctx, 1));
+            int ntab = 0;
+            for (;;) {
+                FV_TRY(claim.zero(ctx));
+                hipLaunchKernelGGL(storage_code_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->minv.p, p->mvtable, ntab,
+                                   p->mvcode.p, claim.p, offered.p);
+                FV_LAUNCH_CHECK(ctx);
+                int32_t hc = 0;
+                FV_TRY(fv_copy(ctx, &hc, claim.p, sizeof hc));
+                if (!hc) {
+                    p->mvcode_n = ntab;
+                    break;
+                }
+                if (ntab == FV_STORAGE_CODES)
+                    break;
+                FV_TRY(fv_copy(ctx, &p->mvtable.v[ntab], offered.p, sizeof(double)));
+                ntab++;
+            }
+        }
+        p->mvcode_epoch = p->minv_epoch;
+        p->mvcode_sigma = p->minv_sigma;
+        p->mvcode_sepoch = p->storage_epoch;
+        p->mvcode_ptr = p->minv.p;
+    }
+    if (p->mvcode_n > 0) {
+        *code = p->mvcode.p;
+        *tab = p->mvtable;
+    }
+    return FV_OK;
+}
+
 // The z-form divides by M^-1: every row must have one (a free cell without faces and without storage has M^-1 = 0).
 // Checked once per Jacobi diagonal.
 __global__ __launch_bounds__(FV_BLOCK) void minv_bad_kernel(int64_t n, const double *__restrict__ minv, int32_t *__restrict__ bad)
@@ -772,7 +839,7 @@ extern "C" int fv_loop_form(fv_problem *p, int32_t *bytes_per_row)
 {
     if (!p || !bytes_per_row)
         return FV_ERR_ARG;
-    *bytes_per_row = p->loop_bytes;
+    *bytes_per_row = p->loop_bytes - ((p->loop_bytes > 0 && p->loop_minv_coded) ? 7 : 0); // (M^-1 as a code byte in the vector pass)
     return FV_OK;
 }
 
@@ -1226,13 +1293,17 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                     FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
             }
             if (zloop == 2) {
+                const uint8_t *mvc = nullptr;
+                StorageTable mvt{};
+                FV_TRY(fv_minv_codes(p, &mvc, &mvt)); // (cached per Jacobi diagonal)
                 if (iter == 0 && sys.x_next)
                     hipLaunchKernelGGL(pcg_update_z_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)x, sys.x_next,
-                                       p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p);
+                                       p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p, mvc, mvt);
                 else
                     hipLaunchKernelGGL(pcg_update_z_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)nullptr,
                                        sys.x_next ? sys.x_next : x, p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p,
-                                       p->part_rz.p, p->part_rr.p);
+                                       p->part_rz.p, p->part_rr.p, mvc, mvt);
+                p->loop_minv_coded = mvc != nullptr;
                 zr_is_z = 1;
                 FV_PROF(3);
                 FV_PROF(4);

@@ -445,7 +445,7 @@ static void set_resident_blocks(const fv_ctx *ctx)
 
 extern int g_gradient_knots_per_pass; // fv_gradient.hip
 extern int g_comm_single_rank_collectives; // fv_comm.hip
-extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform; // fv_pcg.hip
+extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform, g_minv_codes; // fv_pcg.hip
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
@@ -553,6 +553,8 @@ extern "C" int fv_tune(int key, int value)
         g_fused_sell = value;
     else if (key == 58 && value >= 1 && value <= 8)
         g_sell_blocks = value;
+    else if (key == 59 && (value == 0 || value == 1))
+        g_minv_codes = value;
     else if (key == 56 && value >= 1 && value <= 8)
         g_fused_sell_blocks = value;
     else if (key == 50 && (value == 0 || value == 1))

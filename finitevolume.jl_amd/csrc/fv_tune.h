@@ -87,6 +87,7 @@ extern "C" {
  *  55: the fused step on the SELL form (irregular meshes) [1]
  *  56: experiment: resident blocks per CU the SELL step's grid is sized for [4]
  *  58: experiment: resident blocks per CU the SELL SpMV's grid is sized for [8]
+ *  59: M^-1 as one-byte codes in the vector pass of the many-iteration loop where it takes at most 16 distinct values [1]
  *  45: streaming-hint experiments on the fused step (bit 0: z' stored non-temporally, 1: v' too, 2: x / v plain loads, 3: x_out
  *      plain store, 4: matrix plain loads) [0] */
 int fv_tune(int key, int value);

@@ -292,7 +292,7 @@ int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int6
 /* The PCG loop of the most recent solve with several iterations (cg! of src/transient.jl:52 / src/FiniteVolume.jl:161): 0 = K1 + K2 +
  * K3 per iteration (the SpMV form's bytes + 88 per row); 113 = the direction update and the product as one pass of the fused kernel
  * (z = M^-1 r and p in, p' and q out, three upper diagonals, a code byte: 57) + the vector update in the z-form (x, z, p, q, M^-1 in,
- * x, z out: 56). */
+ * x, z out: 56); 91 with the matrix as codes, 7 fewer again where M^-1 takes few distinct values and comes as a code byte. */
 int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */

@@ -391,3 +391,31 @@ def test_fused_row_blocks_on_random_schedules_against_the_unfused_driver(fv, see
     assert relerr(_gather(a, n), _gather(b, n)) < 1e-11, (sched, tune)
     # (the fused launches run wherever a call holds a burst of one-iteration steps: certainly in a tight run of 8 small steps or more)
     assert any(x[4][0] > 0 for x in a) or not any(dt < 1.0 and k >= 8 and rtol <= 1e-11 for dt, k, rtol in sched), (sched, [x[4] for x in a])
+
+
+def test_minv_as_codes_in_the_many_iteration_loop_gives_the_same_bits(fv):
+    """fv_tune key 59: where the Jacobi diagonal takes at most 16 distinct values (one conductivity on a regular grid) the vector
+    pass of the many-iteration loop reads M^-1 as a code byte — the same doubles out of the table: iteration counts and heads bit
+    for bit, 84 instead of 91 B per row and iteration; a heterogeneous field keeps the stream."""
+    case = _problem(fv, BOX, seed=17, uniform_k=True)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+
+    def run(case, key):
+        lib = fv.load()
+        assert lib.fv_tune(59, key) == 0
+        try:
+            p = fv.Problem.create(case[3], case[4], len(case[5]), case[7]).assemble(case[6], case[9], case[8])
+            st = p.transient_begin(0.1, case[5], case[10])
+            its = [p.run_fixed(st, dt, k, rtol=1e-12, maxiter=3000)[0].copy() for dt, k in ((40.0, 5), (7.0, 4), (300.0, 3))]
+            out = (st.node_values(), np.concatenate(its), p.loop_form())
+            p.close()
+        finally:
+            lib.fv_tune(59, 1)
+        return out
+
+    a, b = run(case, 1), run(case, 0)
+    assert (a[1] > 3).all() and a[2] == 84 and b[2] == 91, (a[1], a[2], b[2])
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    hetero = _problem(fv, BOX, seed=17)
+    c, d = run(hetero, 1), run(hetero, 0)
+    assert c[2] == 113 and d[2] == 113 and np.array_equal(c[0], d[0])
