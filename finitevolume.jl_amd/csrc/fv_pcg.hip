@@ -864,8 +864,14 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
 {
     // zsrc (UNSPEC only): the K2S was a z-form one: what it left is p' = M^-1 r0' in zsrc and nothing in r
     __shared__ double smem[4];
-    if (scal->done)
-        return;
+    {
+        // (done = 3 with THIS step's index was written by block 0 of this very launch: a block that starts after block 0 has finished
+        // — a grid that is not resident all at once: other processes or ranks on the device — must still do its share of the
+        // fall-back; it takes the same decision from the same sums)
+        const int d0 = *reinterpret_cast<volatile int32_t *>(&scal->done);
+        if (d0 && !(d0 == 3 && chain_index >= 0 && *reinterpret_cast<volatile int32_t *>(&scal->chain_step) == chain_index))
+            return;
+    }
     const double rzn = reduce_partials(part_rz, nparts, smem);
     const double rrn = reduce_partials(part_rr, nparts, smem);
     const double beta = rzn / scal->rz[it & 1];
@@ -916,8 +922,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_pupdate_kernel(int64_t n, int it
         if (converged)
             scal->done = 1;
         else if (chain_index >= 0) { // unpolled chain: stop here; the host resumes this step at iteration it + 1
-            scal->done = 3;
             scal->chain_step = chain_index;
+            __threadfence();
+            scal->done = 3;
         }
     }
 }
@@ -940,8 +947,11 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
                                                                        const double *__restrict__ zsrc = nullptr)
 {
     __shared__ double smem[4];
-    if (scal->done)
-        return;
+    {
+        const int d0 = *reinterpret_cast<volatile int32_t *>(&scal->done); // (as in pcg_pupdate_kernel: block 0 of this launch may have closed the chain already)
+        if (d0 && !(d0 == 3 && *reinterpret_cast<volatile int32_t *>(&scal->chain_step) == prev_index))
+            return;
+    }
     const double rzn = reduce_partials(sums.prev_rz, sums.nprev, smem);
     const double rrn = reduce_partials(sums.prev_rr, sums.nprev, smem);
     const bool converged = rrn <= scal->tol2x[prev_index & 1] && !force_unconverged;
@@ -986,8 +996,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_chain_boundary_kernel(int64_t n,
             scal->rz[1] = rzn;
             scal->rr = rrn;
             scal->iters = 1;
-            scal->done = 3;
             scal->chain_step = prev_index;
+            __threadfence();
+            scal->done = 3;
         }
         return;
     }
@@ -1450,8 +1461,10 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
         p->vready = false;
         p->z_where = 0; // the launch that stopped the chain wrote r
         p->last_iters = 2; // at least
-        const int32_t zero = 0;
-        FV_HIP(ctx, hipMemcpyAsync(&p->scal.p->done, &zero, sizeof zero, hipMemcpyHostToDevice, ctx->stream));
+        // (a device-side memset: an asynchronous copy out of a variable on this stack frame may read it after the frame is gone — the
+        // flag then stayed set now and then, the resumed step's launches were no-ops and it ran into maxiter; found by the fuzz of the
+        // row-block driver, whose three host threads shift the timing)
+        FV_HIP(ctx, hipMemsetAsync(&p->scal.p->done, 0, sizeof(int32_t), ctx->stream));
     } else if (info) {
         info->converged = hs->done == 1;
         info->iters = hs->iters;
