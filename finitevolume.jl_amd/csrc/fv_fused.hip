@@ -1079,11 +1079,7 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
     if (p->sym_nrest > 0) {
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GF, &GR));
-        hipLaunchKernelGGL(q_to_v_slices_kernel, dim3(fv_blocks(p->sym_nrest * 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->sym_nrest,
-                           (const int32_t *)p->sym_rest.p, (const double *)p->pnext.p, (const double *)p->minv.p, (const double *)p->D.p, sigma,
-                           p->qv2.p);
-        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GF, &GR, false, sigma)); // (stored in the v-form by the launch itself)
     }
     out.npq = GF + GR;
     *out_sums = out;

@@ -944,10 +944,13 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
                 const double xr = (shift || DOT) ? x[row] : 0.0;
                 if (shift)
                     sum += sigma * shift[row] * xr;
+                // q_shifted == 2: the fused step's products of the slices outside the symmetric form, stored in the v-form
+                // v = -M^-1 (q - sigma D x) right away (fv_spmv_rest); the partial x.q is of q itself
+                const double out = (DOT && epi.q_shifted == 2) ? -(epi.minv[row] * (sum - (epi.sigma * epi.D[row]) * xr)) : sum;
                 if (NT)
-                    __builtin_nontemporal_store(sum, y + row);
+                    __builtin_nontemporal_store(out, y + row);
                 else
-                    y[row] = sum;
+                    y[row] = out;
                 if (DOT)
                     dacc += xr * sum;
             }
@@ -2585,7 +2588,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 // The slices the symmetric form leaves to the slice-by-slice kernel (first / last plane, irregular ones), on their own: the
 // fused step (fv_fused.hip) forms every other product itself.  `vals`: the value array the lane-major copy was filled from
 // (spmv_apply has done that for the same array and tag before the fused regime is entered).
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done)
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done, double vform_sigma)
 {
     fv_ctx *ctx = p->ctx;
     *nparts = 0;
@@ -2593,7 +2596,13 @@ int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, 
         return FV_OK;
     FV_TRY(ensure_dia_vals(p, vals, vals == p->vals.p ? 0.0 : p->shifted_sigma, !p->dist));
     const int GR = stream_grid(p->sym_nrest);
-    const StepInitEpilogue epi{};
+    StepInitEpilogue epi{};
+    if (vform_sigma != 0.0) { // y receives -M^-1 (q - sigma D x) instead of q
+        epi.q_shifted = 2;
+        epi.minv = p->minv.p;
+        epi.D = p->D.p;
+        epi.sigma = vform_sigma;
+    }
     if (g_nt)
         hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
                            (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
