@@ -2221,9 +2221,18 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             boundary.ncsr = d->n_bnd_csr;
             int nb = 0;
             FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
-            FV_TRY(spmv_apply(p, p->pnext.p, p->qv2.p, sig_mv, folded, SPMV_DOT, fout.pq + fout.npq, nullptr, false, &nb, &boundary));
-            FV_TRY(fv_fused_convert_groups(p, d->bnd_dia.p, d->n_bnd_dia, sigma));
-            FV_TRY(fv_fused_convert_groups(p, d->bnd_csr.p, d->n_bnd_csr, sigma));
+            if (d->n_bnd_csr == 0) { // slabs of a structured grid: sliced-DIA boundary slices, stored in the v-form by the launch itself
+                StepInitEpilogue vform{};
+                vform.q_shifted = 2;
+                vform.minv = p->minv.p;
+                vform.D = p->D.p;
+                vform.sigma = sigma;
+                FV_TRY(spmv_apply(p, p->pnext.p, p->qv2.p, sig_mv, folded, SPMV_DOT, fout.pq + fout.npq, &vform, false, &nb, &boundary));
+            } else {
+                FV_TRY(spmv_apply(p, p->pnext.p, p->qv2.p, sig_mv, folded, SPMV_DOT, fout.pq + fout.npq, nullptr, false, &nb, &boundary));
+                FV_TRY(fv_fused_convert_groups(p, d->bnd_dia.p, d->n_bnd_dia, sigma));
+                FV_TRY(fv_fused_convert_groups(p, d->bnd_csr.p, d->n_bnd_csr, sigma));
+            }
             FV_TRY(fv_diag_mark(ctx, 4, ctx->stream));
             fout.npq += nb;
             if (fout.npq > FV_FUSED_PARTS) {
