@@ -425,6 +425,8 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_prolong_kernel(int64_t n, const 
     }
 }
 
+// (the preconditioner's role: AlgebraicMultigrid.ruge_stuben + aspreconditioner at /root/reference/src/FiniteVolume.jl:159-161 and
+// src/transient.jl:54; iteration-level parity with it is unpinned by the survey's own decision)
 // ------------------------------------------------------------------ K-cycle (Notay's AGMG): a coarse system A_l e = b is solved by
 // two steps of flexible CG preconditioned by the cycle of level l instead of by one application of that cycle:
 //   c1 = cycle(b), v1 = A c1, rho1 = c1.v1, alpha1 = c1.b, r1 = b - (alpha1 / rho1) v1,

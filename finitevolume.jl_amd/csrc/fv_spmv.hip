@@ -257,6 +257,8 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_wstream_kernel(int64_t n, const
 }
 
 // ------------------------------------------------------------------ SELL-64 with 16-bit column offsets (irregular meshes)
+// (the `A * x` inside cg! of /root/reference/src/FiniteVolume.jl:161 and src/transient.jl:52 on the reference's DFN meshes,
+// examples/fractures/ex.jl:9-15)
 // After the locality re-numbering (fv_reorder.hip) every neighbour of a DFN cell sits within a few thousand rows, so a column is
 // row + a 16-bit offset, and rows of a 64-row group have about the same length: group g stores width(g) blocks of 64 values and
 // 64 offsets, block k holding entry k of every row (lane-major: a wave's load of a block is one contiguous 512 + 128 bytes), the
