@@ -2173,6 +2173,7 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
 {
     fv_ctx *ctx = p->ctx;
     *used_sell = false;
+    // (a pure-CSR operator hands over its traversal order of ALL groups: the SELL form then covers every group, in ascending order)
     if (mode != SPMV_INIT && !p->dist && p->nhalo == 0)
         FV_TRY(ensure_sell(p, list == p->group_order.p ? nullptr : list, count, vals, vals_tag));
     if (mode == SPMV_INIT || p->sell_state != 1 || p->dist || p->nhalo > 0) {
