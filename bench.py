@@ -402,6 +402,24 @@ def main():
     print(json.dumps(out))
 
 
+def hetero_face_K(ns, F, N):
+    """The bench's heterogeneous conductivity, one value per face: K = 1e-5 exp(g), g a smooth field of unit variance (sums of
+    sines of the cell indices), evaluated from the cell the face list reaches the face in (regulargrid emits up to three faces
+    per cell, cell by cell: face f belongs to cell ~ f N / F) — sigma = 1 without the 5 GB of face ends on the host."""
+    n1, n2, n3 = ns
+    K = np.empty(F)
+    for lo in range(0, F, 1 << 24):  # (in pieces: 3e8 faces)
+        hi = min(lo + (1 << 24), F)
+        cell = (np.arange(lo, hi, dtype=np.float64) * (N / F)).astype(np.int64)
+        i3 = cell % n3
+        i2 = (cell // n3) % n2
+        i1 = cell // (n3 * n2)
+        g = (np.sin(2 * np.pi * i1 / 97.0) + np.sin(2 * np.pi * i2 / 61.0) + np.sin(2 * np.pi * i3 / 43.0)) / np.sqrt(1.5)
+        K[lo:hi] = 1e-5 * np.exp(g)
+        del cell, i1, i2, i3, g
+    return K
+
+
 def hetero_block(fv, ctx, args):
     """The headline workload with a smooth heterogeneous conductivity (sigma = 1 in log K) instead of one value: SURVEY 8d names both
     for the 10^8-cell configuration.  The operator's diagonals then take as many values as there are faces, so the fused step
@@ -410,19 +428,7 @@ def hetero_block(fv, ctx, args):
     mins, maxs = spacing_box(ns)
     dn, src = box_setup(ns)
     p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
-    # a smooth log-conductivity of unit variance, evaluated per face from the cell the face list reaches it in (regulargrid emits
-    # up to three faces per cell, cell by cell: face f belongs to cell ~ f / 3): sigma = 1 without the 5 GB of face ends on the host
-    n1, n2, n3 = ns
-    K = np.empty(p.F)
-    for lo in range(0, p.F, 1 << 24):  # (in pieces: 3e8 faces)
-        hi = min(lo + (1 << 24), p.F)
-        cell = (np.arange(lo, hi, dtype=np.float64) * (p.N / p.F)).astype(np.int64)
-        i3 = cell % n3
-        i2 = (cell // n3) % n2
-        i1 = cell // (n3 * n2)
-        g = (np.sin(2 * np.pi * i1 / 97.0) + np.sin(2 * np.pi * i2 / 61.0) + np.sin(2 * np.pi * i3 / 43.0)) / np.sqrt(1.5)
-        K[lo:hi] = 1e-5 * np.exp(g)
-        del cell, i1, i2, i3, g
+    K = hetero_face_K(ns, p.F, p.N)
     p.assemble(K, src, np.full(len(dn), 1e3))
     del K
     st = p.transient_begin(0.1, None, np.full(p.N, 1e3))

@@ -1299,7 +1299,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_PROF(1);
             FV_PROF(2);
             if (zloop == 1) {
-                zloop = fv_fused_iteration_applicable(p, sigma, folded != nullptr) ? 2 : 0;
+                // the loop keeps z = M^-1 r and recovers r as z / M^-1: every row needs M^-1 > 0 (a free row whose diagonal is
+                // zero — all conductances 0, no storage — has M^-1 = 0 by definition and must stay with the classic loop,
+                // which leaves that row alone).  Cached per Jacobi diagonal like the z-form K2S's check.
+                bool mpos = false;
+                FV_TRY(minv_positive(p, &mpos));
+                zloop = mpos && fv_fused_iteration_applicable(p, sigma, folded != nullptr) ? 2 : 0;
                 if (zloop == 2 && !p->pnext.p) // the pass writes the new direction beside the old one (halo rows of other tiles still read it)
                     FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
             }

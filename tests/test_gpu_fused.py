@@ -210,6 +210,37 @@ def test_matrix_as_codes_gives_the_same_bits(fv):
     assert a[2][2] == b[2][2] and np.array_equal(a[0], b[0])
 
 
+def test_many_iteration_loop_leaves_a_row_with_a_zero_diagonal_alone(fv):
+    """a free cell all of whose faces carry conductance 0 has a zero diagonal in a steady solve, M^-1 = 0 by definition
+    (fv_pcg.hip: jacobi diagonal), and the loop that keeps z = M^-1 r and recovers r as z / M^-1 would form 0 / 0 there.  The loop
+    through the fused kernel is therefore gated on M^-1 > 0 like the z-form K2S; the classic K1 + K2 + K3 loop runs and leaves the
+    row where it started, as it does with fv_tune 46 = 0 — same residual history, same heads, nothing NaN."""
+    case = _problem(fv, BOX, seed=17)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    N = len(vol)
+    n1, n2, n3 = BOX
+    cell = ((n1 // 2) * n2 + n2 // 2) * n3 + n3 // 2 + 1  # an interior cell, 1-based
+    K = K.copy()
+    K[(nb[:, 0] == cell) | (nb[:, 1] == cell)] = 0.0
+    src = np.zeros(N)
+    lib = fv.load()
+    out = {}
+    try:
+        for key in (1, 0):
+            assert lib.fv_tune(46, key) == 0
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+            head, res, ch = p.solve_steady(None, 1e-9, 400, want_resnorm=True)
+            out[key] = (head, np.asarray(ch.data["resnorm"]), ch.iters, p.loop_form(), p.spmv_form()[0])
+            p.close()
+    finally:
+        lib.fv_tune(46, 1)
+    assert out[1][4] == 4  # the tiled symmetric form serves the operator: the loop through the fused kernel WOULD be taken
+    assert out[1][3] == 0  # ... and is not: a row with M^-1 = 0
+    assert np.isfinite(out[1][0]).all() and np.isfinite(out[1][1]).all()
+    assert out[1][0][cell - 1] == 0.0  # the isolated row stays at the x0 = 0 it started from
+    assert out[1][2] == out[0][2] and np.array_equal(out[1][1], out[0][1]) and np.array_equal(out[1][0], out[0][0])
+
+
 # ------------------------------------------------------------------ the fused step on row blocks (loopback transport)
 def _run_row_blocks(fv, case, nranks, group_id, schedule, planes_per_rank, Ss=0.1, tune=()):
     """One host thread per rank (own context on device 0, fv_comm_init_local), whole planes per rank: the row-block driver

@@ -1,0 +1,186 @@
+"""The oracle directly under the kernel instantiations behind the bench line.
+
+`bench.py`'s headline is `fused_step_kernel<16, 0, true>`: uniform K = 1e-5 on a regular box, dt = 60 s, PCG rtol 1e-10, one
+iteration per step, the three upper diagonals read as one 16-bit word of codes per row (51 B per row).  These tests run THAT
+workload (`bench.box_setup`, `bench.spacing_box`) on the HIP path and on the oracle and assert that the fused launches really
+ran in the coded instantiation: `fused_form()` launches >= steps - 2 and 51 B per row.  The same with the bench's heterogeneous
+field (`bench.hetero_face_K`: the matrix streamed as doubles, 73 B per row) at the time step at which its steps take one
+iteration, and at dt = 60 s, where they take two or three (the loop of DESIGN 4d).
+
+Two oracle runs stand beside every device run, from ONE oracle assembly (/root/reference/src/FiniteVolume.jl:75-139):
+
+(R) the reference's fixed-dt integration — scalebyvolume! (src/transient.jl:7-22), backwardeuleronestep! (:60-76),
+    fixedbackwardeulerstep! (:130-134), the outer loop (:136-154) — with IterativeSolvers' cg run to 1e-14: the exact discrete
+    solution.  Bar: heads <= 1e-8 relative (north_star).  The drawdown 1e3 - head itself (1e-2 of a metre under heads of 1e3)
+    agrees only as far as the bench's solver tolerance lets it: at rtol 1e-10 ONE iteration is all a step takes — on the device
+    and in the reference's own cg at that tolerance alike, where 1e-14 needs three — and it leaves ~3e-3 of the step's change
+    undone.  That is the tolerance the workload states, not a kernel property; the test bounds it (< 1e-2) and prints it.
+(S) the same steps with the solver at the SAME tolerance as the device: `oracle.pcg_jacobi` — the Jacobi-preconditioned CG
+    north_star names, on (A + D/dt) u+ = b + D u/dt, stopping at ||r|| <= rtol ||rhs|| — from the same start.  Same iteration
+    count on every step, and the drawdown <= 1e-6 relative: this is the comparison that pins the fused kernel's arithmetic.
+
+A third leg runs the device at rtol 1e-13 (several iterations per step: the many-iteration loop through the same kernel, with
+the matrix as codes) against (S) at that tolerance and (R); the drawdown then agrees with (R) to ~1e-5, the tolerance again."""
+import time
+
+import numpy as np
+import pytest
+
+import bench
+
+pytestmark = pytest.mark.gpu
+HEAD_RTOL = 1e-8
+DRAW_RTOL = 1e-6
+
+
+def relerr(a, b):
+    return np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b)
+
+
+class OracleSystem:
+    """The oracle's grid, assembly and storage term of one workload; integrations (R) and (S) on it."""
+
+    def __init__(self, o, mins, maxs, ns, K, src, dn, dh, Ss):
+        self.o, self.src, self.dn, self.dh = o, src, dn, dh
+        _, n1, n2, aol, vol = o.regulargrid(mins, maxs, ns, want_coords=False)
+        freenode, n2f = o.getfreenodes(len(vol), dn)
+        self.f2n = o.freenodei2nodei(n2f)
+        self.A = o.assembleA(n1, n2, aol, K, src, dn, dh)
+        self.b = o.assembleb(n1, n2, aol, K, src, dn, dh)
+        self.Ssvol = Ss * vol
+        self.D = self.Ssvol[self.f2n - 1]
+        self.scaled = False
+
+    def heads(self, u):
+        return self.o.freenodes2nodes(u, self.src, self.dn, self.dh)[0]
+
+    def same_algorithm(self, u0_value, schedule, rtol):
+        """(S): Jacobi-PCG on the symmetric system (A + D/dt) u+ = b + D u/dt at the device's tolerance."""
+        u = np.full(self.A.n, u0_value)
+        iters = []
+        for dt, steps in schedule:
+            shift = self.D / dt
+            for _ in range(steps):
+                u, ch = self.o.pcg_jacobi(self.A, self.b + shift * u, x0=u, shift=shift, tol=rtol, maxiter=20000)
+                assert ch.isconverged
+                iters.append(ch.iters)
+        return self.heads(u), iters
+
+    def reference(self, u0_value, schedule, tol=1e-14):
+        """(R): the reference's integration, cg to `tol`."""
+        o = self.o
+        if not self.scaled:  # scalebyvolume! works in place: on a copy, (S) keeps the symmetric operator
+            self.As = self.A.copy()
+            o.scalebyvolume_A(self.As, self.Ssvol, self.f2n)
+            self.bs = o.scalebyvolume_b(self.b.copy(), self.Ssvol, self.f2n)
+            self.scaled = True
+        u = np.full(self.A.n, u0_value)
+        iters = []
+
+        def solver(Am, rhs, x0):
+            x, ch = o.cg(Am, rhs, x0=x0, tol=tol, maxiter=20000)
+            assert ch.isconverged
+            iters.append(ch.iters)
+            return x
+
+        t = 0.0
+        for dt, steps in schedule:
+            us, ts = o.backwardeulerintegrate_generic(u, self.As, self.bs, dt, t, t + dt * steps, stepper=o.fixedbackwardeulerstep, linearsolver=solver)
+            assert len(us) == steps + 1
+            u, t = us[-1], ts[-1]
+            del us
+        return self.heads(u), iters
+
+
+def _device_run(fv, mins, maxs, ns, K, src, dn, dh, Ss, u0_value, schedule, rtol):
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    p.assemble(K, src, dh)
+    st = p.transient_begin(Ss, None, np.full(p.N, u0_value))
+    its, fused = [], []
+    for dt, steps in schedule:
+        f0 = p.fused_form()[0]
+        it, info, _ = p.run_fixed(st, dt, steps, rtol=rtol, maxiter=2000)
+        assert info.converged
+        its.append(it.copy())
+        launches, brow, _ = p.fused_form()
+        fused.append((launches - f0, brow))
+    head = st.node_values()
+    loop = p.loop_form()
+    p.close()
+    return head, its, fused, loop
+
+
+def _check(tag, dev, sysm, sched, rtol, t_setup, want_fused=None):
+    """dev = _device_run's tuple at `rtol`; (S) at the same tolerance, then (R) at 1e-14, both on `sysm`."""
+    head, its, fused, loop = dev
+    its_flat = np.concatenate(its).tolist()
+    t0 = time.perf_counter()
+    shead, sit = sysm.same_algorithm(1e3, sched, rtol)
+    t_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rhead, rit = sysm.reference(1e3, sched)
+    t_r = time.perf_counter() - t0
+    draw, sdraw, rdraw = 1e3 - head, 1e3 - shead, 1e3 - rhead
+    print("%s: oracle set-up %.1f s, (S) %.1f s, (R) %.1f s; PCG iterations device %s | (S) %s | (R) cg to 1e-14 %s; fused launches / B per row %s, loop form %d; "
+          "drawdown max %.3e; heads rel: vs (S) %.2e, vs (R) %.2e; drawdown rel: vs (S) %.2e, vs (R) %.2e, (S) vs (R) %.2e" %
+          (tag, t_setup, t_s, t_r, its_flat, sit, rit, fused, loop, rdraw.max(), relerr(head, shead), relerr(head, rhead),
+           relerr(draw, sdraw), relerr(draw, rdraw), relerr(sdraw, rdraw)))
+    assert rdraw.max() > 1e-4
+    assert its_flat == sit  # the same algorithm at the same tolerance: the same iteration count on every step
+    assert relerr(head, shead) < HEAD_RTOL and relerr(draw, sdraw) < DRAW_RTOL
+    assert relerr(head, rhead) < HEAD_RTOL
+    # against the exact discrete solution the drawdown is as good as the tolerance the workload states — for the device and for
+    # the CPU run of the same algorithm alike (their distance to (R) is the same to 1e-3 of itself)
+    assert relerr(draw, rdraw) < 1e-2 and abs(relerr(draw, rdraw) - relerr(sdraw, rdraw)) <= 1e-3 * relerr(sdraw, rdraw) + DRAW_RTOL
+
+
+@pytest.mark.parametrize("n,steps", [(216, 10), (464, 5)])
+def test_bench_workload_coded_fused_step_vs_oracle(fv, oracle, n, steps):
+    """Uniform K: `fused_step_kernel<16, 0, true>` (the matrix as codes, 51 B per row) against the oracle, at 216^3 and at the
+    bench's own 464^3 (~70 GB of host memory for the oracle's COO -> CSC assembly of 3e8 faces, a few minutes on one core)."""
+    ns = [n] * 3
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    dh = np.full(len(dn), 1e3)
+    sched = [(60.0, steps)]
+    dev = _device_run(fv, mins, maxs, ns, np.array([1e-5]), src, dn, dh, 0.1, 1e3, sched, rtol=1e-10)
+    head, its, fused, loop = dev
+    assert (its[0] == 1).all()  # the headline's regime: one PCG iteration per step
+    assert fused[0][0] >= steps - 2 and fused[0][1] == 51  # the fused launches ran, in the coded instantiation
+    t0 = time.perf_counter()
+    F = 3 * n**3 - 3 * n * n
+    sysm = OracleSystem(oracle, mins, maxs, ns, np.full(F, 1e-5), src, dn, dh, 0.1)
+    _check("%d^3 uniform K, dt = 60 s, rtol 1e-10" % n, dev, sysm, sched, 1e-10, time.perf_counter() - t0)
+    if n == 216:  # third leg: several iterations per step (the loop through the same kernel, matrix and M^-1 as codes)
+        tight = _device_run(fv, mins, maxs, ns, np.array([1e-5]), src, dn, dh, 0.1, 1e3, sched, rtol=1e-13)
+        shead, sit = sysm.same_algorithm(1e3, sched, 1e-13)
+        rhead, rit = sysm.reference(1e3, sched)
+        draw, sdraw, rdraw = 1e3 - tight[0], 1e3 - shead, 1e3 - rhead
+        print("216^3 uniform K, rtol 1e-13: PCG iterations device %s | (S) %s, loop form %d B per row and iteration; heads rel vs (S) %.2e, vs (R) %.2e; "
+              "drawdown rel vs (S) %.2e, vs (R) %.2e, (S) vs (R) %.2e" %
+              (tight[1][0].tolist(), sit, tight[3], relerr(tight[0], shead), relerr(tight[0], rhead), relerr(draw, sdraw), relerr(draw, rdraw), relerr(sdraw, rdraw)))
+        assert (tight[1][0] >= 2).all() and tight[3] in (84, 91)
+        assert np.abs(tight[1][0] - np.array(sit)).max() <= 1
+        assert relerr(tight[0], shead) < HEAD_RTOL and relerr(tight[0], rhead) < HEAD_RTOL
+        assert relerr(draw, rdraw) < 1e-4 and relerr(draw, rdraw) < 2 * relerr(sdraw, rdraw) + DRAW_RTOL  # (1e-13 is a tolerance too)
+
+
+def test_bench_heterogeneous_field_fused_step_and_loop_vs_oracle(fv, oracle):
+    """The bench's sigma = 1 field at 320^3 (3.3e7 cells): 8 steps of dt = 7.5 s — one iteration each, the fused step with the
+    matrix streamed as doubles (73 B per row: `fused_step_kernel<16, 0, false>`) — then 4 steps of dt = 60 s, which take two or
+    three iterations each (what `config.heterogeneous_K` of the bench line runs)."""
+    n = 320
+    ns = [n] * 3
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    dh = np.full(len(dn), 1e3)
+    F = 3 * n**3 - 3 * n * n
+    K = bench.hetero_face_K(ns, F, n**3)
+    sched = [(7.5, 8), (60.0, 4)]
+    dev = _device_run(fv, mins, maxs, ns, K, src, dn, dh, 0.1, 1e3, sched, rtol=1e-10)
+    head, its, fused, loop = dev
+    assert (its[0] == 1).all() and fused[0][0] >= 8 - 2 and fused[0][1] == 73
+    assert (its[1] >= 2).all()
+    t0 = time.perf_counter()
+    sysm = OracleSystem(oracle, mins, maxs, ns, K, src, dn, dh, 0.1)
+    _check("320^3 sigma = 1 field, dt = 7.5 s then 60 s, rtol 1e-10", dev, sysm, sched, 1e-10, time.perf_counter() - t0)
