@@ -500,10 +500,16 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
         k1.update(achieved=form_bytes / (k1_ms * 1e-3) / 1e9, frac=form_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, avg_launch_ms=k1_ms, launches=20,
                   measured="20 launches back to back after the timed regions (inside the stepping loop the product is part of the fused launch)",
                   effective_csr={"bytes_per_launch": csr_bytes, "GB/s": csr_bytes / (k1_ms * 1e-3) / 1e9, "frac": csr_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        chunks = p.fused_traversal() == 1
+        what = ("x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' with z'.q' of step k + 1, "
+                "stored as v' = -M^-1 (q' - D z'/dt); ")
         roof = {"bound": "hbm", "achieved": fbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": "fused_step_kernel<16, 0, %s>: x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' " % ("true" if fbytes_row < 60 else "false") +
-                          "with z'.q' of step k + 1, stored as v' = -M^-1 (q' - D z'/dt); 2-D tiles of 16 lines x 128 columns marching through the planes, "
-                          "z' tile and U1/U2 ring in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms; first/last plane's products by spmv_dia_kernel",
+                "kernel": ("fused_chunk_kernel<512, 5, 0>: " + what + "contiguous chunks of ~5100 rows of a plane (no column halos) marching through the planes, z' chunk "
+                           "double-buffered and the 16-bit matrix words of two planes in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms "
+                           "(rows next to a Dirichlet cell: out of a table by a per-row code); first/last plane's products by spmv_dia_kernel") if chunks else
+                          ("fused_step_kernel<16, 0, %s>: " % ("true" if fbytes_row < 60 else "false") + what +
+                           "2-D tiles of 16 lines x 128 columns marching through the planes, "
+                           "z' tile and U1/U2 ring in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms; first/last plane's products by spmv_dia_kernel"),
                 "form": "fused step, v-form (x, z, v in; x_out, z', v' out; 3 upper diagonals%s; storage codes): %d B per row" % (" as one 16-bit word of codes per row (one conductivity: each diagonal takes a handful of values)" if fbytes_row < 60 else "", fbytes_row),
                 "algorithmic_bytes_per_launch": fbytes,
                 "bytes_model": "every array once (fv_fused_form): 48 n of vectors + 1 n of storage codes + 24 B of matrix per row whose product the kernel forms (2 B where the matrix comes as codes; + 8 where the diagonal is streamed); the unfused pair K1 + K2S moves 41 n + 49 n",
@@ -511,8 +517,8 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
         tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tfile):
             try:
-                tj = json.load(open(tfile)).get("fused_%d" % ns)
-                if tj and abs(tj.get("form_bytes", 0) - fbytes) <= 0.01 * fbytes:
+                tj = json.load(open(tfile)).get(("fused_%d" if chunks or fbytes_row >= 60 else "fused_tiles_%d") % ns)
+                if tj and abs(tj.get("form_bytes", 0) - fbytes) <= 0.01 * fbytes and ("chunk" in tj.get("kernel", "")) == chunks:
                     roof["traffic"] = tj["bytes"]
                     roof["traffic_source"] = tj.get("source")
                     roof["frac_traffic"] = tj["bytes"] / t / 1e9 / HBM_PEAK_GBS

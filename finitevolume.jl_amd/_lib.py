@@ -53,7 +53,7 @@ _i64p = C.c_void_p  # arrays are passed as raw addresses (host or device)
 _f64p = C.c_void_p
 
 # name -> (restype, argtypes): every symbol include/fvhip.h declares
-ABI_VERSION = 2  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
+ABI_VERSION = 3  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
 FV_OPT_REORDER = 1
 # the experimenter's panel (finitevolume.jl_amd/csrc/fv_tune.h): exported, but not part of include/fvhip.h
 PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int])}
@@ -109,6 +109,7 @@ SIGNATURES = {
     "fv_update_form": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_loop_form": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_fused_form": (C.c_int, [c_prob, P(C.c_int64), P(C.c_int32), P(C.c_int64)]),
+    "fv_fused_traversal": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_problem_reorder_info": (C.c_int, [c_prob, P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double)]),
     "fv_comm_unique_id": (C.c_int, [C.c_char_p]),
     "fv_comm_init": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p]),

@@ -321,6 +321,12 @@ class Problem:
         self.check(load().fv_fused_form(self.handle, C.byref(n), C.byref(b), C.byref(t)))
         return n.value, b.value, t.value
 
+    def fused_traversal(self):
+        """0: the most recent fused launch walked 2-D tiles (or none has run), 1: contiguous chunks of a plane (fv_fused_traversal)."""
+        k = C.c_int32()
+        self.check(load().fv_fused_traversal(self.handle, C.byref(k)))
+        return k.value
+
     def profile(self, on=True):
         """True / 1: time K1, K2 and K3 launches; 2: the SpMV (K1) only; False: off."""
         self.check(load().fv_profile_enable(self.handle, int(on)))

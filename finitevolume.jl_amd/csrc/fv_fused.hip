@@ -41,6 +41,8 @@ int g_fused_dist_spare = 1; // fv_tune key 51: CUs per XCD a row block's fused l
 int g_fused_sell_blocks = 4; // fv_tune key 56 (experiment): resident blocks per CU the SELL step's grid is sized for
 int g_fused_sell = 1;  // fv_tune key 55: the fused step on the SELL form (irregular meshes) too
 int g_fused_dist = 1;  // fv_tune key 50: the fused step on row blocks too (0: row blocks keep the K1 + K2S pair)
+int g_fused_chunk = 1;  // fv_tune key 60: the coded fused step / pass on CHUNKS of a plane (fused_chunk_kernel: no column halos) where it applies;
+                        // 0 = always the 2-D tiles; 2..7 = experiment: force the (threads, pairs per thread) variant (1024, 2), (1024, 3), (768, 4), (512, 6), (512, 5) [the default], (768, 3)
 int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
                         // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
 
@@ -52,10 +54,13 @@ constexpr int KF_NSUM = 6;
 struct KfArgs {
     // geometry: lines of nz rows, planes of d3 rows, nplanes = one past the last plane whose product this kernel forms
     int32_t nz, L, d3, nplanes, P, seglen, tilesC, tiles, nsegs;
+    int32_t chunk; // fused_chunk_kernel: rows of a plane per work item (tiles = chunks per plane)
     // the symmetric arrays (row 0 pointers: zero-padded in front and behind), flags per 64-row slice, storage codes
     const double *dg, *u1, *u2, *u3;
     const uint8_t *ok, *code;
-    const uint16_t *mcode; // CODED: per row, codes of U1 | U2 << 5 | U3 << 10 into mt
+    const uint16_t *mcode; // CODED: per row, codes of U1 | U2 << 5 | U3 << 10 into mt; bit 15: the row's slice is one whose products the symmetric kernels form
+    const uint8_t *kcode;  // fused_chunk_kernel: per row, storage code | diagonal code << 4 (0: the diagonal follows from the arms, k: kdiag.v[k])
+    StorageTable kdiag;
     MatrixTables mt;
     StorageTable sD; // sigma x the distinct values of D
     // vectors
@@ -626,6 +631,373 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
     }
 }
 
+// ------------------------------------------------------------------ the same step / pass on CHUNKS of a plane (round 4)
+// The 2-D tiles above pay for their column halos: a halo element left or right of a tile is 8 bytes out of a 128-byte line that
+// belongs to the neighbouring tile, and the PMC counted 1.15 x the form's bytes at 464^3 with the matrix as codes.
+// Lines are consecutive in memory (row = line x nz + column), so a CONTIGUOUS range of a plane's rows — C of them, whatever the
+// line length — needs no column halo at all: the -1 / +1 neighbours of a row are its neighbours in the range (across a line end the
+// matrix entry is zero), the -line / +line neighbours sit nz rows before / behind, and the halo of a chunk is the nz rows in
+// front of it and the nz rows behind it, read as whole lines of consecutive doubles.  With the matrix as 16-bit codes the LDS
+// that the U1 / U2 ring of doubles took holds a chunk of C = 6144 rows where the tile had 2048: halo rows 2 nz / C = 15 % of the
+// own rows at 16 bytes each (z, v) instead of 12.5 % at 16 plus 1.6 % at 256 (column halos: whole lines for one value) —
+// 2.4 instead of ~6.5 extra bytes per row of 51.
+// What differs from the tile kernel besides the traversal: (1) every quantity that needs a row's diagonal — M^-1, the residual
+// sums, the product's diagonal term — is formed when the row's plane is the CENTRE plane of a step (its codes are then in the
+// ring slot being read), so the ring has two plane slots, not three, and holds the 16-bit words themselves; a row carries
+// x_out - x from the step that formed x_out to the step that needs it.  (2) A thread owns NP pairs of rows, NT x 2 rows apart.
+// (3) Slices whose diagonal is streamed (rows next to a Dirichlet cell) get it prefetched one plane step ahead.
+// LDS: z' double-buffered 2 x (C + 2 nz) doubles, code ring 2 x (C + nz) words, tables: 139 KB at nz = 464, C = 6128.
+// Results: the same arithmetic per row in the same order as the tile kernel; partial sums group differently (other blocks).
+template <int NT, int NP, int MODE>
+__global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
+{
+    constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
+    extern __shared__ __align__(16) unsigned char kc_lds[];
+    const int tid = (int)threadIdx.x;
+    const int32_t nz = a.nz, d3 = a.d3, C = a.chunk;
+    const int ZL = C + 2 * nz, WL = C + nz;
+    double *zs = reinterpret_cast<double *>(kc_lds);          // 2 x ZL: [nz rows before | C own | nz rows behind]
+    uint16_t *ws = reinterpret_cast<uint16_t *>(zs + 2 * ZL); // 2 x WL: [nz rows before | C own], slot = plane parity
+    double *tab = reinterpret_cast<double *>(ws + 2 * WL); // sigma D by the low nibble of a row's code byte
+    double *dtab = tab + FV_STORAGE_CODES;                 // the diagonal of a row whose code byte has a high nibble k > 0: dtab[k]
+    double *mtab = dtab + FV_STORAGE_CODES;
+    double *red = mtab + 3 * FV_MATRIX_CODES;
+    PcgScalars *scal = a.scal;
+    double alpha = 0.0;
+    if (MODE == 1) { // K3's scalars, as in fused_step_kernel
+        if (*reinterpret_cast<volatile int32_t *>(&scal->done))
+            return;
+        const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
+        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
+        const bool converged = rrn <= scal->tol2;
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->rz[(a.chain_index + 1) & 1] = rzn;
+            scal->rr = rrn;
+            scal->iters = a.chain_index + 1;
+            if (a.hist && a.chain_index < a.hist_cap)
+                a.hist[a.chain_index] = sqrt(rrn);
+            if (converged)
+                scal->done = 1;
+        }
+        if (converged)
+            return;
+        alpha = rzn / scal->rz[a.chain_index & 1];
+    }
+    if (MODE == 0) {
+        if (!kf_step_prologue<NT>(a, red, alpha))
+            return;
+    }
+    { // alpha is the same number in every lane: kept in scalar registers
+        const long long ab = __double_as_longlong(alpha);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
+        alpha = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    if (tid < FV_STORAGE_CODES) {
+        tab[tid] = a.sD.v[tid];
+        dtab[tid] = a.kdiag.v[tid];
+    }
+    if (tid < 3 * FV_MATRIX_CODES)
+        mtab[tid] = a.mt.v[tid];
+    const double *T1 = mtab, *T2 = mtab + FV_MATRIX_CODES, *T3 = mtab + 2 * FV_MATRIX_CODES;
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t items = (int64_t)a.tiles * a.nsegs, per_xcd = (items + 7) / 8;
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
+        const int64_t item = (int64_t)xcd * per_xcd + j;
+        if (item >= items)
+            break;
+        const int32_t seg = (int32_t)(item / a.tiles), chunk = (int32_t)(item % a.tiles);
+        const int32_t cs = chunk * C, Cl = (cs + C <= d3) ? C : d3 - cs; // the chunk's rows of a plane: [cs, cs + Cl)
+        const int32_t p0 = 1 + seg * a.seglen, p1 = (p0 + a.seglen < a.nplanes) ? p0 + a.seglen : a.nplanes;
+        if (p0 >= p1 || Cl <= 0)
+            continue;
+        const bool vec_first = p0 == 1, vec_last = p1 == a.nplanes && a.nplanes == a.P - 1;
+        bool own[NP];
+        uint32_t ob[NP]; // byte offset of the pair's doubles inside a plane
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int lr = 2 * (tid + NT * k);
+            own[k] = lr < Cl;
+            ob[k] = (uint32_t)(cs + (own[k] ? lr : 0)) * 8u; // rows beyond the chunk read its first row: finite, never used
+        }
+        // halo roles: h < nz the row cs - nz + h (z' slot h, code slot h), else the row cs + Cl + (h - nz) (z' slot nz + Cl + h - nz)
+        int32_t hb[HR];
+        int hs[HR];
+        bool hv[HR], hbefore[HR];
+#pragma unroll
+        for (int r = 0; r < HR; r++) {
+            const int h = tid + NT * r;
+            hv[r] = h < 2 * nz;
+            hbefore[r] = h < nz;
+            const int32_t grow = !hv[r] ? cs : (hbefore[r] ? cs - nz + h : cs + Cl + (h - nz));
+            hb[r] = grow * 8;
+            hs[r] = hbefore[r] ? h : nz + Cl + (h - nz);
+        }
+        auto PB = [&](const void *arr, int32_t pl, int esz) -> const char * {
+            return reinterpret_cast<const char *>(arr) + (uint64_t)((int64_t)pl * d3) * (uint64_t)esz;
+        };
+        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return *reinterpret_cast<const double2 *>(PB(arr, pl, 8) + ob[k]); };
+        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 {
+            const double *b = reinterpret_cast<const double *>(PB(arr, pl, 8) + ob[k]);
+            return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
+        };
+        auto C2 = [&](int32_t pl, int k) -> uint32_t { // the pair's code bytes: storage code | diagonal code << 4 (fv_chunk_codes)
+            return (uint32_t) * reinterpret_cast<const uint16_t *>(PB(a.kcode, pl, 1) + (ob[k] >> 3));
+        };
+        auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
+        auto MW = [&](int32_t pl, int k) -> uint32_t { return *reinterpret_cast<const uint32_t *>(PB(a.mcode, pl, 2) + (ob[k] >> 2)); };
+        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + (int64_t)hb[r]); };
+        auto HW = [&](int32_t pl, int r) -> uint16_t { return *reinterpret_cast<const uint16_t *>(PB(a.mcode, pl, 2) + (int64_t)(hb[r] >> 2)); };
+        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]) = val; };
+        auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
+            double *q = reinterpret_cast<double *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]);
+            __builtin_nontemporal_store(val.x, q);
+            __builtin_nontemporal_store(val.y, q + 1);
+        };
+        __syncthreads(); // the tables; the previous item's last LDS reads
+        // ---------------- prologue: z' of plane p0 - 1 (registers), plane p0 (LDS, with halo and codes), batch p0 + 1 in flight
+        double2 Zm[NP], DX[NP], Za[NP], Va[NP], Xa[NP];
+        uint32_t Mc[NP], Ma[NP], Wa[NP]; // M: the pair's code bytes | (centre plane only) U3 codes of the plane before << 18; W: its matrix words (bit 15: this kernel forms the row's product)
+        int zb = p0 & 1;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const double2 vv = P2(a.v, p0 - 1, k), zz = P2(a.z, p0 - 1, k);
+            Zm[k] = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
+            if (MODE == 1 && vec_first && own[k])
+                ST2(a.znext, 0, k, Zm[k]);
+            if (MODE == 0 && vec_first && own[k]) { // plane 0: its whole vector part, with the stored diagonal
+                const double2 xi = P2(a.x, 0, k), dd = P2(a.dg, 0, k), ss = SD(C2(0, k));
+                const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
+                ST2(a.xout, 0, k, make_double2(ra.xn, rb.xn));
+                ST2(a.znext, 0, k, Zm[k]);
+                acc[0] += ra.r * (ra.mv * ra.r) + rb.r * (rb.mv * rb.r);
+                acc[1] += ra.r * ra.r + rb.r * rb.r;
+                acc[2] += ra.c * ra.zn + rb.c * rb.zn;
+                acc[3] += ra.c * ra.c + rb.c * rb.c;
+                acc[4] += ra.h * ra.h + rb.h * rb.h;
+            }
+            const uint32_t wm = MW(p0 - 1, k);
+            const uint32_t u3m = ((wm >> 10) & 31u) | (((wm >> 26) & 31u) << 5);
+            const double2 v0 = P2(a.v, p0, k), z0 = P2(a.z, p0, k);
+            const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
+            const uint32_t c0 = C2(p0, k);
+            DX[k] = make_double2(0.0, 0.0);
+            if (MODE == 1 && own[k])
+                ST2(a.znext, p0, k, Zc0);
+            if (MODE == 0) {
+                const double2 xi = P2(a.x, p0, k);
+                const double2 xn = make_double2(xi.x + alpha * z0.x, xi.y + alpha * z0.y);
+                DX[k] = make_double2(xn.x - xi.x, xn.y - xi.y);
+                if (own[k]) {
+                    const double2 ss = SD(c0);
+                    ST2(a.xout, p0, k, xn);
+                    ST2(a.znext, p0, k, Zc0);
+                    const double hx = ss.x * xn.x, hy = ss.y * xn.y;
+                    acc[4] += hx * hx + hy * hy;
+                }
+            }
+            if (own[k]) {
+                const int lr = 2 * (tid + NT * k);
+                *reinterpret_cast<double2 *>(zs + zb * ZL + nz + lr) = Zc0;
+                *reinterpret_cast<uint32_t *>(ws + (p0 & 1) * WL + nz + lr) = MW(p0, k);
+            }
+            Mc[k] = c0 | (u3m << 18);
+        }
+#pragma unroll
+        for (int r = 0; r < HR; r++)
+            if (hv[r]) {
+                zs[zb * ZL + hs[r]] = H1(a.z, p0, r) + alpha * H1(a.v, p0, r);
+                if (hbefore[r])
+                    ws[(p0 & 1) * WL + hs[r]] = HW(p0, r);
+            }
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            Za[k] = P2(a.z, p0 + 1, k);
+            Va[k] = P2nt(a.v, p0 + 1, k);
+            Xa[k] = MODE == 0 ? P2nt(a.x, p0 + 1, k) : make_double2(0.0, 0.0);
+            Wa[k] = MW(p0 + 1, k);
+            Ma[k] = C2(p0 + 1, k);
+        }
+        double hz[HR], hq[HR];
+        uint16_t hw[HR];
+#pragma unroll
+        for (int r = 0; r < HR; r++) {
+            hz[r] = hq[r] = 0.0;
+            hw[r] = 0;
+            if (hv[r] && p0 + 1 < p1) {
+                hz[r] = H1(a.z, p0 + 1, r);
+                hq[r] = H1(a.v, p0 + 1, r);
+                if (hbefore[r])
+                    hw[r] = HW(p0 + 1, r);
+            }
+        }
+        __syncthreads();
+        for (int32_t p = p0; p < p1; p++) {
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+                asm volatile("" : "+v"(ob[k])); // (opaque: one 32-bit offset per pair beside the scalar plane bases, no 64-bit lane addresses kept alive)
+            const bool inseg = p + 1 < p1, more = p + 2 <= p1;
+            const bool vec_n = inseg || vec_last;   // plane p + 1's vector part is ours
+            const bool lastplane = p + 1 == a.P - 1; // ... and it never becomes a centre plane: its diagonal terms now, from the stored diagonal
+            const double *zc = zs + zb * ZL + nz;
+            double *zn_ = zs + (zb ^ 1) * ZL + nz;
+            const uint16_t *wc_ = ws + (p & 1) * WL + nz;
+            uint16_t *wn_ = ws + ((p + 1) & 1) * WL + nz;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int lr = own[k] ? 2 * (tid + NT * k) : 0; // (pairs beyond the chunk compute on its first rows; nothing of theirs is kept)
+                // ---- (a) plane p + 1: z', x_out; its z' and codes into the other LDS slots
+                const double2 Zn = make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y);
+                double2 dxn = make_double2(0.0, 0.0);
+                const uint32_t Mn = Ma[k];
+                if (MODE == 0) {
+                    const double2 xn = make_double2(Xa[k].x + alpha * Za[k].x, Xa[k].y + alpha * Za[k].y);
+                    dxn = make_double2(xn.x - Xa[k].x, xn.y - Xa[k].y);
+                    if (vec_n && own[k]) {
+                        ST2nt(a.xout, p + 1, k, xn);
+                        const double2 sa = SD(Mn);
+                        const double hx = sa.x * xn.x, hy = sa.y * xn.y;
+                        acc[4] += hx * hx + hy * hy;
+                        if (lastplane) {
+                            const double2 dd = P2(a.dg, p + 1, k);
+                            const double cx = dd.x * Zn.x, cy = dd.y * Zn.y;
+                            const double rx = cx - sa.x * dxn.x, ry = cy - sa.y * dxn.y;
+                            acc[0] += rx * ((1.0 / dd.x) * rx) + ry * ((1.0 / dd.y) * ry);
+                            acc[1] += rx * rx + ry * ry;
+                            acc[2] += cx * Zn.x + cy * Zn.y;
+                            acc[3] += cx * cx + cy * cy;
+                        }
+                    }
+                }
+                if (vec_n && own[k])
+                    ST2(a.znext, p + 1, k, Zn);
+                if (inseg && own[k]) {
+                    *reinterpret_cast<double2 *>(zn_ + lr) = Zn;
+                    *reinterpret_cast<uint32_t *>(wn_ + lr) = Wa[k];
+                }
+                // ---- (b) the batch of plane p + 2 into the registers (a) has just emptied
+                if (more) {
+                    Za[k] = P2(a.z, p + 2, k);
+                    Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
+                    if (MODE == 0)
+                        Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
+                    Wa[k] = MW(p + 2, k);
+                    Ma[k] = C2(p + 2, k);
+                }
+                // ---- (c) centre plane p: its diagonal, the residual sums of its rows, its product
+                const double *zrow = zc + lr;
+                const uint16_t *wrow = wc_ + lr;
+                const double2 Zc = *reinterpret_cast<const double2 *>(zrow);
+                const double x1m0 = zrow[-1], x1p1 = zrow[2];
+                const double2 x2m = *reinterpret_cast<const double2 *>(zrow - nz), x2p = *reinterpret_cast<const double2 *>(zrow + nz);
+                const uint32_t wc = *reinterpret_cast<const uint32_t *>(wrow), wl = *reinterpret_cast<const uint32_t *>(wrow - nz);
+                const uint32_t wm1 = wrow[-1];
+                const uint32_t M = Mc[k];
+                const double2 V1c = make_double2(T1[wc & 31u], T1[(wc >> 16) & 31u]), V2c = make_double2(T2[(wc >> 5) & 31u], T2[(wc >> 21) & 31u]);
+                const double2 A3c = make_double2(T3[(wc >> 10) & 31u], T3[(wc >> 26) & 31u]);
+                const double v1m0 = T1[wm1 & 31u];
+                const double2 V2m = make_double2(T2[(wl >> 5) & 31u], T2[(wl >> 21) & 31u]);
+                const double2 A3m = make_double2(T3[(M >> 18) & 31u], T3[(M >> 23) & 31u]);
+                const double2 Sc = SD(M);
+                // the diagonal: zero row sum — from the six arms, in the order the assembly added them (+ sigma D) —, or, on a row
+                // whose stored diagonal is something else (a Dirichlet neighbour), out of the table by the row's code
+                double2 d;
+                {
+                    double so = A3m.x + V2m.x;
+                    so += v1m0;
+                    so += A3c.x;
+                    so += V2c.x;
+                    so += V1c.x;
+                    d.x = -so + Sc.x;
+                    so = A3m.y + V2m.y;
+                    so += V1c.x;
+                    so += A3c.y;
+                    so += V2c.y;
+                    so += V1c.y;
+                    d.y = -so + Sc.y;
+                    if (M & 0xf0f0u) {
+                        if (M & 0xf0u)
+                            d.x = dtab[(M >> 4) & 15u];
+                        if (M & 0xf000u)
+                            d.y = dtab[(M >> 12) & 15u];
+                    }
+                }
+                double t0 = A3m.x * Zm[k].x + d.x * Zc.x, t1 = A3m.y * Zm[k].y + d.y * Zc.y;
+                t0 += V2m.x * x2m.x;
+                t1 += V2m.y * x2m.y;
+                t0 += v1m0 * x1m0;
+                t1 += V1c.x * Zc.x;
+                t0 += V1c.x * Zc.y;
+                t1 += V1c.y * x1p1;
+                t0 += V2c.x * x2p.x;
+                t1 += V2c.y * x2p.y;
+                t0 += A3c.x * Zn.x;
+                t1 += A3c.y * Zn.y;
+                if (MODE == 1 && own[k] && (wc & 0x8000u)) {
+                    ST2nt(a.vnext, p, k, make_double2(t0, t1)); // q itself: the vector pass reads it once
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
+                if (MODE == 0 && own[k]) {
+                    const double mx = 1.0 / d.x, my = 1.0 / d.y;
+                    if (wc & 0x8000u) {
+                        ST2(a.vnext, p, k, make_double2(-(mx * (t0 - Sc.x * Zc.x)), -(my * (t1 - Sc.y * Zc.y))));
+                        acc[5] += Zc.x * t0 + Zc.y * t1;
+                    }
+                    const double cx = d.x * Zc.x, cy = d.y * Zc.y;
+                    const double rx = cx - Sc.x * DX[k].x, ry = cy - Sc.y * DX[k].y;
+                    acc[0] += rx * (mx * rx) + ry * (my * ry);
+                    acc[1] += rx * rx + ry * ry;
+                    acc[2] += cx * Zc.x + cy * Zc.y;
+                    acc[3] += cx * cx + cy * cy;
+                }
+                // ---- the pair's state for the next step; the streamed diagonal of plane p + 1 where it is not derived
+                Zm[k] = Zc;
+                DX[k] = dxn;
+                Mc[k] = (Mn & 0xffffu) | ((((wc >> 10) & 31u) | (((wc >> 26) & 31u) << 5)) << 18);
+            }
+            // ---- halo of plane p + 1 into the other slots; the halo of plane p + 2 in flight
+#pragma unroll
+            for (int r = 0; r < HR; r++) {
+                if (hv[r] && inseg) {
+                    zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
+                    if (hbefore[r])
+                        ws[((p + 1) & 1) * WL + hs[r]] = hw[r];
+                }
+                if (hv[r] && p + 2 < p1) {
+                    hz[r] = H1(a.z, p + 2, r);
+                    hq[r] = H1(a.v, p + 2, r);
+                    if (hbefore[r])
+                        hw[r] = HW(p + 2, r);
+                }
+            }
+            __syncthreads();
+            zb ^= 1;
+        }
+    }
+    double sgather = 0.0;
+    if (MODE == 0 && a.bm > 0) { // the assembled b's share of |rhs|^2 over its support, as in fused_step_kernel
+        __syncthreads();
+        for (int64_t k = (int64_t)blockIdx.x * NT + tid; k < a.bm; k += (int64_t)gridDim.x * NT) {
+            const int32_t i = a.bidx[k];
+            const double bi = a.b[i];
+            const double xn = a.x[i] + alpha * a.z[i];
+            const double sd = a.code ? tab[a.code[i]] : tab[0];
+            sgather += bi * (2.0 * (sd * xn) + bi);
+        }
+    }
+    const int G = (int)gridDim.x;
+    for (int k = MODE == 1 ? KF_NSUM - 1 : 0; k < KF_NSUM; k++) {
+        const double t = kf_block_sum<NT>(acc[k], red);
+        if (tid == 0)
+            (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (MODE == 0 && a.bm > 0) {
+        const double t = kf_block_sum<NT>(sgather, red);
+        if (tid == 0)
+            a.out.sbb[G + blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------ the fused step on the SELL form (irregular meshes)
 // The same step (kf_step_prologue, vrow, the same six sums) for operators stored as SELL-64 with 16-bit column offsets
 // (fv_spmv.hip): one wave per 64-row group, a lane per row.  A neighbour's z' is z + alpha v of that row — two gathers that hit the
@@ -949,6 +1321,112 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
     return true;
 }
 
+// ---- the chunk kernel's plan: variant (threads, pairs per thread), rows per chunk, chunks per plane, segments of planes, grid, LDS
+constexpr size_t KC_LDS_MAX = 160 * 1024;
+struct KcPlan {
+    int nt, np, grid;
+    size_t lds;
+};
+static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt)
+{
+    return (size_t)(16 * (C + 2 * nz) + 4 * (C + nz) + 8 * (2 * FV_STORAGE_CODES + 3 * FV_MATRIX_CODES + nt / 64));
+}
+// false: the 2-D tiles serve the launch (no codes, lines longer than the block, chunks that would not fit the LDS)
+static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
+{
+    if (!g_fused_chunk || !a.mcode || p->kc_state != 1 || !p->kc_code.p)
+        return false;
+    a.kcode = p->kc_code.p;
+    a.kdiag = p->kc_dtab;
+    static const int variants[6][2] = {{1024, 2}, {1024, 3}, {768, 4}, {512, 6}, {512, 5}, {768, 3}};
+    // (512 threads x 5 pairs is the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD; 464^3, one
+    // process, ms per step: tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44)
+    const int pick = g_fused_chunk >= 2 && g_fused_chunk <= 7 ? g_fused_chunk - 2 : 4;
+    const int nt = variants[pick][0], np = variants[pick][1];
+    const int64_t nz = a.nz, d3 = a.d3;
+    if (nz > nt) // the 2 nz halo rows are covered in two rounds of the block: longer lines stay with the tiles
+        return false;
+    const int64_t fixed = (int64_t)kc_lds_bytes(0, nz, nt);
+    int64_t cmax = ((int64_t)KC_LDS_MAX - fixed) / 20 / 16 * 16;
+    if (cmax > 2 * (int64_t)nt * np)
+        cmax = 2 * (int64_t)nt * np;
+    if (cmax < 2048 || cmax < 2 * nz) // (a chunk shorter than two lines: the halo would outweigh it)
+        return false;
+    fv_ctx *ctx = p->ctx;
+    int resident = ctx->num_cus / 8 * 8; // one block per CU (its LDS)
+    if (p->dist && p->dist->nranks > 1 && resident >= 64)
+        resident -= 8 * g_fused_dist_spare;
+    if (resident < 8)
+        resident = 8;
+    if (resident > FV_FUSED_PARTS)
+        resident = FV_FUSED_PARTS;
+    // chunks per plane K (equal chunks of C rows, C a multiple of 16) and segments of planes m: rounds x (planes per segment + 3)
+    // x (rows per chunk + its halo's weight), smallest first
+    const int64_t kmin = (d3 + cmax - 1) / cmax;
+    double best = -1.0;
+    int64_t bestK = kmin, bestC = cmax;
+    int bestm = 1;
+    for (int64_t K = kmin; K <= kmin + 8; K++) {
+        const int64_t Cr = ((d3 + K - 1) / K + 15) / 16 * 16;
+        if (Cr > cmax || Cr < 2 * nz)
+            continue;
+        const int64_t Ke = (d3 + Cr - 1) / Cr;
+        for (int m = 1; m <= 64 && m <= a.nplanes - 1; m++) {
+            const int64_t rounds = (Ke * m + resident - 1) / resident;
+            const double cost = (double)rounds * (double)((a.nplanes - 1 + m - 1) / m + 3) * ((double)Cr + 0.6 * (double)nz);
+            if (best < 0.0 || cost < best) {
+                best = cost;
+                bestK = Ke;
+                bestC = Cr;
+                bestm = m;
+            }
+        }
+    }
+    if (best < 0.0)
+        return false;
+    if (g_fused_segs > 0 && g_fused_segs <= a.nplanes - 1)
+        bestm = g_fused_segs;
+    a.chunk = (int32_t)bestC;
+    a.tiles = (int32_t)bestK;
+    a.tilesC = 1;
+    a.nsegs = bestm;
+    a.seglen = (a.nplanes - 1 + bestm - 1) / bestm;
+    int64_t g = (((int64_t)a.tiles * a.nsegs + 7) / 8) * 8;
+    if (g > resident)
+        g = resident;
+    pl.nt = nt;
+    pl.np = np;
+    pl.grid = (int)g;
+    pl.lds = kc_lds_bytes(bestC, nz, nt);
+    return true;
+}
+template <int NT, int NP, int MODE>
+static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
+{
+    static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
+    if (!raised) {
+        FV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_chunk_kernel<NT, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KC_LDS_MAX));
+        raised = true;
+    }
+    hipLaunchKernelGGL((fused_chunk_kernel<NT, NP, MODE>), dim3(pl.grid), dim3(NT), pl.lds, ctx->stream, a);
+    return FV_OK;
+}
+template <int MODE>
+static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
+{
+    if (pl.nt == 1024 && pl.np == 2)
+        return kc_launch_one<1024, 2, MODE>(ctx, a, pl);
+    if (pl.nt == 1024 && pl.np == 3)
+        return kc_launch_one<1024, 3, MODE>(ctx, a, pl);
+    if (pl.nt == 768 && pl.np == 4)
+        return kc_launch_one<768, 4, MODE>(ctx, a, pl);
+    if (pl.nt == 768)
+        return kc_launch_one<768, 3, MODE>(ctx, a, pl);
+    if (pl.np == 5)
+        return kc_launch_one<512, 5, MODE>(ctx, a, pl);
+    return kc_launch_one<512, 6, MODE>(ctx, a, pl);
+}
+
 // the SELL variant of fv_fused_step (same contract)
 static int fused_sell_step(fv_problem *p, const double *x, double *x_next, double sigma, double dt, double rtol, int chain_index, int mode,
                            const FusedSums &in, bool force_prev_unconverged, const double *folded, int64_t bsupport, FusedSums *out_sums)
@@ -1064,7 +1542,14 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     // (the sparse-b partials sit right behind the vector part's: sbb[GF .. 2 GF))
     a.out = out;
     const bool coded = kf_codes(p, a);
-    if (TLr == 16) {
+    KcPlan kc{};
+    const bool chunks = coded && kc_plan(p, a, kc);
+    if (chunks) {
+        out.nvec = kc.grid; // (the plan has its own grid: one partial sum of each kind per block)
+        out.nbb = a.bm > 0 ? 2 * kc.grid : kc.grid;
+        a.out = out;
+        FV_TRY(kc_launch<0>(ctx, a, kc));
+    } else if (TLr == 16) {
         if (coded)
             hipLaunchKernelGGL((fused_step_kernel<16, 0, true>), dim3(GF), dim3(1024), 0, ctx->stream, a);
         else
@@ -1078,10 +1563,12 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     FV_LAUNCH_CHECK(ctx);
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
+    const int GK = chunks ? kc.grid : GF;
     if (p->sym_nrest > 0) {
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GF, &GR, false, sigma)); // (stored in the v-form by the launch itself)
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GK, &GR, false, sigma)); // (stored in the v-form by the launch itself)
     }
-    out.npq = GF + GR;
+    out.npq = GK + GR;
+    p->fused_chunked = chunks;
     *out_sums = out;
     {
         // every array once: x, z, v in and x_out, z', v' out on all rows (48) + a code byte; the three upper diagonals on the rows
@@ -1167,7 +1654,11 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     a.hist_cap = p->hist_cap;
     a.n = p->n;
     const bool coded = kf_codes(p, a);
-    if (TLr == 16) {
+    KcPlan kc{};
+    const bool chunks = coded && kc_plan(p, a, kc);
+    if (chunks)
+        FV_TRY(kc_launch<1>(ctx, a, kc));
+    else if (TLr == 16) {
         if (coded)
             hipLaunchKernelGGL((fused_step_kernel<16, 1, true>), dim3(GF), dim3(1024), 0, ctx->stream, a);
         else
@@ -1181,8 +1672,10 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     p->loop_bytes = coded ? 91 : 113;
     FV_LAUNCH_CHECK(ctx);
     int GR = 0;
+    const int GK = chunks ? kc.grid : GF;
     if (p->sym_nrest > 0)
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GF, &GR, true));
-    *npq = GF + GR;
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true));
+    *npq = GK + GR;
+    p->fused_chunked = chunks;
     return FV_OK;
 }

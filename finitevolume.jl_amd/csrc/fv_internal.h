@@ -270,6 +270,11 @@ struct fv_problem {
     int sym_mcode_n = -1;
     int64_t sym_mcode_epoch = -1;
     int last_form = -1; // FV_SPMV_* of the most recent spmv_apply (fv_spmv_form)
+    // the fused step's chunk kernel (fv_fused.hip): per row, storage code | diagonal code << 4 (build_chunk_codes, fv_spmv.hip); built with
+    // the symmetric copy's values (same assembly, same folded shift, same storage codes); kc_state: 0 not applicable, 1 built
+    DevBuf<uint8_t> kc_code;
+    StorageTable kc_dtab = {};
+    int kc_state = 0, kc_ndiag = 0;
     int sym_state = -1; // -1 not looked at yet, 0 not applicable (no such structure, or not symmetric), 1 built
 
     // numeric
@@ -357,6 +362,7 @@ struct fv_problem {
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
     int64_t fused_launches = 0, fused_bytes_launch = 0;
+    bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;

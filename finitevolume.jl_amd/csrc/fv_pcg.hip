@@ -835,6 +835,14 @@ extern "C" int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_pe
     return FV_OK;
 }
 
+extern "C" int fv_fused_traversal(fv_problem *p, int32_t *kind)
+{
+    if (!p || !kind)
+        return FV_ERR_ARG;
+    *kind = p->fused_chunked ? 1 : 0;
+    return FV_OK;
+}
+
 extern "C" int fv_loop_form(fv_problem *p, int32_t *bytes_per_row)
 {
     if (!p || !bytes_per_row)

@@ -451,7 +451,7 @@ extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zf
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare, g_fused_sell, g_fused_sell_blocks; // fv_fused.hip
+extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare, g_fused_sell, g_fused_sell_blocks, g_fused_chunk; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
 {
@@ -563,6 +563,8 @@ extern "C" int fv_tune(int key, int value)
         g_fused_dist = value;
     else if (key == 51 && value >= 0 && value <= 4)
         g_fused_dist_spare = value;
+    else if (key == 60 && value >= 0 && value <= 7)
+        g_fused_chunk = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
         g_alloc_skew_bytes = value / 512 * 512;
     else
@@ -1880,6 +1882,101 @@ static int build_matrix_codes(fv_problem *p)
     return FV_OK;
 }
 
+// Bit 15 of a row's matrix word: the row's 64-row slice is one whose products the symmetric kernels form (bit 0 of sym_ok) — the
+// chunk kernel of the fused step (fv_fused.hip) then needs no flag stream.  The 5-bit codes below it are untouched.
+__global__ __launch_bounds__(FV_BLOCK) void matrix_code_ok_kernel(int64_t n, const uint8_t *__restrict__ ok, uint16_t *__restrict__ code)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK)
+        code[i] = (uint16_t)((code[i] & 0x7fffu) | ((ok[i >> 6] & 1) ? 0x8000u : 0u));
+}
+
+// The code byte per row of the fused step's chunk kernel (fv_internal.h: kc_code): low nibble = the row's storage code (0 where
+// the storage term takes one value), high nibble = where the row's diagonal comes from: 0 = from its six arms — the stored
+// double is, bit for bit, minus their sum in assembly order plus the folded sigma D of the row's storage code, what
+// symdia_rowsum_kernel checks per slice, here per row —, k > 0 = entry k of a table of at most 15 stored diagonals (rows next
+// to a Dirichlet cell on a regular grid with one conductivity: a handful of values).  Rows of the first and the last plane never
+// are a centre plane of that kernel and keep 0.  More than 15 distinct values: no codes (kc_state = 0), the 2-D tiles run.
+__global__ __launch_bounds__(FV_BLOCK) void chunk_code_kernel(int64_t n, int32_t d1, int32_t d2, int32_t d3, const double *__restrict__ dg,
+                                                               const double *__restrict__ u1, const double *__restrict__ u2,
+                                                               const double *__restrict__ u3, const uint8_t *__restrict__ dcode, StorageTable tshift,
+                                                               int shift_mode, const uint8_t *__restrict__ ok, StorageTable dtab, int ntab,
+                                                               uint8_t *__restrict__ code, int32_t *__restrict__ claim, double *__restrict__ offered)
+{
+    bool offered_one = false;
+    for (int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * FV_BLOCK) {
+        const uint8_t sc = dcode ? dcode[r] : (uint8_t)0;
+        int nib = 0;
+        if (r >= d3 && r < n - d3) {
+            bool derived = false;
+            if (ok[r >> 6] & 1) {
+                double so = u3[r - d3] + u2[r - d2];
+                so += u1[r - d1];
+                so += u3[r];
+                so += u2[r];
+                so += u1[r];
+                double cand = -so;
+                if (shift_mode)
+                    cand += tshift.v[shift_mode == 1 ? sc : 0];
+                derived = __double_as_longlong(cand) == __double_as_longlong(dg[r]);
+            }
+            if (!derived) {
+                const long long bits = __double_as_longlong(dg[r]);
+                for (int k = 1; k <= ntab; k++)
+                    if (__double_as_longlong(dtab.v[k]) == bits)
+                        nib = k;
+                if (nib == 0) {
+                    nib = -1;
+                    if (!offered_one) {
+                        offered_one = true;
+                        if (*reinterpret_cast<volatile int32_t *>(claim) == 0 && atomicCAS(claim, 0, 1) == 0)
+                            *offered = dg[r];
+                    }
+                }
+            }
+        }
+        if (nib >= 0)
+            code[r] = (uint8_t)((sc & 15) | (nib << 4));
+    }
+}
+
+static int build_chunk_codes(fv_problem *p, const uint8_t *dcode, int shift_mode)
+{
+    fv_ctx *ctx = p->ctx;
+    p->kc_state = 0;
+    if (shift_mode < 0 || p->sym_mcode_n <= 0 || !p->sym_mcode.p || p->sym_d[0] != 1)
+        return FV_OK;
+    const int64_t n = p->n;
+    if (!p->kc_code.p)
+        FV_TRY(p->kc_code.alloc(ctx, (size_t)n + 64));
+    const double *dg = p->sym_vals.p + p->sym_front;
+    DevBuf<int32_t> claim;
+    DevBuf<double> offered;
+    FV_TRY(claim.alloc(ctx, 1));
+    FV_TRY(offered.alloc(ctx, 1));
+    int64_t g = (n + FV_BLOCK - 1) / FV_BLOCK;
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    int ntab = 0;
+    p->kc_dtab = StorageTable{};
+    for (;;) {
+        FV_TRY(claim.zero(ctx));
+        hipLaunchKernelGGL(chunk_code_kernel, dim3((unsigned)g), dim3(FV_BLOCK), 0, ctx->stream, n, (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], (int32_t)p->sym_d[2],
+                           dg, dg + p->sym_ld, dg + 2 * p->sym_ld, dg + 3 * p->sym_ld, dcode, p->sym_shift, shift_mode, (const uint8_t *)p->sym_ok.p, p->kc_dtab,
+                           ntab, p->kc_code.p, claim.p, offered.p);
+        FV_LAUNCH_CHECK(ctx);
+        int32_t hc = 0;
+        FV_TRY(fv_copy(ctx, &hc, claim.p, sizeof hc));
+        if (!hc)
+            break;
+        if (ntab == FV_STORAGE_CODES - 1)
+            return FV_OK; // too many distinct diagonals among the rows that do not derive theirs
+        ntab++;
+        FV_TRY(fv_copy(ctx, &p->kc_dtab.v[ntab], offered.p, sizeof(double)));
+    }
+    p->kc_state = 1;
+    p->kc_ndiag = ntab;
+    return FV_OK;
+}
+
 static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
 {
     fv_ctx *ctx = p->ctx;
@@ -1908,6 +2005,8 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
         }
     }
     // which slices can do without the diagonal stream (bit 1 of sym_ok)
+    const uint8_t *kc_dcode = nullptr;
+    int kc_mode = 0;
     {
         const int64_t ns = (p->n + 63) >> 6;
         int mode = 0;
@@ -1942,11 +2041,23 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
         FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
         p->sym_nderived = h;
         p->sym_shift_mode = h > 0 ? mode : 0;
+        if (on) {
+            kc_mode = mode;
+            kc_dcode = sa.code;
+        } else
+            kc_mode = -1;
     }
     if (p->sym_mcode_epoch != p->assemble_epoch) { // (the upper diagonals do not depend on the folded shift)
         FV_TRY(build_matrix_codes(p));
         p->sym_mcode_epoch = p->assemble_epoch;
+        if (p->sym_mcode_n > 0 && p->sym_mcode.p) {
+            hipLaunchKernelGGL(matrix_code_ok_kernel, dim3(fv_blocks(p->n) > 4096 ? 4096 : fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n,
+                               (const uint8_t *)p->sym_ok.p, p->sym_mcode.p);
+            FV_LAUNCH_CHECK(ctx);
+        }
     }
+    // the chunk kernel's code bytes (diagonal of this copy, its folded shift, the storage codes of the moment)
+    FV_TRY(build_chunk_codes(p, kc_dcode, kc_mode));
     p->sym_epoch = p->assemble_epoch;
     p->sym_tag = src_tag;
     return FV_OK;

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FVHIP_ABI_VERSION 2 /* 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
+#define FVHIP_ABI_VERSION 3 /* 3: fv_fused_traversal; 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
 
 enum {
     FV_OK = 0,
@@ -294,6 +294,11 @@ int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int6
  * (z = M^-1 r and p in, p' and q out, three upper diagonals, a code byte: 57) + the vector update in the z-form (x, z, p, q, M^-1 in,
  * x, z out: 56); 91 with the matrix as codes, 7 fewer again where M^-1 takes few distinct values and comes as a code byte. */
 int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
+/* How the most recent fused launch (fv_fused_form / fv_loop_form) walked the planes of the operator: 0 = 2-D tiles of 16 lines x 128
+ * columns (or it has not run), 1 = contiguous chunks of a plane's rows (no column halos; where the matrix comes as codes and the
+ * rows whose diagonal does not follow from their arms share at most 15 values).  A measurement aid like the two above: the step it
+ * reports on is backwardeuleronestep! / cg! of src/transient.jl:50-76 either way. */
+int fv_fused_traversal(fv_problem *p, int32_t *kind);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128

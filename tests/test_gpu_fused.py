@@ -52,12 +52,12 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
             it, info, _ = p.run_fixed(st, dt, nsteps, rtol=rtol, maxiter=2000)
             assert info.converged
             its.append(it.copy())
-        out = (st.node_values(), np.concatenate(its), p.fused_form(), p.spmv_form()[0])
+        out = (st.node_values(), np.concatenate(its), p.fused_form(), p.spmv_form()[0], p.fused_traversal(), p.loop_form())
         p.close()
     finally:
         lib.fv_tune(41, 1)
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0, 44: 16, 46: 1, 49: 1}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 42: 2, 43: 0, 44: 16, 46: 1, 49: 1, 60: 1}.get(k, 0))
     return out
 
 
@@ -199,7 +199,7 @@ def test_matrix_as_codes_gives_the_same_bits(fv):
     many-iteration loop; a heterogeneous field keeps the doubles."""
     case = _problem(fv, BOX, seed=13, uniform_k=True)
     sched = [(DT, 17, 1e-11), (40.0, 4, 1e-12), (DT, 10, 1e-11)]
-    coded = _run(fv, case, True, sched)
+    coded = _run(fv, case, True, sched, tune=((60, 0),))  # (the same 2-D tiles on both sides: the chunk traversal groups the partial sums differently)
     plain = _run(fv, case, True, sched, tune=((49, 0),))
     assert coded[2][0] > 15 and plain[2][0] == coded[2][0]
     assert coded[2][2] < 0.75 * plain[2][2]  # bytes per launch of the storage form: 2 instead of 24 of matrix per row
@@ -208,6 +208,44 @@ def test_matrix_as_codes_gives_the_same_bits(fv):
     a = _run(fv, hetero, True, [(DT, 12, 1e-11)])
     b = _run(fv, hetero, True, [(DT, 12, 1e-11)], tune=((49, 0),))
     assert a[2][2] == b[2][2] and np.array_equal(a[0], b[0])
+
+
+# ------------------------------------------------------------------ the chunk traversal (round 4; fused_chunk_kernel, fv_tune key 60)
+@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True)])
+def test_chunk_traversal_against_the_tiles_and_the_oracle(fv, oracle, ns, lateral):
+    """With the matrix as codes the fused step walks contiguous chunks of a plane's rows instead of 2-D tiles (no column halos,
+    the diagonal of rows next to a Dirichlet cell out of a table by a per-row code, everything that needs a diagonal formed when
+    the row's plane is the centre plane).  Same Jacobi-PCG step: identical iteration counts, heads to rounding of the tiles' run
+    (partial sums group differently) — one-iteration steps, a many-iteration stretch (the loop through the same kernel), loose
+    steps (zero iterations), an injected chain break —, every (threads, pairs per thread) variant; the oracle's heads within 1e-8."""
+    case = _problem(fv, ns, lateral=lateral, seed=21, uniform_k=True)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    sched = [(DT, 14, 1e-11), (40.0, 3, 1e-12), (DT, 9, 1e-11), (DT, 6, 1e-3), (DT, 7, 1e-12)]
+    tiles = _run(fv, case, True, sched, tune=((60, 0),))
+    assert tiles[4] == 0 and tiles[2][1] == 51 and tiles[2][0] > 20
+    for variant in (1, 2, 3, 4, 5, 6, 7):
+        got = _run(fv, case, True, sched, tune=((60, variant),))
+        assert got[4] == 1 and got[2][1] == 51 and got[2][0] == tiles[2][0], (variant, got[2], got[4])
+        assert np.array_equal(got[1], tiles[1]), (variant, got[1], tiles[1])
+        assert relerr(got[0], tiles[0]) < 1e-12, (variant, relerr(got[0], tiles[0]))
+    chunks = _run(fv, case, True, sched)
+    assert chunks[4] == 1
+    for brk in (0, 5):
+        a = _run(fv, case, True, sched[:1], tune=((14, brk),))
+        b = _run(fv, case, True, sched[:1], tune=((14, brk), (60, 0)))
+        assert a[4] == 1 and b[4] == 0 and np.array_equal(a[1], b[1]) and (a[1] > 1).sum() >= 1 and relerr(a[0], b[0]) < 1e-11
+    # the many-iteration loop alone: a steady-ish long step from the start state
+    la = _run(fv, case, True, [(300.0, 4, 1e-12)])
+    lb = _run(fv, case, True, [(300.0, 4, 1e-12)], tune=((60, 0),))
+    assert la[4] == 1 and lb[4] == 0 and la[5] in (84, 91) and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
+    # the oracle: the same schedule, its CG run to 1e-14 (every step its own solve)
+    t, u = 0.0, u0
+    for dt, steps, _ in sched:
+        ous, ots = oracle.backwardeulerintegrate(u, (t, t + dt * steps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
+                                                 dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
+        u, t = ous[-1], ots[-1]
+    print("chunks vs tiles %.2e, chunks vs oracle %.2e (change over the run %.2e)" % (relerr(chunks[0], tiles[0]), relerr(chunks[0], u), relerr(chunks[0] - u0, u - u0)))
+    assert relerr(chunks[0], u) < 1e-8
 
 
 def test_many_iteration_loop_leaves_a_row_with_a_zero_diagonal_alone(fv):
@@ -285,7 +323,7 @@ def _run_row_blocks(fv, case, nranks, group_id, schedule, planes_per_rank, Ss=0.
             t.join(timeout=300)
     finally:
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 44: 16, 49: 1, 50: 1, 51: 1}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 44: 16, 49: 1, 50: 1, 51: 1, 60: 1}.get(k, 0))
     assert not errors, errors
     assert all(not t.is_alive() for t in threads), "a rank did not finish (deadlock in the protocol?)"
     return out

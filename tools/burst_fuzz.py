@@ -34,6 +34,8 @@ def run(fv, nseeds=12, tight=False, verbose=True):
             lib.fv_tune(22, merged)
             p = fv.Problem.regulargrid(mins, maxs, ns, dn)
             K = 1e-5 * np.exp(rng.standard_normal(1)[0] * 0 + np.random.default_rng(100 + seed).standard_normal(p.F))
+            if os.environ.get("FV_FUZZ_UNIFORM"):  # one conductivity: the matrix as codes, the fused step on chunks of a plane (fused_chunk_kernel)
+                K = np.array([1e-5 * (1.0 + seed)])
             p.assemble(K, src, np.full(len(dn), 1e3))
             st = p.transient_begin(0.1, None, np.full(p.N, 1e3) + np.random.default_rng(200 + seed).standard_normal(p.N))
             its = []
