@@ -420,6 +420,39 @@ def hetero_face_K(ns, F, N):
     return K
 
 
+def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes, fused_launch_bytes):
+    """A roofline-shaped object for the regime a block of fixed-dt steps ran in: the bytes one step must move with
+    every array of every launch touched once, over the wall time of a step.
+    One-iteration steps through the fused launch: fv_fused_form's bytes.  Steps of several PCG iterations (the carried residual, then
+    the loop of DESIGN 4d): K0' (carried set-up: x, x_prev, z or r, D, M^-1 in, r, p out = 64 n) + K1 (the tiled SpMV's form, with p.q)
+    + the first vector update (x, z, p, q, M^-1 in, x, z out = 56 n; 49 with M^-1 as a code byte) + per further iteration the loop
+    form fv_loop_form reports (fused pass + vector update: 113 n, 91 / 84 with codes) — or K1 + K2 + K3 where that loop is not taken."""
+    n = p.n
+    its = np.asarray(iters, dtype=np.float64)
+    mean_it = float(its.mean())
+    if fused_launches >= 0.8 * len(its) and mean_it <= 1.0:
+        bytes_step = float(fused_launch_bytes)
+        model = "one fused launch per step (fv_fused_form): %d B per row" % fused_row_bytes
+    else:
+        form_id, form_name, form_bytes = p.spmv_form()
+        loop = p.loop_form()
+        if loop:
+            upd = 49 if loop in (84, 106) else 56
+            per_it = loop * n
+            first = 64 * n + form_bytes + upd * n
+            bytes_step = float(np.mean(np.where(its >= 1, first + np.maximum(its - 1, 0) * per_it, 64 * n)))
+            model = ("per step: carried set-up K0' 64 n + K1 (%s) %d B per row + first vector update %d n, then per further iteration the fused pass + the "
+                     "z-form vector update = %d n; weighted with the iteration count of every step" % (form_name, form_bytes // max(n, 1), upd, loop))
+        else:
+            per_it = form_bytes + 88 * n
+            bytes_step = float(np.mean(64 * n + its * per_it))
+            model = "per step: carried set-up 64 n + per iteration K1 (%s) + 88 n for K2 + K3" % form_name
+    gbs = bytes_step / sec_per_step / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_step": bytes_step, "bytes_per_row_per_step": bytes_step / max(n, 1), "pcg_iters_per_step": mean_it,
+            "measured": "wall time of the stepping loop / steps (all launches of a step, polls included)", "bytes_model": model}
+
+
 def hetero_block(fv, ctx, args):
     """The headline workload with a smooth heterogeneous conductivity (sigma = 1 in log K) instead of one value: SURVEY 8d names both
     for the 10^8-cell configuration.  The operator's diagonals then take as many values as there are faces, so the fused step
@@ -446,7 +479,8 @@ def hetero_block(fv, ctx, args):
     out = {"workload": "same %d^3 box, K = 1e-5 exp(g) per face with g a smooth field of unit variance (sums of sines of the cell indices), %d steps x 3 regions" % (args.ns, args.steps),
            "dof_updates_per_s": p.N * args.steps / sec, "ms_per_step": sec / args.steps * 1e3, "ms_per_step_each": [s / args.steps * 1e3 for s in secs],
            "pcg_iters_per_step": float(iters.mean()), "converged": bool(info.converged), "last_relres": info.relres,
-           "fused_launches": launches - f0, "bytes_per_row": brow, "GB/s": bl / (sec / args.steps) / 1e9 if launches > f0 else None}
+           "fused_launches": launches - f0}
+    out["roofline"] = step_regime_roofline(p, iters, sec / args.steps, launches - f0, brow, bl)
     # ... and at a time step short enough for this field's stiffest cells to converge in one PCG iteration: the regime of the
     # headline, where the fused step streams the matrix as doubles
     if out["pcg_iters_per_step"] > 1.0:
@@ -466,8 +500,8 @@ def hetero_block(fv, ctx, args):
         l1, brow1, bl1 = p.fused_form()
         out["one_iteration_regime"] = {"dt": dt1, "steps": n1s, "dof_updates_per_s": p.N * n1s / sec1, "ms_per_step": sec1 / n1s * 1e3,
                                        "ms_per_step_each": [s / n1s * 1e3 for s in secs1], "pcg_iters_per_step": float(np.mean(its1)),
-                                       "converged": bool(info1.converged), "fused_launches": l1 - f1, "bytes_per_row": brow1,
-                                       "GB/s": bl1 / (sec1 / n1s) / 1e9 if l1 - f1 >= 0.8 * 3 * n1s else None}
+                                       "converged": bool(info1.converged), "fused_launches": l1 - f1,
+                                       "roofline": step_regime_roofline(p, it1, sec1 / n1s, (l1 - f1) / 3.0, brow1, bl1)}
     p.close()
     return out
 
