@@ -120,6 +120,24 @@ SIGNATURES = {
     "fv_comm_init_local": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
     "fv_param_gradient_integral": (C.c_int, [c_prob, C.c_int64, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+    "fv_trajectory_create": (C.c_int, [c_prob, P(C.c_void_p)]),
+    "fv_trajectory_destroy": (C.c_int, [C.c_void_p]),
+    "fv_trajectory_clear": (C.c_int, [C.c_void_p]),
+    "fv_trajectory_push_state": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "fv_trajectory_push_free": (C.c_int, [C.c_void_p, _f64p, C.c_double]),
+    "fv_trajectory_size": (C.c_int, [C.c_void_p, P(C.c_int64)]),
+    "fv_trajectory_times": (C.c_int, [C.c_void_p, _f64p, C.c_int64]),
+    "fv_trajectory_get_free": (C.c_int, [C.c_void_p, C.c_int64, _f64p]),
+    "fv_trajectory_get_nodes": (C.c_int, [C.c_void_p, C.c_int64, _f64p]),
+    "fv_trajectory_eval_free": (C.c_int, [C.c_void_p, C.c_double, _f64p]),
+    "fv_trajectory_reverse_time": (C.c_int, [C.c_void_p, C.c_double]),
+    "fv_trajectory_record": (C.c_int, [c_prob, C.c_void_p, C.c_double]),
+    "fv_observation_create": (C.c_int, [c_prob, C.c_int64, _i64p, C.c_int64, _f64p, _f64p, _f64p, P(C.c_void_p)]),
+    "fv_observation_destroy": (C.c_int, [C.c_void_p]),
+    "fv_observation_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_double, P(C.c_double)]),
+    "fv_adjoint_run": (C.c_int, [c_prob, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int64, C.c_int64,
+                                 C.c_void_p, P(C.c_int64), P(C.c_int64), C.c_void_p]),
+    "fv_param_gradient_integral_traj": (C.c_int, [c_prob, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int, _f64p, C.c_int, _f64p, _f64p, _f64p]),
     "fv_param_jacobian_apply": (C.c_int, [c_prob, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     "fv_dist_setup_bounds": (C.c_int, [c_prob, C.c_int, C.c_int, _i64p, P(c_prob)]),
     "fv_problem_create_regulargrid_slab": (C.c_int, [c_ctx, _f64p, _f64p, _i64p, C.c_int64, _i64p, C.c_int64, C.c_int64, P(c_prob)]),

@@ -10,7 +10,8 @@ host, as in the reference (Interpolations / QuadGK there, numpy / scipy here).
 """
 import numpy as np
 
-from .core import DeviceMatrix, _assembled_problem, af64
+from .core import SQRT_EPS as SQRT_EPS_
+from .core import DeviceMatrix, Observation, _assembled_problem, af64
 from .transient import DeviceOperator, _integrate_generic, backwardeulerintegrate
 
 
@@ -48,9 +49,47 @@ class LinearInterpolant2(LinearInterpolant):
         return LinearInterpolant.__call__(self, t)[int(i) - 1]
 
 
+class DeviceStates:
+    """`us` of a run kept in HBM (backwardeulerintegrate(..., keep="device"), the lambdas of a device adjoint sweep): indexing
+    downloads one stored state — node vectors for a forward run (after freenodes2nodes, transient.jl:172), free-cell vectors for
+    lambdas (`free=True`)."""
+
+    def __init__(self, trajectory, free=False):
+        self.trajectory, self.free = trajectory, free
+
+    def __len__(self):
+        return len(self.trajectory)
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        k = k + len(self) if k < 0 else k
+        return self.trajectory.free_values(k) if self.free else self.trajectory.node_values(k)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
+class DeviceSolution:
+    """getcontinuoussolution of DeviceStates: u_c(t) interpolated on the device and downloaded when called (node vector, or the
+    free-cell vector for lambdas); the adjoint sweep and the gradient integral read the trajectory itself."""
+
+    def __init__(self, states, ts, two=False):
+        self.states, self.trajectory, self.two = states, states.trajectory, two
+        self.ts = np.asarray(ts, dtype=np.float64)
+
+    def __call__(self, *args):
+        t = args[-1]
+        free = self.trajectory.at(t)
+        v = free if self.states.free else self.trajectory.problem.freenodes2nodes(free)
+        return v[int(args[0]) - 1] if self.two else v
+
+
 def getcontinuoussolution(us, ts, val=None):
     """transient.jl:176-186: piecewise-linear-in-time interpolant of the stored states.
     Returns uc(t) -> vector (Gridded(Linear())); with val=2 an itp(i, t) of the 2-D form."""
+    if isinstance(us, DeviceStates):
+        return DeviceSolution(us, ts, two=(val == 2))
     return LinearInterpolant2(us, ts) if val == 2 else LinearInterpolant(us, ts)
 
 
@@ -62,6 +101,24 @@ def adjointintegrate(*args, **kwargs):
       adjointintegrate(A, getdgdu, tspan; dt0=1.0, kwargs...)     (A = transpose of the scaled operator)
 
     Returns (lambdas, ts) in terms of λ (reversed in time), vectors over the free cells."""
+    if isinstance(args[0], BoundForcing) and isinstance(args[0].uc, DeviceSolution):
+        # device-resident sweep (fv_adjoint_run): the forward states stay in HBM, the forcing of every solve is a kernel over the
+        # observation rows.  The operator is the forward run's own problem (same mesh, parameters and storage term), as
+        # adjointintegrate would assemble it again from the same arguments (transient.jl:189-193).
+        from .transient import adaptivebackwardeulerstep, fixedbackwardeulerstep
+
+        forcing, tspan = args[0], args[1]
+        uc = forcing.uc
+        p = uc.trajectory.problem
+        stepper = kwargs.pop("stepper", kwargs.pop("stepper_", adaptivebackwardeulerstep))
+        if stepper not in (adaptivebackwardeulerstep, fixedbackwardeulerstep) or any(k in kwargs for k in ("linearsolver", "callback")):
+            raise ValueError("the device-resident adjoint sweep runs the adaptive or the fixed stepper with the device PCG")
+        obs = forcing.observation(p)
+        lam, _, _, _ = p.adjoint_run(uc.trajectory, obs, tspan[0], tspan[1], dt0=kwargs.pop("dt0", 1.0), adaptive=stepper is adaptivebackwardeulerstep,
+                                     atol=kwargs.pop("atol", 1e-4), rtol=kwargs.pop("rtol", SQRT_EPS_), maxiter=kwargs.pop("maxiter", 1000))
+        if kwargs:
+            raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
+        return DeviceStates(lam, free=True), [float(t) for t in lam.ts]
     if callable(args[0]):
         getdgdu, tspan, Ss, volumes, neighbors, aol, K, sources, dnodes, dheads = args[:10]
         metaindex = args[10] if len(args) > 10 else None
@@ -188,6 +245,48 @@ class DeviceJacobian:
     dot = __matmul__
 
 
+class BoundForcing:
+    """t -> dgdu(uc, t): what the reference's callers write as a closure (`t->dgdu(uc_p, t)`, examples/transientadjoint/ex.jl:118),
+    kept as an object so that adjointintegrate can see the solution and the observation series behind it."""
+
+    def __init__(self, forcing, uc):
+        self.forcing, self.uc = forcing, uc
+
+    def __call__(self, t):
+        return self.forcing(self.uc, t)
+
+    def observation(self, problem):
+        return self.forcing.observation(problem)
+
+
+class ObservationForcing:
+    """dgdu of getadjointfunctions (transientadjointutils.jl:13-21): callable as dgdu(u, t) like the reference's closure; `bind(uc)`
+    gives the t -> dgdu(uc, t) object the device-resident sweep recognises."""
+
+    def __init__(self, host, sigma, obsfreenodes, uobs, f2n):
+        self.host, self.sigma, self.obs, self.uobs, self.f2n = host, sigma, [int(i) for i in obsfreenodes], uobs, f2n
+        self._dev = {}
+
+    def __call__(self, u, t):
+        return self.host(u, t)
+
+    def bind(self, uc):
+        return BoundForcing(self, uc)
+
+    def observation(self, problem):
+        """The device form of the observation data: uobs at the observation rows and sigma(i, t) sampled at uobs's knots (sigma is
+        taken as linear in t between them — exact for the constant-in-time weights of the reference's example)."""
+        key = id(problem)
+        if key not in self._dev:
+            if not isinstance(self.uobs, LinearInterpolant):
+                raise TypeError("the device-resident adjoint needs uobs as a piecewise-linear solution object (getcontinuoussolution)")
+            nodes = self.f2n[np.asarray(self.obs, dtype=np.int64) - 1] - 1
+            tk = self.uobs.ts
+            S = np.array([[self.sigma(i, float(t)) for i in self.obs] for t in tk], dtype=np.float64).reshape(len(tk), len(self.obs))
+            self._dev = {key: Observation(problem, self.obs, tk, self.uobs.U[:, nodes], S)}
+        return self._dev[key]
+
+
 def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex=None, logtransformconductivity=False, **kwargs):
     """transientadjointutils.jl:1-55 -> g, dgdu, dfdp, dgdp, du0dp, G.  device=True (keyword): dfdp(u, t, p) returns a
     DeviceJacobian — its product with lambda runs on the GPU — instead of a scipy matrix."""
@@ -208,12 +307,14 @@ def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neigh
         uo, ue = uobs(t), u(t)
         return float(sum(sigma(i, t) ** 2 * (ue[f2n[i - 1] - 1] - uo[f2n[i - 1] - 1]) ** 2 for i in obsfreenodes))
 
-    def dgdu(u, t):
+    def dgdu_host(u, t):
         uo, ue = uobs(t), u(t)
         result = np.zeros(nfree)
         for i in obsfreenodes:
             result[i - 1] = 2 * sigma(i, t) ** 2 * (ue[f2n[i - 1] - 1] - uo[f2n[i - 1] - 1])
         return result
+
+    dgdu = ObservationForcing(dgdu_host, sigma, obsfreenodes, uobs, f2n)
 
     def split(p):
         p = af64(p)
@@ -263,6 +364,8 @@ def getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, Ss, volumes, neigh
 
     def G(p):
         limit = max(300 // 21, 50)  # quadgk(...; maxevals=3*10^2, order=21) in the reference
+        if isinstance(p, DeviceSolution):  # the states are in HBM: the exact piecewise integral on the device (fv_observation_integral)
+            return dgdu.observation(p.trajectory.problem).integral(p.trajectory, tspan[0], tspan[1])
         if callable(p):
             # the integrand is a polynomial between the knots of the two interpolants: integrate piece by piece
             knots = {float(tspan[0]), float(tspan[1])}
@@ -290,6 +393,37 @@ def devicegradientintegral(uc, lambdas, ts_lambda, tspan, Ss, volumes, neighbors
     call does (see getadjointfunctions); "storage" by the volume of the node behind f; None not at all."""
     from .core import Problem, _metaindex_array, _split_neighbors, getfreenodes, getnodei2dirichleti
 
+    if isinstance(uc, DeviceSolution):
+        # u and lambda both in HBM: no state crosses PCIe (fv_param_gradient_integral_traj); lambdas: DeviceStates of the sweep
+        if not isinstance(lambdas, DeviceStates):
+            raise TypeError("with a device solution the lambdas must be the DeviceStates of the device adjoint sweep")
+        p = uc.trajectory.problem
+        K, dh = af64(conductivities), af64(dirichletheads)
+        nK, N, ndir = len(K), len(sources), len(dh)
+        n1, n2 = _split_neighbors(neighbors)
+        F = len(n1)
+        freenode, n2f = getfreenodes(N, dirichletnodes)
+        nfree = int(freenode.sum())
+        vols = Ss * af64(volumes)
+        if scale == "reference":
+            fk, fd, rs = p.param_gradient_integral_traj(uc.trajectory, lambdas.trajectory, tspan[0], tspan[1], False, 1.0 / vols[:nfree], logtransformconductivity)
+        elif scale == "storage":
+            fk, fd, rs = p.param_gradient_integral_traj(uc.trajectory, lambdas.trajectory, tspan[0], tspan[1], True, None, logtransformconductivity)
+        elif scale is None:
+            fk, fd, rs = p.param_gradient_integral_traj(uc.trajectory, lambdas.trajectory, tspan[0], tspan[1], False, None, logtransformconductivity)
+        else:
+            raise ValueError("scale must be 'reference', 'storage' or None")
+        mi = _metaindex_array(metaindex, F)
+        m = (mi - 1) if mi is not None else np.arange(F)
+        out = np.zeros(nK + N + ndir)
+        out[:nK] = np.bincount(m, weights=fk, minlength=nK)
+        out[nK + np.nonzero(freenode)[0]] = rs
+        n2d = getnodei2dirichleti(np.zeros(N), dirichletnodes)
+        a, b = n1 - 1, n2 - 1
+        for fr, di in ((a, b), (b, a)):
+            sel = freenode[fr] & ~freenode[di]
+            out[nK + N :] += np.bincount(n2d[di[sel]] - 1, weights=fd[sel], minlength=ndir)
+        return out
     if not isinstance(uc, LinearInterpolant):
         raise TypeError("devicegradientintegral needs the piecewise-linear solution object (getcontinuoussolution)")
     K, dh = af64(conductivities), af64(dirichletheads)

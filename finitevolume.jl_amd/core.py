@@ -399,9 +399,135 @@ class Problem:
         self.check(load().fv_transient_run_adaptive(self.handle, state.slot, float(t0), float(tfinal), float(dt0), float(atol), float(rtol), int(maxiter), int(max_outer), ptr(ts), C.byref(nout), C.byref(nsol), C.byref(info)))
         return ts[: nout.value + 1].copy(), nsol.value, info
 
+    # ---- trajectories in HBM and the adjoint sweep over them (fv_trajectory.hip)
+    def new_trajectory(self):
+        return Trajectory(self)
+
+    def record(self, trajectory, t0=0.0):
+        """While set, run_adaptive pushes its initial state and every outer state, run_fixed every step's state at t0 + k dt
+        (fv_trajectory_record); None stops it."""
+        self.check(load().fv_trajectory_record(self.handle, trajectory.handle if trajectory is not None else None, float(t0)))
+
+    def adjoint_run(self, u, obs, t0, tfinal, dt0=1.0, adaptive=True, atol=1e-4, rtol=SQRT_EPS, maxiter=1000, max_outer=1 << 20):
+        """adjointintegrate (transient.jl:188-205) with the forcing dgdu(u_c, T - t) of getadjointfunctions evaluated on the device from
+        the trajectory `u` and the Observation `obs` (fv_adjoint_run).  -> (Trajectory of lambda, outer steps, solves, info)."""
+        lam = Trajectory(self)
+        nout, nsol = C.c_int64(), C.c_int64()
+        info = SolveInfo()
+        self.check(load().fv_adjoint_run(self.handle, u.handle, obs.handle, float(t0), float(tfinal), float(dt0), int(bool(adaptive)), float(atol), float(rtol),
+                                         int(maxiter), int(max_outer), lam.handle, C.byref(nout), C.byref(nsol), C.byref(info)))
+        return lam, nout.value, nsol.value, info
+
+    def param_gradient_integral_traj(self, u, lam, t0, t1, scale_by_storage=False, lam_scale=None, logtransformconductivity=False):
+        """fv_param_gradient_integral_traj: the integral of (b_p - A_p u)' w over [t0, t1] with u and lambda read from trajectories in HBM."""
+        sc = af64(lam_scale) if lam_scale is not None else None
+        fk, fd, rs = np.empty(self.F), np.empty(self.F), np.empty(self.n)
+        self.check(load().fv_param_gradient_integral_traj(self.handle, u.handle, lam.handle, float(t0), float(t1), int(bool(scale_by_storage)), ptr(sc),
+                                                          int(bool(logtransformconductivity)), ptr(fk), ptr(fd), ptr(rs)))
+        return fk, fd, rs
+
     def close(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             load().fv_problem_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Trajectory:
+    """The stored states of a run — the reference's `us`, `ts` (transient.jl:136-154) — kept in HBM (fv_trajectory): knot k is a
+    free-cell vector on the device at time ts[k]."""
+
+    def __init__(self, problem):
+        self.problem = problem
+        h = C.c_void_p()
+        problem.check(load().fv_trajectory_create(problem.handle, C.byref(h)))
+        self.handle = h
+
+    def push(self, state, t):
+        self.problem.check(load().fv_trajectory_push_state(self.handle, state.slot, float(t)))
+        return self
+
+    def push_free(self, u_free, t):
+        u = af64(u_free)
+        self.problem.check(load().fv_trajectory_push_free(self.handle, ptr(u), float(t)))
+        return self
+
+    def __len__(self):
+        k = C.c_int64()
+        self.problem.check(load().fv_trajectory_size(self.handle, C.byref(k)))
+        return k.value
+
+    @property
+    def ts(self):
+        t = np.empty(max(len(self), 1), np.float64)
+        self.problem.check(load().fv_trajectory_times(self.handle, ptr(t), len(t)))
+        return t[: len(self)]
+
+    def free_values(self, k):
+        out = np.empty(self.problem.n, np.float64)
+        self.problem.check(load().fv_trajectory_get_free(self.handle, int(k), ptr(out)))
+        return out
+
+    def node_values(self, k):
+        out = np.empty(self.problem.N, np.float64)
+        self.problem.check(load().fv_trajectory_get_nodes(self.handle, int(k), ptr(out)))
+        return out
+
+    def at(self, t):
+        """u_c(t) over the free cells (linear between the knots; IndexError outside them, like the interpolant)."""
+        out = np.empty(self.problem.n, np.float64)
+        try:
+            self.problem.check(load().fv_trajectory_eval_free(self.handle, float(t), ptr(out)))
+        except FVError as e:
+            if "BoundsError" in str(e):
+                raise IndexError(str(e)) from None
+            raise
+        return out
+
+    def reverse_time(self, T):
+        self.problem.check(load().fv_trajectory_reverse_time(self.handle, float(T)))
+        return self
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.problem, "handle", None):
+            load().fv_trajectory_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Observation:
+    """Observation rows (1-based free indices, `obsfreenodes`) with uobs_i(t) and sigma(i, t) as piecewise-linear series over
+    `tobs`, on the device (fv_observation): what dgdu and g of transientadjointutils.jl:4-21 read."""
+
+    def __init__(self, problem, obs_free, tobs, uobs, sigma=None):
+        self.problem = problem
+        idx = np.ascontiguousarray(obs_free, dtype=np.int64)
+        t = af64(tobs)
+        U = np.ascontiguousarray(uobs, dtype=np.float64).reshape(len(t), len(idx))
+        S = np.ascontiguousarray(sigma, dtype=np.float64).reshape(len(t), len(idx)) if sigma is not None else None
+        h = C.c_void_p()
+        problem.check(load().fv_observation_create(problem.handle, len(idx), ptr(idx), len(t), ptr(t), ptr(U), ptr(S), C.byref(h)))
+        self.handle = h
+
+    def integral(self, u, t0, t1):
+        """G = the integral of g(u_c, t) over [t0, t1] (transientadjointutils.jl:46-49), exact between the knots."""
+        G = C.c_double()
+        self.problem.check(load().fv_observation_integral(u.handle, self.handle, float(t0), float(t1), C.byref(G)))
+        return G.value
+
+    def close(self):
+        if getattr(self, "handle", None) and getattr(self.problem, "handle", None):
+            load().fv_observation_destroy(self.handle)
         self.handle = None
 
     def __del__(self):

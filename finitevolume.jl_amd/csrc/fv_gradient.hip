@@ -175,6 +175,22 @@ extern "C" int fv_param_jacobian_apply(fv_problem *p, const double *x_free, cons
     return fv_free_out(p, row_src, gs.p);
 }
 
+// one pass over kc knots already on the device (X, L: kc vectors of n doubles in the internal numbering, ts_dev their times)
+int fv_param_gradient_integral_device(fv_problem *p, int64_t kc, const double *ts_dev, const double *X, const double *L, const double *D,
+                                      int logtransform, int accumulate, double *gk, double *gd, double *gs)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t n = p->n, F = p->F;
+    if (F > 0)
+        hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, ts_dev, X, L, D,
+                           (const int32_t *)p->node1.p, (const int32_t *)p->node2.p, (const int32_t *)p->nodemap.p, (const double *)p->cond.p,
+                           (const double *)p->aol.p, (const double *)p->dheads.p, logtransform ? 1 : 0, accumulate, gk, gd);
+    if (n > 0)
+        hipLaunchKernelGGL(gradient_row_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (int)kc, ts_dev, L, D, accumulate, gs);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
 extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const double *ts, const double *x_knots, const double *lam_knots,
                                           int scale_by_storage, int logtransform, double *face_k, double *face_dir, double *row_src)
 {

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -362,6 +363,8 @@ struct fv_problem {
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
     int64_t fused_launches = 0, fused_bytes_launch = 0;
+    fv_trajectory *recording = nullptr; // fv_trajectory_record: fixed / adaptive runs push the state of every outer step here
+    double record_t = 0.0;              // ... the time of the last recorded state of a fixed-dt run
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;
@@ -470,6 +473,21 @@ inline int fv_step_precond(const fv_problem *p)
         return p->auto_steps_amg ? FV_PRECOND_AMG : FV_PRECOND_JACOBI;
     return p->precond;
 }
+
+// ---- fv_transient.hip / fv_trajectory.hip: the stepper loop with hooks, trajectories kept in HBM
+constexpr int FV_STEP_W = 2; // internal step mode: (D/dt + A) w+ = rhs + D w/dt with the caller's rhs as it is (the adjoint sweep's own state w = gamma / D)
+struct FvStepHooks {
+    int mode = FV_STEP_FORWARD;
+    std::function<int(double t, const double **rhs_dev)> forcing;  // unset: the assembled b (forward) / none
+    const double *norm_weight = nullptr;                          // step-doubling error = || weight .* (onestep - twostep) ||
+    std::function<int(const double *state_dev, double t)> record; // sees the initial state and the state of every outer step
+};
+int fv_step_raw(fv_problem *p, double *usrc, double *udst, double dt, const double *rhs_dev, int mode, double rtol, int64_t maxiter, fv_solve_info *info);
+int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, bool fixed, double atol, double rtol, int64_t maxiter, int64_t max_outer,
+                   double *ts_out, int64_t *n_outer, int64_t *n_solves, fv_solve_info *last_info, const FvStepHooks &h);
+int fv_trajectory_push_device(fv_trajectory *tr, const double *state_dev, double t, const double *scale_dev); // knot = scale .* state (scale may be null)
+int fv_norm2_diff_weighted_device(fv_problem *p, const double *a, const double *b, const double *w, double *out_host);
+int fv_slot_new(fv_problem *p, int32_t *slot);
 
 // ---- fv_amg.hip
 int fv_amg_prepare(fv_problem *p, double sigma);

@@ -349,8 +349,10 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
         sys.b_times_D = bhat_dev != nullptr;
     } else {
         sys.rhs = bhat_dev; // may be null: zero forcing
-        hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 1);
-        FV_LAUNCH_CHECK(ctx);
+        if (mode == FV_STEP_ADJOINT) { // (FV_STEP_W: the caller keeps w = g / D as its state — fv_adjoint_run — and no scaling pass is needed)
+            hipLaunchKernelGGL(scale_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->D.p, udst, 1);
+            FV_LAUNCH_CHECK(ctx);
+        }
     }
     if (fv_step_precond(p) == FV_PRECOND_AMG) { // the V-cycle path steps in place: no ping-pong, no carried residual
         sys.x_next = nullptr;
@@ -438,7 +440,7 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     for (int64_t s = 0; s < nsteps && rc == FV_OK; s++) {
         // One-iteration regime: a burst of steps is enqueued without polling the device in between (each step is the
         // prepared set-up + K1 + K2S + K3; a step that does not converge in its iteration stops the chain on the device).
-        if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1) {
+        if (pingpong && g_carry_speculate && g_chain_steps >= 2 && prev != nullptr && p->spec_valid && p->last_iters == 1 && !p->recording) {
             int L = 0;
             while (L < g_chain_steps && L < 32 && s + L < nsteps && ((s_base + s + L) % refresh) != 0)
                 L++;
@@ -483,6 +485,10 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             if (iters_per_step)
                 iters_per_step[s] = inf.iters;
             prev = nullptr;
+            if (rc == FV_OK && p->recording) {
+                p->record_t += dt;
+                rc = fv_trajectory_push_device(p->recording, u, p->record_t, nullptr);
+            }
             continue;
         }
         const bool carry = prev != nullptr && ((s_base + s) % refresh) != 0;
@@ -498,6 +504,10 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
                 alt = t;
             } else
                 prev = u; // converged on entry: state unchanged, zero increment
+        }
+        if (rc == FV_OK && p->recording) { // fv_trajectory_record: the state of every step stays in HBM (no bursts while recording)
+            p->record_t += dt;
+            rc = fv_trajectory_push_device(p->recording, u, p->record_t, nullptr);
         }
     }
     if (pingpong && alt) { // hand the buffers back: the caller's slot owns the current state — also after a failed step, where
@@ -552,18 +562,30 @@ struct TwoStep {
 };
 } // namespace
 
-static int adaptive_twostep(fv_problem *p, double *uk, double dt, double *onestep, bool have_onestep, double *two1, double *two, double atol,
-                            double rtol, int64_t maxiter, fv_solve_info *inf, int64_t *nsolves, TwoStep *out)
+// One solve of the stepper: the hooks' forcing at the solve's start time (transient.jl:60-62: getb(t)), the hooks' step mode.
+static int hooked_step(fv_problem *p, const FvStepHooks &h, double *src, double *dst, double t, double dt, double rtol, int64_t maxiter, fv_solve_info *inf)
+{
+    const double *rhs = nullptr;
+    if (h.forcing)
+        FV_TRY(h.forcing(t, &rhs));
+    return fv_step_raw(p, src, dst, dt, rhs, h.mode, rtol, maxiter, inf);
+}
+
+static int adaptive_twostep(fv_problem *p, const FvStepHooks &h, double *uk, double t, double dt, double *onestep, bool have_onestep, double *two1, double *two,
+                            double atol, double rtol, int64_t maxiter, fv_solve_info *inf, int64_t *nsolves, TwoStep *out)
 {
     if (!have_onestep) {
-        FV_TRY(step_impl(p, uk, onestep, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
+        FV_TRY(hooked_step(p, h, uk, onestep, t, dt, rtol, maxiter, inf));
         ++*nsolves;
     }
-    FV_TRY(step_impl(p, uk, two1, 0.5 * dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
-    FV_TRY(step_impl(p, two1, two, 0.5 * dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, inf, false));
+    FV_TRY(hooked_step(p, h, uk, two1, t, 0.5 * dt, rtol, maxiter, inf));
+    FV_TRY(hooked_step(p, h, two1, two, t + 0.5 * dt, 0.5 * dt, rtol, maxiter, inf));
     *nsolves += 2;
     double err = 0.0;
-    FV_TRY(fv_norm2_diff_device(p, onestep, two, &err)); // norm(onestep - twostep), transient.jl:81
+    if (h.norm_weight)
+        FV_TRY(fv_norm2_diff_weighted_device(p, onestep, two, h.norm_weight, &err)); // the state the caller sees is weight .* vector
+    else
+        FV_TRY(fv_norm2_diff_device(p, onestep, two, &err)); // norm(onestep - twostep), transient.jl:81
     if (err < atol) {
         out->result = two;
         out->last = dt;
@@ -576,15 +598,18 @@ static int adaptive_twostep(fv_problem *p, double *uk, double dt, double *oneste
     return FV_OK;
 }
 
-extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, double atol, double rtol,
-                                         int64_t maxiter, int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves,
-                                         fv_solve_info *last_info)
+int fv_step_raw(fv_problem *p, double *usrc, double *udst, double dt, const double *rhs_dev, int mode, double rtol, int64_t maxiter, fv_solve_info *info)
 {
-    if (!p || !(tfinal >= t0) || max_outer < 0 || (max_outer > 0 && !ts_out))
-        return FV_ERR_ARG;
+    return step_impl(p, usrc, udst, dt, rhs_dev, mode, rtol, maxiter, info, false);
+}
+
+// The loop itself, for the forward run (fv_transient_run_adaptive) and the device-resident adjoint sweep (fv_adjoint_run, fv_trajectory.hip):
+// the hooks give the step mode, the forcing of a solve by its start time, the weight of the error norm and a recorder that sees
+// the state of every outer step (the reference's `us`).  fixed: the fixed stepper (transient.jl:130-134) in the same outer loop.
+int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, bool fixed, double atol, double rtol, int64_t maxiter, int64_t max_outer,
+                   double *ts_out, int64_t *n_outer, int64_t *n_solves, fv_solve_info *last_info, const FvStepHooks &h)
+{
     fv_ctx *ctx = p->ctx;
-    FV_HIP(ctx, hipSetDevice(ctx->device));
-    FV_TRY(need_transient(p, "fv_transient_run_adaptive"));
     if (!(dt0 > 0)) {
         fv_set_error(ctx, "time step must be positive");
         return FV_ERR_DT;
@@ -606,9 +631,18 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
         double dt = dt0 < tfinal - t0 ? dt0 : tfinal - t0;
         if (ts_out && max_outer > 0)
             ts_out[0] = t0;
+        if (h.record)
+            rc = h.record(U, t0);
         while (rc == FV_OK && t < tfinal && nout < max_outer) {
             TwoStep ts{};
-            rc = adaptive_twostep(p, U, dt, S1, false, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
+            if (fixed) { // fixedbackwardeulerstep!: one solve, laststeptime = dt, never grows
+                rc = hooked_step(p, h, U, S1, t, dt, rtol, maxiter, &inf);
+                nsolves++;
+                ts.result = S1;
+                ts.last = dt;
+                ts.increase = false;
+            } else
+                rc = adaptive_twostep(p, h, U, t, dt, S1, false, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
             if (rc != FV_OK)
                 break;
             const double *unew = ts.result;
@@ -621,7 +655,7 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
                 }
                 std::swap(S1, S2); // the half step just computed is the next trial's full step
                 while (rc == FV_OK && elapsed < dt) {
-                    rc = adaptive_twostep(p, E, target, S1, failed, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
+                    rc = adaptive_twostep(p, h, E, t + elapsed, target, S1, failed, S2, S3, atol, rtol, maxiter, &inf, &nsolves, &ts);
                     if (rc != FV_OK)
                         break;
                     if (ts.last == target) {
@@ -657,6 +691,11 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
             nout++;
             if (ts_out)
                 ts_out[nout] = t;
+            if (h.record) {
+                rc = h.record(U, t);
+                if (rc != FV_OK)
+                    break;
+            }
             const double remaining = tfinal - t;
             const double want = ts.increase ? 2 * ts.last : ts.last;
             dt = remaining < want ? remaining : want;
@@ -664,7 +703,7 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
         if (rc == FV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = FV_ERR_HIP;
         if (rc == FV_ERR_HIP)
-            fv_set_error(ctx, "fv_transient_run_adaptive: device copy failed: %s", hipGetErrorString(hipGetLastError()));
+            fv_set_error(ctx, "fv_stepper_run: device copy failed: %s", hipGetErrorString(hipGetLastError()));
         if (rc == FV_OK && t < tfinal) { // the reference always reaches tfinal (transient.jl:143-152): never hand u(t) back as u(tfinal)
             fv_set_error(ctx, "fv_transient_run_adaptive: %lld outer steps (max_outer) taken and t = %.17g < tfinal = %.17g; the state is u(t)",
                          (long long)nout, t, tfinal);
@@ -681,6 +720,21 @@ extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0,
     if (last_info)
         *last_info = inf;
     return rc;
+}
+
+extern "C" int fv_transient_run_adaptive(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, double atol, double rtol,
+                                         int64_t maxiter, int64_t max_outer, double *ts_out, int64_t *n_outer, int64_t *n_solves,
+                                         fv_solve_info *last_info)
+{
+    if (!p || !(tfinal >= t0) || max_outer < 0 || (max_outer > 0 && !ts_out))
+        return FV_ERR_ARG;
+    fv_ctx *ctx = p->ctx;
+    FV_HIP(ctx, hipSetDevice(ctx->device));
+    FV_TRY(need_transient(p, "fv_transient_run_adaptive"));
+    FvStepHooks h;
+    if (p->recording) // fv_trajectory_record: every outer state stays in HBM (the reference's `us`)
+        h.record = [p](const double *state, double t) { return fv_trajectory_push_device(p->recording, state, t, nullptr); };
+    return fv_stepper_run(p, slot, t0, tfinal, dt0, false, atol, rtol, maxiter, max_outer, ts_out, n_outer, n_solves, last_info, h);
 }
 
 // ------------------------------------------------------------------ kernel-level entry points

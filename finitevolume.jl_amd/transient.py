@@ -275,8 +275,39 @@ def backwardeulerintegrate(u0, *args, **kwargs):
         if kwargs:
             raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
         return [u0.copy(), first.node_values()], [float(t) for t in ts]
+    if keep == "device":
+        # every outer state, as the reference keeps them, but in HBM (fv_trajectory): the default stepper or the fixed one, the
+        # device PCG, a constant b.  -> (DeviceStates, ts); getcontinuoussolution(us, ts) of it is what the device-resident adjoint
+        # sweep (adjointintegrate with a bound forcing) and devicegradientintegral read.
+        from .adjoint import DeviceStates
+
+        if auto_solver:
+            kwargs.pop("linearsolver")
+        stepper = kwargs.pop("stepper", adaptivebackwardeulerstep)
+        if getb is not None or any(k in kwargs for k in ("linearsolver", "callback")) or stepper not in (adaptivebackwardeulerstep, fixedbackwardeulerstep):
+            raise ValueError('keep="device" runs the adaptive or the fixed stepper with the device PCG and a constant b')
+        atol = kwargs.pop("atol", 1e-4)
+        if kwargs:
+            raise TypeError("unexpected keyword arguments %s" % sorted(kwargs))
+        tr = p.new_trajectory()
+        r, m = rtol if rtol is not None else SQRT_EPS, maxiter if maxiter is not None else 1000
+        p.record(tr, tspan[0])
+        try:
+            if stepper is adaptivebackwardeulerstep:
+                p.run_adaptive(first, tspan[0], tspan[1], dt0=dt0, atol=atol, rtol=r, maxiter=m)
+            else:  # fixed: the outer loop of transient.jl:141-152 (the last step clipped to tfinal), one solve per step
+                tr.push(first, tspan[0])
+                now, request = tspan[0], min(dt0, tspan[1] - tspan[0])
+                while now < tspan[1]:
+                    p.record(tr, now)
+                    it, info, _ = p.run_fixed(first, request, 1, rtol=r, maxiter=m)
+                    now += request
+                    request = min(tspan[1] - now, request)
+        finally:
+            p.record(None)
+        return DeviceStates(tr), [float(x) for x in tr.ts]
     if keep != "all":
-        raise ValueError('keep must be "all" or "last"')
+        raise ValueError('keep must be "all", "last" or "device"')
     op = DeviceOperator(p)
     # constant-b method: the assembled b stays on the device (bhat = None); getb method: host closure per step
     us, ts = _integrate_generic(first, op, getb if getb is not None else None, dt0, tspan[0], tspan[1], _history="device", **kwargs)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FVHIP_ABI_VERSION 3 /* 3: fv_fused_traversal; 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
+#define FVHIP_ABI_VERSION 3 /* 3: fv_fused_traversal, fv_trajectory_*, fv_observation_*, fv_adjoint_run, fv_param_gradient_integral_traj; 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
 
 enum {
     FV_OK = 0,
@@ -53,6 +53,8 @@ enum {
 
 typedef struct fv_ctx fv_ctx;         /* one GPU + its streams (+ RCCL communicator) */
 typedef struct fv_problem fv_problem; /* device-resident mesh, CSR operator, vectors */
+typedef struct fv_trajectory fv_trajectory;   /* the stored states of a run (the reference's `us`, `ts`), kept in HBM */
+typedef struct fv_observation fv_observation; /* observation rows with their uobs(t), sigma(t) series on the device */
 
 /* What IterativeSolvers' ConvergenceHistory carries for the callers of
  * solvediffusion (FiniteVolume.jl:161,164: ch.isconverged, ch.data[:resnorm]). */
@@ -299,6 +301,49 @@ int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
  * rows whose diagonal does not follow from their arms share at most 15 values).  A measurement aid like the two above: the step it
  * reports on is backwardeuleronestep! / cg! of src/transient.jl:50-76 either way. */
 int fv_fused_traversal(fv_problem *p, int32_t *kind);
+
+/* ---------------------------------------------------------------- trajectories in HBM and the adjoint sweep over them
+ * The reference keeps every outer state of a run on the host (`us`, `ts`: src/transient.jl:136-154), interpolates it linearly in
+ * time (getcontinuoussolution, :176-180) and evaluates the adjoint's forcing dgdu(u_c, T - t) — non-zero on the observation rows
+ * only (src/transientadjointutils.jl:13-21) — through that interpolant at every solve of adjointintegrate (:188-205).  These entry
+ * points keep the states where they were computed: an fv_trajectory is a list of (time, free-cell vector in HBM), an
+ * fv_observation the observation rows with uobs_i(t) and sigma(i, t) as piecewise-linear series on the device, and
+ * fv_adjoint_run integrates the adjoint ODE with the reference's stepper without a host vector per solve.  A trajectory belongs
+ * to its problem (destroy it first); knot times must increase. */
+int fv_trajectory_create(fv_problem *p, fv_trajectory **out);                       /* needs fv_transient_begin */
+int fv_trajectory_destroy(fv_trajectory *tr);
+int fv_trajectory_clear(fv_trajectory *tr);
+int fv_trajectory_push_state(fv_trajectory *tr, int32_t slot, double t);            /* append a copy of a state vector (push!(us, ...), transient.jl:144) */
+int fv_trajectory_push_free(fv_trajectory *tr, const double *u_free, double t);     /* ... of a host vector over the free cells */
+int fv_trajectory_size(fv_trajectory *tr, int64_t *nknots);
+int fv_trajectory_times(fv_trajectory *tr, double *ts, int64_t cap);                /* `ts` */
+int fv_trajectory_get_free(fv_trajectory *tr, int64_t k, double *u_free);           /* us[k+1] before freenodes2nodes */
+int fv_trajectory_get_nodes(fv_trajectory *tr, int64_t k, double *u_nodes);         /* us[k+1] after it (transient.jl:172) */
+int fv_trajectory_eval_free(fv_trajectory *tr, double t, double *u_free);           /* u_c(t), transient.jl:176-180; BoundsError outside the knots */
+int fv_trajectory_reverse_time(fv_trajectory *tr, double T);                        /* knots reversed, t -> T - t (transient.jl:204) */
+/* While a trajectory is set, fv_transient_run_adaptive pushes its initial state and the state of every outer step, and
+ * fv_transient_run_fixed the state of every step at t0 + k dt (the initial state is the caller's to push); NULL stops it. */
+int fv_trajectory_record(fv_problem *p, fv_trajectory *tr, double t0);
+/* obs_free: 1-based free-cell indices (obsfreenodes); tobs[nt] increasing; uobs / sigma: nt x nobs, one row per knot (sigma NULL: 1). */
+int fv_observation_create(fv_problem *p, int64_t nobs, const int64_t *obs_free, int64_t nt, const double *tobs, const double *uobs,
+                          const double *sigma, fv_observation **out);
+int fv_observation_destroy(fv_observation *o);
+/* G = int_t0^t1 sum_i sigma(i,t)^2 (u_i(t) - uobs_i(t))^2 dt (g and G of transientadjointutils.jl:4-12, 46-49), exact for the
+ * piecewise-linear series: a 6-point Gauss-Legendre rule between consecutive knots of either. */
+int fv_observation_integral(fv_trajectory *u, fv_observation *o, double t0, double t1, double *G);
+/* adjointintegrate(t -> dgdu(u_c, t), (t0, tfinal), ...) of src/transient.jl:188-205 with dgdu of transientadjointutils.jl:13-21:
+ * gamma(0) = 0, d gamma/dt = transpose(D^-1 A) gamma + dgdu(T - t), the adaptive stepper (adaptive != 0; atol as in
+ * backwardeulerintegrate) or the fixed one, first step dt0; lambda_out (empty on entry) receives lambda(t) = gamma(T - t) at
+ * ascending times, T = tfinal.  Uses the operator of the last fv_assemble and the storage term of fv_transient_begin. */
+int fv_adjoint_run(fv_problem *p, fv_trajectory *u, fv_observation *o, double t0, double tfinal, double dt0, int adaptive, double atol,
+                   double rtol, int64_t maxiter, int64_t max_outer, fv_trajectory *lambda_out, int64_t *n_outer, int64_t *n_solves,
+                   fv_solve_info *last_info);
+/* fv_param_gradient_integral over [t0, t1] with u and lambda read from trajectories (their merged knots, both interpolated on
+ * the device).  scale_by_storage: lambda_f / (Ss volume of the node behind f); or lam_scale_free[f] (host, free-indexed) as the
+ * factor of lambda_f — the reference's scalebyvolume! of the transposed Jacobian divides by volumes[f] with the FREE index f
+ * (src/transient.jl:25-34); both NULL / 0: no scaling. */
+int fv_param_gradient_integral_traj(fv_problem *p, fv_trajectory *u, fv_trajectory *lam, double t0, double t1, int scale_by_storage,
+                                    const double *lam_scale_free, int logtransform, double *face_k, double *face_dir, double *row_src);
 
 /* ---------------------------------------------------------------- multi-GPU (RCCL over xGMI) */
 #define FV_COMM_ID_BYTES 128
