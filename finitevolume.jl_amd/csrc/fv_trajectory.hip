@@ -163,9 +163,11 @@ int traj_new_knot(fv_trajectory *tr, double **out)
     fv_problem *p = tr->p;
     const size_t nvec = (size_t)p->n + FV_VEC_PAD;
     if (tr->blocks.empty() || tr->used_in_block == tr->block_knots) {
-        // blocks of ~256 MB (at least one knot, at most 64): few allocations, little slack
-        size_t per = ((size_t)1 << 28) / (nvec * sizeof(double));
-        per = per < 1 ? 1 : (per > 64 ? 64 : per);
+        // blocks of 1, 2, 4, ... 16 GB (at least one knot, at most 256): a hipMalloc is a device-wide synchronisation of a millisecond
+        // or two — one per three knots of a 10^7-cell run doubled the cost of a recorded step —, so few of them
+        const size_t shift = tr->blocks.size() < 4 ? tr->blocks.size() : 4;
+        size_t per = (((size_t)1 << 30) << shift) / (nvec * sizeof(double));
+        per = per < 1 ? 1 : (per > 256 ? 256 : per);
         void *base = nullptr;
         const hipError_t e = hipMalloc(&base, per * nvec * sizeof(double));
         if (e != hipSuccess) {

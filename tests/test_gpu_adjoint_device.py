@@ -175,3 +175,63 @@ def test_device_adjoint_sweep_under_the_renumbering(fv):
     scale = max(np.abs(np.asarray(l)).max() for l in lam_h)
     assert scale > 0 and max(np.abs(lam_d[k] - np.asarray(lam_h[k])).max() for k in range(len(lam_h))) <= 1e-9 * scale
     assert abs(G(duc) - G(uc)) <= 1e-10 * abs(G(uc))
+
+
+def test_theisadjoint_workflow_with_every_state_in_hbm(fv):
+    """test/theisadjoint.jl:12-84 with the forward states, the sweep and the gradient integral on the device (keep="device",
+    dgdu.bind(uc), integratedfdplambda(complete=True)): the gradient equals the host-closure workflow's and holds up against central
+    finite differences of G (G itself integrated on the device) on its largest conductivity and head entries."""
+    import math
+
+    atol, steadyhead, side, thick = 1e-4, 0.0, 50.0, 10.0
+    mins, maxs, ns = [-side, -side, 0.0], [side, side, thick], [25, 25, 2]
+    meanloghyco, Q, Ss = math.log(1e-5), 1e-3, 0.1
+    sigma = lambda i, t: 0.03  # noqa: E731
+    coords, neighbors, aol, volumes = fv.regulargrid(mins, maxs, ns)
+    F, N = len(aol), coords.shape[1]
+    center = np.nonzero((coords[0] == 0) & (coords[1] == 0))[0]
+    sources = np.zeros(N)
+    sources[center] = -2 * Q / (2 * len(center) - 2)
+    sources[center[0]] = sources[center[-1]] = -Q / (2 * len(center) - 2)
+    dnodes = np.nonzero(np.hypot(coords[0], coords[1]) - side >= 0)[0] + 1
+    dheads = np.full(len(dnodes), steadyhead)
+    u0 = np.full(N, steadyhead)
+    tspan = (0.0, 60 * 60 * 24 * 1e1)
+    kw = dict(atol=atol, dt0=60.0)
+    mesh = (Ss, volumes, neighbors, aol)
+    us, ts = fv.backwardeulerintegrate(u0, tspan, *mesh, np.full(F, meanloghyco + 1), sources, dnodes, dheads, None, True, **kw)
+    uobs = fv.getcontinuoussolution(us, ts)
+    K0 = np.full(F, meanloghyco)
+    p0 = np.r_[K0, sources, dheads]
+    rest = (K0, sources, dnodes, dheads, None, True)
+    freenodes, n2f = fv.getfreenodes(N, dnodes)
+    obsfreenodes = [int(n2f[i]) for i in center]
+    g, dgdu, dfdp, dgdp, du0dp, G = fv.getadjointfunctions(sigma, obsfreenodes, uobs, u0, tspan, *mesh, *rest, **kw)
+    # host-closure workflow (every state and every forcing through the host)
+    us_i, ts_i = fv.backwardeulerintegrate(u0, tspan, *mesh, *rest, **kw)
+    uc = fv.getcontinuoussolution(us_i, ts_i)
+    lam_h, ts_h = fv.adjointintegrate(lambda t: dgdu(uc, t), tspan, *mesh, *rest, **kw)
+    idl_h = fv.integratedfdplambda(fv.getcontinuoussolution(us_i, ts_i, 2), p0, lam_h, ts_h, tspan, *mesh, *rest, complete=True)
+    dG_h = fv.gradientintegrate(lam_h[0], du0dp, lambda t: dgdp(uc, t, p0), idl_h, tspan)
+    # the same with every state in HBM
+    dus, dts = fv.backwardeulerintegrate(u0, tspan, *mesh, *rest, keep="device", **kw)
+    assert dts == ts_i and len(dts) > 300
+    duc = fv.getcontinuoussolution(dus, dts)
+    lam_d, ts_d = fv.adjointintegrate(dgdu.bind(duc), tspan, *mesh, *rest, **kw)
+    assert ts_d == ts_h
+    idl_d = fv.integratedfdplambda(duc, p0, lam_d, ts_d, tspan, *mesh, *rest, complete=True)
+    dG_d = fv.gradientintegrate(lam_d[0], du0dp, lambda t: dgdp(duc, t, p0), idl_d, tspan)
+    assert np.abs(dG_d - dG_h).max() <= 1e-9 * np.abs(dG_h).max()
+    assert abs(G(duc) - G(uc)) <= 1e-11 * abs(G(uc))
+
+    def Gdev(pv):  # the objective with the forward states of the perturbed parameters kept in HBM as well
+        s, t = fv.backwardeulerintegrate(u0, tspan, *mesh, pv[:F], pv[F : F + N], dnodes, pv[F + N :], None, True, keep="device", **kw)
+        return G(fv.getcontinuoussolution(s, t))
+
+    deltap = 1e-4
+    for i in np.r_[np.argsort(-np.abs(dG_d[:F]), kind="stable")[:3], F + N + np.argsort(-np.abs(dG_d[F + N :]), kind="stable")[:1]]:
+        pp, pm = p0.copy(), p0.copy()
+        pp[i] += deltap
+        pm[i] -= deltap
+        x1 = (Gdev(pp) - Gdev(pm)) / (2 * deltap)
+        assert abs(x1 - dG_d[i]) <= (2e-3 if i < F else 5e-2) * max(abs(x1), abs(dG_d[i])), (int(i), x1, dG_d[i])
