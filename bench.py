@@ -426,7 +426,8 @@ def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes
     One-iteration steps through the fused launch: fv_fused_form's bytes.  Steps of several PCG iterations (the carried residual, then
     the loop of DESIGN 4d): K0' (carried set-up: x, x_prev, z or r, D, M^-1 in, r, p out = 64 n) + K1 (the tiled SpMV's form, with p.q)
     + the first vector update (x, z, p, q, M^-1 in, x, z out = 56 n; 49 with M^-1 as a code byte) + per further iteration the loop
-    form fv_loop_form reports (fused pass + vector update: 113 n, 91 / 84 with codes) — or K1 + K2 + K3 where that loop is not taken."""
+    form fv_loop_form reports (fused pass with the lagging x-update + the slim vector update: 105 n, 83 / 76 with codes) — or K1 + K2 + K3 where that loop
+    is not taken."""
     n = p.n
     its = np.asarray(iters, dtype=np.float64)
     mean_it = float(its.mean())
@@ -437,12 +438,13 @@ def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes
         form_id, form_name, form_bytes = p.spmv_form()
         loop = p.loop_form()
         if loop:
-            upd = 49 if loop in (84, 106) else 56
+            first_upd = 49 if loop in (76, 98) else 56  # (the loop's first vector update is the classic one: x, z, p, q, M^-1 in, x, z out)
             per_it = loop * n
-            first = 64 * n + form_bytes + upd * n
+            first = 64 * n + form_bytes + first_upd * n
+            upd = first_upd
             bytes_step = float(np.mean(np.where(its >= 1, first + np.maximum(its - 1, 0) * per_it, 64 * n)))
-            model = ("per step: carried set-up K0' 64 n + K1 (%s) %d B per row + first vector update %d n, then per further iteration the fused pass + the "
-                     "z-form vector update = %d n; weighted with the iteration count of every step" % (form_name, form_bytes // max(n, 1), upd, loop))
+            model = ("per step: carried set-up K0' 64 n + K1 (%s) %d B per row + first vector update %d n, then per further iteration the fused pass (with the lagging x-update) + the "
+                     "slim vector update = %d n; weighted with the iteration count of every step" % (form_name, form_bytes // max(n, 1), upd, loop))
         else:
             per_it = form_bytes + 88 * n
             bytes_step = float(np.mean(64 * n + its * per_it))
@@ -608,14 +610,14 @@ def multi_iteration_block(p, args):
     del st
     form_id, form_name, form_bytes = p.spmv_form()
     nit = int(np.sum(iters))
-    loop = p.loop_form()  # 113: direction update + product in one pass of the fused kernel (57) and the z-form vector update (56);
-    upd = 49 if loop in (84, 106) else 56  # 91 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
+    loop = p.loop_form()  # 105: direction update, lagging x-update and product in one pass of the fused kernel (73) + the slim vector update z' = z + alpha w (32);
+    upd = 25 if loop in (76, 98) else 32  # 83 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
     per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
-           "bytes_model": ("fused pass p' = z + beta p, q = (A + D/dt) p' (%d n: z, p in, p', q out, the 3 upper diagonals%s, storage codes) + z-form vector update (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 50 else "", upd, ": M^-1 as a code byte" if upd == 49 else "") if loop
+           "bytes_model": ("fused pass x += alpha p, p' = z + beta p, w = -M^-1 (A + D/dt) p' (%d n: z, p, x in, p', w, x out, the 3 upper diagonals%s, storage codes) + vector update z' = z + alpha w (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 60 else "", upd, ": M^-1 as a code byte" if upd == 25 else "") if loop
                            else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}

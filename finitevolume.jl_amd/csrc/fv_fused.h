@@ -31,6 +31,9 @@ int fv_fused_convert_groups(fv_problem *p, const int32_t *groups, int64_t count,
 // fv_spmv.hip: y = A x (values with the shift folded in) over the slices the symmetric form leaves to the slice-by-slice
 // kernel, partial x.y per block; use_done: a no-op once the solve's done flag is set
 // vform_sigma != 0: y receives v = -M^-1 (q - vform_sigma D x) instead of q (the fused step's v-form), the partial sums are of x.q
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done = false, double vform_sigma = 0.0);
+// wform: y receives w = -M^-1 q (the many-iteration loop's form of the product)
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done = false, double vform_sigma = 0.0,
+                 bool wform = false);
 bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded);
-int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq);
+// x: the iterate, updated in place by x += alpha_last * p (the lagging update of the previous iteration) when xapply is set
+int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq, double *x, bool xapply);

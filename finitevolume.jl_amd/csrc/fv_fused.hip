@@ -74,6 +74,7 @@ struct KfArgs {
     PcgScalars *scal;
     FusedSums in, out;
     int nt;          // streaming-hint experiment (fv_tune key 45)
+    int xapply;      // MODE 1: apply the lagging x-update of the previous iteration, x += scal->alpha_last * p (p = a.v, the old direction)
     int mode;        // 0: scalars of this step already in scal (set-up finalised by an earlier launch); 1: merged boundary
     int chain_index; // index of this step in its burst
     int force_prev_unconverged;
@@ -276,6 +277,9 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         if (!kf_step_prologue<NT>(a, red, alpha))
             return;
     }
+    // MODE 1: x += ax * p_old, the x-update of the previous iteration, which lags one pass behind (its direction is this pass's a.v)
+    const bool XU = MODE == 0 || a.xapply != 0;
+    const double ax = MODE == 1 && a.xapply ? scal->alpha_last : 0.0;
     // ---------------------------------------------------------------- the pass
     if (tid < FV_STORAGE_CODES)
         tab[tid] = a.sD.v[tid];
@@ -388,8 +392,13 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
         {
             const double2 vv = P2(a.v, p0 - 1), zz = P2(a.z, p0 - 1);
             Zm = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
-            if (MODE == 1 && vec_first && own)
+            if (MODE == 1 && vec_first && own) {
                 ST2(a.znext, 0, Zm);
+                if (XU) {
+                    const double2 xi = P2(a.x, 0);
+                    ST2(a.xout, 0, make_double2(xi.x + ax * vv.x, xi.y + ax * vv.y));
+                }
+            }
             if (MODE == 0 && vec_first && own) { // plane 0: its vector part
                 const double2 xi = P2(a.x, 0), dd = P2(a.dg, 0), ss = SD(C2(0));
                 const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
@@ -411,8 +420,13 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             const VRow ra = vrow(xi.x, zz.x, vv.x, own ? dd.x : 1.0, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, own ? dd.y : 1.0, ss.y, alpha);
             Zc0 = make_double2(ra.zn, rb.zn);
             Mc = make_double2(ra.mv, rb.mv);
-            if (MODE == 1 && own)
+            if (MODE == 1 && own) {
                 ST2(a.znext, p0, Zc0);
+                if (XU) {
+                    const double2 xp = P2(a.x, p0);
+                    ST2(a.xout, p0, make_double2(xp.x + ax * vv.x, xp.y + ax * vv.y));
+                }
+            }
             if (MODE == 0 && own) {
                 ST2(a.xout, p0, make_double2(ra.xn, rb.xn));
                 ST2(a.znext, p0, Zc0);
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 (hu_is_u2 ? u2s + s1 * U2T : u1s + s1 * U1T)[hu] = ub;
             }
         }
-        double2 Xa = MODE == 0 ? P2nt(a.x, p0 + 1) : make_double2(0.0, 0.0), Va = P2nt(a.v, p0 + 1), Za = P2(a.z, p0 + 1);
+        double2 Xa = XU ? P2nt(a.x, p0 + 1) : make_double2(0.0, 0.0), Va = P2nt(a.v, p0 + 1), Za = P2(a.z, p0 + 1);
         uint32_t Ca = C2(p0 + 1);
         int fla = own ? (int)a.ok[((int64_t)(p0 + 1) * d3 + o) >> 6] : 0;
         __syncthreads();
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             int flb = 0;
             double hq = 0.0, hzv = 0.0, hub = 0.0;
             if (more) {
-                if (MODE == 0)
+                if (XU)
                     Xb = (a.nt & 4) ? P2(a.x, p + 2) : P2nt(a.x, p + 2);
                 Vb = (a.nt & 4) ? P2(a.v, p + 2) : P2nt(a.v, p + 2);
                 Zb = P2(a.z, p + 2);
@@ -512,8 +526,11 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
             const double2 Zn = make_double2(ua.zn, ub.zn);
             const double2 Zc = *reinterpret_cast<const double2 *>(zs + zb * ZT + zo);
             const double2 Pn = make_double2(A3c.x * Zc.x + Dn.x * Zn.x, A3c.y * Zc.y + Dn.y * Zn.y);
-            if (MODE == 1 && vec_n && own)
+            if (MODE == 1 && vec_n && own) {
                 ST2(a.znext, p + 1, Zn);
+                if (XU)
+                    ST2(a.xout, p + 1, make_double2(Xa.x + ax * Va.x, Xa.y + ax * Va.y));
+            }
             if (MODE == 0 && vec_n && own) {
                 double *xo = reinterpret_cast<double *>(const_cast<char *>(PB(a.xout, p + 1, 8)) + ob);
                 if (a.nt & 8)
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
                 t0 += A3c.x * Zn.x;
                 t1 += A3c.y * Zn.y;
                 if (MODE == 1 && (flc & 1)) {
-                    ST2nt(a.vnext, p, make_double2(t0, t1)); // q itself: the vector pass reads it once
+                    ST2nt(a.vnext, p, make_double2(-(Mc.x * t0), -(Mc.y * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
                 if (MODE == 0 && (flc & 1)) {
@@ -687,6 +704,14 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         if (!kf_step_prologue<NT>(a, red, alpha))
             return;
     }
+    // MODE 1: x += ax * p_old, the x-update of the previous iteration, which lags one pass behind (its direction is this pass's a.v)
+    const bool XU = MODE == 0 || a.xapply != 0;
+    double ax = MODE == 1 && a.xapply ? scal->alpha_last : 0.0;
+    if (MODE == 1) {
+        const long long ab = __double_as_longlong(ax);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
+        ax = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
     { // alpha is the same number in every lane: kept in scalar registers
         const long long ab = __double_as_longlong(alpha);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
@@ -763,8 +788,13 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         for (int k = 0; k < NP; k++) {
             const double2 vv = P2(a.v, p0 - 1, k), zz = P2(a.z, p0 - 1, k);
             Zm[k] = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
-            if (MODE == 1 && vec_first && own[k])
+            if (MODE == 1 && vec_first && own[k]) {
                 ST2(a.znext, 0, k, Zm[k]);
+                if (XU) {
+                    const double2 xi = P2(a.x, 0, k);
+                    ST2(a.xout, 0, k, make_double2(xi.x + ax * vv.x, xi.y + ax * vv.y));
+                }
+            }
             if (MODE == 0 && vec_first && own[k]) { // plane 0: its whole vector part, with the stored diagonal
                 const double2 xi = P2(a.x, 0, k), dd = P2(a.dg, 0, k), ss = SD(C2(0, k));
                 const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
@@ -782,8 +812,13 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
             const uint32_t c0 = C2(p0, k);
             DX[k] = make_double2(0.0, 0.0);
-            if (MODE == 1 && own[k])
+            if (MODE == 1 && own[k]) {
                 ST2(a.znext, p0, k, Zc0);
+                if (XU) {
+                    const double2 xi = P2(a.x, p0, k);
+                    ST2(a.xout, p0, k, make_double2(xi.x + ax * v0.x, xi.y + ax * v0.y));
+                }
+            }
             if (MODE == 0) {
                 const double2 xi = P2(a.x, p0, k);
                 const double2 xn = make_double2(xi.x + alpha * z0.x, xi.y + alpha * z0.y);
@@ -814,7 +849,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         for (int k = 0; k < NP; k++) {
             Za[k] = P2(a.z, p0 + 1, k);
             Va[k] = P2nt(a.v, p0 + 1, k);
-            Xa[k] = MODE == 0 ? P2nt(a.x, p0 + 1, k) : make_double2(0.0, 0.0);
+            Xa[k] = XU ? P2nt(a.x, p0 + 1, k) : make_double2(0.0, 0.0);
             Wa[k] = MW(p0 + 1, k);
             Ma[k] = C2(p0 + 1, k);
         }
@@ -872,6 +907,8 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                         }
                     }
                 }
+                if (MODE == 1 && XU && vec_n && own[k]) // (before (b) refills the registers: p_old of plane p + 1 is Va)
+                    ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
                 if (vec_n && own[k]) {
                     if (a.nt & 1)
                         ST2nt(a.znext, p + 1, k, Zn);
@@ -886,7 +923,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 if (more) {
                     Za[k] = P2(a.z, p + 2, k);
                     Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
-                    if (MODE == 0)
+                    if (XU)
                         Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
                     Wa[k] = MW(p + 2, k);
                     Ma[k] = C2(p + 2, k);
@@ -941,7 +978,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 t0 += A3c.x * Zn.x;
                 t1 += A3c.y * Zn.y;
                 if (MODE == 1 && own[k] && (wc & 0x8000u)) {
-                    ST2nt(a.vnext, p, k, make_double2(t0, t1)); // q itself: the vector pass reads it once
+                    ST2nt(a.vnext, p, k, make_double2(-((1.0 / d.x) * t0), -((1.0 / d.y) * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
                 if (MODE == 0 && own[k]) {
@@ -1635,7 +1672,7 @@ bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded)
 // One pass of the many-iteration regime: the scalars of K3 for iteration `it` (from the sums the vector pass left in
 // part_rz / part_rr), p' = z + beta p into p->pnext (z = p->r, which holds M^-1 r between the passes; p = p->pvec), q = (A + sigma D) p'
 // into p->q, partial p'.q into part_pq (*npq pieces, the slice-by-slice launch's behind the kernel's).
-int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq)
+int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq, double *x, bool xapply)
 {
     fv_ctx *ctx = p->ctx;
     KfArgs a{};
@@ -1652,7 +1689,10 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     a.z = p->r.p;
     a.v = p->pvec.p;
     a.znext = p->pnext.p;
-    a.vnext = p->q.p;
+    a.vnext = p->q.p; // receives w = -M^-1 q
+    a.x = x;
+    a.xout = x;
+    a.xapply = xapply ? 1 : 0;
     a.scal = p->scal.p;
     a.in = FusedSums{};
     a.in.arz = const_cast<double *>(part_rz);
@@ -1680,12 +1720,14 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
         else
             hipLaunchKernelGGL((fused_step_kernel<8, 1, false>), dim3(GF), dim3(512), 0, ctx->stream, a);
     }
-    p->loop_bytes = coded ? 91 : 113;
+    // per row and iteration: z, p, x in and p', w, x out (48) + the three upper diagonals (24, or 2 as codes) + a storage code byte in the
+    // pass; z, w in, z' out (24) + M^-1 (8, or a code byte: fv_loop_form subtracts 7) in the vector update
+    p->loop_bytes = coded ? 83 : 105;
     FV_LAUNCH_CHECK(ctx);
     int GR = 0;
     const int GK = chunks ? kc.grid : GF;
     if (p->sym_nrest > 0)
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true));
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true, 0.0, true)); // (stored as w as well)
     *npq = GK + GR;
     p->fused_chunked = chunks;
     return FV_OK;

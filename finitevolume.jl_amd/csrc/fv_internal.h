@@ -152,7 +152,12 @@ struct PcgScalars {
     int32_t done;  // 0 running, 1 converged, 2 breakdown (p.Ap <= 0 or NaN), 3 a chain of unpolled one-iteration steps broke here
     int32_t chain_step; // done == 3: index (within the burst) of the step that needs more than its one iteration
     uint32_t zero_mask; // bursts of chained steps: bit j set = step j of the burst was already converged at its set-up (0 iterations)
-    double tol2x[2]; // tol2 of the chained steps by parity of their index (row-block bursts: a step's verdict is taken while the next step's scalars are written)
+    double tol2x[2]; // tol2 of the chained steps by parity of their index (row-block bursts: a step's verdict is taken while the next step's scalars are written)    // the many-iteration loop through the fused kernel (fv_fused_iteration): the x-update of iteration i is applied by the pass of
+    // iteration i + 1, which reads that direction anyway.  xlag >= 0: the iteration whose x += alpha_last * lag_p is still to be
+    // applied (the loop's last one: pcg_xflush_kernel does it once the loop has stopped); -1: x is up to date.
+    double alpha_last;
+    const double *lag_p;
+    int32_t xlag, pad_;
 };
 
 // Plan and buffers of a row block in a distributed run (built by fv_dist_setup).
@@ -171,6 +176,7 @@ struct fv_dist {
     int64_t n_int_dia = 0, n_int_csr = 0, n_bnd_dia = 0, n_bnd_csr = 0;
     int64_t int_lo = 0, int_hi = 0; // the interior groups as a slice range [lo, hi) when they are contiguous (else empty)
     bool split_built = false;
+    int64_t fused_bursts = 0; // bursts since the call began (the agreement is renewed every 16th)
     int fused_agreed = -1; // per fv_dist_run_fixed call: -1 not yet asked, 1 every rank can run the fused step, 0 at least one cannot
 };
 
@@ -350,7 +356,8 @@ struct fv_problem {
     double mvcode_sigma = 0.0;
     const double *mvcode_ptr = nullptr;
     bool loop_minv_coded = false;
-    bool zf_minv_ok = false; // M^-1 > 0 on every row, for (zf_minv_sigma, zf_minv_epoch, zf_storage_epoch)
+    int zf_minv_bits = 3;    // bit 0: M^-1 > 0 fails on some row for sigma > 0, bit 1: for sigma = 0 — for (zf_minv_epoch, zf_storage_epoch) = (assembly, storage)
+    bool zf_minv_ok = false;
     double zf_minv_sigma = -1.0;
     int64_t zf_minv_epoch = -2, zf_storage_epoch = -2;
     DevBuf<double> part_pq, part_rz, part_rr, part_bb;

@@ -312,10 +312,93 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_z_kernel(int64_t n, int i
     if (threadIdx.x == 0) {
         part_rz[blockIdx.x] = t0;
         part_rr[blockIdx.x] = t1;
-        if (blockIdx.x == 0)
+        if (blockIdx.x == 0) {
             scal->pq = pq;
+            scal->xlag = -1; // (this kernel updates x itself: nothing lags behind it)
+        }
     }
 }
+
+// The vector update of that loop from its second iteration on: the pass before it (fv_fused_iteration) has left w = -M^-1 q in
+// place of q and will apply x += alpha p itself one pass later (it reads that direction anyway), so what is left here is
+//     z' = z + alpha w ;  r' = z' / M^-1 ;  sums r'.z', r'.r'
+// — z, w in, z' out, M^-1 as its stream or as a code byte: 25 / 32 B per row where pcg_update_z_kernel moves 49 / 56.  Block 0
+// records the update that now lags (alpha, the direction it belongs to, its iteration) for the next pass / pcg_xflush_kernel.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_update_w_kernel(int64_t n, int it, double *__restrict__ z, const double *__restrict__ w,
+                                                                 const double *__restrict__ pv, const double *__restrict__ minv,
+                                                                 const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
+                                                                 double *__restrict__ part_rz, double *__restrict__ part_rr,
+                                                                 const uint8_t *__restrict__ mcode, StorageTable mtab)
+{
+    __shared__ double smem[4];
+    __shared__ double mvtab[FV_STORAGE_CODES];
+    if (scal->done)
+        return;
+    if (mcode && threadIdx.x < FV_STORAGE_CODES)
+        mvtab[threadIdx.x] = mtab.v[threadIdx.x];
+    const double pq = reduce_partials(part_pq, npq, smem); // (its barriers publish mvtab)
+    if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->pq = pq;
+            scal->done = 2;
+        }
+        return;
+    }
+    const double alpha = scal->rz[it & 1] / pq;
+    double arz = 0.0, arr = 0.0;
+    const int64_t n2 = n >> 1;
+    double2 *z2 = reinterpret_cast<double2 *>(z);
+    const double2 *w2 = reinterpret_cast<const double2 *>(w);
+    const double2 *m2 = reinterpret_cast<const double2 *>(minv);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        double2 zv = z2[i];
+        const double2 wv = nt_load2(w2 + i);
+        double2 mv;
+        if (mcode) {
+            const uint32_t c = reinterpret_cast<const uint16_t *>(mcode)[i];
+            mv = make_double2(mvtab[c & 255u], mvtab[c >> 8]);
+        } else
+            mv = m2[i];
+        zv.x += alpha * wv.x;
+        zv.y += alpha * wv.y;
+        const double2 rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+        z2[i] = zv;
+        arz += rv.x * zv.x + rv.y * zv.y;
+        arr += rv.x * rv.x + rv.y * rv.y;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double zi = z[i] + alpha * w[i], ri = zi / minv[i];
+        z[i] = zi;
+        arz += ri * zi;
+        arr += ri * ri;
+    }
+    const double t0 = block_sum(arz, smem);
+    const double t1 = block_sum(arr, smem);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+        if (blockIdx.x == 0) {
+            scal->pq = pq;
+            scal->alpha_last = alpha;
+            scal->lag_p = pv;
+            scal->xlag = it;
+        }
+    }
+}
+
+// x += alpha_last * lag_p when an x-update of that loop is still outstanding (the loop has stopped: converged, out of iterations, broken
+// down — the host cannot know at which launch), then pcg_xflush_clear_kernel marks it done.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_xflush_kernel(int64_t n, double *__restrict__ x, const PcgScalars *__restrict__ scal)
+{
+    if (scal->xlag < 0)
+        return;
+    const double alpha = scal->alpha_last;
+    const double *__restrict__ pv = scal->lag_p;
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        x[i] += alpha * pv[i];
+}
+__global__ void pcg_xflush_clear_kernel(PcgScalars *__restrict__ scal) { scal->xlag = -1; }
 
 // K3's scalars alone (the verdict on iteration `it`), for the end of a chunk of that loop: the next pass's prologue would
 // take it, but the host polls first.  The pass that follows repeats the same values.
@@ -774,34 +857,49 @@ static int fv_minv_codes(fv_problem *p, const uint8_t **code, StorageTable *tab)
 }
 
 // The z-form divides by M^-1: every row must have one (a free cell without faces and without storage has M^-1 = 0).
-// Checked once per Jacobi diagonal.
-__global__ __launch_bounds__(FV_BLOCK) void minv_bad_kernel(int64_t n, const double *__restrict__ minv, int32_t *__restrict__ bad)
+// M^-1 = 1 / (diagA + sigma D) is positive and finite on every row for EVERY sigma > 0 when no row has a negative part and each has
+// a positive one — a property of the assembly and the storage term, not of the time step: checked once per (assembly, storage)
+// and not once per sigma (an adaptive run changes dt at almost every solve; on the Theis problem this check, a memset and a
+// synchronous 4-byte copy, came to 2 of 13 launches per solve).  Bit 0: some row fails for sigma > 0; bit 1: for sigma = 0.
+__global__ __launch_bounds__(FV_BLOCK) void minv_bad_kernel(int64_t n, const double *__restrict__ diagA, const double *__restrict__ D,
+                                                             int32_t *__restrict__ bad)
 {
     int b = 0;
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride()) {
-        const double m = minv[i];
-        b |= !(m > 0.0 && m < 1.0e300);
+        const double a = diagA[i], d = D ? D[i] : 0.0;
+        const bool pos_a = a > 1.0e-300 && a < 1.0e300, pos_d = d > 1.0e-300 && d < 1.0e300;
+        if (!((a >= 0.0 && a < 1.0e300) && (d >= 0.0 && d < 1.0e300) && (pos_a || pos_d)))
+            b |= 1;
+        if (!pos_a)
+            b |= 2;
     }
-    if (__any(b) && (threadIdx.x & 63) == 0)
-        atomicOr(bad, 1);
+    b |= __shfl_xor(b, 32, 64);
+    b |= __shfl_xor(b, 16, 64);
+    b |= __shfl_xor(b, 8, 64);
+    b |= __shfl_xor(b, 4, 64);
+    b |= __shfl_xor(b, 2, 64);
+    b |= __shfl_xor(b, 1, 64);
+    if (b && (threadIdx.x & 63) == 0)
+        atomicOr(bad, b);
 }
 static int minv_positive(fv_problem *p, bool *ok)
 {
     fv_ctx *ctx = p->ctx;
-    if (!(p->zf_minv_sigma == p->minv_sigma && p->zf_minv_epoch == p->minv_epoch && p->zf_storage_epoch == p->storage_epoch)) {
+    if (!(p->zf_minv_epoch == p->assemble_epoch && p->zf_storage_epoch == p->storage_epoch)) {
         DevBuf<int32_t> flag;
         FV_TRY(flag.alloc(ctx, 1));
         FV_TRY(flag.zero(ctx));
-        hipLaunchKernelGGL(minv_bad_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->minv.p, flag.p);
+        hipLaunchKernelGGL(minv_bad_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const double *)p->diagA.p,
+                           p->transient_ready ? (const double *)p->D.p : (const double *)nullptr, flag.p);
         FV_LAUNCH_CHECK(ctx);
-        int32_t h = 1;
+        int32_t h = 3;
         FV_TRY(fv_copy(ctx, &h, flag.p, sizeof h));
-        p->zf_minv_ok = h == 0;
-        p->zf_minv_sigma = p->minv_sigma;
-        p->zf_minv_epoch = p->minv_epoch;
+        p->zf_minv_bits = h;
+        p->zf_minv_epoch = p->assemble_epoch;
         p->zf_storage_epoch = p->storage_epoch;
     }
-    *ok = p->zf_minv_ok;
+    // (minv_sigma: the shift of the Jacobi diagonal in use — fv_pcg_solve sets it before anyone asks)
+    *ok = p->minv_sigma > 0.0 ? !(p->zf_minv_bits & 1) : (p->minv_sigma == 0.0 && !(p->zf_minv_bits & 2));
     return FV_OK;
 }
 
@@ -1240,6 +1338,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
     int zloop = 0, zr_is_z = 0; // the many-iteration loop through the fused kernel: 0 no, 1 to be decided after the first product, 2 yes
+    bool wloop_first = true, wloop_lag = false; // ... its first vector update is the classic one; afterwards x lags one pass behind
     while (it < maxiter) {
         const int64_t m = (maxiter - it < chunk) ? (maxiter - it) : chunk;
         int32_t iters_before = 0;
@@ -1300,7 +1399,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             FV_PROF(0);
             int npq = 0;
             if (zloop == 2) {
-                FV_TRY(fv_fused_iteration(p, iter - 1, folded, p->part_rz.p, p->part_rr.p, Gv, &npq));
+                // (from the loop's second pass on the x-update of the iteration before lags one pass behind: this pass applies it)
+                FV_TRY(fv_fused_iteration(p, iter - 1, folded, p->part_rz.p, p->part_rr.p, Gv, &npq, sys.x_next ? sys.x_next : x, wloop_lag));
                 p->pvec.swap(p->pnext);
             } else
                 FV_TRY(spmv_apply(p, p->pvec.p, p->q.p, sig_mv, folded, SPMV_DOT, p->part_pq.p, nullptr, true, &npq));
@@ -1320,13 +1420,21 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 const uint8_t *mvc = nullptr;
                 StorageTable mvt{};
                 FV_TRY(fv_minv_codes(p, &mvc, &mvt)); // (cached per Jacobi diagonal)
-                if (iter == 0 && sys.x_next)
-                    hipLaunchKernelGGL(pcg_update_z_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)x, sys.x_next,
-                                       p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p, mvc, mvt);
-                else
-                    hipLaunchKernelGGL(pcg_update_z_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)nullptr,
-                                       sys.x_next ? sys.x_next : x, p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p,
-                                       p->part_rz.p, p->part_rr.p, mvc, mvt);
+                if (wloop_first) { // the loop's first iteration: the classic product left q, this update moves x itself
+                    if (iter == 0 && sys.x_next)
+                        hipLaunchKernelGGL(pcg_update_z_kernel<true>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)x, sys.x_next,
+                                           p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p, p->part_rz.p, p->part_rr.p, mvc, mvt);
+                    else
+                        hipLaunchKernelGGL(pcg_update_z_kernel<false>, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, zr_is_z, (const double *)nullptr,
+                                           sys.x_next ? sys.x_next : x, p->r.p, p->pvec.p, p->q.p, p->minv.p, p->part_pq.p, npq, p->scal.p,
+                                           p->part_rz.p, p->part_rr.p, mvc, mvt);
+                    wloop_first = false;
+                } else { // the pass left w = -M^-1 q and owes x its update: z' = z + alpha w here, x += alpha p in the next pass
+                    hipLaunchKernelGGL(pcg_update_w_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, iter, p->r.p, (const double *)p->q.p,
+                                       (const double *)p->pvec.p, (const double *)p->minv.p, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rz.p,
+                                       p->part_rr.p, mvc, mvt);
+                    wloop_lag = true;
+                }
                 p->loop_minv_coded = mvc != nullptr;
                 zr_is_z = 1;
                 FV_PROF(3);
@@ -1404,6 +1512,11 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             chunk *= 2;
     }
 #undef FV_PROF
+    if (wloop_lag) { // the last x-update of the loop through the fused kernel, wherever the loop stopped
+        hipLaunchKernelGGL(pcg_xflush_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.x_next ? sys.x_next : x, (const PcgScalars *)p->scal.p);
+        hipLaunchKernelGGL(pcg_xflush_clear_kernel, dim3(1), dim3(1), 0, ctx->stream, p->scal.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     if (!polled) {
@@ -1997,7 +2110,13 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             // step and the K1 + K2S pair issue their collectives and halo exchanges in different orders, so the ranks must not
             // mix them.  Agreed once per fv_dist_run_fixed call (one 1-double all-reduce and a host read-back).
             const bool local = zf && folded && sarg.D == nullptr && bsupport >= 0 && fv_fused_applicable(p, sigma);
-            if (d->fused_agreed < 0) {
+            // Agreed at the first burst of a call, again at every burst while the answer is "no" (a rank whose storage form was not
+            // established yet at the first burst no longer pins the whole run to the unfused pair), and every 16th burst while it is
+            // "yes" (all ranks then fall back together should one of them lose the form).  One 1-double all-reduce and
+            // a host read-back each time — every rank reaches this point at the same bursts, so the collective always matches.
+            const bool ask = d->fused_agreed < 0 || d->fused_agreed == 0 || (d->fused_bursts % 16) == 0;
+            d->fused_bursts++;
+            if (ask) {
                 bool all = local;
                 if (d->nranks > 1) {
                     double *h = reinterpret_cast<double *>(static_cast<char *>(ctx->pinned) + 2048);
@@ -2430,6 +2549,7 @@ extern "C" int fv_dist_run_fixed(fv_problem *p, double dt, int64_t nsteps, doubl
     fv_solve_info inf = {};
     int rc = FV_OK;
     p->dist->fused_agreed = -1; // (the ranks agree on the fused step at this call's first burst: dist_step)
+    p->dist->fused_bursts = 0;
     // ping-pong state + residual carry-over, as in fv_transient_run_fixed (identical decisions on every rank:
     // they depend only on the step index and on the all-reduced iteration count)
     const int64_t refresh = g_carry_refresh;

@@ -950,7 +950,9 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_dia_kernel(int64_t n, int64_t n
                     sum += sigma * shift[row] * xr;
                 // q_shifted == 2: the fused step's products of the slices outside the symmetric form, stored in the v-form
                 // v = -M^-1 (q - sigma D x) right away (fv_spmv_rest); the partial x.q is of q itself
-                const double out = (DOT && epi.q_shifted == 2) ? -(epi.minv[row] * (sum - (epi.sigma * epi.D[row]) * xr)) : sum;
+                // q_shifted == 3: the many-iteration loop's w-form, w = -M^-1 q (fv_fused_iteration)
+                const double out = (DOT && epi.q_shifted == 2) ? -(epi.minv[row] * (sum - (epi.sigma * epi.D[row]) * xr))
+                                   : (DOT && epi.q_shifted == 3) ? -(epi.minv[row] * sum) : sum;
                 if (NT)
                     __builtin_nontemporal_store(out, y + row);
                 else
@@ -2201,8 +2203,13 @@ static int launch_wstream(fv_problem *p, int G, const double *vals, const double
 static int ensure_sell(fv_problem *p, const int32_t *list, int64_t count, const double *vals, double tag)
 {
     fv_ctx *ctx = p->ctx;
-    if (p->sell_state == 0 || !g_sell)
+    if (p->sell_state == 0)
         return FV_OK;
+    if (!g_sell) { // the A/B switch turned off on a live problem: no path may use a copy that is no longer kept up to date
+        if (p->sell_state == 1)
+            p->sell_vals_epoch = -1;
+        return FV_OK;
+    }
     const int64_t ns = (p->n + 63) >> 6;
     if (p->sell_state < 0) {
         p->sell_state = 0;
@@ -2250,18 +2257,31 @@ static int ensure_sell(fv_problem *p, const int32_t *list, int64_t count, const 
             }
         } while (0);
         fv_pool_end();
+        auto drop = [&]() { // (not applicable, or no memory for it: the CSR wave-stream kernel serves these groups as before)
+            p->sell_ptr.release();
+            p->sell_list.release();
+            p->sell_rest.release();
+            p->sell_vals.release();
+            p->sell_dcol.release();
+            p->sell_w.release();
+        };
+        if (rc == FV_ERR_NOMEM) {
+            drop();
+            return FV_OK;
+        }
         FV_TRY(rc);
         // worth it when nearly every group fits and the padding stays small (10 B per stored entry against 12 per real one)
         int64_t nnz_groups = p->nnz; // (an upper bound when some groups are DIA slices)
         if (p->sell_n * 10 < count * 9 || p->sell_blocks * 64 * 10 > nnz_groups * 12 + 4 * p->n) {
-            p->sell_ptr.release();
-            p->sell_list.release();
-            p->sell_rest.release();
+            drop();
             return FV_OK;
         }
-        FV_TRY(p->sell_vals.alloc(ctx, (size_t)p->sell_blocks * 64 + 64));
-        FV_TRY(p->sell_dcol.alloc(ctx, (size_t)p->sell_blocks * 64 + 64));
-        FV_TRY(p->sell_w.alloc(ctx, (size_t)ns));
+        // (an extra ~10 B per entry on the largest irregular meshes: when it does not fit, the solve goes on with the CSR form)
+        if (p->sell_vals.alloc(ctx, (size_t)p->sell_blocks * 64 + 64) != FV_OK || p->sell_dcol.alloc(ctx, (size_t)p->sell_blocks * 64 + 64) != FV_OK ||
+            p->sell_w.alloc(ctx, (size_t)ns) != FV_OK) {
+            drop();
+            return FV_OK;
+        }
         FV_HIP(ctx, hipMemsetAsync(p->sell_w.p, 0, (size_t)ns, ctx->stream));
         p->sell_vals_epoch = -1;
         p->sell_state = 1;
@@ -2287,7 +2307,7 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
     // (a pure-CSR operator hands over its traversal order of ALL groups: the SELL form then covers every group, in ascending order)
     if (mode != SPMV_INIT && !p->dist && p->nhalo == 0)
         FV_TRY(ensure_sell(p, list == p->group_order.p ? nullptr : list, count, vals, vals_tag));
-    if (mode == SPMV_INIT || p->sell_state != 1 || p->dist || p->nhalo > 0) {
+    if (mode == SPMV_INIT || p->sell_state != 1 || !g_sell || p->sell_vals_epoch != p->assemble_epoch || p->sell_tag != vals_tag || p->dist || p->nhalo > 0) {
         const int G = stream_grid(count);
         FV_TRY(launch_wstream(p, G, vals, x, y, shift, sigma, mode, partials, scal, list, count, epi));
         *nparts = G;
@@ -2702,7 +2722,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 // The slices the symmetric form leaves to the slice-by-slice kernel (first / last plane, irregular ones), on their own: the
 // fused step (fv_fused.hip) forms every other product itself.  `vals`: the value array the lane-major copy was filled from
 // (spmv_apply has done that for the same array and tag before the fused regime is entered).
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done, double vform_sigma)
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done, double vform_sigma, bool wform)
 {
     fv_ctx *ctx = p->ctx;
     *nparts = 0;
@@ -2716,6 +2736,9 @@ int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, 
         epi.minv = p->minv.p;
         epi.D = p->D.p;
         epi.sigma = vform_sigma;
+    } else if (wform) { // y receives w = -M^-1 q
+        epi.q_shifted = 3;
+        epi.minv = p->minv.p;
     }
     if (g_nt)
         hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,

@@ -157,8 +157,8 @@ def test_device_adjoint_sweep_under_the_renumbering(fv):
     us, ts = fv.backwardeulerintegrate(u0, tspan, *mesh, K, src_obs, *rest[1:], **kw)
     uobs = fv.getcontinuoussolution(us, ts)
     us_i, ts_i = fv.backwardeulerintegrate(u0, tspan, *mesh, K, *rest, **kw)
-    ctx = fv.default_context()
-    ctx.set_option(1, 2)  # FV_OPT_REORDER: always
+    lib = fv.load()
+    assert lib.fv_tune(31, 2) == 0  # the process-wide default of FV_OPT_REORDER: always (as the `forced` fixture of test_gpu_reorder.py)
     try:
         dus, dts = fv.backwardeulerintegrate(u0, tspan, *mesh, K, *rest, keep="device", **kw)
         assert dus.trajectory.problem.reorder_info()["reordered"]
@@ -169,7 +169,7 @@ def test_device_adjoint_sweep_under_the_renumbering(fv):
         g, dgdu, dfdp, dgdp, du0dp, G = fv.getadjointfunctions(lambda i, t: 1e-3, obsfree, uobs, u0, tspan, *mesh, K, *rest, **kw)
         lam_d, ts_d = fv.adjointintegrate(dgdu.bind(duc), tspan, *mesh, K, *rest, **kw)
     finally:
-        ctx.set_option(1, 1)
+        lib.fv_tune(31, 1)
     lam_h, ts_h = fv.adjointintegrate(lambda t: dgdu(uc, t), tspan, *mesh, K, *rest, **kw)
     assert ts_d == ts_h
     scale = max(np.abs(np.asarray(l)).max() for l in lam_h)

@@ -1,7 +1,8 @@
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 rm -rf $O/aprof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/aprof -- python3 $R/tools/amg_box.py 256 3.0 0 > $O/aprof.log 2>&1
 FV_AMG_VERBOSE=1 python3 $R/tools/amg_box.py 256 3.0 0 > $O/aprof_verbose.log 2>&1

@@ -1,8 +1,9 @@
 # one rank through the row-block driver (FV_BENCH_FORCE_DIST=1) under rocprofv3: which kernels a step of the block launches
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 rm -rf $O/dprof
 export FV_BENCH_FORCE_DIST=1
 export MASTER_PORT=29655

@@ -1,7 +1,8 @@
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 rm -rf $O/fprof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fprof -- python3 $R/tools/frac_step.py 200 > $O/fprof.log 2>&1
 cd $R

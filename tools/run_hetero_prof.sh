@@ -1,8 +1,9 @@
 # kernel-trace stats of the bench's heterogeneous-conductivity block (sigma = 1 field on the 464^3 box: 2-3 PCG iterations per step at dt = 60 s)
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 rm -rf $O/hprof
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hprof -- python3 $R/bench.py --steps 20 --warmup 5 --repeats 1 --no-cpu-baseline --no-other-configs --no-multi-iteration --no-profile > $O/hprof.json 2> $O/hprof.err
 cd $R

@@ -1,7 +1,8 @@
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 MASK=${1:-15364}
 PM=${2:-1024}
 timeout -k 10 120 $R/tools/fused_proto 9 70 200 3 2 0 $MASK > $O/fused_small.log 2>&1

@@ -1,8 +1,9 @@
 # the round's evidence in one call: default bench line, the driver's command, kernel-trace stats of the headline loop, PMC passes
-set -e
+set -eu
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (gpurun does)}
 O=$R/gpurun_out
+mkdir -p $O
 cd $R
 timeout -k 10 600 python bench.py > $O/r03_bench464_default_run.json 2> $O/r03_bench464_default_run.err
 timeout -k 10 300 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r03_bench464_driver_command.json 2> $O/r03_bench464_driver_command.err
