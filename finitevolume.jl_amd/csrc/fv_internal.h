@@ -372,6 +372,10 @@ struct fv_problem {
     int64_t fused_launches = 0, fused_bytes_launch = 0;
     fv_trajectory *recording = nullptr; // fv_trajectory_record: fixed / adaptive runs push the state of every outer step here
     double record_t = 0.0;              // ... the time of the last recorded state of a fixed-dt run
+    DevBuf<double> small_part;     // the single-launch solver of small systems (fv_small.hip): per-block partial sums,
+    DevBuf<uint32_t> small_bar;    // its grid barrier's arrival counter and failure flag,
+    uint32_t small_bar_base = 0;   // ... the counter's value when the next launch begins
+    int64_t small_solves = 0;      // solves it has done
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;
@@ -466,6 +470,8 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
 // StorageArg; *bytes_saved = bytes per row against streaming the doubles; ignore_switch: whatever fv_tune key 35 says
 int fv_storage_form(fv_problem *p, StorageArg *out, int *bytes_saved, bool ignore_switch);
 int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info, uint32_t *zero_mask = nullptr);
+// fv_small.hip: Jacobi-PCG of a small system in one persistent launch; *handled = false: not a case for it
+int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it, bool *handled);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
                    int *npartials = nullptr);

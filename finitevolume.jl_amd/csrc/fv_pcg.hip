@@ -1166,6 +1166,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         return FV_ERR_STATE;
     }
     const int64_t n = p->n;
+    { // small systems: the whole solve in one launch (fv_small.hip)
+        bool handled = false;
+        FV_TRY(fv_pcg_small(p, x, sys, rtol, maxiter, info, time_it, &handled));
+        if (handled)
+            return FV_OK;
+    }
     const int Gv = vec_grid(n);
     const double *folded = nullptr;
     if (sys.fold_shift && sigma != 0.0)

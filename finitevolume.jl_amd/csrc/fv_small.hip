@@ -1,0 +1,331 @@
+// Jacobi-PCG of a SMALL system in one launch (round 4).
+//
+// The reference's own workloads are small: test/theis.jl:21-54 is 15 650 unknowns and ~3 300 solves, the inversions of
+// examples/ run 51 x 51 x 2 cells.  At that size the kernels of the PCG loop are a few microseconds each and a solve is bound by
+// its launches and its host polls: 13 launches and 3 synchronous copies per one-iteration solve, 69 us per solve on the Theis
+// problem (profiles/r04_small_end.json) where the kernels themselves add up to ~45.  Here the whole solve — the step's initial
+// residual b' - A x0, the Jacobi diagonal, every iteration of defaultlinearsolver's CG (/root/reference/src/transient.jl:50-58;
+// IterativeSolvers' stopping rule ||r|| <= rtol ||rhs||) with the preconditioner north_star names — is ONE persistent kernel of at
+// most 32 resident blocks of 1024 threads that meet at a grid barrier between the phases (three per iteration: after the product's p.q, after the
+// vector update's sums, after the new direction).  The operator is the canonical CSR the assembly built, the shift sigma D is
+// applied on the fly; the vectors (a few hundred KB) live in the L2.  Same arithmetic as the classic loop's kernels row by row; the
+// sums are grouped by this kernel's blocks.  The barrier's spin is bounded: if the blocks should ever fail to meet (they are all
+// resident by construction) a flag is raised, every block leaves and the host reports the error — the grid always drains.
+#include "fv_internal.h"
+#include "fv_device.h"
+
+#include <cmath>
+
+int g_small_n = 1 << 15; // fv_tune key 61: systems of at most this many rows are solved by the single-launch kernel (0 = never)
+
+namespace {
+
+constexpr int SM_MAXG = 32;
+constexpr int SM_BLOCK = 1024; // few, fat blocks: the barrier's cost grows with the number of blocks that meet (8 blocks: ~3.5 us, 62: ~14)
+
+struct SmallArgs {
+    int64_t n, rows_per_block;
+    const int32_t *rowptr, *colind;
+    const double *vals, *diagA, *D, *rhs;
+    double sigma, dt, rtol;
+    int implicit, b_times_D, x0_zero, G;
+    double *x, *r, *pv, *q, *minv;
+    double *part; // 4 x SM_MAXG: p.q | r.z | r.r | rhs.rhs
+    PcgScalars *scal;
+    int64_t maxiter;
+    double *hist;
+    int64_t hist_cap;
+    uint32_t *bar; // [0] arrivals (monotonic across launches), [1] failure flag
+    uint32_t bar_base;
+};
+
+struct GridBarrier {
+    uint32_t *bar;
+    uint32_t target;
+    int G;
+    bool failed;
+    __device__ void sync()
+    {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            target += (uint32_t)G;
+            __threadfence(); // this block's writes are visible device-wide before it is counted
+            atomicAdd(bar, 1u);
+            long spins = 0;
+            while ((int32_t)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > 200000000L) {
+                    atomicExch(bar + 1, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __threadfence(); // ... and the other blocks' writes are visible to this one (the CU's own cache is invalidated)
+        }
+        __syncthreads();
+        if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            failed = true;
+    }
+};
+
+__device__ inline double small_block_sum(double v, double *smem) // all threads get the sum; smem: SM_BLOCK / 64 doubles; fixed order
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < SM_BLOCK / 64; w++)
+        t += smem[w];
+    return t;
+}
+
+// every block reduces the same G per-block values in the same order
+__device__ inline double small_total(const double *part, int G)
+{
+    double s = 0.0;
+    for (int g = 0; g < G; g++)
+        s += __hip_atomic_load(part + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return s;
+}
+
+__global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
+{
+    __shared__ double smem[SM_BLOCK / 64];
+    GridBarrier gb{a.bar, a.bar_base, a.G, false};
+    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block, hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+    double *part_pq = a.part, *part_rz = a.part + SM_MAXG, *part_rr = a.part + 2 * SM_MAXG, *part_bb = a.part + 3 * SM_MAXG;
+    const bool shift = a.sigma != 0.0 && a.D != nullptr;
+    auto product = [&](const double *v, int64_t i) -> double { // ((A + sigma D) v)_i, entries in column order like every other form
+        double s = 0.0;
+        const int32_t e = a.rowptr[i + 1];
+        for (int32_t k = a.rowptr[i]; k < e; k++)
+            s += a.vals[k] * v[a.colind[k]];
+        if (shift)
+            s += a.sigma * a.D[i] * v[i];
+        return s;
+    };
+    // ---- set-up (pcg_init_kernel): r0, M^-1, p = M^-1 r0, the three sums
+    double arz = 0.0, arr = 0.0, abb = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
+        double bi = a.rhs ? a.rhs[i] : 0.0, ri;
+        if (a.implicit) { // rhs = b' + D x0/dt, r0 = b' - A x0: the D x0/dt terms of rhs and of the shifted operator cancel
+            const double di = a.D[i];
+            if (a.b_times_D)
+                bi *= di;
+            double q0 = 0.0;
+            const int32_t e = a.rowptr[i + 1];
+            for (int32_t k = a.rowptr[i]; k < e; k++)
+                q0 += a.vals[k] * a.x[a.colind[k]];
+            const double rhsv = bi + di * (a.x[i] / a.dt);
+            ri = bi - q0;
+            bi = rhsv;
+        } else
+            ri = a.x0_zero ? bi : bi - product(a.x, i);
+        const double d = shift ? a.diagA[i] + a.sigma * a.D[i] : a.diagA[i];
+        const double mi = d > 0.0 ? 1.0 / d : 0.0; // (a free cell without any face has an empty row: left where it is)
+        a.minv[i] = mi;
+        const double zi = mi * ri;
+        a.r[i] = ri;
+        a.pv[i] = zi;
+        arz += ri * zi;
+        arr += ri * ri;
+        abb += bi * bi;
+    }
+    {
+        const double t0 = small_block_sum(arz, smem), t1 = small_block_sum(arr, smem), t2 = small_block_sum(abb, smem);
+        if (threadIdx.x == 0) {
+            part_rz[blockIdx.x] = t0;
+            part_rr[blockIdx.x] = t1;
+            part_bb[blockIdx.x] = t2;
+        }
+    }
+    gb.sync();
+    if (gb.failed)
+        return;
+    double rz = small_total(part_rz, a.G), rr = small_total(part_rr, a.G);
+    const double bb = small_total(part_bb, a.G);
+    const double tol2 = a.rtol * a.rtol * bb;
+    int done = rr <= tol2 ? 1 : 0;
+    int64_t it = 0;
+    double pq = 0.0;
+    while (!done && it < a.maxiter) {
+        // ---- K1: q = (A + sigma D) p, p.q
+        double apq = 0.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
+            const double qi = product(a.pv, i);
+            a.q[i] = qi;
+            apq += a.pv[i] * qi;
+        }
+        {
+            const double t = small_block_sum(apq, smem);
+            if (threadIdx.x == 0)
+                part_pq[blockIdx.x] = t;
+        }
+        gb.sync();
+        if (gb.failed)
+            return;
+        pq = small_total(part_pq, a.G);
+        if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
+            done = 2;
+            break;
+        }
+        const double alpha = rz / pq;
+        // ---- K2: x += alpha p; r -= alpha q; sums r.M^-1 r, r.r
+        arz = arr = 0.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
+            a.x[i] += alpha * a.pv[i];
+            const double ri = a.r[i] - alpha * a.q[i];
+            a.r[i] = ri;
+            arz += ri * (a.minv[i] * ri);
+            arr += ri * ri;
+        }
+        {
+            const double t0 = small_block_sum(arz, smem), t1 = small_block_sum(arr, smem);
+            if (threadIdx.x == 0) {
+                part_rz[blockIdx.x] = t0;
+                part_rr[blockIdx.x] = t1;
+            }
+        }
+        gb.sync();
+        if (gb.failed)
+            return;
+        const double rzn = small_total(part_rz, a.G);
+        rr = small_total(part_rr, a.G);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && a.hist && it < a.hist_cap)
+            a.hist[it] = sqrt(rr);
+        it++;
+        if (rr <= tol2) {
+            rz = rzn;
+            done = 1;
+            break;
+        }
+        // ---- K3: p = M^-1 r + beta p
+        const double beta = rzn / rz;
+        rz = rzn;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK)
+            a.pv[i] = a.minv[i] * a.r[i] + beta * a.pv[i];
+        gb.sync(); // the next product reads the other blocks' p
+        if (gb.failed)
+            return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        PcgScalars *s = a.scal;
+        s->rz[0] = s->rz[1] = rz;
+        s->rr = rr;
+        s->tol2 = tol2;
+        s->bnorm2 = bb;
+        s->pq = pq;
+        s->iters = (int32_t)it;
+        s->done = done;
+        s->chain_step = 0;
+        s->zero_mask = 0;
+        s->xlag = -1;
+        s->pad_ = (int32_t)gb.target; // the barrier's count at the end of this launch: the next launch's base
+    }
+}
+
+} // namespace
+
+// *handled = false: not a case for this kernel (the classic loop runs).  x: initial guess in, solution out.
+int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it, bool *handled)
+{
+    fv_ctx *ctx = p->ctx;
+    *handled = false;
+    const int64_t n = p->n;
+    if (g_small_n <= 0 || n <= 0 || n > g_small_n || p->dist || p->nhalo > 0 || sys.x_next || sys.carry_prev || sys.speculate || sys.use_spec || sys.chain_index >= 0 ||
+        sys.resume_it > 0 || p->profile || !p->rowptr.p || !p->colind.p || !p->vals.p || !p->diagA.p)
+        return FV_OK;
+    if ((sys.implicit_step ? fv_step_precond(p) : p->precond) == FV_PRECOND_AMG)
+        return FV_OK;
+    if (!p->small_part.p) {
+        FV_TRY(p->small_part.alloc(ctx, (size_t)4 * SM_MAXG));
+        FV_TRY(p->small_bar.alloc(ctx, 2));
+        FV_TRY(p->small_bar.zero(ctx));
+        p->small_bar_base = 0;
+    }
+    SmallArgs a{};
+    a.n = n;
+    // one row per thread where 32 blocks of 1024 threads allow it: a thread's rows are walked one after the other, each a chain of three dependent
+    // loads (row pointer, column, vector entry) — with eight rows per thread a pass over 15 650 rows took 16 us, the whole solve 46
+    int G = (int)((n + SM_BLOCK - 1) / SM_BLOCK);
+    G = G < 1 ? 1 : (G > SM_MAXG ? SM_MAXG : G);
+    if (G > ctx->num_cus) // (every block must be resident for the barrier)
+        G = ctx->num_cus;
+    a.G = G;
+    a.rows_per_block = (n + G - 1) / G;
+    a.rowptr = p->rowptr.p;
+    a.colind = p->colind.p;
+    a.vals = p->vals.p;
+    a.diagA = p->diagA.p;
+    a.D = sys.sigma != 0.0 || sys.implicit_step ? p->D.p : nullptr;
+    a.rhs = sys.rhs;
+    a.sigma = sys.sigma;
+    a.dt = sys.dt;
+    a.rtol = rtol;
+    a.implicit = sys.implicit_step ? 1 : 0;
+    a.b_times_D = sys.b_times_D ? 1 : 0;
+    a.x0_zero = sys.x0_zero ? 1 : 0;
+    a.x = x;
+    a.r = p->r.p;
+    a.pv = p->pvec.p;
+    a.q = p->q.p;
+    a.minv = p->minv.p;
+    a.part = p->small_part.p;
+    a.scal = p->scal.p;
+    a.maxiter = maxiter;
+    a.hist = p->hist.p;
+    a.hist_cap = p->hist_cap;
+    a.bar = p->small_bar.p;
+    a.bar_base = p->small_bar_base;
+    if (time_it)
+        FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (sys.x0_zero && !sys.implicit_step)
+        FV_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(pcg_small_kernel, dim3(G), dim3(SM_BLOCK), 0, ctx->stream, a);
+    FV_LAUNCH_CHECK(ctx);
+    if (time_it)
+        FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
+    uint32_t *hbar = reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->pinned) + 1024);
+    FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipMemcpyAsync(hbar, p->small_bar.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hbar[1]) {
+        FV_HIP(ctx, hipMemsetAsync(p->small_bar.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+        p->small_bar_base = 0;
+        fv_set_error(ctx, "fv_pcg_small: the blocks of the single-launch solver did not meet at their grid barrier");
+        return FV_ERR_STATE;
+    }
+    p->small_bar_base = hbar[0];
+    // what the classic loop leaves behind it
+    p->minv_valid = true;
+    p->minv_sigma = sys.sigma;
+    p->minv_epoch = p->assemble_epoch;
+    p->z_where = 0;
+    p->spec_valid = false;
+    p->vready = false;
+    p->last_iters = hs->iters;
+    p->loop_bytes = 0;
+    p->fused_chunked = false;
+    p->small_solves++;
+    if (info) {
+        info->converged = hs->done == 1;
+        info->iters = hs->iters;
+        info->bnorm = std::sqrt(hs->bnorm2);
+        info->relres = hs->bnorm2 > 0 ? std::sqrt(hs->rr / hs->bnorm2) : std::sqrt(hs->rr);
+        info->solve_ms = 0.0;
+        info->resnorm_len = 0;
+        if (time_it) {
+            float ms = 0.f;
+            FV_HIP(ctx, hipEventSynchronize(ctx->ev1));
+            FV_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+            info->solve_ms = ms;
+        }
+    }
+    if (hs->done == 2)
+        fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs->pq); // (reported like the classic loop: info->converged = 0)
+    *handled = true;
+    return FV_OK;
+}

@@ -451,6 +451,7 @@ extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zf
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
+extern int g_small_n; // fv_small.hip
 extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare, g_fused_sell, g_fused_sell_blocks, g_fused_chunk; // fv_fused.hip
 
 extern "C" int fv_tune(int key, int value)
@@ -563,6 +564,8 @@ extern "C" int fv_tune(int key, int value)
         g_fused_dist = value;
     else if (key == 51 && value >= 0 && value <= 4)
         g_fused_dist_spare = value;
+    else if (key == 61 && value >= 0)
+        g_small_n = value;
     else if (key == 60 && value >= 0 && value <= 7)
         g_fused_chunk = value;
     else if (key == 32 && value >= 0 && value <= (1 << 20))
