@@ -32,18 +32,18 @@
 #include "fv_fused.h"
 
 int g_fused = 1;       // fv_tune key 41: 0 = never use the fused step
-int g_fused_blocks = 2; // fv_tune key 42 (experiment): resident blocks per CU the grid is sized for (8-line tiles)
-int g_fused_segs = 0;   // fv_tune key 43 (experiment): segments of planes per tile, 0 = chosen to fill whole rounds
+static const int g_fused_blocks = 2; // (round 3's experiment key 42, frozen) resident blocks per CU the grid is sized for (8-line tiles)
+static const int g_fused_segs = 0;   // (experiment key 43, frozen) segments of planes per tile, 0 = chosen to fill whole rounds
 int g_fused_codes = 1;  // fv_tune key 49: the matrix as 16-bit codes per row where its diagonals take few distinct values (0: always the doubles)
 int g_fused_iter = 1;   // fv_tune key 46: the many-iteration loop through the fused kernel too (direction update + product in one pass, z kept instead of r)
-int g_fused_nt = 0;     // fv_tune key 45 (experiment): bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
-int g_fused_dist_spare = 1; // fv_tune key 51: CUs per XCD a row block's fused launch leaves to the halo exchange
-int g_fused_sell_blocks = 4; // fv_tune key 56 (experiment): resident blocks per CU the SELL step's grid is sized for
+static const int g_fused_nt = 0;     // (experiment key 45, frozen: every bit lost its A/B) bit 0 = z' stored non-temporally, bit 1 = v' too, bit 2 = x / v loaded with plain loads, bit 3 = x_out stored plainly, bit 4 = matrix loaded with plain loads
+int g_fused_dist_spare = 1; // (key 51, frozen) CUs per XCD a row block's fused launch leaves to the halo exchange
+static const int g_fused_sell_blocks = 4; // (experiment key 56, frozen) resident blocks per CU the SELL step's grid is sized for
 int g_fused_sell = 1;  // fv_tune key 55: the fused step on the SELL form (irregular meshes) too
 int g_fused_dist = 1;  // fv_tune key 50: the fused step on row blocks too (0: row blocks keep the K1 + K2S pair)
 int g_fused_chunk = 1;  // fv_tune key 60: the coded fused step / pass on CHUNKS of a plane (fused_chunk_kernel: no column halos) where it applies;
-                        // 0 = always the 2-D tiles; 2..7 = experiment: force the (threads, pairs per thread) variant (1024, 2), (1024, 3), (768, 4), (512, 6), (512, 5) [the default], (768, 3)
-int g_fused_lines = 16; // fv_tune key 44: lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
+                        // 0 = always the 2-D tiles
+static const int g_fused_lines = 16; // (key 44, frozen) lines per tile, 8 (blocks of 512 threads, two per CU) or 16 (1024 threads, one per CU: fewer halo rows per
                         // own row; 464^3, same process: 1.351 against 1.438 ms per step, the K1 + K2S pair 1.696)
 
 namespace {
@@ -1386,11 +1386,10 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
         return false;
     a.kcode = p->kc_code.p;
     a.kdiag = p->kc_dtab;
-    static const int variants[6][2] = {{1024, 2}, {1024, 3}, {768, 4}, {512, 6}, {512, 5}, {768, 3}};
-    // (512 threads x 5 pairs is the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD; 464^3, one
-    // process, ms per step: tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44)
-    const int pick = g_fused_chunk >= 2 && g_fused_chunk <= 7 ? g_fused_chunk - 2 : 4;
-    const int nt = variants[pick][0], np = variants[pick][1];
+    // 512 threads x 5 pairs of rows per thread: the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD.
+    // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
+    // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
+    const int nt = 512, np = 5;
     const int64_t nz = a.nz, d3 = a.d3;
     if (nz > nt) // the 2 nz halo rows are covered in two rounds of the block: longer lines stay with the tiles
         return false;
@@ -1462,17 +1461,7 @@ static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 template <int MODE>
 static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
-    if (pl.nt == 1024 && pl.np == 2)
-        return kc_launch_one<1024, 2, MODE>(ctx, a, pl);
-    if (pl.nt == 1024 && pl.np == 3)
-        return kc_launch_one<1024, 3, MODE>(ctx, a, pl);
-    if (pl.nt == 768 && pl.np == 4)
-        return kc_launch_one<768, 4, MODE>(ctx, a, pl);
-    if (pl.nt == 768)
-        return kc_launch_one<768, 3, MODE>(ctx, a, pl);
-    if (pl.np == 5)
-        return kc_launch_one<512, 5, MODE>(ctx, a, pl);
-    return kc_launch_one<512, 6, MODE>(ctx, a, pl);
+    return kc_launch_one<512, 5, MODE>(ctx, a, pl);
 }
 
 // the SELL variant of fv_fused_step (same contract)

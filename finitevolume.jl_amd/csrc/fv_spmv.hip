@@ -422,7 +422,8 @@ static int g_march = 1;      // plane-marching sliced-DIA kernel on structured g
 static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
-static int g_symdia = 1; // fv_tune key 27: symmetric plane-marching form where the marching kernel runs (0 off)
+static int g_symdia = 1; // fv_tune key 27 >= 3: symmetric plane-marching form where the marching kernel runs
+static int g_march_form = 1; // fv_tune key 27 >= 2: the plane-marching kernels at all (0: structured operators stay with the slice-by-slice kernel)
 static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
 static int g_tile_blocks = 2; // fv_tune key 39 (experiment): resident blocks per CU the tiled kernel's grid is sized for
 static int g_tile_segs = 0;   // fv_tune key 40 (experiment): segments of planes per tile column, 0 = chosen to fill whole rounds
@@ -452,32 +453,23 @@ extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
 extern int g_small_n; // fv_small.hip
-extern int g_fused, g_fused_blocks, g_fused_segs, g_fused_lines, g_fused_nt, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_dist_spare, g_fused_sell, g_fused_sell_blocks, g_fused_chunk; // fv_fused.hip
+extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk; // fv_fused.hip
 
+// The selectors that are left after round 4's pruning (csrc/fv_tune.h): every value of every key gives correct
+// results — each names an alternative kernel or policy that the tests compare with the default — and the launch-shape / streaming-hint /
+// diagnosis experiments of rounds 1-3 (among them two keys whose settings produced wrong results by design) are frozen at their measured best.
 extern "C" int fv_tune(int key, int value)
 {
-    if (key == 0 && (value == 1 || value == 2))
-        g_spmv_form = value;
-    else if (key == 1 && (value == 2 || value == 4 || value == 8))
-        g_spmv_unroll = value;
-    else if (key == 2 && (value == 0 || value == 1))
-        g_use_order = value;
-    else if (key == 3 && (value == 0 || value == 1))
-        g_fold_shift = value;
-    else if (key == 4 && (value == 0 || value == 1))
-        g_nt = value;
-    else if (key == 5 && (value == 0 || value == 1))
-        g_fuse_init = value;
-    else if (key == 6 && (value == 0 || value == 1))
-        g_use_dia = value;
-    else if (key == 7 && value >= 0)
+    if (key == 7 && value >= 0)
         g_carry_refresh = value;
     else if (key == 8 && (value == 0 || value == 1))
         g_carry_speculate = value;
     else if (key == 9 && value >= 0 && value <= 2)
         g_march = value;
-    else if (key == 19 && value >= 0)
-        g_march_min_mb = value;
+    else if (key == 13 && value >= 0 && value <= 32)
+        g_chain_steps = value;
+    else if (key == 14 && value >= -1 && value < 32)
+        g_chain_test_break = value;
     else if (key == 20 && (value == 0 || value >= 2))
         g_gradient_knots_per_pass = value;
     else if (key == 21 && (value == 0 || value == 1))
@@ -486,31 +478,12 @@ extern "C" int fv_tune(int key, int value)
         g_defer_reduce = value;
     else if (key == 25 && value >= 0)
         g_trace_spmv = value;
-    else if (key == 26 && ((value >= 0 && value <= 3) || value == 7))
-        g_k2s_nt = value;
-    else if (key == 10 && value >= 0 && value <= 16)
-        g_march_segs = value;
-    else if (key == 11 && (value == 0 || value == 1))
-        g_dia_packed = value;
-    else if (key == 12 && value >= 0 && value <= 2)
-        g_sparse_b = value;
-    else if (key == 17 && value >= 0 && value <= 3)
-        g_march_dbg = value;
-    else if (key == 18 && (value == 0 || value == 1))
-        g_march_wide = value;
-    else if (key == 13 && value >= 0 && value <= 32)
-        g_chain_steps = value;
-    else if (key == 14 && value >= -1 && value < 32)
-        g_chain_test_break = value;
-    else if (key == 27 && (value == 0 || value == 1))
-        g_symdia = value;
-    else if (key == 28 && value >= 0 && value <= 7)
-        g_symdia_nt = value;
-    else if (key == 29 && value >= 0 && value <= 15)
-        g_symdia_dbg = value;
-    else if (key == 30 && value >= 1 && value <= 8)
-        g_blocks_per_cu = value;
-    else if (key == 31 && value >= 0 && value <= 2)
+    else if (key == 27 && value >= 0 && value <= 4) { // the richest SpMV form a structured operator may take: 0 CSR stream, 1 slices, 2 marching, 3 symmetric marching, 4 tiled
+        g_use_dia = value >= 1;
+        g_march_form = value >= 2;
+        g_symdia = value >= 3;
+        g_sym_tile = value >= 4;
+    } else if (key == 31 && value >= 0 && value <= 2)
         g_reorder = value;
     else if (key == 33 && (value == 0 || value == 1))
         g_resume_runs = value;
@@ -522,54 +495,28 @@ extern "C" int fv_tune(int key, int value)
         g_zform = value;
     else if (key == 37 && (value == 0 || value == 1))
         g_sym_rowsum = value;
-    else if (key == 38 && (value == 0 || value == 1))
-        g_sym_tile = value;
-    else if (key == 39 && value >= 1 && value <= 4)
-        g_tile_blocks = value;
-    else if (key == 40 && value >= 0 && value <= 256)
-        g_tile_segs = value;
     else if (key == 41 && (value == 0 || value == 1))
         g_fused = value;
-    else if (key == 42 && value >= 1 && value <= 4)
-        g_fused_blocks = value;
-    else if (key == 43 && value >= 0 && value <= 256)
-        g_fused_segs = value;
-    else if (key == 44 && (value == 8 || value == 16))
-        g_fused_lines = value;
-    else if (key == 45 && value >= 0 && value <= 31)
-        g_fused_nt = value;
     else if (key == 46 && (value == 0 || value == 1))
         g_fused_iter = value;
     else if (key == 47 && (value == 0 || value == 1))
         g_reorder_device = value;
-    else if (key == 48 && value >= 0 && value <= 64)
-        g_reorder_blocks = value;
     else if (key == 49 && (value == 0 || value == 1))
         g_fused_codes = value;
+    else if (key == 50 && (value == 0 || value == 1))
+        g_fused_dist = value;
     else if (key == 52 && value >= 0 && value <= 8)
         g_amg_kcycle = value;
-    else if (key == 53 && value >= 0)
-        g_amg_stream = value;
     else if (key == 54 && (value == 0 || value == 1))
         g_sell = value;
     else if (key == 55 && (value == 0 || value == 1))
         g_fused_sell = value;
-    else if (key == 58 && value >= 1 && value <= 8)
-        g_sell_blocks = value;
     else if (key == 59 && (value == 0 || value == 1))
         g_minv_codes = value;
-    else if (key == 56 && value >= 1 && value <= 8)
-        g_fused_sell_blocks = value;
-    else if (key == 50 && (value == 0 || value == 1))
-        g_fused_dist = value;
-    else if (key == 51 && value >= 0 && value <= 4)
-        g_fused_dist_spare = value;
+    else if (key == 60 && (value == 0 || value == 1))
+        g_fused_chunk = value;
     else if (key == 61 && value >= 0)
         g_small_n = value;
-    else if (key == 60 && value >= 0 && value <= 7)
-        g_fused_chunk = value;
-    else if (key == 32 && value >= 0 && value <= (1 << 20))
-        g_alloc_skew_bytes = value / 512 * 512;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -2469,7 +2416,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         // 216^3 0.139 / 0.170 / 0.107 ms, a 58-plane share of the bench box 0.172 / 0.211 / 0.142, 116 planes 0.344 / 0.354 /
         // 0.275, 320^3 0.494 / 0.496 / 0.340, 464^3 - / 1.51 / 1.00; profiles/r02_sym_sizes.log): wherever the operator has that
         // shape the size rule does not apply.
-        const bool may_march = g_march && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
+        const bool may_march = g_march && g_march_form && mode != SPMV_INIT && p->order_stride >= 4096 && dcount > 0 && (!subset || subset->win_hi > subset->win_lo);
         bool sym = false;
         // the whole operator, or a row block's interior pass (a row block as a whole — no subset — keeps the seven-diagonal
         // forms: its sym_ok flags only cover the interior window)

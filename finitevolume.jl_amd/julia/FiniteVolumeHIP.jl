@@ -687,4 +687,118 @@ function integratedfdplambda(u2, p::Vector, lambdas::Vector, ts_lambda::Vector, 
 	return result
 end
 
+# ---------------------------------------------------------------- the adjoint workflow with every state in HBM (ABI 3)
+# examples/transientadjoint/ex.jl:100-123 runs nine forward + adjoint pairs per objective call; the reference keeps `us` on the
+# host and evaluates the forcing t -> dgdu(uc_p, t) through its interpolant at every solve (transient.jl:188-205,
+# transientadjointutils.jl:13-21).  Here the states stay where they were computed (fv_trajectory), the observation series live on
+# the device (fv_observation) and the sweep is one library call (fv_adjoint_run).  Usage, in the shape of the example:
+#     uc   = devicesolution(u0, tspan, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, i->i, true; atol=atol, dt0=dt0)
+#     obs  = deviceobservation(uc.problem, obsfreenodes, tobs, uobs_at_obs, sigma_at_obs)      # series at the observation rows, one row per knot of tobs
+#     G    = objectiveintegral(uc, obs, tspan)                                                   # G(uc_p) of transientadjointutils.jl:46-49
+#     lam  = adjointintegrate(uc, obs, tspan; atol=atol, dt0=dt0)                                # a DeviceSolution of lambda
+#     idl  = integratedfdplambda(uc, lam, tspan, 1 ./ (Ss .* volumes)[1:nfree], true)            # per-face / per-row terms of the integral of dfdp' lambda
+mutable struct DeviceTrajectory       # fv_trajectory: (time, free-cell vector in HBM) knots of a run — the reference's `us`, `ts`
+	problem::Problem
+	handle::Ptr{Cvoid}
+	function DeviceTrajectory(p::Problem)
+		h = Ref{Ptr{Cvoid}}(C_NULL)
+		check(p.ctx, ccall((:fv_trajectory_create, libfvhip), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), p.handle, h))
+		tr = new(p, h[])
+		finalizer(t -> (t.handle == C_NULL || ccall((:fv_trajectory_destroy, libfvhip), Cint, (Ptr{Cvoid},), t.handle); t.handle = C_NULL), tr)
+		return tr
+	end
+end
+
+function knottimes(tr::DeviceTrajectory)
+	n = Ref{Int64}(0)
+	check(tr.problem.ctx, ccall((:fv_trajectory_size, libfvhip), Cint, (Ptr{Cvoid}, Ref{Int64}), tr.handle, n))
+	ts = Array{Float64}(undef, n[])
+	check(tr.problem.ctx, ccall((:fv_trajectory_times, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Int64), tr.handle, ts, n[]))
+	return ts
+end
+
+function knotnodevalues(tr::DeviceTrajectory, k::Integer)     # us[k] after freenodes2nodes (transient.jl:172); k is 1-based
+	u = Array{Float64}(undef, tr.problem.N)
+	check(tr.problem.ctx, ccall((:fv_trajectory_get_nodes, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), tr.handle, k - 1, u))
+	return u
+end
+
+function knotfreevalues(tr::DeviceTrajectory, k::Integer)
+	u = Array{Float64}(undef, tr.problem.n)
+	check(tr.problem.ctx, ccall((:fv_trajectory_get_free, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Float64}), tr.handle, k - 1, u))
+	return u
+end
+
+struct DeviceSolution                # getcontinuoussolution of a trajectory: uc(t) over the free cells, interpolated on the device
+	trajectory::DeviceTrajectory
+	problem::Problem
+end
+function (uc::DeviceSolution)(t)
+	u = Array{Float64}(undef, uc.problem.n)
+	check(uc.problem.ctx, ccall((:fv_trajectory_eval_free, libfvhip), Cint, (Ptr{Cvoid}, Float64, Ptr{Float64}), uc.trajectory.handle, t, u))
+	return u
+end
+
+# backwardeulerintegrate(...) of transient.jl:156-163 with `us` kept in HBM: the default stepper, the device PCG, a constant b
+function devicesolution(u0, tspan, Ss::Number, volumes::Vector, neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Vector, conductivities::Vector, sources::Vector, dirichletnodes::Array{Int, 1}, dirichletheads::Vector, metaindex=nothing, logtransformconductivity=false; dt0=1.0, atol=1e-4, rtol=sqrt(eps(Float64)), maxiter=1000, maxsteps=1 << 20)
+	p = transientproblem(u0, Ss, volumes, neighbors, areasoverlengths, conductivities, sources, dirichletnodes, dirichletheads, metaindex, logtransformconductivity)
+	tr = DeviceTrajectory(p)
+	check(p.ctx, ccall((:fv_trajectory_record, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), p.handle, tr.handle, tspan[1]))
+	ts = Array{Float64}(undef, maxsteps + 1)
+	nouter = Ref{Int64}(0)
+	nsolves = Ref{Int64}(0)
+	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
+	rc = ccall((:fv_transient_run_adaptive, libfvhip), Cint, (Ptr{Cvoid}, Int32, Float64, Float64, Float64, Float64, Float64, Int64, Int64, Ptr{Float64}, Ref{Int64}, Ref{Int64}, Ref{SolveInfo}),
+		p.handle, Int32(0), tspan[1], tspan[2], dt0, atol, rtol, maxiter, maxsteps, ts, nouter, nsolves, info)
+	ccall((:fv_trajectory_record, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64), p.handle, C_NULL, 0.0)
+	check(p.ctx, rc)
+	return DeviceSolution(tr, p)
+end
+
+mutable struct DeviceObservation      # fv_observation: obsfreenodes with uobs_i(t), sigma(i, t) as series over tobs (rows: knots)
+	problem::Problem
+	handle::Ptr{Cvoid}
+end
+function deviceobservation(p::Problem, obsfreenodes, tobs::Vector, uobs::Matrix, sigma::Union{Nothing, Matrix}=nothing)
+	size(uobs) == (length(tobs), length(obsfreenodes)) || error("uobs must be length(tobs) x length(obsfreenodes)")
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	U = Float64[uobs[k, j] for j = 1:size(uobs, 2), k = 1:size(uobs, 1)]   # one row per knot in memory
+	S = sigma === nothing ? Ptr{Float64}(C_NULL) : Float64[sigma[k, j] for j = 1:size(sigma, 2), k = 1:size(sigma, 1)]
+	check(p.ctx, ccall((:fv_observation_create, libfvhip), Cint, (Ptr{Cvoid}, Int64, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+		p.handle, length(obsfreenodes), Int64[obsfreenodes...], length(tobs), Float64[tobs...], U, S, h))
+	o = DeviceObservation(p, h[])
+	finalizer(x -> (x.handle == C_NULL || ccall((:fv_observation_destroy, libfvhip), Cint, (Ptr{Cvoid},), x.handle); x.handle = C_NULL), o)
+	return o
+end
+
+function objectiveintegral(uc::DeviceSolution, obs::DeviceObservation, tspan)    # G(uc_p), transientadjointutils.jl:46-49
+	G = Ref{Float64}(0.0)
+	check(uc.problem.ctx, ccall((:fv_observation_integral, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Ref{Float64}), uc.trajectory.handle, obs.handle, tspan[1], tspan[2], G))
+	return G[]
+end
+
+# adjointintegrate(t->dgdu(uc_p, t), tspan, ...) of transient.jl:188-205 with dgdu evaluated on the device at T - t
+function adjointintegrate(uc::DeviceSolution, obs::DeviceObservation, tspan; dt0=1.0, atol=1e-4, rtol=sqrt(eps(Float64)), maxiter=1000, maxsteps=1 << 20, fixedstep=false)
+	p = uc.problem
+	lam = DeviceTrajectory(p)
+	nouter = Ref{Int64}(0)
+	nsolves = Ref{Int64}(0)
+	info = Ref(SolveInfo(0, 0, 0.0, 0.0, 0.0, 0))
+	check(p.ctx, ccall((:fv_adjoint_run, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Float64, Cint, Float64, Float64, Int64, Int64, Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{SolveInfo}),
+		p.handle, uc.trajectory.handle, obs.handle, tspan[1], tspan[2], dt0, fixedstep ? 0 : 1, atol, rtol, maxiter, maxsteps, lam.handle, nouter, nsolves, info))
+	return DeviceSolution(lam, p)
+end
+
+# the integral over tspan of dfdp(uc, t, p)' * lambda(t), per face (conductivity and Dirichlet-head terms) and per free row (sources):
+# integratedfdplambda / gradientintegrate's I2 (transient.jl:208-219) with both factors read from HBM
+function integratedfdplambda(uc::DeviceSolution, lam::DeviceSolution, tspan, lambdascale::Union{Nothing, Vector}, logtransformconductivity::Bool; scalebystorage::Bool=false)
+	p = uc.problem
+	facek = Array{Float64}(undef, p.F)
+	facedir = Array{Float64}(undef, p.F)
+	rowsrc = Array{Float64}(undef, p.n)
+	check(p.ctx, ccall((:fv_param_gradient_integral_traj, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Float64, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+		p.handle, uc.trajectory.handle, lam.trajectory.handle, tspan[1], tspan[2], scalebystorage ? 1 : 0, lambdascale === nothing ? Ptr{Float64}(C_NULL) : Float64[lambdascale...], logtransformconductivity ? 1 : 0, facek, facedir, rowsrc))
+	return facek, facedir, rowsrc
+end
+
 end # module

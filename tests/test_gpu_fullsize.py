@@ -261,13 +261,10 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
     try:
         ys, forms = {}, {}
         tiled_ok = ns[2] % 2 == 0  # the tiled traversal wants lines of an even number of rows
-        for name, knobs in (("sym march", {9: 2, 6: 1, 27: 1, 37: 1, 38: 0}), ("sym march m=1", {9: 2, 10: 1, 27: 1, 38: 0}), ("sym march m=5", {9: 2, 10: 5, 38: 0}),
-                            ("sym march, plain loads", {9: 2, 28: 0, 38: 0}),
-                            ("sym march, streamed diagonal", {9: 2, 37: 0, 38: 0}), ("sym march, derived diagonal again", {9: 2, 37: 1, 38: 0}),
-                            ("sym tiled", {9: 2, 38: 1}), ("sym tiled, streamed diagonal", {9: 2, 38: 1, 37: 0}), ("sym tiled, plain loads", {9: 2, 28: 0}),
-                            ("sym tiled, 3 segments", {9: 2, 40: 3}), ("sym tiled, 36 segments", {9: 2, 40: 36}),
-                            ("march", {9: 2, 6: 1, 18: 1, 27: 0}), ("march m=1", {9: 2, 10: 1}), ("march m=5", {9: 2, 10: 5}), ("march, no windows", {9: 2, 18: 0}),
-                            ("slices", {9: 0, 6: 1}), ("csr", {9: 0, 6: 0})):
+        # fv_tune key 27 = the richest form a structured operator may take: 0 CSR stream, 1 slices, 2 marching, 3 symmetric marching, 4 tiled
+        for name, knobs in (("sym march", {9: 2, 27: 3, 37: 1}), ("sym march, streamed diagonal", {9: 2, 27: 3, 37: 0}), ("sym march, derived diagonal again", {9: 2, 27: 3, 37: 1}),
+                            ("sym tiled", {9: 2, 27: 4}), ("sym tiled, streamed diagonal", {9: 2, 27: 4, 37: 0}),
+                            ("march", {9: 2, 27: 2}), ("slices", {9: 0, 27: 1}), ("csr", {9: 0, 27: 0})):
             for k, v in knobs.items():
                 assert lib.fv_tune(k, v) == 0
             lib.fv_tune(25, 1)
@@ -283,11 +280,8 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
             assert p.spmv_form()[0] == (4 if tiled else 3 if name.startswith("sym") else 2 if name.startswith("march") else 1 if name == "slices" else 0)
             ys[name] = y
             forms[name] = p.spmv_form()[2]
-            lib.fv_tune(10, 0)
-            lib.fv_tune(28, 5)
             lib.fv_tune(37, 1)
-            lib.fv_tune(38, 1)
-            lib.fv_tune(40, 0)
+            lib.fv_tune(27, 4)
         # the DIA forms sum a row's terms in ascending column order with fused multiply-adds, absent entries as zeros: the same
         # bits (the CSR stream rounds every product on its way through LDS, so it only agrees to rounding)
         for name in ys:
@@ -298,7 +292,7 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         assert forms["sym tiled"] == forms["sym march"] and forms["sym tiled, streamed diagonal"] == forms["sym march, streamed diagonal"]
         # the fixed-dt run uses K1 = SpMV + p.q through the same kernel: a few steps must agree between the forms
         heads = {}
-        for name, knobs in (("sym tiled", {9: 2, 6: 1, 27: 1, 37: 1, 38: 1}), ("sym march", {38: 0}), ("sym march, streamed diagonal", {37: 0}), ("march", {9: 2, 6: 1, 27: 0}), ("slices", {9: 0, 6: 1})):
+        for name, knobs in (("sym tiled", {9: 2, 27: 4, 37: 1}), ("sym march", {27: 3}), ("sym march, streamed diagonal", {37: 0}), ("march", {9: 2, 27: 2, 37: 1}), ("slices", {9: 0, 27: 1})):
             for k, v in knobs.items():
                 lib.fv_tune(k, v)
             st = p.new_state()
@@ -315,14 +309,8 @@ def test_structured_spmv_forms_agree_above_the_ordering_threshold(fv, ns, capfd)
         assert forms["sym march folded"] < forms["sym march, streamed diagonal folded"] - 6 * (p.n - 3 * (ns[1] - 2) * ns[2])
     finally:
         lib.fv_tune(9, 1)
-        lib.fv_tune(6, 1)
-        lib.fv_tune(10, 0)
-        lib.fv_tune(18, 1)
-        lib.fv_tune(27, 1)
-        lib.fv_tune(28, 5)
+        lib.fv_tune(27, 4)
         lib.fv_tune(37, 1)
-        lib.fv_tune(38, 1)
-        lib.fv_tune(40, 0)
 
 
 def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(fv, capfd):
@@ -343,11 +331,10 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
     x = rng.standard_normal(p.n)
     lib = fv.load()
     lib.fv_tune(25, 200)  # the kernel choices of the first block products go to stderr: the marching kernel must really run on a block's window
-    # 9 = 2: marching at any size; 1: the library's choice; 27: the symmetric form (default; at any size); 38: its tiled traversal (default)
+    # 9 = 2: marching at any size; 1: the library's choice; 27: the richest form allowed (4 tiled = default, 3 symmetric marching, 2 marching)
     for sigma, forced, sym, tiled in ((0.0, 2, 1, 1), (1 / 60.0, 2, 1, 1), (1 / 60.0, 2, 1, 0), (1 / 60.0, 2, 0, 0), (1 / 60.0, 1, 1, 1)):
         lib.fv_tune(9, forced)
-        lib.fv_tune(27, sym)
-        lib.fv_tune(38, tiled)
+        lib.fv_tune(27, 4 if (sym and tiled) else 3 if sym else 2)
         y_global = p.spmv(x, sigma)
         for nranks in (2, 3):
             for rank in range(nranks):
@@ -359,8 +346,7 @@ def test_row_blocks_above_the_ordering_threshold_use_the_marching_interior_pass(
                 assert np.abs(y - y_global[blk.lo : blk.hi]).max() <= 1e-13 * np.abs(y_global).max(), (nranks, rank, sigma)
                 blk.close()
     lib.fv_tune(25, 0)
-    lib.fv_tune(27, 1)
-    lib.fv_tune(38, 1)
+    lib.fv_tune(27, 4)
     trace = capfd.readouterr().err
     assert "SpMV: symmetric tiled kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace
     assert "SpMV: symmetric plane-marching kernel, n 1227600 (+39600 halo), 18562 slices (subset), plane stride 39600, window [0, 18562)" in trace

@@ -58,7 +58,7 @@ for rep in range(3):
     t = time.perf_counter() - t
     print("row-block driver rows %d  %.3f ms/step (device %.3f)  %.2f it/step" % (blk.nloc, t / steps * 1e3, ms / steps, it.mean()), flush=True)
 if os.environ.get("FV_BLOCK_RATE_AB"):  # in-process A/B of a tune key, e.g. FV_BLOCK_RATE_AB=22 (process-to-process noise is ~10 us)
-    spec = os.environ["FV_BLOCK_RATE_AB"]  # "22" (values 1, 0) or "26=3,0"
+    spec = os.environ["FV_BLOCK_RATE_AB"]  # "22" (values 1, 0) or "50=1,0"
     key = int(spec.split("=")[0])
     vals = [int(v) for v in spec.split("=")[1].split(",")] if "=" in spec else [1, 0]
     for rep in range(4):

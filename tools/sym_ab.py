@@ -17,7 +17,7 @@ lib = fv.load()
 ns_ = sys.argv[1] if len(sys.argv) > 1 else "464"
 variants = sys.argv[2:] or ["27=0", "27=1", "27=1,28=0", "27=1,28=1", "27=1,28=3", "27=1,28=7", "27=1,10=1", "27=1,10=2", "27=1,10=3", "27=1,10=4", "27=1,10=6",
                             "27=1,29=1", "27=1,29=2", "27=1,29=3", "27=1,29=4", "27=1,29=7"]
-DEFAULTS = {27: 1, 28: 4, 29: 0, 10: 0, 9: 1, 30: 8}
+DEFAULTS = {27: 4, 37: 1, 9: 1}
 ns = [int(v) for v in ns_.split("x")] if "x" in ns_ else [int(ns_)] * 3
 mins, maxs = bench.spacing_box(ns)
 dn, src = bench.box_setup(ns)
