@@ -614,12 +614,14 @@ def multi_iteration_block(p, args):
     upd = 25 if loop in (76, 98) else 32  # 83 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
     per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
-    out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)),
+    regime = step_regime_roofline(p, iters, sec / steps, 0, 0, 0)  # every launch of a step: carried set-up, first product and update, the loop
+    out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)), "roofline": regime,
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
            "bytes_model": ("fused pass x += alpha p, p' = z + beta p, w = -M^-1 (A + D/dt) p' (%d n: z, p, x in, p', w, x out, the 3 upper diagonals%s, storage codes) + vector update z' = z + alpha w (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 60 else "", upd, ": M^-1 as a code byte" if upd == 25 else "") if loop
                            else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "frac_note": "frac_of_peak charges one loop iteration's bytes against wall time / iterations, i.e. it leaves the step's set-up, first product and first update (~170 B per row and step) unaccounted; `roofline` counts every launch of a step",
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
     for k, bytes_ in ((("spmv_dot", (loop - upd) * p.n), ("update", upd * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]

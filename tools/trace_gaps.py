@@ -11,13 +11,13 @@ from collections import defaultdict
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # the stepping loop: from the first K2S (or fused step) launch to the last
-MARK = "fused_step_kernel" if any("fused_step_kernel" in r["Kernel_Name"] for r in rows) else "pcg_update_spec_kernel"
+MARK = next((m for m in ("fused_chunk_kernel", "fused_step_kernel") if any(m in r["Kernel_Name"] for r in rows)), "pcg_update_spec_kernel")
 idx = [i for i, r in enumerate(rows) if MARK in r["Kernel_Name"]]
 lo, hi = idx[5], idx[-1]
 dur, gap, cnt = defaultdict(float), defaultdict(float), defaultdict(int)
 steps = sum(1 for i in range(lo, hi) if MARK in rows[i]["Kernel_Name"])
 for i in range(lo, hi):
-    k = rows[i]["Kernel_Name"].split("(")[0].replace("void ", "")[:48]
+    k = rows[i]["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:48]
     d = int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])
     g = int(rows[i + 1]["Start_Timestamp"]) - int(rows[i]["End_Timestamp"])
     dur[k] += d
