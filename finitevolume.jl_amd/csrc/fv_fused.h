@@ -33,7 +33,7 @@ int fv_fused_convert_groups(fv_problem *p, const int32_t *groups, int64_t count,
 // vform_sigma != 0: y receives v = -M^-1 (q - vform_sigma D x) instead of q (the fused step's v-form), the partial sums are of x.q
 // wform: y receives w = -M^-1 q (the many-iteration loop's form of the product)
 int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done = false, double vform_sigma = 0.0,
-                 bool wform = false);
+                 bool wform = false, bool irregular_only = false);
 bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded);
 // x: the iterate, updated in place by x += alpha_last * p (the lagging update of the previous iteration) when xapply is set
 int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq, double *x, bool xapply);

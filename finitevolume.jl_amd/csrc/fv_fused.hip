@@ -55,6 +55,7 @@ struct KfArgs {
     // geometry: lines of nz rows, planes of d3 rows, nplanes = one past the last plane whose product this kernel forms
     int32_t nz, L, d3, nplanes, P, seglen, tilesC, tiles, nsegs;
     int32_t chunk; // fused_chunk_kernel: rows of a plane per work item (tiles = chunks per plane)
+    int32_t pfirst; // ... its first product plane: 1, or 0 when the first and the last plane are centre planes too (kc_ends; nplanes is then P)
     // the symmetric arrays (row 0 pointers: zero-padded in front and behind), flags per 64-row slice, storage codes
     const double *dg, *u1, *u2, *u3;
     const uint8_t *ok, *code;
@@ -733,10 +734,13 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             break;
         const int32_t seg = (int32_t)(item / a.tiles), chunk = (int32_t)(item % a.tiles);
         const int32_t cs = chunk * C, Cl = (cs + C <= d3) ? C : d3 - cs; // the chunk's rows of a plane: [cs, cs + Cl)
-        const int32_t p0 = 1 + seg * a.seglen, p1 = (p0 + a.seglen < a.nplanes) ? p0 + a.seglen : a.nplanes;
+        const int32_t p0 = a.pfirst + seg * a.seglen, p1 = (p0 + a.seglen < a.nplanes) ? p0 + a.seglen : a.nplanes;
         if (p0 >= p1 || Cl <= 0)
             continue;
-        const bool vec_first = p0 == 1, vec_last = p1 == a.nplanes && a.nplanes == a.P - 1;
+        // pfirst = 0 (the end planes are centre planes like the others: their rows' diagonals come out of the table): no plane is
+        // anybody's vector-part-only plane; plane -1 and plane P do not exist — their z' count as zero beside a zero matrix entry
+        const bool vec_first = a.pfirst == 1 && p0 == 1, vec_last = a.pfirst == 1 && p1 == a.nplanes && a.nplanes == a.P - 1;
+        const int64_t nrows8 = (int64_t)a.n * 8; // a halo row outside the vectors (in front of plane 0, behind plane P - 1) is not read
         bool own[NP];
         uint32_t ob[NP]; // byte offset of the pair's doubles inside a plane
 #pragma unroll
@@ -771,6 +775,10 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         };
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
         auto MW = [&](int32_t pl, int k) -> uint32_t { return *reinterpret_cast<const uint32_t *>(PB(a.mcode, pl, 2) + (ob[k] >> 2)); };
+        auto HIN = [&](int32_t pl, int r) -> bool { // the halo row exists (always, unless the end planes are centre planes)
+            const int64_t off = (int64_t)pl * d3 * 8 + (int64_t)hb[r];
+            return off >= 0 && off < nrows8;
+        };
         auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + (int64_t)hb[r]); };
         auto HW = [&](int32_t pl, int r) -> uint16_t { return *reinterpret_cast<const uint16_t *>(PB(a.mcode, pl, 2) + (int64_t)(hb[r] >> 2)); };
         auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]) = val; };
@@ -786,8 +794,9 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         int zb = p0 & 1;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            const double2 vv = P2(a.v, p0 - 1, k), zz = P2(a.z, p0 - 1, k);
-            Zm[k] = make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y);
+            const int32_t pm = p0 > 0 ? p0 - 1 : 0; // (p0 = 0: there is no plane before it; what is loaded here is not used)
+            const double2 vv = P2(a.v, pm, k), zz = P2(a.z, pm, k);
+            Zm[k] = p0 > 0 ? make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y) : make_double2(0.0, 0.0);
             if (MODE == 1 && vec_first && own[k]) {
                 ST2(a.znext, 0, k, Zm[k]);
                 if (XU) {
@@ -806,7 +815,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 acc[3] += ra.c * ra.c + rb.c * rb.c;
                 acc[4] += ra.h * ra.h + rb.h * rb.h;
             }
-            const uint32_t wm = MW(p0 - 1, k);
+            const uint32_t wm = MW(pm, k);
             const uint32_t u3m = ((wm >> 10) & 31u) | (((wm >> 26) & 31u) << 5);
             const double2 v0 = P2(a.v, p0, k), z0 = P2(a.z, p0, k);
             const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
@@ -841,17 +850,19 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
 #pragma unroll
         for (int r = 0; r < HR; r++)
             if (hv[r]) {
-                zs[zb * ZL + hs[r]] = H1(a.z, p0, r) + alpha * H1(a.v, p0, r);
+                const bool in = HIN(p0, r);
+                zs[zb * ZL + hs[r]] = in ? H1(a.z, p0, r) + alpha * H1(a.v, p0, r) : 0.0;
                 if (hbefore[r])
-                    ws[(p0 & 1) * WL + hs[r]] = HW(p0, r);
+                    ws[(p0 & 1) * WL + hs[r]] = in ? HW(p0, r) : (uint16_t)0;
             }
+        const int32_t pn = p0 + 1 < a.P ? p0 + 1 : p0; // (a one-plane segment at the very end: nothing behind it)
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            Za[k] = P2(a.z, p0 + 1, k);
-            Va[k] = P2nt(a.v, p0 + 1, k);
-            Xa[k] = XU ? P2nt(a.x, p0 + 1, k) : make_double2(0.0, 0.0);
-            Wa[k] = MW(p0 + 1, k);
-            Ma[k] = C2(p0 + 1, k);
+            Za[k] = P2(a.z, pn, k);
+            Va[k] = P2nt(a.v, pn, k);
+            Xa[k] = XU ? P2nt(a.x, pn, k) : make_double2(0.0, 0.0);
+            Wa[k] = MW(pn, k);
+            Ma[k] = C2(pn, k);
         }
         double hz[HR], hq[HR];
         uint16_t hw[HR];
@@ -859,7 +870,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         for (int r = 0; r < HR; r++) {
             hz[r] = hq[r] = 0.0;
             hw[r] = 0;
-            if (hv[r] && p0 + 1 < p1) {
+            if (hv[r] && p0 + 1 < p1 && HIN(p0 + 1, r)) {
                 hz[r] = H1(a.z, p0 + 1, r);
                 hq[r] = H1(a.v, p0 + 1, r);
                 if (hbefore[r])
@@ -871,9 +882,10 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
 #pragma unroll
             for (int k = 0; k < NP; k++)
                 asm volatile("" : "+v"(ob[k])); // (opaque: one 32-bit offset per pair beside the scalar plane bases, no 64-bit lane addresses kept alive)
-            const bool inseg = p + 1 < p1, more = p + 2 <= p1;
+            const bool inseg = p + 1 < p1, more = p + 2 <= p1 && p + 2 < a.P;
+            const bool nextp = p + 1 < a.P;          // there is a plane behind the centre plane
             const bool vec_n = inseg || vec_last;   // plane p + 1's vector part is ours
-            const bool lastplane = p + 1 == a.P - 1; // ... and it never becomes a centre plane: its diagonal terms now, from the stored diagonal
+            const bool lastplane = vec_last && p + 1 == a.P - 1; // ... and it never becomes a centre plane: its diagonal terms now, from the stored diagonal
             const double *zc = zs + zb * ZL + nz;
             double *zn_ = zs + (zb ^ 1) * ZL + nz;
             const uint16_t *wc_ = ws + (p & 1) * WL + nz;
@@ -882,7 +894,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             for (int k = 0; k < NP; k++) {
                 const int lr = own[k] ? 2 * (tid + NT * k) : 0; // (pairs beyond the chunk compute on its first rows; nothing of theirs is kept)
                 // ---- (a) plane p + 1: z', x_out; its z' and codes into the other LDS slots
-                const double2 Zn = make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y);
+                const double2 Zn = nextp ? make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y) : make_double2(0.0, 0.0);
                 double2 dxn = make_double2(0.0, 0.0);
                 const uint32_t Mn = Ma[k];
                 if (MODE == 0) {
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 const double2 A3c = make_double2(T3[(wc >> 10) & 31u], T3[(wc >> 26) & 31u]);
                 const double v1m0 = T1[wm1 & 31u];
                 const double2 V2m = make_double2(T2[(wl >> 5) & 31u], T2[(wl >> 21) & 31u]);
-                const double2 A3m = make_double2(T3[(M >> 18) & 31u], T3[(M >> 23) & 31u]);
+                const double2 A3m = p > 0 ? make_double2(T3[(M >> 18) & 31u], T3[(M >> 23) & 31u]) : make_double2(0.0, 0.0);
                 const double2 Sc = SD(M);
                 // the diagonal: zero row sum — from the six arms, in the order the assembly added them (+ sigma D) —, or, on a row
                 // whose stored diagonal is something else (a Dirichlet neighbour), out of the table by the row's code
@@ -1012,10 +1024,15 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                         ws[((p + 1) & 1) * WL + hs[r]] = hw[r];
                 }
                 if (hv[r] && p + 2 < p1) {
+                    const bool in = HIN(p + 2, r);
+                    hz[r] = hq[r] = 0.0;
+                    hw[r] = 0;
+                    if (in) {
                     hz[r] = H1(a.z, p + 2, r);
                     hq[r] = H1(a.v, p + 2, r);
                     if (hbefore[r])
                         hw[r] = HW(p + 2, r);
+                    }
                 }
             }
             __syncthreads();
@@ -1386,6 +1403,11 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
         return false;
     a.kcode = p->kc_code.p;
     a.kdiag = p->kc_dtab;
+    a.pfirst = 1;
+    if (p->kc_ends && !p->dist) { // the first and the last plane are centre planes too: no slice-by-slice launch behind the kernel for them
+        a.pfirst = 0;
+        a.nplanes = a.P;
+    }
     // 512 threads x 5 pairs of rows per thread: the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD.
     // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
@@ -1418,9 +1440,10 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
         if (Cr > cmax || Cr < 2 * nz)
             continue;
         const int64_t Ke = (d3 + Cr - 1) / Cr;
-        for (int m = 1; m <= 64 && m <= a.nplanes - 1; m++) {
+        const int nprod = a.nplanes - a.pfirst; // product planes
+        for (int m = 1; m <= 64 && m <= nprod; m++) {
             const int64_t rounds = (Ke * m + resident - 1) / resident;
-            const double cost = (double)rounds * (double)((a.nplanes - 1 + m - 1) / m + 3) * ((double)Cr + 0.6 * (double)nz);
+            const double cost = (double)rounds * (double)((nprod + m - 1) / m + 3) * ((double)Cr + 0.6 * (double)nz);
             if (best < 0.0 || cost < best) {
                 best = cost;
                 bestK = Ke;
@@ -1431,13 +1454,11 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
     }
     if (best < 0.0)
         return false;
-    if (g_fused_segs > 0 && g_fused_segs <= a.nplanes - 1)
-        bestm = g_fused_segs;
     a.chunk = (int32_t)bestC;
     a.tiles = (int32_t)bestK;
     a.tilesC = 1;
     a.nsegs = bestm;
-    a.seglen = (a.nplanes - 1 + bestm - 1) / bestm;
+    a.seglen = (a.nplanes - a.pfirst + bestm - 1) / bestm;
     int64_t g = (((int64_t)a.tiles * a.nsegs + 7) / 8) * 8;
     if (g > resident)
         g = resident;
@@ -1601,8 +1622,9 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     // the slices the symmetric form leaves out (first / last plane, irregular ones): classic product of z' into v', then v-form
     int GR = 0;
     const int GK = chunks ? kc.grid : GF;
-    if (p->sym_nrest > 0) {
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GK, &GR, false, sigma)); // (stored in the v-form by the launch itself)
+    const bool ends = chunks && a.pfirst == 0;
+    if (ends ? p->sym_nrest_irr > 0 : p->sym_nrest > 0) {
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->qv2.p, folded, out.pq + GK, &GR, false, sigma, false, ends)); // (stored in the v-form by the launch itself)
     }
     out.npq = GK + GR;
     p->fused_chunked = chunks;
@@ -1610,7 +1632,7 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     {
         // every array once: x, z, v in and x_out, z', v' out on all rows (48) + a code byte; the three upper diagonals on the rows
         // whose product this kernel forms (24), + the stored diagonal where it is not re-derived (8)
-        const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - p->sym_nrest, nder = p->sym_nderived;
+        const int64_t nok = (p->dist ? p->dist->int_hi - p->dist->int_lo : p->ndia) - (ends ? p->sym_nrest_irr : p->sym_nrest), nder = ends ? nok : p->sym_nderived; // (chunks: no diagonal stream at all)
         const int mb = coded ? 2 : 24;
         p->fused_bytes = (nder * 2 >= nok ? 73 : 81) - 24 + mb;
         p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + mb * 64 * nok + 8 * 64 * (nok - nder);
@@ -1715,8 +1737,9 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     FV_LAUNCH_CHECK(ctx);
     int GR = 0;
     const int GK = chunks ? kc.grid : GF;
-    if (p->sym_nrest > 0)
-        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true, 0.0, true)); // (stored as w as well)
+    const bool ends = chunks && a.pfirst == 0;
+    if (ends ? p->sym_nrest_irr > 0 : p->sym_nrest > 0)
+        FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true, 0.0, true, ends)); // (stored as w as well)
     *npq = GK + GR;
     p->fused_chunked = chunks;
     return FV_OK;

@@ -279,6 +279,11 @@ struct fv_problem {
     int last_form = -1; // FV_SPMV_* of the most recent spmv_apply (fv_spmv_form)
     // the fused step's chunk kernel (fv_fused.hip): per row, storage code | diagonal code << 4 (build_chunk_codes, fv_spmv.hip); built with
     // the symmetric copy's values (same assembly, same folded shift, same storage codes); kc_state: 0 not applicable, 1 built
+    DevBuf<uint8_t> sym_reg;       // per 64-row slice: offsets all among 0, +-sym_d[k] whatever the marching kernels' windows need (the first / last plane too)
+    DevBuf<int32_t> sym_rest_irr;  // the DIA slices that are not even that (the chunk traversal with kc_ends leaves only these to the slice-by-slice kernel)
+    int64_t sym_nrest_irr = 0;
+    bool kc_ends = false;          // the chunk traversal's centre planes include the first and the last plane
+    int kc_ends_switch = -1;       // fv_tune key 60's end-plane choice as it was when the codes were built
     DevBuf<uint8_t> kc_code;
     StorageTable kc_dtab = {};
     int kc_state = 0, kc_ndiag = 0;

@@ -422,6 +422,7 @@ static int g_march = 1;      // plane-marching sliced-DIA kernel on structured g
 static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
 static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
 int g_fold_shift = 1;
+int g_chunk_ends = 1; // (part of fv_tune key 60: value 2 keeps the first / last plane's products with the slice-by-slice launch)
 static int g_symdia = 1; // fv_tune key 27 >= 3: symmetric plane-marching form where the marching kernel runs
 static int g_march_form = 1; // fv_tune key 27 >= 2: the plane-marching kernels at all (0: structured operators stay with the slice-by-slice kernel)
 static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
@@ -513,8 +514,10 @@ extern "C" int fv_tune(int key, int value)
         g_fused_sell = value;
     else if (key == 59 && (value == 0 || value == 1))
         g_minv_codes = value;
-    else if (key == 60 && (value == 0 || value == 1))
-        g_fused_chunk = value;
+    else if (key == 60 && value >= 0 && value <= 2) { // 1: chunks, the first / last plane's products included; 2: chunks, those planes by the slice-by-slice launch; 0: tiles
+        g_fused_chunk = value != 0;
+        g_chunk_ends = value == 1;
+    }
     else if (key == 61 && value >= 0)
         g_small_n = value;
     else
@@ -1578,7 +1581,7 @@ __global__ __launch_bounds__(FV_TILE_T, 4) void spmv_symdia_tile_kernel(int64_t 
 __global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                 int32_t d1, int32_t d2, int32_t d3, int64_t step, int64_t ncols,
                                                                 int64_t win_lo, int64_t win_hi, uint8_t *__restrict__ ok,
-                                                                int32_t *__restrict__ rest)
+                                                                int32_t *__restrict__ rest, uint8_t *__restrict__ reg, int32_t *__restrict__ rest_irr)
 {
     const int64_t sl = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (sl >= nslices)
@@ -1586,6 +1589,8 @@ __global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, 
     if (sl < win_lo || sl >= win_hi) { // outside the window this form serves (a row block's boundary slices): not ours either way
         ok[sl] = 0;
         rest[sl] = 0;
+        reg[sl] = 0;
+        rest_irr[sl] = 0;
         return;
     }
     const int noff = sl_noff[sl];
@@ -1593,13 +1598,19 @@ __global__ __launch_bounds__(FV_BLOCK) void symdia_flag_kernel(int64_t nslices, 
     // of the slices one plane step before and after it must lie inside [0, ncols)
     const int64_t base = sl << 6, bp = (sl - step) << 6, bn = (sl + step) << 6;
     bool good = noff > 0 && bp >= 32 && bn + 96 <= ncols && base >= d2 && base + 64 + d2 <= ncols;
+    bool regular = noff > 0;
     for (int k = 0; k < noff; k++) {
         int32_t o = sl_off[sl * DIA_K + k];
         o = o < 0 ? -o : o;
-        good = good && (o == 0 || o == d1 || o == d2 || o == d3);
+        regular = regular && (o == 0 || o == d1 || o == d2 || o == d3);
     }
+    good = good && regular;
     ok[sl] = good ? 1 : 0;
     rest[sl] = (noff > 0 && !good) ? 1 : 0;
+    // the offsets alone (whatever the windows of the marching / tiled kernels need): the fused step's chunk traversal, which clamps
+    // nothing and reads no window, forms the products of these slices too — the first and the last plane of a box
+    reg[sl] = regular ? 1 : 0;
+    rest_irr[sl] = (noff > 0 && !regular) ? 1 : 0;
 }
 
 // the four arrays from the (possibly diagonal-folded) CSR values; absent entries keep the zeros of the allocation
@@ -1719,8 +1730,10 @@ static int build_symdia(fv_problem *p)
         return FV_OK;
     const int32_t d1 = off[4], d2 = off[5], d3 = off[6];
     FV_TRY(p->sym_ok.alloc(ctx, (size_t)ns));
-    DevBuf<int32_t> restflag;
+    FV_TRY(p->sym_reg.alloc(ctx, (size_t)ns));
+    DevBuf<int32_t> restflag, restirr;
     FV_TRY(restflag.alloc(ctx, (size_t)ns));
+    FV_TRY(restirr.alloc(ctx, (size_t)ns));
     int sh = (int)(d3 % 64);
     if (sh > 32)
         sh -= 64; // signed lane shift of the march (spmv_apply computes the same)
@@ -1728,13 +1741,17 @@ static int build_symdia(fv_problem *p)
     // windows would land in the halo slots — goes to the slice-by-slice kernel like the last plane of a whole operator, so
     // that "planes 1 .. P - 2" is the symmetric form's range everywhere; the fused step relies on it)
     hipLaunchKernelGGL(symdia_flag_kernel, dim3(fv_blocks(ns)), dim3(FV_BLOCK), 0, ctx->stream, ns, (const uint8_t *)p->sl_noff.p,
-                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n, win_lo, win_hi, p->sym_ok.p, restflag.p);
+                       (const int32_t *)p->sl_off.p, d1, d2, d3, ((int64_t)d3 - sh) / 64, p->n, win_lo, win_hi, p->sym_ok.p, restflag.p, p->sym_reg.p, restirr.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY(p->sym_rest.alloc(ctx, (size_t)ns));
     FV_TRY(fv_compact_flags(ctx, restflag.p, ns, p->sym_rest.p, &p->sym_nrest));
+    FV_TRY(p->sym_rest_irr.alloc(ctx, (size_t)ns));
+    FV_TRY(fv_compact_flags(ctx, restirr.p, ns, p->sym_rest_irr.p, &p->sym_nrest_irr));
     if (!p->dist && (p->ndia - p->sym_nrest) * 10 < ns * 9) { // too few slices of that shape to bother
         p->sym_ok.release();
         p->sym_rest.release();
+        p->sym_reg.release();
+        p->sym_rest_irr.release();
         return FV_OK;
     }
     p->sym_d[0] = d1;
@@ -1836,10 +1853,13 @@ static int build_matrix_codes(fv_problem *p)
 
 // Bit 15 of a row's matrix word: the row's 64-row slice is one whose products the symmetric kernels form (bit 0 of sym_ok) — the
 // chunk kernel of the fused step (fv_fused.hip) then needs no flag stream.  The 5-bit codes below it are untouched.
-__global__ __launch_bounds__(FV_BLOCK) void matrix_code_ok_kernel(int64_t n, const uint8_t *__restrict__ ok, uint16_t *__restrict__ code)
+// reg (may be null): slices of regular offsets whose windows the marching kernels cannot serve — the first / last plane —, which the
+// chunk traversal takes as well when their diagonals fit its table (kc_ends)
+__global__ __launch_bounds__(FV_BLOCK) void matrix_code_ok_kernel(int64_t n, const uint8_t *__restrict__ ok, const uint8_t *__restrict__ reg,
+                                                                   uint16_t *__restrict__ code)
 {
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK)
-        code[i] = (uint16_t)((code[i] & 0x7fffu) | ((ok[i >> 6] & 1) ? 0x8000u : 0u));
+        code[i] = (uint16_t)((code[i] & 0x7fffu) | (((ok[i >> 6] & 1) || (reg && reg[i >> 6])) ? 0x8000u : 0u));
 }
 
 // The code byte per row of the fused step's chunk kernel (fv_internal.h: kc_code): low nibble = the row's storage code (0 where
@@ -1851,16 +1871,17 @@ __global__ __launch_bounds__(FV_BLOCK) void matrix_code_ok_kernel(int64_t n, con
 __global__ __launch_bounds__(FV_BLOCK) void chunk_code_kernel(int64_t n, int32_t d1, int32_t d2, int32_t d3, const double *__restrict__ dg,
                                                                const double *__restrict__ u1, const double *__restrict__ u2,
                                                                const double *__restrict__ u3, const uint8_t *__restrict__ dcode, StorageTable tshift,
-                                                               int shift_mode, const uint8_t *__restrict__ ok, StorageTable dtab, int ntab,
-                                                               uint8_t *__restrict__ code, int32_t *__restrict__ claim, double *__restrict__ offered)
+                                                               int shift_mode, const uint8_t *__restrict__ ok, const uint8_t *__restrict__ reg,
+                                                               StorageTable dtab, int ntab, uint8_t *__restrict__ code, int32_t *__restrict__ claim,
+                                                               double *__restrict__ offered)
 {
     bool offered_one = false;
     for (int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * FV_BLOCK) {
         const uint8_t sc = dcode ? dcode[r] : (uint8_t)0;
         int nib = 0;
-        if (r >= d3 && r < n - d3) {
+        if (reg || (r >= d3 && r < n - d3)) { // (reg: the first and the last plane are centre planes of the chunk traversal too)
             bool derived = false;
-            if (ok[r >> 6] & 1) {
+            if ((ok[r >> 6] & 1) || (reg && reg[r >> 6])) {
                 double so = u3[r - d3] + u2[r - d2];
                 so += u1[r - d1];
                 so += u3[r];
@@ -1895,6 +1916,7 @@ static int build_chunk_codes(fv_problem *p, const uint8_t *dcode, int shift_mode
 {
     fv_ctx *ctx = p->ctx;
     p->kc_state = 0;
+    p->kc_ends = false;
     if (shift_mode < 0 || p->sym_mcode_n <= 0 || !p->sym_mcode.p || p->sym_d[0] != 1)
         return FV_OK;
     const int64_t n = p->n;
@@ -1907,34 +1929,52 @@ static int build_chunk_codes(fv_problem *p, const uint8_t *dcode, int shift_mode
     FV_TRY(offered.alloc(ctx, 1));
     int64_t g = (n + FV_BLOCK - 1) / FV_BLOCK;
     g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
-    int ntab = 0;
-    p->kc_dtab = StorageTable{};
-    for (;;) {
-        FV_TRY(claim.zero(ctx));
-        hipLaunchKernelGGL(chunk_code_kernel, dim3((unsigned)g), dim3(FV_BLOCK), 0, ctx->stream, n, (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], (int32_t)p->sym_d[2],
-                           dg, dg + p->sym_ld, dg + 2 * p->sym_ld, dg + 3 * p->sym_ld, dcode, p->sym_shift, shift_mode, (const uint8_t *)p->sym_ok.p, p->kc_dtab,
-                           ntab, p->kc_code.p, claim.p, offered.p);
-        FV_LAUNCH_CHECK(ctx);
-        int32_t hc = 0;
-        FV_TRY(fv_copy(ctx, &hc, claim.p, sizeof hc));
-        if (!hc)
+    // first with the first / last plane among the centre planes (their rows next to the Dirichlet planes add a few diagonals to the
+    // table; not on row blocks, whose end planes belong to the boundary passes), then — should the table overflow — without them
+    for (int ends = (p->dist || !p->sym_reg.p || !g_chunk_ends) ? 0 : 1; ends >= 0; ends--) {
+        int ntab = 0;
+        bool fits = true;
+        p->kc_dtab = StorageTable{};
+        for (;;) {
+            FV_TRY(claim.zero(ctx));
+            hipLaunchKernelGGL(chunk_code_kernel, dim3((unsigned)g), dim3(FV_BLOCK), 0, ctx->stream, n, (int32_t)p->sym_d[0], (int32_t)p->sym_d[1],
+                               (int32_t)p->sym_d[2], dg, dg + p->sym_ld, dg + 2 * p->sym_ld, dg + 3 * p->sym_ld, dcode, p->sym_shift, shift_mode,
+                               (const uint8_t *)p->sym_ok.p, ends ? (const uint8_t *)p->sym_reg.p : (const uint8_t *)nullptr, p->kc_dtab, ntab,
+                               p->kc_code.p, claim.p, offered.p);
+            FV_LAUNCH_CHECK(ctx);
+            int32_t hc = 0;
+            FV_TRY(fv_copy(ctx, &hc, claim.p, sizeof hc));
+            if (!hc)
+                break;
+            if (ntab == FV_STORAGE_CODES - 1) { // too many distinct diagonals among the rows that do not derive theirs
+                fits = false;
+                break;
+            }
+            ntab++;
+            FV_TRY(fv_copy(ctx, &p->kc_dtab.v[ntab], offered.p, sizeof(double)));
+        }
+        if (fits) {
+            p->kc_state = 1;
+            p->kc_ndiag = ntab;
+            p->kc_ends = ends != 0;
             break;
-        if (ntab == FV_STORAGE_CODES - 1)
-            return FV_OK; // too many distinct diagonals among the rows that do not derive theirs
-        ntab++;
-        FV_TRY(fv_copy(ctx, &p->kc_dtab.v[ntab], offered.p, sizeof(double)));
+        }
     }
-    p->kc_state = 1;
-    p->kc_ndiag = ntab;
+    if (p->kc_state == 1) { // bit 15 of the matrix words: the rows whose products the chunk traversal forms (the tiles ignore the end planes' bits: their flags are sym_ok's)
+        hipLaunchKernelGGL(matrix_code_ok_kernel, dim3(fv_blocks(p->n) > 4096 ? 4096 : fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n,
+                           (const uint8_t *)p->sym_ok.p, p->kc_ends ? (const uint8_t *)p->sym_reg.p : (const uint8_t *)nullptr, p->sym_mcode.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
     return FV_OK;
 }
 
 static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
 {
     fv_ctx *ctx = p->ctx;
-    if (p->sym_epoch == p->assemble_epoch && p->sym_tag == src_tag && p->sym_rowsum_switch == g_sym_rowsum)
+    if (p->sym_epoch == p->assemble_epoch && p->sym_tag == src_tag && p->sym_rowsum_switch == g_sym_rowsum && p->kc_ends_switch == g_chunk_ends)
         return FV_OK;
     p->sym_rowsum_switch = g_sym_rowsum;
+    p->kc_ends_switch = g_chunk_ends;
     double *dg = p->sym_vals.p + p->sym_front, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld;
     const int32_t d1 = (int32_t)p->sym_d[0], d2 = (int32_t)p->sym_d[1], d3 = (int32_t)p->sym_d[2];
     hipLaunchKernelGGL(symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
@@ -2004,7 +2044,7 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
         p->sym_mcode_epoch = p->assemble_epoch;
         if (p->sym_mcode_n > 0 && p->sym_mcode.p) {
             hipLaunchKernelGGL(matrix_code_ok_kernel, dim3(fv_blocks(p->n) > 4096 ? 4096 : fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n,
-                               (const uint8_t *)p->sym_ok.p, p->sym_mcode.p);
+                               (const uint8_t *)p->sym_ok.p, (const uint8_t *)nullptr, p->sym_mcode.p);
             FV_LAUNCH_CHECK(ctx);
         }
     }
@@ -2672,14 +2712,17 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
 // The slices the symmetric form leaves to the slice-by-slice kernel (first / last plane, irregular ones), on their own: the
 // fused step (fv_fused.hip) forms every other product itself.  `vals`: the value array the lane-major copy was filled from
 // (spmv_apply has done that for the same array and tag before the fused regime is entered).
-int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done, double vform_sigma, bool wform)
+int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, double *partials, int *nparts, bool use_done, double vform_sigma, bool wform,
+                 bool irregular_only)
 {
     fv_ctx *ctx = p->ctx;
     *nparts = 0;
-    if (p->sym_state != 1 || p->sym_nrest <= 0)
+    const int64_t nrest = irregular_only ? p->sym_nrest_irr : p->sym_nrest; // (irregular_only: the chunk traversal has formed the end planes' products itself)
+    const int32_t *rest = irregular_only ? p->sym_rest_irr.p : p->sym_rest.p;
+    if (p->sym_state != 1 || nrest <= 0)
         return FV_OK;
     FV_TRY(ensure_dia_vals(p, vals, vals == p->vals.p ? 0.0 : p->shifted_sigma, !p->dist));
-    const int GR = stream_grid(p->sym_nrest);
+    const int GR = stream_grid(nrest);
     StepInitEpilogue epi{};
     if (vform_sigma != 0.0) { // y receives -M^-1 (q - sigma D x) instead of q
         epi.q_shifted = 2;
@@ -2691,12 +2734,12 @@ int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, 
         epi.minv = p->minv.p;
     }
     if (g_nt)
-        hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
-                           (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
+        hipLaunchKernelGGL((spmv_dia_kernel<true, true, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, nrest,
+                           rest, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
                            partials, use_done ? (const PcgScalars *)p->scal.p : (const PcgScalars *)nullptr, epi);
     else
-        hipLaunchKernelGGL((spmv_dia_kernel<true, false, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, p->sym_nrest,
-                           (const int32_t *)p->sym_rest.p, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
+        hipLaunchKernelGGL((spmv_dia_kernel<true, false, false>), dim3(GR), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, nrest,
+                           rest, p->dia_pos.p, p->sl_noff.p, p->sl_off.p, p->dia_vals.p, x, y, (const double *)nullptr, 0.0,
                            partials, use_done ? (const PcgScalars *)p->scal.p : (const PcgScalars *)nullptr, epi);
     FV_LAUNCH_CHECK(ctx);
     *nparts = GR;

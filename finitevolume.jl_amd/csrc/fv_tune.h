@@ -42,7 +42,8 @@ extern "C" {
  *  54: SELL-64 with 16-bit column offsets (FV_SPMV_SELL) for the groups the CSR wave-stream kernel would serve [1]
  *  55: the fused step on the SELL form (irregular meshes) [1]
  *  59: M^-1 as one-byte codes in the vector pass of the many-iteration loop where it takes at most 16 distinct values [1]
- *  60: the coded fused step / pass on contiguous chunks of a plane (fused_chunk_kernel) [1]; 0 = the 2-D tiles
+ *  60: the coded fused step / pass on contiguous chunks of a plane (fused_chunk_kernel): 1 = with the first / last plane's products formed by it
+ *      too [1], 2 = those planes by the slice-by-slice launch, 0 = the 2-D tiles
  *  61: systems of at most this many rows are solved by the single-launch kernel of fv_small.hip [32768]; 0 = never */
 int fv_tune(int key, int value);
 #ifdef __cplusplus
