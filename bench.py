@@ -552,6 +552,15 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
                 "avg_launch_ms": ms / cnt, "launches": cnt, "spmv": k1}
         tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
         if os.path.exists(tfile):
+            try:  # K1's own stamp
+                t1 = json.load(open(tfile)).get(str(ns))
+                if t1 and t1.get("form") == form_id and abs(t1.get("form_bytes", 0) - form_bytes) <= 0.01 * form_bytes:
+                    k1["traffic"] = t1["bytes"]
+                    k1["traffic_source"] = t1.get("source")
+                    k1["frac_traffic"] = t1["bytes"] / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            except Exception:
+                pass
+        if os.path.exists(tfile):
             try:
                 tj = json.load(open(tfile)).get(("fused_%d" if chunks or fbytes_row >= 60 else "fused_tiles_%d") % ns)
                 if tj and abs(tj.get("form_bytes", 0) - fbytes) <= 0.01 * fbytes and ("chunk" in tj.get("kernel", "")) == chunks:
