@@ -990,11 +990,19 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 t0 += A3c.x * Zn.x;
                 t1 += A3c.y * Zn.y;
                 if (MODE == 1 && own[k] && (wc & 0x8000u)) {
-                    ST2nt(a.vnext, p, k, make_double2(-((1.0 / d.x) * t0), -((1.0 / d.y) * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
+                    const double wx = 1.0 / d.x;
+                    double wy = wx;
+                    if (__double_as_longlong(d.y) != __double_as_longlong(d.x))
+                        wy = 1.0 / d.y;
+                    ST2nt(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
                 if (MODE == 0 && own[k]) {
-                    const double mx = 1.0 / d.x, my = 1.0 / d.y;
+                    // (the two rows of a pair almost always share their diagonal — one conductivity, interior rows —: one division then)
+                    const double mx = 1.0 / d.x;
+                    double my = mx;
+                    if (__double_as_longlong(d.y) != __double_as_longlong(d.x))
+                        my = 1.0 / d.y;
                     if (wc & 0x8000u) {
                         const double2 vn = make_double2(-(mx * (t0 - Sc.x * Zc.x)), -(my * (t1 - Sc.y * Zc.y)));
                         if (a.nt & 2)
