@@ -211,11 +211,22 @@ static int dist_setup_canonical(fv_problem *pg, int nranks, int rank, const int6
         pg->D.swap(D);
         std::swap(pg->slots[0], state.p);
     };
+    // dist_setup_impl reads exactly these fields of the global problem: n, Ss, ns / slab_lo / slab_hi (slab problems are never
+    // re-numbered), rowptr, colind, vals, diagpos, b, diagA, D and slots[0] — the eight arrays swapped here — and the flag
+    // `reordered`.  None of the global problem's derived copies (lane-major / symmetric copies, storage and matrix codes, M^-1,
+    // AMG hierarchy: all in the internal numbering) is consulted, and while the canonical arrays stand in, the epochs that key
+    // those copies are parked on values no copy carries, so that any future read of one by this routine rebuilds instead of
+    // silently mixing numberings.
+    const int64_t assemble_epoch = pg->assemble_epoch, storage_epoch = pg->storage_epoch;
+    pg->assemble_epoch = -7;
+    pg->storage_epoch = -7;
     exchange();
     pg->reordered = false;
     const int rc = dist_setup_impl(pg, nranks, rank, bounds, out);
     pg->reordered = true;
     exchange();
+    pg->assemble_epoch = assemble_epoch;
+    pg->storage_epoch = storage_epoch;
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return rc;
 }
