@@ -28,6 +28,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -42,8 +43,8 @@ struct AmgLevel {
     // transfer to the next level
     DevBuf<int32_t> agg;         // n: coarse index, -1 = not represented below (row without couplings)
     DevBuf<int32_t> memptr, mem; // nc+1 / members of every aggregate, ascending
-    // cycle workspace
-    DevBuf<double> x, b, t;
+    // cycle workspace (levels >= 1: u = the iterate before the last smoothing pass, whose fused product writes the level's result)
+    DevBuf<double> x, b, t, u;
     // K-cycle workspace (levels solved by two flexible-CG steps, amg_kcycle): v1 = A c1, r1, c2, v2 = A c2, partial sums
     DevBuf<double> kv1, kr1, kc2, kv2, kpart;
 };
@@ -291,6 +292,123 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_runs_kernel(int64_t m, const uin
     atomicAdd(&rowcnt[(int32_t)(kk / nc)], 1);
 }
 
+// The same product without the global sort, for the aggregates of one pairwise pass (one to three members, a few dozen entries):
+// LANES lanes per coarse row stage its members' entries in LDS with their columns renamed, in fine order (members ascending, each
+// row front to back), rank them by (coarse column, position) — a stable sort of at most CAP entries — and sum every run front to
+// back: the sums and their order are those of the stable radix sort above, bit for bit.  COUNT pass: distinct columns per coarse
+// row; FILL pass: the entries at rowptr_c.  A coarse row with more than CAP entries is left to the launch with the next larger
+// CAP (its index goes to `big`; stat = {rows left, largest entry count}).
+template <int LANES, int CAP, bool FILL, bool BIG>
+__global__ __launch_bounds__(FV_BLOCK) void amg_merge_kernel(int64_t nc, int64_t n, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
+                                                              const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                              const double *__restrict__ vals, const int32_t *__restrict__ agg, int32_t *__restrict__ rowcnt,
+                                                              const int32_t *__restrict__ rowptr_c, int32_t *__restrict__ colind_c, double *__restrict__ vals_c,
+                                                              int32_t *__restrict__ big, int32_t *__restrict__ stat, int lower_cap)
+{
+    constexpr int GROUPS = FV_BLOCK / LANES;
+    __shared__ uint32_t s_col[GROUPS][CAP], s_scol[GROUPS][CAP];
+    __shared__ double s_val[FILL ? GROUPS : 1][FILL ? CAP : 1], s_sval[FILL ? GROUPS : 1][FILL ? CAP : 1];
+    const int g = threadIdx.x / LANES, sub = threadIdx.x % LANES;
+    const int64_t I = BIG ? (int64_t)big[blockIdx.x] : (int64_t)blockIdx.x * GROUPS + g;
+    int E = 0;
+    int32_t m0 = 0, m1 = 0;
+    if (I < nc) {
+        m0 = memptr[I];
+        m1 = memptr[I + 1];
+        for (int32_t m = m0; m < m1; m++) {
+            const int32_t row = mem[m];
+            E += rowptr[row + 1] - rowptr[row];
+        }
+    }
+    if (E > CAP) { // (uniform over the group)
+        if (!FILL && sub == 0) {
+            if (!BIG)
+                big[atomicAdd(&stat[0], 1)] = (int32_t)I;
+            atomicMax(&stat[1], E);
+        }
+        E = 0;
+        m1 = m0;
+    } else if (E <= lower_cap) { // a smaller launch has this row
+        E = 0;
+        m1 = m0;
+    }
+    int at = 0;
+    for (int32_t m = m0; m < m1; m++) {
+        const int32_t row = mem[m];
+        const int32_t s = rowptr[row], e = rowptr[row + 1];
+        for (int32_t k = s + sub; k < e; k += LANES) {
+            const int32_t j = colind[k];
+            const int32_t c = j < n ? agg[j] : -1;
+            s_col[g][at + (k - s)] = (uint32_t)c; // (no aggregate: 0xffffffff, sorts behind everything)
+            if (FILL)
+                s_val[g][at + (k - s)] = vals[k];
+        }
+        at += e - s;
+    }
+    if (BIG)
+        __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    for (int e = sub; e < E; e += LANES) {
+        const uint32_t c = s_col[g][e];
+        int rank = 0;
+        for (int q = 0; q < E; q++) {
+            const uint32_t cq = s_col[g][q];
+            rank += (cq < c) || (cq == c && q < e);
+        }
+        s_scol[g][rank] = c;
+        if (FILL)
+            s_sval[g][rank] = s_val[g][e];
+    }
+    if (BIG)
+        __syncthreads();
+    else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    int heads = 0;
+    for (int e = sub; e < E; e += LANES) {
+        const uint32_t c = s_scol[g][e];
+        if (c == 0xffffffffu || (e > 0 && s_scol[g][e - 1] == c))
+            continue;
+        heads++;
+        if (FILL) {
+            int pos = 0; // distinct columns before this one
+            for (int q = 1; q <= e; q++)
+                pos += s_scol[g][q] != s_scol[g][q - 1];
+            double v = s_sval[g][e];
+            for (int q = e + 1; q < E && s_scol[g][q] == c; q++)
+                v += s_sval[g][q];
+            const int32_t o = rowptr_c[I] + pos;
+            colind_c[o] = (int32_t)c;
+            vals_c[o] = v;
+        }
+    }
+    if (!FILL) {
+        if (BIG) {
+            __shared__ int s_heads;
+            if (threadIdx.x == 0)
+                s_heads = 0;
+            __syncthreads();
+            if (heads)
+                atomicAdd(&s_heads, heads);
+            __syncthreads();
+            if (threadIdx.x == 0 && E > 0)
+                rowcnt[I] = s_heads;
+        } else {
+#pragma unroll
+            for (int off = LANES / 2; off > 0; off >>= 1)
+                heads += __shfl_xor(heads, off, LANES);
+            if (sub == 0 && E > 0)
+                rowcnt[I] = heads;
+        }
+    }
+}
+
 __global__ __launch_bounds__(FV_BLOCK) void amg_aggD_kernel(int64_t nc, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
                                                              const double *__restrict__ D, double *__restrict__ Dc)
 {
@@ -351,6 +469,174 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_spmv_kernel(int64_t n, const int
     }
 }
 
+// ---- products of the coarse levels with the consumer of the product folded in.  A cycle visits levels 1 and 2 several times per
+// PCG iteration; every vector pass it does not launch is a launch and 16-40 bytes per row less.  What follows the row sum:
+//   PLAIN   y = A x
+//   SMOOTH  xout = x + omega dinv (b - A x)            (the cycle's last smoothing pass; xout is another vector than x: Jacobi)
+//   KDOT2   y = A x, partial sums of x.y and x.b        (K-cycle: v1 = A c1, rho1, alpha1)
+//   KDOT3   y = A x, partial sums of x.v1, x.y, x.r1    (K-cycle: v2 = A c2, gamma, beta, alpha2)
+enum { AMG_PLAIN = 0, AMG_SMOOTH = 1, AMG_KDOT2 = 2, AMG_KDOT3 = 3 };
+constexpr int AMG_KG = FV_MAX_PARTIALS; // stride of the K-cycle's partial sums: one per block of the launch that forms them
+
+struct AmgOp {
+    int64_t n;
+    const int32_t *rowptr, *colind;
+    const double *vals;
+    const double *x;
+    const double *D; // storage term of the level (null: none), times sigma
+    double sigma;
+    double *y;
+    const double *b, *dinv;
+    double omega;
+    double *xout;
+    const double *v1, *r1;
+    double *part;
+};
+
+template <int EPI>
+__device__ inline void amg_row_done(const AmgOp &a, int64_t row, double s, double &acc0, double &acc1, double &acc2)
+{
+    const double xr = (EPI != AMG_PLAIN || a.D) ? a.x[row] : 0.0;
+    if (a.D)
+        s += a.sigma * a.D[row] * xr;
+    if (EPI == AMG_SMOOTH) {
+        a.xout[row] = xr + a.omega * a.dinv[row] * (a.b[row] - s);
+        return;
+    }
+    a.y[row] = s;
+    if (EPI == AMG_KDOT2) {
+        acc0 += xr * s;
+        acc1 += xr * a.b[row];
+    }
+    if (EPI == AMG_KDOT3) {
+        acc0 += xr * a.v1[row];
+        acc1 += xr * s;
+        acc2 += xr * a.r1[row];
+    }
+}
+
+template <int EPI>
+__device__ inline void amg_block_done(const AmgOp &a, double acc0, double acc1, double acc2, double *smem)
+{
+    if (EPI == AMG_KDOT2) {
+        const double t0 = block_sum(acc0, smem);
+        const double t1 = block_sum(acc1, smem);
+        if (threadIdx.x == 0) {
+            a.part[blockIdx.x] = t0;
+            a.part[AMG_KG + blockIdx.x] = t1;
+        }
+    }
+    if (EPI == AMG_KDOT3) {
+        const double t0 = block_sum(acc0, smem);
+        const double t1 = block_sum(acc1, smem);
+        const double t2 = block_sum(acc2, smem);
+        if (threadIdx.x == 0) {
+            a.part[2 * AMG_KG + blockIdx.x] = t0;
+            a.part[3 * AMG_KG + blockIdx.x] = t1;
+            a.part[4 * AMG_KG + blockIdx.x] = t2;
+        }
+    }
+}
+
+// Large levels: a wave takes 64 consecutive rows, streams their entries (one contiguous range of vals / colind) with lane-contiguous
+// 16- and 8-byte loads, leaves the products in its own LDS tile and every lane sums its row in column order (the form of
+// spmv_wstream_kernel, fv_spmv.hip); every XCD walks its own contiguous share of the row groups.
+template <int WT, int EPI>
+__global__ __launch_bounds__(FV_BLOCK) void amg_stream_kernel(AmgOp a)
+{
+    constexpr int NIT = WT / 128, WPB = FV_BLOCK / 64;
+    __shared__ double prod_all[WPB][WT + 2];
+    __shared__ double smem[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *prod = prod_all[wave];
+    const int64_t ngroups = (a.n + 63) >> 6;
+    const int64_t per_xcd = (ngroups + 7) >> 3;
+    const int64_t pstride = (int64_t)(gridDim.x >> 3) * WPB;
+    const int64_t xbase = (int64_t)(blockIdx.x & 7) * per_xcd;
+    const int64_t xend = (xbase + per_xcd < ngroups) ? xbase + per_xcd : ngroups;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    int32_t s = 0, e = 0;
+    int64_t pos = xbase + (int64_t)(blockIdx.x >> 3) * WPB + wave;
+    if (pos < xend && (pos << 6) + lane < a.n) {
+        s = a.rowptr[(pos << 6) + lane];
+        e = a.rowptr[(pos << 6) + lane + 1];
+    }
+    for (; pos < xend; pos += pstride) {
+        const int64_t r0 = pos << 6;
+        const int nr = (int)((a.n - r0 < 64) ? (a.n - r0) : 64);
+        const int32_t my_s = s, my_e = e;
+        const int32_t k0 = __builtin_amdgcn_readfirstlane(my_s);
+        const int32_t k1 = __builtin_amdgcn_readlane(my_e, nr - 1);
+        const int32_t ka = k0 & ~1;
+        s = 0;
+        e = 0;
+        if (pos + pstride < xend && ((pos + pstride) << 6) + lane < a.n) { // the next group's row pointers, one pass ahead
+            s = a.rowptr[((pos + pstride) << 6) + lane];
+            e = a.rowptr[((pos + pstride) << 6) + lane + 1];
+        }
+        double sum = 0.0;
+        if (k1 - ka <= WT) {
+            double2 v[NIT];
+            int2 c[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int32_t j = ka + 2 * (lane + it * 64);
+                if (j < k1) { // (vals / colind carry two padding entries past nnz)
+                    v[it] = *reinterpret_cast<const double2 *>(a.vals + j);
+                    c[it] = *reinterpret_cast<const int2 *>(a.colind + j);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int32_t j = ka + 2 * (lane + it * 64);
+                if (j < k1) {
+                    double2 pr;
+                    pr.x = v[it].x * a.x[c[it].x];
+                    pr.y = v[it].y * a.x[c[it].y];
+                    *reinterpret_cast<double2 *>(prod + (j - ka)) = pr;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int32_t k = my_s - ka, ke = my_e - ka; k < ke; k++)
+                sum += prod[k];
+            __builtin_amdgcn_wave_barrier(); // reads done before the next pass overwrites the tile
+        } else { // more than WT entries in 64 rows: every lane walks its own row
+            for (int32_t k = my_s; k < my_e; k++)
+                sum += a.vals[k] * a.x[a.colind[k]];
+        }
+        if (lane < nr)
+            amg_row_done<EPI>(a, r0 + lane, sum, acc0, acc1, acc2);
+    }
+    amg_block_done<EPI>(a, acc0, acc1, acc2, smem);
+}
+
+// Small levels (launch-bound either way): LPR lanes per row, grid-stride
+template <int LPR, int EPI>
+__global__ __launch_bounds__(FV_BLOCK) void amg_rows_kernel(AmgOp a)
+{
+    __shared__ double smem[4];
+    constexpr int RPB = FV_BLOCK / LPR;
+    const int sub = threadIdx.x % LPR;
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0;
+    for (int64_t row0 = (int64_t)blockIdx.x * RPB; row0 < a.n; row0 += (int64_t)gridDim.x * RPB) {
+        const int64_t row = row0 + threadIdx.x / LPR;
+        double s = 0.0;
+        if (row < a.n) {
+            const int32_t e = a.rowptr[row + 1];
+            for (int32_t k = a.rowptr[row] + sub; k < e; k += LPR)
+                s += a.vals[k] * a.x[a.colind[k]];
+        }
+#pragma unroll
+        for (int off = LPR / 2; off > 0; off >>= 1)
+            s += __shfl_xor(s, off, LPR);
+        if (sub == 0 && row < a.n)
+            amg_row_done<EPI>(a, row, s, acc0, acc1, acc2);
+    }
+    amg_block_done<EPI>(a, acc0, acc1, acc2, smem);
+}
+
 __global__ __launch_bounds__(FV_BLOCK) void amg_smooth0_kernel(int64_t n, const double *__restrict__ dinv, const double *__restrict__ b, double omega,
                                                                 double *__restrict__ x)
 {
@@ -391,27 +677,31 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_smooth_dot_kernel(int64_t n, con
     }
 }
 
-// b_c[I] = sum over the members of (b - t): 8 lanes per aggregate (aggregates of a high-conductivity region can have
-// thousands of members), fixed lane partition + shuffle tree, so the sum order is fixed
+// b_c[I] = sum over the members of (b - t): LPA lanes per aggregate, fixed lane partition + shuffle tree, so the sum order is fixed
+template <int LPA>
 __global__ __launch_bounds__(FV_BLOCK) void amg_restrict_kernel(int64_t nc, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
                                                                  const double *__restrict__ b, const double *__restrict__ t,
-                                                                 double *__restrict__ bc)
+                                                                 double *__restrict__ bc, const double *__restrict__ dinv_c, double omega,
+                                                                 double *__restrict__ uc)
 {
-    const int64_t I = (int64_t)blockIdx.x * (FV_BLOCK / 8) + threadIdx.x / 8;
-    const int sub = threadIdx.x % 8;
+    const int64_t I = (int64_t)blockIdx.x * (FV_BLOCK / LPA) + threadIdx.x / LPA;
+    const int sub = threadIdx.x % LPA;
     double s = 0.0;
     if (I < nc) {
         const int32_t e = memptr[I + 1];
-        for (int32_t k = memptr[I] + sub; k < e; k += 8) {
+        for (int32_t k = memptr[I] + sub; k < e; k += LPA) {
             const int32_t m = mem[k];
             s += b[m] - t[m];
         }
     }
-    s += __shfl_xor(s, 4, 8);
-    s += __shfl_xor(s, 2, 8);
-    s += __shfl_xor(s, 1, 8);
-    if (sub == 0 && I < nc)
+#pragma unroll
+    for (int off = LPA / 2; off > 0; off >>= 1)
+        s += __shfl_xor(s, off, LPA);
+    if (sub == 0 && I < nc) {
         bc[I] = s;
+        if (uc) // the coarse cycle's first smoothing pass from a zero iterate, while b_c is in a register
+            uc[I] = omega * dinv_c[I] * s;
+    }
 }
 
 __global__ __launch_bounds__(FV_BLOCK) void amg_prolong_kernel(int64_t n, const int32_t *__restrict__ agg, const double *__restrict__ xc,
@@ -434,55 +724,18 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_prolong_kernel(int64_t n, const 
 //   e = (alpha1 / rho1 - gamma alpha2 / (rho1 rho2)) c1 + (alpha2 / rho2) c2.
 // Unsmoothed aggregation loses a factor per level in a V-cycle; the K-cycle keeps every level near its two-grid rate.  All scalars
 // stay on the device: the dot kernels leave per-block partials, the consumers reduce them in their first microseconds.
-constexpr int AMG_KG = 256; // blocks (= partial sums per quantity) of the K-cycle's vector kernels
-
-__global__ __launch_bounds__(FV_BLOCK) void amg_kdot2_kernel(int64_t n, const double *__restrict__ c1, const double *__restrict__ v1,
-                                                              const double *__restrict__ b, double *__restrict__ part)
-{
-    __shared__ double smem[4];
-    double s0 = 0.0, s1 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK) {
-        const double c = c1[i];
-        s0 += c * v1[i];
-        s1 += c * b[i];
-    }
-    const double t0 = block_sum(s0, smem);
-    const double t1 = block_sum(s1, smem);
-    if (threadIdx.x == 0) {
-        part[blockIdx.x] = t0;
-        part[AMG_KG + blockIdx.x] = t1;
-    }
-}
-
 __global__ __launch_bounds__(FV_BLOCK) void amg_kres_kernel(int64_t n, const double *__restrict__ b, const double *__restrict__ v1,
-                                                             const double *__restrict__ part, int nparts, double *__restrict__ r1)
+                                                             const double *__restrict__ part, int nparts, double *__restrict__ r1,
+                                                             const double *__restrict__ dinv, double omega, double *__restrict__ u)
 {
     __shared__ double smem[4];
     const double rho1 = reduce_partials(part, nparts, smem);
     const double alpha1 = reduce_partials(part + AMG_KG, nparts, smem);
     const double f = rho1 > 0.0 ? alpha1 / rho1 : 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK)
-        r1[i] = b[i] - f * v1[i];
-}
-
-__global__ __launch_bounds__(FV_BLOCK) void amg_kdot3_kernel(int64_t n, const double *__restrict__ c2, const double *__restrict__ v1,
-                                                              const double *__restrict__ v2, const double *__restrict__ r1, double *__restrict__ part)
-{
-    __shared__ double smem[4];
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * FV_BLOCK) {
-        const double c = c2[i];
-        s0 += c * v1[i];
-        s1 += c * v2[i];
-        s2 += c * r1[i];
-    }
-    const double t0 = block_sum(s0, smem);
-    const double t1 = block_sum(s1, smem);
-    const double t2 = block_sum(s2, smem);
-    if (threadIdx.x == 0) {
-        part[2 * AMG_KG + blockIdx.x] = t0;
-        part[3 * AMG_KG + blockIdx.x] = t1;
-        part[4 * AMG_KG + blockIdx.x] = t2;
+        const double ri = b[i] - f * v1[i];
+        r1[i] = ri;
+        u[i] = omega * dinv[i] * ri; // (the second cycle's first smoothing pass)
     }
 }
 
@@ -569,22 +822,62 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_gemv_kernel(int64_t n, const dou
 }
 
 // ------------------------------------------------------------------ host side: hierarchy
+// one product of level L with the epilogue `epi` (the AmgOp fields of that epilogue filled in by the caller); *grid: blocks launched
+// (= partial sums per quantity of the K-cycle epilogues)
+static int amg_level_op(fv_ctx *ctx, const AmgLevel *L, int epi, AmgOp op, double sigma, int *grid = nullptr)
+{
+    op.n = L->n;
+    op.rowptr = L->rowptr;
+    op.colind = L->colind;
+    op.vals = L->vals;
+    op.D = (sigma != 0.0) ? L->D : nullptr;
+    op.sigma = sigma;
+    const double avg = L->n > 0 ? (double)L->nnz / (double)L->n : 0.0;
+    const dim3 blk(FV_BLOCK);
+    int G;
+#define FV_AMG_OP(KERNEL)                                                                                \
+    switch (epi) {                                                                                       \
+    case AMG_SMOOTH: hipLaunchKernelGGL((KERNEL, AMG_SMOOTH>), dim3(G), blk, 0, ctx->stream, op); break; \
+    case AMG_KDOT2: hipLaunchKernelGGL((KERNEL, AMG_KDOT2>), dim3(G), blk, 0, ctx->stream, op); break;   \
+    case AMG_KDOT3: hipLaunchKernelGGL((KERNEL, AMG_KDOT3>), dim3(G), blk, 0, ctx->stream, op); break;   \
+    default: hipLaunchKernelGGL((KERNEL, AMG_PLAIN>), dim3(G), blk, 0, ctx->stream, op); break;          \
+    }
+    // (measured, round 4: the same products with the values rounded to single precision — a third of the matrix bytes less — take
+    // the same time: on these irregular rows the kernel is bound by its 8-byte gathers of x, not by the streams)
+    if (g_amg_stream && L->o_vals.p && L->n >= g_amg_stream && avg <= 14.0) {
+        // 4 row groups per block and pass, a multiple of 8 blocks (XCD shares), at most 8 blocks per CU
+        int64_t g = ((((L->n + 63) >> 6) + 3) / 4 + 7) / 8 * 8;
+        const int64_t cap = (int64_t)ctx->num_cus * 8 / 8 * 8;
+        if (g > cap)
+            g = cap;
+        if (g > AMG_KG)
+            g = AMG_KG;
+        if (g < 8)
+            g = 8;
+        G = (int)g;
+        FV_AMG_OP(amg_stream_kernel<1024)
+    } else if (avg > 12.0) {
+        const unsigned nb = fv_blocks(L->n, FV_BLOCK / 16);
+        G = nb < (unsigned)AMG_KG ? (int)nb : AMG_KG;
+        FV_AMG_OP(amg_rows_kernel<16)
+    } else {
+        const unsigned nb = fv_blocks(L->n, FV_BLOCK / 8);
+        G = nb < (unsigned)AMG_KG ? (int)nb : AMG_KG;
+        FV_AMG_OP(amg_rows_kernel<8)
+    }
+#undef FV_AMG_OP
+    FV_LAUNCH_CHECK(ctx);
+    if (grid)
+        *grid = G;
+    return FV_OK;
+}
+
 static int amg_level_spmv(fv_ctx *ctx, const AmgLevel *L, const double *x, double *y, double sigma)
 {
-    const double *D = (sigma != 0.0) ? L->D : nullptr;
-    const double avg = L->n > 0 ? (double)L->nnz / (double)L->n : 0.0;
-    // large levels: the library's wave-private CSR stream (fv_spmv.hip: contiguous 16-byte loads of values and columns per wave, row
-    // sums out of the wave's LDS tile) — 64 rows x 16 entries per pass; a level of a few thousand rows is launch-bound either way
-    if (g_amg_stream && L->o_vals.p && L->n >= g_amg_stream && avg <= 14.0)
-        return fv_csr_stream_spmv(ctx, L->n, L->rowptr, L->colind, L->vals, x, y, D, sigma);
-    if (avg > 12.0)
-        hipLaunchKernelGGL(amg_spmv_kernel<16>, dim3(fv_blocks(L->n, FV_BLOCK / 16)), dim3(FV_BLOCK), 0, ctx->stream, L->n, L->rowptr, L->colind,
-                           L->vals, x, y, D, sigma);
-    else
-        hipLaunchKernelGGL(amg_spmv_kernel<8>, dim3(fv_blocks(L->n, FV_BLOCK / 8)), dim3(FV_BLOCK), 0, ctx->stream, L->n, L->rowptr, L->colind,
-                           L->vals, x, y, D, sigma);
-    FV_LAUNCH_CHECK(ctx);
-    return FV_OK;
+    AmgOp op{};
+    op.x = x;
+    op.y = y;
+    return amg_level_op(ctx, L, AMG_PLAIN, op, sigma);
 }
 
 // One pairwise pass on the CSR (n, rowptr, colind, vals): agg (n entries) and the number of aggregates.
@@ -600,6 +893,8 @@ static int amg_pairwise(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int
     FV_TRY(agg.alloc(ctx, (size_t)n));
     FV_HIP(ctx, hipMemsetAsync(partner.p, 0xff, (size_t)n * sizeof(int32_t), ctx->stream)); // AMG_UNMATCHED
     const dim3 g(fv_blocks(n)), b(FV_BLOCK);
+    // (measured, round 4: walking a compacted list of the still unmatched rows in the later rounds is SLOWER — 1.15 ms against 0.51 ms
+    // per round at 16.6 M rows with a fifth of them on the list: the rows of a wave are then no longer neighbours in colind / vals)
     for (int r = 0; r < g_rounds; r++) {
         hipLaunchKernelGGL(amg_pick_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, (const int32_t *)partner.p, cand.p, g_theta);
         hipLaunchKernelGGL(amg_match_kernel, g, b, 0, ctx->stream, n, (const int32_t *)cand.p, partner.p);
@@ -665,6 +960,52 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
     DevBuf<uint64_t> key, key2;
     DevBuf<double> val2;
     DevBuf<int32_t> head, pos, rowcnt;
+    // the merge of the member rows (amg_merge_kernel); FV_AMG_GALERKIN=sort keeps the global sort (the tests compare the two, bit for bit)
+    const char *how = getenv("FV_AMG_GALERKIN");
+    if (!(how && !strcmp(how, "sort"))) {
+        constexpr int CAP_S = 64, CAP_B = 2048;
+        DevBuf<int32_t> big, stat;
+        FV_TRY(rowcnt.alloc(ctx, (size_t)nc + 1));
+        FV_TRY(rowcnt.zero(ctx));
+        FV_TRY(big.alloc(ctx, (size_t)nc));
+        FV_TRY(stat.alloc(ctx, 2));
+        FV_TRY(stat.zero(ctx));
+        const dim3 gs(fv_blocks(nc, FV_BLOCK / 16)), blk(FV_BLOCK);
+        hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, false, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg, rowcnt.p,
+                           (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p, 0);
+        FV_LAUNCH_CHECK(ctx);
+        int32_t hstat[2] = {0, 0};
+        FV_HIP(ctx, hipMemcpyAsync(hstat, stat.p, sizeof hstat, hipMemcpyDeviceToHost, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (hstat[1] <= CAP_B) {
+            const int nbig = hstat[0];
+            if (nbig > 0) {
+                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, false, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
+                                   agg, rowcnt.p, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p, CAP_S);
+                FV_LAUNCH_CHECK(ctx);
+            }
+            FV_TRY(rowptr_c.alloc(ctx, (size_t)nc + 1));
+            FV_TRY(fv_exclusive_scan_i32(ctx, rowcnt.p, rowptr_c.p, nc, nnz_c));
+            FV_TRY(colind_c.alloc(ctx, (size_t)*nnz_c + 2)); // (+ two zero entries: the wave-stream kernel reads pairs)
+            FV_TRY(vals_c.alloc(ctx, (size_t)*nnz_c + 2));
+            FV_HIP(ctx, hipMemsetAsync(colind_c.p + *nnz_c, 0, 2 * sizeof(int32_t), ctx->stream));
+            FV_HIP(ctx, hipMemsetAsync(vals_c.p + *nnz_c, 0, 2 * sizeof(double), ctx->stream));
+            hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, true, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg,
+                               (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p, 0);
+            if (nbig > 0)
+                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, true, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
+                                   agg, (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p, CAP_S);
+            FV_LAUNCH_CHECK(ctx);
+            if (D) {
+                FV_TRY(Dc.alloc(ctx, (size_t)nc));
+                hipLaunchKernelGGL(amg_aggD_kernel, dim3(fv_blocks(nc)), dim3(FV_BLOCK), 0, ctx->stream, nc, memptr, mem, D, Dc.p);
+                FV_LAUNCH_CHECK(ctx);
+            }
+            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            return FV_OK;
+        }
+        rowcnt.release(); // an aggregate with more than CAP_B entries: the sort takes the whole pass
+    }
     FV_TRY(key.alloc(ctx, (size_t)nnz));
     FV_TRY(key2.alloc(ctx, (size_t)nnz));
     FV_TRY(val2.alloc(ctx, (size_t)nnz));
@@ -844,6 +1185,7 @@ static int amg_build_pooled(fv_problem *p)
         FV_TRY(amg_members(ctx, L->n, L->agg.p, L->nc, L->memptr, L->mem));
         FV_TRY(C->x.alloc(ctx, (size_t)C->n));
         FV_TRY(C->b.alloc(ctx, (size_t)C->n));
+        FV_TRY(C->u.alloc(ctx, (size_t)C->n));
         a->lev.push_back(C);
     }
     for (AmgLevel *l : a->lev) {
@@ -937,9 +1279,11 @@ static int amg_top_spmv(fv_problem *p, const double *x, double *t, double sigma)
     return fv_spmv_launch(p, x, t, sigma, nullptr, p->amg->fold);
 }
 
-static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part, const double *dot_q, double *dot_part_q);
+static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part, const double *dot_q, double *dot_part_q,
+                     bool first_ready);
 
-// x_l ~ A_l^-1 b_l by two flexible-CG steps preconditioned by the cycle of level l (l >= 1, not the coarsest)
+// x_l ~ A_l^-1 b_l by two flexible-CG steps preconditioned by the cycle of level l (l >= 1, not the coarsest).  Whoever formed b has
+// left omega dinv b in the level's u (the restriction above it); the inner products ride on the two products with A_l.
 static int amg_kcycle(fv_problem *p, size_t l, const double *b, double *x, double sigma)
 {
     fv_ctx *ctx = p->ctx;
@@ -952,17 +1296,26 @@ static int amg_kcycle(fv_problem *p, size_t l, const double *b, double *x, doubl
         FV_TRY(L->kpart.alloc(ctx, (size_t)5 * AMG_KG));
     }
     const unsigned nb = fv_blocks(L->n);
-    const int G = nb < (unsigned)AMG_KG ? (int)nb : AMG_KG;
-    const dim3 g(G), blk(FV_BLOCK);
-    FV_TRY(amg_cycle(p, l, b, x, sigma, nullptr, nullptr, nullptr)); // c1
-    FV_TRY(amg_level_spmv(ctx, L, x, L->kv1.p, sigma));
-    hipLaunchKernelGGL(amg_kdot2_kernel, g, blk, 0, ctx->stream, L->n, (const double *)x, (const double *)L->kv1.p, b, L->kpart.p);
-    hipLaunchKernelGGL(amg_kres_kernel, g, blk, 0, ctx->stream, L->n, b, (const double *)L->kv1.p, (const double *)L->kpart.p, G, L->kr1.p);
+    const dim3 g(nb < 256u ? nb : 256u), blk(FV_BLOCK);
+    int G = 0;
+    FV_TRY(amg_cycle(p, l, b, x, sigma, nullptr, nullptr, nullptr, true)); // c1
+    AmgOp op{};
+    op.x = x;
+    op.y = L->kv1.p;
+    op.b = b;
+    op.part = L->kpart.p;
+    FV_TRY(amg_level_op(ctx, L, AMG_KDOT2, op, sigma, &G)); // v1 = A c1, rho1 = c1.v1, alpha1 = c1.b
+    hipLaunchKernelGGL(amg_kres_kernel, g, blk, 0, ctx->stream, L->n, b, (const double *)L->kv1.p, (const double *)L->kpart.p, G, L->kr1.p,
+                       (const double *)L->dinv.p, g_omega, L->u.p);
     FV_LAUNCH_CHECK(ctx);
-    FV_TRY(amg_cycle(p, l, L->kr1.p, L->kc2.p, sigma, nullptr, nullptr, nullptr)); // c2
-    FV_TRY(amg_level_spmv(ctx, L, L->kc2.p, L->kv2.p, sigma));
-    hipLaunchKernelGGL(amg_kdot3_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->kc2.p, (const double *)L->kv1.p, (const double *)L->kv2.p,
-                       (const double *)L->kr1.p, L->kpart.p);
+    FV_TRY(amg_cycle(p, l, L->kr1.p, L->kc2.p, sigma, nullptr, nullptr, nullptr, true)); // c2
+    op = AmgOp{};
+    op.x = L->kc2.p;
+    op.y = L->kv2.p;
+    op.v1 = L->kv1.p;
+    op.r1 = L->kr1.p;
+    op.part = L->kpart.p;
+    FV_TRY(amg_level_op(ctx, L, AMG_KDOT3, op, sigma, &G)); // v2 = A c2, gamma = c2.v1, beta = c2.v2, alpha2 = c2.r1
     hipLaunchKernelGGL(amg_kcomb_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->kc2.p, (const double *)L->kpart.p, G, x);
     FV_LAUNCH_CHECK(ctx);
     return FV_OK;
@@ -971,8 +1324,10 @@ static int amg_kcycle(fv_problem *p, size_t l, const double *b, double *x, doubl
 // x_l = V(b_l) on level l (x, b: the level's vectors; level 0: the caller's)
 // dot_part (top level only): per-block partials of b.x, i.e. the PCG's r.z, written by the last smoothing pass
 // dot_q / dot_part_q (with dot_part): also the partials of x.dot_q (flexible PCG: z.q)
+// first_ready: the first smoothing pass from a zero iterate, omega dinv b, is already there — in x on level 0 (left by the PCG's vector
+// update), in the level's u below (left by the restriction or the K-cycle's residual kernel)
 static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double sigma, double *dot_part = nullptr, const double *dot_q = nullptr,
-                     double *dot_part_q = nullptr)
+                     double *dot_part_q = nullptr, bool first_ready = false)
 {
     fv_ctx *ctx = p->ctx;
     fv_amg *a = p->amg;
@@ -997,25 +1352,38 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
         return FV_OK;
     }
     AmgLevel *C = a->lev[l + 1];
-    hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, x);
-    FV_LAUNCH_CHECK(ctx);
+    const bool c_last = l + 2 == a->lev.size();
+    const bool c_kcycle = a->kcycle && (int)(l + 1) <= g_amg_kcycle && !c_last;
+    double *u = l == 0 ? x : L->u.p; // the iterate before the last smoothing pass
+    if (!first_ready) {
+        hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, u);
+        FV_LAUNCH_CHECK(ctx);
+    }
     if (l == 0)
-        FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
+        FV_TRY(amg_top_spmv(p, u, L->t.p, sigma));
     else
-        FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
-    hipLaunchKernelGGL(amg_restrict_kernel, dim3(fv_blocks(C->n, FV_BLOCK / 8)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
-                       (const int32_t *)L->mem.p, b, (const double *)L->t.p, C->b.p);
+        FV_TRY(amg_level_spmv(ctx, L, u, L->t.p, sigma));
+    // (4 lanes per aggregate: the aggregates of two pairwise passes have ~5 members)
+    hipLaunchKernelGGL(amg_restrict_kernel<4>, dim3(fv_blocks(C->n, FV_BLOCK / 4)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
+                       (const int32_t *)L->mem.p, b, (const double *)L->t.p, C->b.p, (const double *)C->dinv.p, g_omega,
+                       c_last ? (double *)nullptr : C->u.p);
     FV_LAUNCH_CHECK(ctx);
-    if (a->kcycle && (int)(l + 1) <= g_amg_kcycle && l + 2 < a->lev.size())
+    if (c_kcycle)
         FV_TRY(amg_kcycle(p, l + 1, C->b.p, C->x.p, sigma));
     else
-        FV_TRY(amg_cycle(p, l + 1, C->b.p, C->x.p, sigma));
-    hipLaunchKernelGGL(amg_prolong_kernel, g, blk, 0, ctx->stream, L->n, (const int32_t *)L->agg.p, (const double *)C->x.p, x);
+        FV_TRY(amg_cycle(p, l + 1, C->b.p, C->x.p, sigma, nullptr, nullptr, nullptr, !c_last));
+    hipLaunchKernelGGL(amg_prolong_kernel, g, blk, 0, ctx->stream, L->n, (const int32_t *)L->agg.p, (const double *)C->x.p, u);
     FV_LAUNCH_CHECK(ctx);
-    if (l == 0)
-        FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
-    else
-        FV_TRY(amg_level_spmv(ctx, L, x, L->t.p, sigma));
+    if (l > 0) { // x = u + omega dinv (b - A u) in the product's own launch
+        AmgOp op{};
+        op.x = u;
+        op.b = b;
+        op.dinv = L->dinv.p;
+        op.omega = g_omega;
+        op.xout = x;
+        return amg_level_op(ctx, L, AMG_SMOOTH, op, sigma);
+    }
+    FV_TRY(amg_top_spmv(p, x, L->t.p, sigma));
     if (dot_part)
         hipLaunchKernelGGL(amg_smooth_dot_kernel, dim3(vec_grid(L->n)), blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b,
                            (const double *)L->t.p, g_omega, x, dot_part, dot_q, dot_part_q);
@@ -1067,7 +1435,8 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_pcg_start_kernel(int64_t n, cons
 __global__ __launch_bounds__(FV_BLOCK) void amg_pcg_update_kernel(int64_t n, int it, double *__restrict__ x, double *__restrict__ r,
                                                                    const double *__restrict__ pv, const double *__restrict__ q,
                                                                    const double *__restrict__ part_pq, int npq, PcgScalars *__restrict__ scal,
-                                                                   double *__restrict__ part_rr)
+                                                                   double *__restrict__ part_rr, const double *__restrict__ dinv, double omega,
+                                                                   double *__restrict__ z0)
 {
     __shared__ double smem[4];
     const double pq = reduce_partials(part_pq, npq, smem);
@@ -1084,6 +1453,8 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_pcg_update_kernel(int64_t n, int
         const double ri = r[i] - alpha * q[i];
         x[i] += alpha * pv[i];
         r[i] = ri;
+        if (z0) // the cycle's first smoothing pass from a zero iterate, while the new residual is in a register
+            z0[i] = omega * dinv[i] * ri;
         arr += ri * ri;
     }
     const double t = block_sum(arr, smem);
@@ -1155,7 +1526,8 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
         int npq = 0;
         FV_TRY(fv_spmv_launch(p, p->pvec.p, p->q.p, sigma, p->part_pq.p, fold, &npq));
         hipLaunchKernelGGL(amg_pcg_update_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (int)it, x, p->r.p, (const double *)p->pvec.p,
-                           (const double *)p->q.p, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rr.p);
+                           (const double *)p->q.p, (const double *)p->part_pq.p, npq, p->scal.p, p->part_rr.p,
+                           fused_dot ? (const double *)a->lev[0]->dinv.p : (const double *)nullptr, g_omega, fused_dot ? a->z.p : (double *)nullptr);
         hipLaunchKernelGGL(amg_pcg_check_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, (int)it, (const double *)p->part_rr.p, Gv, p->scal.p,
                            p->hist.p, p->hist_cap);
         FV_LAUNCH_CHECK(ctx);
@@ -1163,7 +1535,8 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (hs->done)
             break;
-        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr, flexible ? (const double *)p->q.p : nullptr, p->part_bb.p));
+        FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr, flexible ? (const double *)p->q.p : nullptr, p->part_bb.p,
+                         fused_dot));
         if (!fused_dot)
             hipLaunchKernelGGL(amg_dot_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)p->r.p, (const double *)a->z.p,
                                p->part_rz.p);
@@ -1232,3 +1605,5 @@ extern "C" int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, d
     FV_TRY(fv_amg_apply_device(p, p->tmp.p, p->rhs.p, sigma));
     return fv_free_out(p, z_free, p->rhs.p);
 }
+
+FV_WARM_TU(amg) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -196,9 +196,9 @@ static int fv_reorder_free(fv_problem *p)
         }
     }
     std::vector<int32_t> a((size_t)F), b((size_t)F), map((size_t)N);
-    FV_HIP(ctx, hipMemcpy(a.data(), p->node1.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
-    FV_HIP(ctx, hipMemcpy(b.data(), p->node2.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
-    FV_HIP(ctx, hipMemcpy(map.data(), p->nodemap.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, a.data(), p->node1.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, b.data(), p->node2.p, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, map.data(), p->nodemap.p, (size_t)N * sizeof(int32_t), hipMemcpyDeviceToHost));
     int64_t m = 0;
     double sum = 0.0;
     for (int64_t k = 0; k < F; k++) { // faces between two free cells, in canonical free indices
@@ -223,7 +223,7 @@ static int fv_reorder_free(fv_problem *p)
         return FV_OK;
     FV_TRY(p->perm.alloc(ctx, (size_t)n));
     FV_TRY(p->iperm.alloc(ctx, (size_t)n));
-    FV_HIP(ctx, hipMemcpy(p->perm.p, perm.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, p->perm.p, perm.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(apply_perm_kernel, dim3(fv_blocks(N)), dim3(FV_BLOCK), 0, ctx->stream, N, (const int32_t *)p->perm.p, p->nodemap.p, p->f2n.p,
                        p->iperm.p);
     FV_LAUNCH_CHECK(ctx);
@@ -333,7 +333,7 @@ static int check_sources(fv_ctx *ctx, const int32_t *dn_dev, int64_t ndir, const
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (first != big) {
         int32_t node0 = 0;
-        FV_HIP(ctx, hipMemcpy(&node0, dn_dev + first, sizeof node0, hipMemcpyDeviceToHost));
+        FV_HIP(ctx, fv_memcpy_sync(ctx, &node0, dn_dev + first, sizeof node0, hipMemcpyDeviceToHost));
         const long long node = (long long)node0 + 1;
         if (badnode)
             *badnode = node;
@@ -837,12 +837,12 @@ extern "C" int fv_problem_free_rows_before(fv_problem *p, int64_t node, int64_t 
     std::vector<int32_t> chunk(4096);
     for (int64_t at = node; at < p->N; at += (int64_t)chunk.size()) {
         const int64_t m = p->N - at < (int64_t)chunk.size() ? p->N - at : (int64_t)chunk.size();
-        FV_HIP(ctx, hipMemcpy(chunk.data(), p->nodemap.p + at, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+        FV_HIP(ctx, fv_memcpy_sync(ctx, chunk.data(), p->nodemap.p + at, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int64_t k = 0; k < m; k++)
             if (chunk[(size_t)k] >= 0) { // the first free cell at or after `node`: its (canonical) free index is the answer
                 int32_t idx = chunk[(size_t)k];
                 if (p->reordered) // nodemap holds the internal index: callers only ever see the rank among the free nodes
-                    FV_HIP(ctx, hipMemcpy(&idx, p->iperm.p + idx, sizeof idx, hipMemcpyDeviceToHost));
+                    FV_HIP(ctx, fv_memcpy_sync(ctx, &idx, p->iperm.p + idx, sizeof idx, hipMemcpyDeviceToHost));
                 *rows = idx;
                 return FV_OK;
             }
@@ -1243,3 +1243,5 @@ extern "C" int fv_problem_create_from_csc(fv_ctx *ctx, int64_t n, const int64_t 
     *out = p;
     return FV_OK;
 }
+
+FV_WARM_TU(assembly) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -311,7 +311,7 @@ extern "C" int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok)
     DevBuf<double> a, b;
     FV_TRY(a.alloc(ctx, (size_t)count));
     FV_TRY(b.alloc(ctx, (size_t)count));
-    FV_HIP(ctx, hipMemcpy(a.p, host.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, a.p, host.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice));
     // cleared on the stream the receive runs on: stream2 is non-blocking, a memset on the null stream could land after the data
     FV_HIP(ctx, hipMemsetAsync(b.p, 0, (size_t)count * sizeof(double), ctx->stream2));
     ncclComm_t comm = (ncclComm_t)ctx->comm;
@@ -322,13 +322,13 @@ extern "C" int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok)
     FV_NCCL(ctx, ncclGroupEnd());
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream2));
     std::vector<double> got((size_t)count);
-    FV_HIP(ctx, hipMemcpy(got.data(), b.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, got.data(), b.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     bool good = true;
     for (int64_t i = 0; i < count; i++)
         good = good && got[(size_t)i] == 1000.0 * prev + (double)(i % 997);
     FV_NCCL(ctx, ncclAllReduce(a.p, a.p, (size_t)count, ncclDouble, ncclSum, comm, ctx->stream));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FV_HIP(ctx, hipMemcpy(got.data(), a.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, got.data(), a.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
     const double ranks = (double)ctx->nranks;
     for (int64_t i = 0; i < count; i++)
         good = good && got[(size_t)i] == 1000.0 * (ranks * (ranks - 1.0) / 2.0) + ranks * (double)(i % 997);

@@ -28,6 +28,47 @@ extern "C" int fv_abi_version(void) { return FVHIP_ABI_VERSION; }
 // reported something since: then that message is the one the failing call produced
 extern "C" const char *fv_last_error(fv_ctx *ctx) { return (ctx && ctx->err_seq > g_err_noctx_seq) ? ctx->err.c_str() : g_err.c_str(); }
 
+__global__ void fv_warm_ctx_kernel() {}
+void fv_warm_amg(hipStream_t);
+void fv_warm_assembly(hipStream_t);
+void fv_warm_dist(hipStream_t);
+void fv_warm_fused(hipStream_t);
+void fv_warm_gradient(hipStream_t);
+void fv_warm_grid(hipStream_t);
+void fv_warm_pcg(hipStream_t);
+void fv_warm_reorder(hipStream_t);
+void fv_warm_small(hipStream_t);
+void fv_warm_spmv(hipStream_t);
+void fv_warm_trajectory(hipStream_t);
+void fv_warm_transient(hipStream_t);
+
+// every code object of the library loaded before the first call that needs one (FV_WARM_TU, fv_internal.h); once per process and device
+static int fv_warm_modules(fv_ctx *ctx)
+{
+    static bool done[64] = {};
+    if (ctx->device < 64) {
+        if (done[ctx->device])
+            return FV_OK;
+        done[ctx->device] = true;
+    }
+    hipLaunchKernelGGL(fv_warm_ctx_kernel, dim3(1), dim3(64), 0, ctx->stream);
+    fv_warm_amg(ctx->stream);
+    fv_warm_assembly(ctx->stream);
+    fv_warm_dist(ctx->stream);
+    fv_warm_fused(ctx->stream);
+    fv_warm_gradient(ctx->stream);
+    fv_warm_grid(ctx->stream);
+    fv_warm_pcg(ctx->stream);
+    fv_warm_reorder(ctx->stream);
+    fv_warm_small(ctx->stream);
+    fv_warm_spmv(ctx->stream);
+    fv_warm_trajectory(ctx->stream);
+    fv_warm_transient(ctx->stream);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
 static int ctx_init(fv_ctx *ctx)
 {
     FV_HIP(ctx, hipSetDevice(ctx->device));
@@ -46,6 +87,7 @@ static int ctx_init(fv_ctx *ctx)
     FV_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_comp, hipEventDisableTiming));
     ctx->pinned_bytes = 4096;
     FV_HIP(ctx, hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault));
+    FV_TRY(fv_warm_modules(ctx));
     return FV_OK;
 }
 
@@ -325,6 +367,7 @@ int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, 
 }
 
 // ------------------------------------------------------------------ scratch pool of a set-up phase (see fv_internal.h)
+#include <chrono>
 #include <map>
 #include <unordered_map>
 namespace {
@@ -334,6 +377,13 @@ struct DevPool {
     std::unordered_map<void *, size_t> capacity; // blocks handed out while the pool is on
 };
 thread_local DevPool t_pool;
+// FV_TRACE_ALLOC=1: every device allocation / release that takes more than 0.1 ms goes to stderr (where a set-up phase loses its time)
+bool trace_alloc()
+{
+    static const bool on = getenv("FV_TRACE_ALLOC") != nullptr;
+    return on;
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 } // namespace
 
 hipError_t fv_dev_malloc(void **p, size_t bytes)
@@ -348,7 +398,10 @@ hipError_t fv_dev_malloc(void **p, size_t bytes)
             return hipSuccess;
         }
     }
+    const double t0 = trace_alloc() ? now_s() : 0.0;
     const hipError_t e = hipMalloc(p, bytes);
+    if (trace_alloc() && now_s() - t0 > 1e-4)
+        fprintf(stderr, "[alloc] hipMalloc %.1f MB: %.0f us\n", (double)bytes / 1048576.0, (now_s() - t0) * 1e6);
     if (e == hipSuccess && pool.depth > 0)
         pool.capacity[*p] = bytes;
     return e;
@@ -365,7 +418,10 @@ void fv_dev_free(void *p)
             return;
         }
     }
+    const double t0 = trace_alloc() ? now_s() : 0.0;
     (void)hipFree(p);
+    if (trace_alloc() && now_s() - t0 > 1e-4)
+        fprintf(stderr, "[alloc] hipFree: %.0f us\n", (now_s() - t0) * 1e6);
 }
 
 void fv_pool_begin() { t_pool.depth++; }

@@ -298,7 +298,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
     // entry offsets of every rank's row block
     std::vector<int32_t> eb((size_t)nranks + 1);
     for (int r = 0; r <= nranks; r++)
-        FV_HIP(ctx, hipMemcpy(&eb[(size_t)r], pg->rowptr.p + d->bounds[(size_t)r], sizeof(int32_t), hipMemcpyDeviceToHost));
+        FV_HIP(ctx, fv_memcpy_sync(ctx, &eb[(size_t)r], pg->rowptr.p + d->bounds[(size_t)r], sizeof(int32_t), hipMemcpyDeviceToHost));
     const int64_t e0 = eb[(size_t)rank], e1 = eb[(size_t)rank + 1];
     const int64_t nnz_loc = e1 - e0;
     d->entry_lo = e0;
@@ -338,7 +338,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
             std::vector<int32_t> hb((size_t)nranks + 1);
             bool bad = false;
             for (int r = 0; r <= nranks && !bad; r++)
-                bad = hipMemcpy(&hb[(size_t)r], hscan.p + d->bounds[(size_t)r], sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess;
+                bad = fv_memcpy_sync(ctx, &hb[(size_t)r], hscan.p + d->bounds[(size_t)r], sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess;
             if (bad) {
                 fv_set_error(ctx, "fv_dist_setup: read-back of halo offsets failed");
                 rc = FV_ERR_HIP;
@@ -393,7 +393,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
                 break;
             d->send_counts[(size_t)q] = cnt;
             host_lists[(size_t)q].resize((size_t)cnt);
-            if (cnt > 0 && hipMemcpy(host_lists[(size_t)q].data(), tmp.p, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+            if (cnt > 0 && fv_memcpy_sync(ctx, host_lists[(size_t)q].data(), tmp.p, (size_t)cnt * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
                 fv_set_error(ctx, "fv_dist_setup: read-back of a send list failed");
                 rc = FV_ERR_HIP;
                 break;
@@ -410,7 +410,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
             all.reserve((size_t)total);
             for (int q = 0; q < nranks; q++)
                 all.insert(all.end(), host_lists[(size_t)q].begin(), host_lists[(size_t)q].end());
-            if (total > 0 && hipMemcpy(d->send_idx.p, all.data(), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+            if (total > 0 && fv_memcpy_sync(ctx, d->send_idx.p, all.data(), (size_t)total * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
                 rc = FV_ERR_HIP;
                 break;
             }
@@ -504,3 +504,5 @@ extern "C" int fv_dist_get_plan(fv_problem *p, int64_t *rowptr_loc, int64_t *col
     }
     return FV_OK;
 }
+
+FV_WARM_TU(dist) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -1752,3 +1752,5 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     p->fused_chunked = chunks;
     return FV_OK;
 }
+
+FV_WARM_TU(fused) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

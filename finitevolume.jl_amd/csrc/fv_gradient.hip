@@ -246,8 +246,10 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the host buffers of the next pass may be the caller's next slice
         accumulate = 1;
     }
-    FV_HIP(ctx, hipMemcpy(face_k, gk.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
-    FV_HIP(ctx, hipMemcpy(face_dir, gd.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, face_k, gk.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, face_dir, gd.p, (size_t)F * sizeof(double), hipMemcpyDeviceToHost));
     FV_TRY(fv_free_out(p, row_src, gs.p));
     return FV_OK;
 }
+
+FV_WARM_TU(gradient) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -413,6 +413,21 @@ struct fv_problem {
 // out[i] = sum(in[0..i-1]) for i in [0, n]; out has n+1 entries. total returned on host.
 int fv_exclusive_scan_i32(fv_ctx *ctx, const int32_t *in, int32_t *out, int64_t n, int64_t *total);
 
+// A blocking copy on the context's own stream.  (hipMemcpy runs on the null stream: its first use in a process creates that stream's
+// queue — measured 8-10 ms inside the first product of a problem — and it does not order against the non-blocking ctx->stream.)
+inline hipError_t fv_memcpy_sync(fv_ctx *ctx, void *dst, const void *src, size_t bytes, hipMemcpyKind kind)
+{
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, ctx->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+}
+
+// ---- one empty kernel per translation unit.  HIP loads a translation unit's code object at the first launch of one of its kernels:
+// 2-8 ms each for the larger ones, 22 ms in all on the path of a first solve (measured: profiles/r04_amg_*).  fv_ctx_create launches
+// the empty kernels once per process and device, so that the first solve of a process costs what every later one costs.
+#define FV_WARM_TU(name)                                                                                 \
+    __global__ void fv_warm_##name##_kernel() {}                                                       \
+    void fv_warm_##name(hipStream_t s) { hipLaunchKernelGGL(fv_warm_##name##_kernel, dim3(1), dim3(64), 0, s); }
+
 // ---- fv_grid.hip
 int fv_grid_axes(const double mins[3], const double maxs[3], const int64_t ns[3], std::vector<double> ax[3]);
 int fv_grid_generate_device(fv_ctx *ctx, const double mins[3], const double maxs[3], const int64_t ns[3], int32_t *node1,

@@ -1790,8 +1790,8 @@ static int dist_build_split(fv_problem *p)
     d->int_lo = d->int_hi = 0;
     if (d->n_int > 0) {
         int32_t first = 0, last = 0;
-        FV_HIP(p->ctx, hipMemcpy(&first, d->groups_int.p, sizeof first, hipMemcpyDeviceToHost));
-        FV_HIP(p->ctx, hipMemcpy(&last, d->groups_int.p + (d->n_int - 1), sizeof last, hipMemcpyDeviceToHost));
+        FV_HIP(p->ctx, fv_memcpy_sync(p->ctx, &first, d->groups_int.p, sizeof first, hipMemcpyDeviceToHost));
+        FV_HIP(p->ctx, fv_memcpy_sync(p->ctx, &last, d->groups_int.p + (d->n_int - 1), sizeof last, hipMemcpyDeviceToHost));
         if ((int64_t)last - first + 1 == d->n_int) {
             d->int_lo = first;
             d->int_hi = (int64_t)last + 1;
@@ -2904,3 +2904,4 @@ extern "C" int fv_dist_state_get(fv_problem *p, double *u_local)
     return fv_copy(p->ctx, u_local, p->slots[0], (size_t)p->n * sizeof(double));
 }
 
+FV_WARM_TU(pcg) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

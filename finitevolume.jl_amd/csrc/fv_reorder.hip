@@ -480,3 +480,5 @@ int fv_device_locality_order(fv_problem *p, int want, int32_t *perm_dev, bool *a
     *adopted = !(want == 1 && *mean_after * 2.0 >= *mean_before);
     return FV_OK;
 }
+
+FV_WARM_TU(reorder) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -329,3 +329,5 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     *handled = true;
     return FV_OK;
 }
+
+FV_WARM_TU(small) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

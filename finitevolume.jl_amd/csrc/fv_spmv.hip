@@ -564,11 +564,11 @@ static int build_group_order(fv_problem *p)
         return FV_OK; // small: x stays cache-resident anyway
     // estimate the far stride from the middle row, then count how many rows agree
     int32_t rp[2] = {0, 0};
-    FV_HIP(ctx, hipMemcpy(rp, p->rowptr.p + n / 2, sizeof rp, hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, rp, p->rowptr.p + n / 2, sizeof rp, hipMemcpyDeviceToHost));
     if (rp[1] <= rp[0])
         return FV_OK;
     int32_t lastcol = 0;
-    FV_HIP(ctx, hipMemcpy(&lastcol, p->colind.p + (rp[1] - 1), sizeof lastcol, hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, &lastcol, p->colind.p + (rp[1] - 1), sizeof lastcol, hipMemcpyDeviceToHost));
     const int64_t stride = (int64_t)lastcol - n / 2;
     if (stride < 32768 || stride > n / 4)
         return FV_OK; // near-diagonal band (natural order is fine) or no plane structure
@@ -606,7 +606,7 @@ static int build_group_order(fv_problem *p)
         return FV_ERR_STATE;
     }
     FV_TRY(p->group_order.alloc(ctx, (size_t)ngroups));
-    FV_HIP(ctx, hipMemcpy(p->group_order.p, order.data(), (size_t)ngroups * sizeof(int32_t), hipMemcpyHostToDevice));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, p->group_order.p, order.data(), (size_t)ngroups * sizeof(int32_t), hipMemcpyHostToDevice));
     p->order_stride = stride;
     return FV_OK;
 }
@@ -1716,14 +1716,14 @@ static int build_symdia(fv_problem *p)
     // some (the middle slice of a grid whose lines are a whole number of slices can be the first line of its plane), so a
     // handful of slices spread over the operator are looked at until one has all seven.
     std::vector<uint8_t> hn((size_t)ns);
-    FV_HIP(ctx, hipMemcpy(hn.data(), p->sl_noff.p, (size_t)ns, hipMemcpyDeviceToHost));
+    FV_HIP(ctx, fv_memcpy_sync(ctx, hn.data(), p->sl_noff.p, (size_t)ns, hipMemcpyDeviceToHost));
     int32_t off[DIA_K];
     bool found = false;
     for (int64_t j = 0; j < 4096 && j < ns && !found; j++) {
         const int64_t cand = (ns / 2 + j * 977) % ns; // 977: a stride unrelated to grid line lengths
         if (hn[(size_t)cand] != 7)
             continue;
-        FV_HIP(ctx, hipMemcpy(off, p->sl_off.p + cand * DIA_K, sizeof off, hipMemcpyDeviceToHost));
+        FV_HIP(ctx, fv_memcpy_sync(ctx, off, p->sl_off.p + cand * DIA_K, sizeof off, hipMemcpyDeviceToHost));
         found = off[3] == 0 && off[0] == -off[6] && off[1] == -off[5] && off[2] == -off[4] && off[6] == p->order_stride;
     }
     if (!found)
@@ -2840,3 +2840,4 @@ int ensure_folded(fv_problem *p, double sigma, const double **out)
     return FV_OK;
 }
 
+FV_WARM_TU(spmv) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

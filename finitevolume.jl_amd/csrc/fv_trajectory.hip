@@ -661,3 +661,5 @@ extern "C" int fv_param_gradient_integral_traj(fv_problem *p, fv_trajectory *u, 
     FV_TRY(fv_copy(ctx, face_dir, gd.p, (size_t)F * sizeof(double)));
     return fv_free_out(p, row_src, gs.p);
 }
+
+FV_WARM_TU(trajectory) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

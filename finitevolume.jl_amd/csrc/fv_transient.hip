@@ -820,3 +820,5 @@ extern "C" int fv_profile_get(fv_problem *p, int kernel, double *total_ms, int64
         *launches = p->prof_launches[kernel];
     return FV_OK;
 }
+
+FV_WARM_TU(transient) // (fv_ctx_create loads every code object of the library up front: fv_warm_modules, fv_ctx.hip)

@@ -1648,6 +1648,43 @@ def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
     assert relerr(res[live], res_j[live]) < 1e-8
 
 
+@pytest.mark.parametrize("case", ["box", "multigraph"])
+def test_amg_galerkin_by_row_merge_is_the_sorted_product_bit_for_bit(fv, case):
+    """The Galerkin products of the set-up by merging the member rows of each aggregate (amg_merge_kernel: a stable rank sort of a
+    coarse row's few dozen entries in LDS; the multigraph's hubs take the launch with the larger capacity) against the global
+    stable radix sort it replaces (FV_AMG_GALERKIN=sort): the same level sizes, and the V-cycle applied to the same vector gives the
+    same bits — same sums in the same order."""
+    rng = np.random.default_rng(3)
+    if case == "box":
+        nb, aol, vol, K, dn, dh = _aniso_box(fv, (40, 36, 30), sigma=2.5)
+        N = len(vol)
+    else:
+        N, F = 30000, 140000
+        n1 = rng.integers(1, N, F)
+        n2 = rng.integers(1, N, F)
+        hub = rng.choice(N, 12, replace=False) + 1  # a dozen hubs with ~600 faces each: coarse rows beyond the small launch's 64 entries
+        n1[: 12 * 600] = np.repeat(hub, 600)
+        aol = np.exp(rng.uniform(-2, 2, F))
+        K = np.exp(rng.normal(0.0, 1.0, F))
+        dn = rng.choice(N, 500, replace=False) + 1
+        dh = rng.uniform(0.0, 2.0, 500)
+        nb = np.stack([n1, n2], 1)
+    out = []
+    for how in ("sort", "merge"):
+        os.environ["FV_AMG_GALERKIN"] = how
+        try:
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, np.zeros(N), dh, None, case == "box")
+            p.set_preconditioner("amg")
+            rows, nnz = p.amg_info()
+            z = p.amg_apply(np.random.default_rng(9).standard_normal(p.n), 0.0)
+            out.append((rows.tolist(), nnz.tolist(), z))
+            p.close()
+        finally:
+            os.environ.pop("FV_AMG_GALERKIN", None)
+    assert len(out[0][0]) >= 3 and out[0][0] == out[1][0] and out[0][1] == out[1][1], (out[0][:2], out[1][:2])
+    assert np.isfinite(out[0][2]).all() and np.array_equal(out[0][2], out[1][2])
+
+
 def test_run_adaptive_degenerate_spans(fv):
     coords, nb, aol, vol, K, dn, dh = _box(fv, (6, 5, 4), sigma=0.5)
     N = len(vol)
