@@ -53,8 +53,7 @@ struct AmgLevel {
 
 struct fv_amg {
     std::vector<AmgLevel *> lev;
-    DevBuf<double> inv;  // coarsest inverse (nco x nco), row-major
-    DevBuf<double> gjrow, gjcol;
+    DevBuf<double> inv, inv2; // coarsest inverse (nco x nco), row-major, and the second copy its Gauss-Jordan steps alternate with
     int64_t nco = 0;
     bool dense = false;
     double sigma = NAN;       // the sigma dinv / inv were built for
@@ -98,7 +97,9 @@ extern "C" int fv_amg_configure(double theta, double omega, int passes, int roun
 }
 
 // ------------------------------------------------------------------ setup kernels
-constexpr int32_t AMG_UNMATCHED = -1, AMG_ISOLATED = -2;
+// (AMG_ALONE: an unmatched row that found no strong unmatched neighbour in some round — it cannot find one later, so the later rounds
+// neither scan it again nor offer it to its neighbours; the leftover rule treats it like any unmatched row)
+constexpr int32_t AMG_UNMATCHED = -1, AMG_ISOLATED = -2, AMG_ALONE = -3;
 
 // Preference of row i for neighbour j: the octave of the coupling strength first, then a hash that is symmetric in
 // (i, j).  Ranking by the raw strength makes the handshake crawl: wherever strengths vary monotonically every row names
@@ -168,7 +169,9 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_match_kernel(int64_t n, const in
     const int32_t c = cand[i];
     if (c == AMG_ISOLATED)
         partner[i] = AMG_ISOLATED;
-    else if (c >= 0 && cand[c] == (int32_t)i)
+    else if (c < 0)
+        partner[i] = AMG_ALONE; // no strong unmatched neighbour now, so none later
+    else if (cand[c] == (int32_t)i)
         partner[i] = c;
 }
 
@@ -296,18 +299,19 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_runs_kernel(int64_t m, const uin
 // LANES lanes per coarse row stage its members' entries in LDS with their columns renamed, in fine order (members ascending, each
 // row front to back), rank them by (coarse column, position) — a stable sort of at most CAP entries — and sum every run front to
 // back: the sums and their order are those of the stable radix sort above, bit for bit.  COUNT pass: distinct columns per coarse
-// row; FILL pass: the entries at rowptr_c.  A coarse row with more than CAP entries is left to the launch with the next larger
-// CAP (its index goes to `big`; stat = {rows left, largest entry count}).
+// row; FILL pass: the entries at rowptr_c.  A coarse row with more than CAP entries (or more members than lanes) is left to the launch
+// with the larger CAP, one workgroup per row, which works through the list `big` (stat = {rows on the list, largest entry count}).
 template <int LANES, int CAP, bool FILL, bool BIG>
 __global__ __launch_bounds__(FV_BLOCK) void amg_merge_kernel(int64_t nc, int64_t n, const int32_t *__restrict__ memptr, const int32_t *__restrict__ mem,
                                                               const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
                                                               const double *__restrict__ vals, const int32_t *__restrict__ agg, int32_t *__restrict__ rowcnt,
                                                               const int32_t *__restrict__ rowptr_c, int32_t *__restrict__ colind_c, double *__restrict__ vals_c,
-                                                              int32_t *__restrict__ big, int32_t *__restrict__ stat, int lower_cap)
+                                                              int32_t *__restrict__ big, int32_t *__restrict__ stat)
 {
     constexpr int GROUPS = FV_BLOCK / LANES;
     __shared__ uint32_t s_col[GROUPS][CAP], s_scol[GROUPS][CAP];
     __shared__ double s_val[FILL ? GROUPS : 1][FILL ? CAP : 1], s_sval[FILL ? GROUPS : 1][FILL ? CAP : 1];
+    __shared__ int32_t s_rs[BIG ? 1 : GROUPS][BIG ? 1 : LANES], s_off[BIG ? 1 : GROUPS][BIG ? 1 : LANES + 1];
     const int g = threadIdx.x / LANES, sub = threadIdx.x % LANES;
     const int64_t I = BIG ? (int64_t)big[blockIdx.x] : (int64_t)blockIdx.x * GROUPS + g;
     int E = 0;
@@ -315,10 +319,37 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_merge_kernel(int64_t nc, int64_t
     if (I < nc) {
         m0 = memptr[I];
         m1 = memptr[I + 1];
+    }
+    if (BIG) {
         for (int32_t m = m0; m < m1; m++) {
             const int32_t row = mem[m];
             E += rowptr[row + 1] - rowptr[row];
         }
+    } else {
+        // the members' row pointers side by side (one lane each), their entry counts scanned over the group: all lanes then walk
+        // the concatenated entries with independent loads instead of member after member
+        const int nm = m1 - m0;
+        int32_t rs = 0, len = 0;
+        if (sub < nm && nm <= LANES) {
+            const int32_t row = mem[m0 + sub];
+            rs = rowptr[row];
+            len = rowptr[row + 1] - rs;
+        }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < LANES; o <<= 1) {
+            const int t = __shfl_up(incl, o, LANES);
+            if (sub >= o)
+                incl += t;
+        }
+        E = nm <= LANES ? __shfl(incl, LANES - 1, LANES) : CAP + 1; // (more members than lanes: the larger launch)
+        s_rs[g][sub] = rs;
+        s_off[g][sub] = incl - len;
+        if (sub == 0)
+            s_off[g][LANES] = E;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     if (E > CAP) { // (uniform over the group)
         if (!FILL && sub == 0) {
@@ -328,26 +359,35 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_merge_kernel(int64_t nc, int64_t
         }
         E = 0;
         m1 = m0;
-    } else if (E <= lower_cap) { // a smaller launch has this row
-        E = 0;
-        m1 = m0;
     }
-    int at = 0;
-    for (int32_t m = m0; m < m1; m++) {
-        const int32_t row = mem[m];
-        const int32_t s = rowptr[row], e = rowptr[row + 1];
-        for (int32_t k = s + sub; k < e; k += LANES) {
+    if (BIG) {
+        int at = 0;
+        for (int32_t m = m0; m < m1; m++) {
+            const int32_t row = mem[m];
+            const int32_t s = rowptr[row], e = rowptr[row + 1];
+            for (int32_t k = s + sub; k < e; k += LANES) {
+                const int32_t j = colind[k];
+                const int32_t c = j < n ? agg[j] : -1;
+                s_col[g][at + (k - s)] = (uint32_t)c; // (no aggregate: 0xffffffff, sorts behind everything)
+                if (FILL)
+                    s_val[g][at + (k - s)] = vals[k];
+            }
+            at += e - s;
+        }
+        __syncthreads();
+    } else {
+        const int nm = m1 - m0;
+        for (int e = sub; e < E; e += LANES) {
+            int m = 0;
+            for (int q = 1; q < nm; q++)
+                m = (e >= s_off[g][q]) ? q : m;
+            const int32_t k = s_rs[g][m] + (e - s_off[g][m]);
             const int32_t j = colind[k];
             const int32_t c = j < n ? agg[j] : -1;
-            s_col[g][at + (k - s)] = (uint32_t)c; // (no aggregate: 0xffffffff, sorts behind everything)
+            s_col[g][e] = (uint32_t)c;
             if (FILL)
-                s_val[g][at + (k - s)] = vals[k];
+                s_val[g][e] = vals[k];
         }
-        at += e - s;
-    }
-    if (BIG)
-        __syncthreads();
-    else {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -776,35 +816,59 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_dense_fill_kernel(int64_t n, con
         M[i * n + i] += sigma * D[i];
 }
 
-// step k, phase 1: save row k and column k
-__global__ __launch_bounds__(FV_BLOCK) void amg_gj_save_kernel(int64_t n, int64_t k, const double *__restrict__ M, double *__restrict__ rowk,
-                                                                double *__restrict__ colk)
+// Block Gauss-Jordan inversion (no pivoting: the matrix is SPD), GJB pivots per launch, from one copy of the matrix into the other.
+// With K the pivot block, P = M[K,K], R = M[K,:], C = M[:,K]:   M'[K,K] = P^-1,  M'[K,j] = P^-1 R[:,j],  M'[i,K] = -C[i,:] P^-1,
+// M'[i,j] = M[i,j] - C[i,:] P^-1 R[:,j]  (i, j outside K) — the sweep of the scalar algorithm, GJB pivots at a time; after the last
+// block M' is the inverse.  Every workgroup inverts the small P for itself in LDS (its first wave, one entry per lane).
+constexpr int GJB = 8;
+__global__ __launch_bounds__(FV_BLOCK) void amg_gj_block_kernel(int64_t n, int64_t k0, int B, const double *__restrict__ M, double *__restrict__ Mo)
 {
-    const int64_t j = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
-    if (j < n) {
-        rowk[j] = M[k * n + j];
-        colk[j] = M[j * n + k];
+    __shared__ double P[GJB][GJB];
+    if (threadIdx.x < GJB * GJB) {
+        const int a = threadIdx.x / GJB, b = threadIdx.x % GJB;
+        P[a][b] = (a < B && b < B) ? M[(k0 + a) * n + (k0 + b)] : (a == b ? 1.0 : 0.0);
     }
-}
-
-// step k, phase 2: in-place Gauss-Jordan update of the whole matrix (no pivoting: the matrix is SPD)
-__global__ __launch_bounds__(FV_BLOCK) void amg_gj_update_kernel(int64_t n, int64_t k, double *__restrict__ M, const double *__restrict__ rowk,
-                                                                  const double *__restrict__ colk)
-{
+    __syncthreads();
+    if (threadIdx.x < GJB * GJB) { // the first wave inverts the block by the scalar sweep, one entry per lane (padding rows: identity)
+        const int a = threadIdx.x / GJB, b = threadIdx.x % GJB;
+        for (int k = 0; k < GJB; k++) {
+            const double ip = 1.0 / P[k][k], pak = P[a][k], pkb = P[k][b], pab = P[a][b];
+            const double v = (a == k) ? ((b == k) ? ip : pkb * ip) : ((b == k) ? -pak * ip : pab - pak * pkb * ip);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // (every lane has read the old block)
+            P[a][b] = v;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    __syncthreads();
     const int64_t j = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (j >= n)
         return;
-    const double piv = rowk[k];
-    const double ip = 1.0 / piv;
+    const bool iK = i >= k0 && i < k0 + B, jK = j >= k0 && j < k0 + B;
     double v;
-    if (i == k)
-        v = (j == k) ? ip : rowk[j] * ip;
-    else if (j == k)
-        v = -colk[i] * ip;
-    else
-        v = M[i * n + j] - colk[i] * rowk[j] * ip;
-    M[i * n + j] = v;
+    if (iK && jK)
+        v = P[i - k0][j - k0];
+    else if (iK) { // P^-1 R[:, j]
+        v = 0.0;
+        for (int b = 0; b < B; b++)
+            v += P[i - k0][b] * M[(k0 + b) * n + j];
+    } else if (jK) { // -C[i, :] P^-1
+        v = 0.0;
+        for (int a = 0; a < B; a++)
+            v -= M[i * n + (k0 + a)] * P[a][j - k0];
+    } else {
+        v = M[i * n + j];
+        for (int a = 0; a < B; a++) {
+            double w = 0.0; // (P^-1 R[:, j])_a
+            for (int b = 0; b < B; b++)
+                w += P[a][b] * M[(k0 + b) * n + j];
+            v -= M[i * n + (k0 + a)] * w;
+        }
+    }
+    Mo[i * n + j] = v;
 }
 
 // y = Minv b, one wave per row
@@ -972,7 +1036,7 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
         FV_TRY(stat.zero(ctx));
         const dim3 gs(fv_blocks(nc, FV_BLOCK / 16)), blk(FV_BLOCK);
         hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, false, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg, rowcnt.p,
-                           (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p, 0);
+                           (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p);
         FV_LAUNCH_CHECK(ctx);
         int32_t hstat[2] = {0, 0};
         FV_HIP(ctx, hipMemcpyAsync(hstat, stat.p, sizeof hstat, hipMemcpyDeviceToHost, ctx->stream));
@@ -981,9 +1045,16 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
             const int nbig = hstat[0];
             if (nbig > 0) {
                 hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, false, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
-                                   agg, rowcnt.p, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p, CAP_S);
+                                   agg, rowcnt.p, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p);
                 FV_LAUNCH_CHECK(ctx);
+                // (an aggregate of more members than the small launch has lanes is passed on without its entry count: the larger
+                // launch has counted it now)
+                FV_HIP(ctx, hipMemcpyAsync(hstat, stat.p, sizeof hstat, hipMemcpyDeviceToHost, ctx->stream));
+                FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
+        }
+        if (hstat[1] <= CAP_B) {
+            const int nbig = hstat[0];
             FV_TRY(rowptr_c.alloc(ctx, (size_t)nc + 1));
             FV_TRY(fv_exclusive_scan_i32(ctx, rowcnt.p, rowptr_c.p, nc, nnz_c));
             FV_TRY(colind_c.alloc(ctx, (size_t)*nnz_c + 2)); // (+ two zero entries: the wave-stream kernel reads pairs)
@@ -991,10 +1062,10 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
             FV_HIP(ctx, hipMemsetAsync(colind_c.p + *nnz_c, 0, 2 * sizeof(int32_t), ctx->stream));
             FV_HIP(ctx, hipMemsetAsync(vals_c.p + *nnz_c, 0, 2 * sizeof(double), ctx->stream));
             hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, true, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg,
-                               (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p, 0);
+                               (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p);
             if (nbig > 0)
                 hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, true, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
-                                   agg, (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p, CAP_S);
+                                   agg, (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p);
             FV_LAUNCH_CHECK(ctx);
             if (D) {
                 FV_TRY(Dc.alloc(ctx, (size_t)nc));
@@ -1200,8 +1271,7 @@ static int amg_build_pooled(fv_problem *p)
     a->dense = last->n <= 2 * (int64_t)g_coarse_max && last->n > 0; // also a tiny problem as a whole: the "cycle" is then the exact inverse
     if (a->dense) {
         FV_TRY(a->inv.alloc(ctx, (size_t)(a->nco * a->nco)));
-        FV_TRY(a->gjrow.alloc(ctx, (size_t)a->nco));
-        FV_TRY(a->gjcol.alloc(ctx, (size_t)a->nco));
+        FV_TRY(a->inv2.alloc(ctx, (size_t)(a->nco * a->nco)));
     }
     FV_TRY(a->z.alloc(ctx, (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD)); // (a row block's halo slots stay zero: the cycle is block-local)
     FV_TRY(a->z.zero(ctx));
@@ -1249,13 +1319,14 @@ static int amg_set_sigma(fv_problem *p, double sigma)
                            sigma != 0.0 ? l->D : (const double *)nullptr, sigma, a->inv.p);
         FV_LAUNCH_CHECK(ctx);
         const dim3 g2(fv_blocks(m), (unsigned)m);
-        for (int64_t k = 0; k < m; k++) {
-            hipLaunchKernelGGL(amg_gj_save_kernel, dim3(fv_blocks(m)), dim3(FV_BLOCK), 0, ctx->stream, m, k, (const double *)a->inv.p, a->gjrow.p,
-                               a->gjcol.p);
-            hipLaunchKernelGGL(amg_gj_update_kernel, g2, dim3(FV_BLOCK), 0, ctx->stream, m, k, a->inv.p, (const double *)a->gjrow.p,
-                               (const double *)a->gjcol.p);
+        double *src = a->inv.p, *dst = a->inv2.p;
+        for (int64_t k = 0; k < m; k += GJB) {
+            hipLaunchKernelGGL(amg_gj_block_kernel, g2, dim3(FV_BLOCK), 0, ctx->stream, m, k, (int)(m - k < GJB ? m - k : GJB), (const double *)src, dst);
+            std::swap(src, dst);
         }
         FV_LAUNCH_CHECK(ctx);
+        if (src != a->inv.p) // (an odd number of steps: the inverse sits in the second copy)
+            a->inv.swap(a->inv2);
     }
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     a->sigma = sigma;

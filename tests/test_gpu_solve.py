@@ -1664,6 +1664,7 @@ def test_amg_galerkin_by_row_merge_is_the_sorted_product_bit_for_bit(fv, case):
         n2 = rng.integers(1, N, F)
         hub = rng.choice(N, 12, replace=False) + 1  # a dozen hubs with ~600 faces each: coarse rows beyond the small launch's 64 entries
         n1[: 12 * 600] = np.repeat(hub, 600)
+        n1[12 * 600 : 12 * 600 + 5000] = hub[0]  # ... and one with 5 600: beyond the large launch's 2 048 too, that pass falls back to the sort
         aol = np.exp(rng.uniform(-2, 2, F))
         K = np.exp(rng.normal(0.0, 1.0, F))
         dn = rng.choice(N, 500, replace=False) + 1

@@ -32,6 +32,9 @@ if os.environ.get("FV_AMG_SWEEP") == "3":  # the K-cycle (fv_tune 52: levels 1 .
     configs = [(0.1, 0.85, 3, 10, k) for k in (0, 1, 2, 3)] + [(0.1, 0.85, 2, 10, k) for k in (0, 1, 2, 3, 5)] + [(0.05, 0.85, 2, 10, 3), (0.1, 0.7, 3, 10, 2), (0.1, 1.0, 3, 10, 2)]
 if os.environ.get("FV_AMG_SWEEP") == "4":  # handshake rounds / threshold under the K-cycle
     configs = [(0.1, 0.85, 2, r, 2) for r in (3, 4, 6, 8, 10)] + [(th, 0.85, 2, 6, 2) for th in (0.05, 0.2, 0.3)] + [(0.1, om, 2, 6, 2) for om in (0.7, 1.0)]
+if os.environ.get("FV_AMG_SWEEP") == "5":  # round 4 (rows without a candidate leave the matching): rounds / threshold / damping / K levels again
+    configs = [(0.1, 0.85, 2, r, 2) for r in (4, 6, 10)] + [(th, 0.85, 2, 10, 2) for th in (0.05, 0.15, 0.25)] + [(0.1, om, 2, 10, 2) for om in (0.75, 0.95)] + \
+              [(0.1, 0.85, 2, 10, k) for k in (1, 3)]
 for cfg in configs:
     theta, omega, passes, rounds = cfg[:4]
     kc = cfg[4] if len(cfg) > 4 else 0
@@ -51,4 +54,4 @@ for cfg in configs:
     print("theta %.2f omega %.2f passes %d rounds %d K-levels %d: rows %s complexity %.2f set-up %.3f s, %d iterations (%s) %.3f s -> %.2f ms per iteration" %
           (theta, omega, passes, rounds, kc, rows.tolist(), nnz.sum() / nnz[0], t_setup, ch.iters, "converged" if ch.isconverged else "NOT converged", t_solve,
            t_solve / max(ch.iters, 1) * 1e3), flush=True)
-lib.fv_amg_configure(0.10, 0.85, 3, 10)
+lib.fv_amg_configure(0.10, 0.85, 2, 10)
