@@ -555,6 +555,9 @@ __device__ inline void amg_row_done(const AmgOp &a, int64_t row, double s, doubl
     }
 }
 
+// (measured, round 4: letting the block that finishes last add the partials up — so that the K-cycle's vector kernels read five numbers
+// instead of reducing 2 048 partials each — needs a device-scope release fence in every block, i.e. a write-back of the XCD's L2 with
+// the product's output in it: the product went from 55 to 284 us.  The partials stay.)
 template <int EPI>
 __device__ inline void amg_block_done(const AmgOp &a, double acc0, double acc1, double acc2, double *smem)
 {
@@ -1199,7 +1202,10 @@ static int amg_build_pooled(fv_problem *p)
         const double *va = L->vals, *Dp = L->D;
         int64_t ncur = L->n, nnz_cur = L->nnz;
         bool stalled = false;
-        for (int pass = 0; pass < g_passes; pass++) {
+        // coarse levels of fewer than a million rows are launch-bound: one pass more there (aggregates of ~8) makes the hierarchy a
+        // level shorter at the same iteration count (256^3 sigma = 3: 7 -> 6 levels, 37 iterations either way, solve 96.1 -> 92.7 ms)
+        const int npasses = (a->lev.size() > 1 && L->n < 1000000 && g_passes < 4) ? g_passes + 1 : g_passes; // (never the operator itself)
+        for (int pass = 0; pass < npasses; pass++) {
             DevBuf<int32_t> agg, memptr, mem, nrp, nci;
             DevBuf<double> nva, nD;
             int64_t nc = 0, nnzc = 0;
