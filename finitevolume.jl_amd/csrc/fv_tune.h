@@ -44,7 +44,14 @@ extern "C" {
  *  59: M^-1 as one-byte codes in the vector pass of the many-iteration loop where it takes at most 16 distinct values [1]
  *  60: the coded fused step / pass on contiguous chunks of a plane (fused_chunk_kernel): 1 = with the first / last plane's products formed by it
  *      too [1], 2 = those planes by the slice-by-slice launch, 0 = the 2-D tiles
- *  61: systems of at most this many rows are solved by the single-launch kernel of fv_small.hip [32768]; 0 = never */
+ *  61: systems of at most this many rows are solved by the single-launch kernel of fv_small.hip [32768]; 0 = never
+ *
+ * Environment variables the library reads besides FV_TUNE (diagnostics and one differential switch, none changes a result):
+ *   FV_TRACE_SPMV=N / FV_TRACE_FUSED=1 / FV_TRACE_REORDER=1  print kernel choices, fused-step eligibility, re-numbering decisions to stderr
+ *   FV_TRACE_ALLOC=1     every device allocation / release that takes more than 0.1 ms, to stderr
+ *   FV_AMG_VERBOSE=1     the AMG set-up phase by phase, to stderr
+ *   FV_AMG_GALERKIN=sort the AMG's Galerkin products by the global stable sort instead of the row merge (the same bits: tested)
+ *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments) */
 int fv_tune(int key, int value);
 #ifdef __cplusplus
 }
