@@ -121,9 +121,26 @@ __device__ inline uint64_t amg_pref(double s, int32_t i, int32_t j)
 
 // every unmatched row names its preferred strong unmatched neighbour (strong: -a_ij >= theta * the row's strongest
 // coupling), -1 if there is none; rows without any negative off-diagonal are marked isolated
+// cut[i] = theta * the row's strongest coupling (0: no negative off-diagonal at all) — the same in every round of a pass, so the
+// rounds read the row once instead of twice
+__global__ __launch_bounds__(FV_BLOCK) void amg_cut_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+                                                            const double *__restrict__ vals, double theta, double *__restrict__ cut)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= n)
+        return;
+    double maxoff = 0.0;
+    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
+        const int32_t j = colind[k];
+        if (j != i && j < n && -vals[k] > maxoff)
+            maxoff = -vals[k];
+    }
+    cut[i] = theta * maxoff;
+}
+
 __global__ __launch_bounds__(FV_BLOCK) void amg_pick_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
                                                              const double *__restrict__ vals, const int32_t *__restrict__ partner,
-                                                             int32_t *__restrict__ cand, double theta)
+                                                             int32_t *__restrict__ cand, const double *__restrict__ cutv)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (i >= n)
@@ -132,17 +149,11 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_pick_kernel(int64_t n, const int
         cand[i] = -1;
         return;
     }
-    double maxoff = 0.0;
-    for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
-        const int32_t j = colind[k];
-        if (j != i && j < n && -vals[k] > maxoff)
-            maxoff = -vals[k];
-    }
-    if (!(maxoff > 0.0)) {
+    const double cut = cutv[i];
+    if (!(cut > 0.0)) {
         cand[i] = AMG_ISOLATED;
         return;
     }
-    const double cut = theta * maxoff;
     uint64_t bestp = 0;
     int32_t best = -1;
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
@@ -962,8 +973,11 @@ static int amg_pairwise(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int
     const dim3 g(fv_blocks(n)), b(FV_BLOCK);
     // (measured, round 4: walking a compacted list of the still unmatched rows in the later rounds is SLOWER — 1.15 ms against 0.51 ms
     // per round at 16.6 M rows with a fifth of them on the list: the rows of a wave are then no longer neighbours in colind / vals)
+    DevBuf<double> cut;
+    FV_TRY(cut.alloc(ctx, (size_t)n));
+    hipLaunchKernelGGL(amg_cut_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, g_theta, cut.p);
     for (int r = 0; r < g_rounds; r++) {
-        hipLaunchKernelGGL(amg_pick_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, (const int32_t *)partner.p, cand.p, g_theta);
+        hipLaunchKernelGGL(amg_pick_kernel, g, b, 0, ctx->stream, n, rowptr, colind, vals, (const int32_t *)partner.p, cand.p, (const double *)cut.p);
         hipLaunchKernelGGL(amg_match_kernel, g, b, 0, ctx->stream, n, (const int32_t *)cand.p, partner.p);
         FV_LAUNCH_CHECK(ctx);
     }
