@@ -243,7 +243,7 @@ class Problem:
         ch = ConvergenceHistory(info, hist[: info.resnorm_len].copy() if hist is not None else None)
         return head, res, ch
 
-    PRECONDITIONERS = {"jacobi": 0, "amg": 1, "auto": 2}
+    PRECONDITIONERS = {"jacobi": 0, "amg": 1, "auto": 2, "amg_gathered": 3}  # (3: row blocks with the coarse levels of the whole operator)
 
     def set_preconditioner(self, kind):
         """"jacobi" (default) or "amg": the aggregation-AMG V-cycle that stands where the reference uses

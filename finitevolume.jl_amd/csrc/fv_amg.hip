@@ -61,6 +61,7 @@ struct fv_amg {
     int64_t storage_epoch = -1; // which fv_transient_begin the aggregated D belongs to
     bool kcycle = false;      // this application of the cycle may use the K-cycle (the PCG loop around it is flexible); fv_amg_apply keeps the linear V-cycle
     bool fold = false;        // level-0 SpMVs use the folded value array (fixed-dt runs), as the PCG around them
+    bool gathered = false;    // row blocks, FV_PRECOND_AMG_GATHERED: levels >= 1 are those of the WHOLE operator, replicated on every rank
     DevBuf<double> z;         // preconditioned residual of the PCG
     DevBuf<int32_t> loc_rowptr, loc_colind; // row blocks: the rank's diagonal block as the level-0 structure
     DevBuf<double> loc_vals;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_member_keys_kernel(int64_t n, co
 
 // Galerkin product with a piecewise-constant P, step 1: every stored entry (i, j, v) becomes (agg[i] * nc + agg[j], v);
 // entries of rows or columns without an aggregate get the largest key and fall off the end of the sort
-__global__ __launch_bounds__(FV_BLOCK) void amg_expand_kernel(int64_t n, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
+__global__ __launch_bounds__(FV_BLOCK) void amg_expand_kernel(int64_t n, int64_t ncols, const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colind,
                                                                const int32_t *__restrict__ agg, uint64_t nc, uint64_t *__restrict__ key)
 {
     const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_expand_kernel(int64_t n, const i
     const int32_t I = agg[i];
     for (int32_t k = rowptr[i]; k < rowptr[i + 1]; k++) {
         const int32_t j = colind[k];
-        const int32_t c = (j < n) ? agg[j] : -1;
+        const int32_t c = (j < ncols) ? agg[j] : -1;
         key[k] = (I < 0 || c < 0) ? nc * nc : (uint64_t)I * nc + (uint64_t)c;
     }
 }
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_merge_kernel(int64_t nc, int64_t
     constexpr int GROUPS = FV_BLOCK / LANES;
     __shared__ uint32_t s_col[GROUPS][CAP], s_scol[GROUPS][CAP];
     __shared__ double s_val[FILL ? GROUPS : 1][FILL ? CAP : 1], s_sval[FILL ? GROUPS : 1][FILL ? CAP : 1];
-    __shared__ int32_t s_rs[BIG ? 1 : GROUPS][BIG ? 1 : LANES], s_off[BIG ? 1 : GROUPS][BIG ? 1 : LANES + 1];
+    __shared__ int32_t s_rs[BIG ? 1 : GROUPS][LANES], s_off[BIG ? 1 : GROUPS][LANES + 1]; // (used by the small launch only)
     const int g = threadIdx.x / LANES, sub = threadIdx.x % LANES;
     const int64_t I = BIG ? (int64_t)big[blockIdx.x] : (int64_t)blockIdx.x * GROUPS + g;
     int E = 0;
@@ -1034,10 +1035,13 @@ static int amg_members(fv_ctx *ctx, int64_t n, const int32_t *agg, int64_t nc, D
 }
 
 // Galerkin coarse operator P^T A P for the aggregation `agg`: CSR with sorted columns + aggregated storage diagonal
+// ncols: columns below it have an aggregate in agg (the rows' own count; a row block with its halo slots for the gathered levels)
 static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowptr, const int32_t *colind, const double *vals, const double *D,
                         const int32_t *agg, int64_t nc, const int32_t *memptr, const int32_t *mem, DevBuf<int32_t> &rowptr_c,
-                        DevBuf<int32_t> &colind_c, DevBuf<double> &vals_c, DevBuf<double> &Dc, int64_t *nnz_c)
+                        DevBuf<int32_t> &colind_c, DevBuf<double> &vals_c, DevBuf<double> &Dc, int64_t *nnz_c, int64_t ncols = -1)
 {
+    if (ncols < 0)
+        ncols = n;
     DevBuf<uint64_t> key, key2;
     DevBuf<double> val2;
     DevBuf<int32_t> head, pos, rowcnt;
@@ -1052,7 +1056,7 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
         FV_TRY(stat.alloc(ctx, 2));
         FV_TRY(stat.zero(ctx));
         const dim3 gs(fv_blocks(nc, FV_BLOCK / 16)), blk(FV_BLOCK);
-        hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, false, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg, rowcnt.p,
+        hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, false, false>), gs, blk, 0, ctx->stream, nc, ncols, memptr, mem, rowptr, colind, vals, agg, rowcnt.p,
                            (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p);
         FV_LAUNCH_CHECK(ctx);
         int32_t hstat[2] = {0, 0};
@@ -1061,7 +1065,7 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
         if (hstat[1] <= CAP_B) {
             const int nbig = hstat[0];
             if (nbig > 0) {
-                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, false, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
+                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, false, true>), dim3(nbig), blk, 0, ctx->stream, nc, ncols, memptr, mem, rowptr, colind, vals,
                                    agg, rowcnt.p, (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr, big.p, stat.p);
                 FV_LAUNCH_CHECK(ctx);
                 // (an aggregate of more members than the small launch has lanes is passed on without its entry count: the larger
@@ -1078,10 +1082,10 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
             FV_TRY(vals_c.alloc(ctx, (size_t)*nnz_c + 2));
             FV_HIP(ctx, hipMemsetAsync(colind_c.p + *nnz_c, 0, 2 * sizeof(int32_t), ctx->stream));
             FV_HIP(ctx, hipMemsetAsync(vals_c.p + *nnz_c, 0, 2 * sizeof(double), ctx->stream));
-            hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, true, false>), gs, blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals, agg,
+            hipLaunchKernelGGL((amg_merge_kernel<16, CAP_S, true, false>), gs, blk, 0, ctx->stream, nc, ncols, memptr, mem, rowptr, colind, vals, agg,
                                (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p);
             if (nbig > 0)
-                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, true, true>), dim3(nbig), blk, 0, ctx->stream, nc, n, memptr, mem, rowptr, colind, vals,
+                hipLaunchKernelGGL((amg_merge_kernel<FV_BLOCK, CAP_B, true, true>), dim3(nbig), blk, 0, ctx->stream, nc, ncols, memptr, mem, rowptr, colind, vals,
                                    agg, (int32_t *)nullptr, (const int32_t *)rowptr_c.p, colind_c.p, vals_c.p, big.p, stat.p);
             FV_LAUNCH_CHECK(ctx);
             if (D) {
@@ -1098,7 +1102,7 @@ static int amg_galerkin(fv_ctx *ctx, int64_t n, int64_t nnz, const int32_t *rowp
     FV_TRY(key2.alloc(ctx, (size_t)nnz));
     FV_TRY(val2.alloc(ctx, (size_t)nnz));
     const uint64_t unc = (uint64_t)nc;
-    hipLaunchKernelGGL(amg_expand_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, rowptr, colind, agg, unc, key.p);
+    hipLaunchKernelGGL(amg_expand_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, ncols, rowptr, colind, agg, unc, key.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY((amg_sort_pairs<uint64_t, double>(ctx, key.p, key2.p, vals, val2.p, (size_t)nnz, amg_bits(unc * unc))));
     key.release();
@@ -1166,6 +1170,151 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_local_fill_kernel(int64_t n, con
         }
 }
 
+// ------------------------------------------------------------------ gathered coarse levels for row blocks (FV_PRECOND_AMG_GATHERED)
+// Block-Jacobi AMG (above) needs no communication but its iteration count grows with the number of ranks: nothing couples the blocks
+// below level 0.  Here every rank still aggregates its own rows only (no aggregate crosses a rank boundary), but the level-1 operator
+// is the Galerkin product of the WHOLE operator: a rank forms its rows of it from its full rows — halo columns renamed by the
+// aggregate ids their owners sent through the ordinary halo exchange —, the ranks' pieces are summed into one CSR that every rank
+// holds (all-reduces of disjoint segments), and the hierarchy below is built from it by every rank for itself: identical everywhere,
+// no communication below level 1.  Per cycle: two halo exchanges (the two level-0 products are those of the whole operator) and one
+// all-reduce of the level-1 right-hand side (each rank restricts its own rows; the other rows' sums are zero).  The coarse work is
+// replicated, not divided — what this buys is an iteration count that no longer depends on the rank count.
+__global__ __launch_bounds__(FV_BLOCK) void amg_global_ids_kernel(int64_t n, int64_t next, const int32_t *__restrict__ agg, double off, double *__restrict__ g)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < next)
+        g[i] = (i < n && agg[i] >= 0) ? off + (double)agg[i] : -1.0;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_to_int_kernel(int64_t m, const double *__restrict__ g, int32_t *__restrict__ a)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < m)
+        a[i] = (int32_t)g[i];
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void amg_row_counts_kernel(int64_t nc, const int32_t *__restrict__ rowptr, double *__restrict__ cnt)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < nc)
+        cnt[i] = (double)(rowptr[i + 1] - rowptr[i]);
+}
+
+// a rank's rows [lo, hi) of the level-1 operator into their places of the gathered arrays (columns as doubles: they travel through
+// the same all-reduce as the values)
+__global__ __launch_bounds__(FV_BLOCK) void amg_scatter_piece_kernel(int64_t lo, int64_t hi, const int32_t *__restrict__ prp, const int32_t *__restrict__ pci,
+                                                                      const double *__restrict__ pva, const int32_t *__restrict__ grp,
+                                                                      double *__restrict__ gc, double *__restrict__ gv)
+{
+    const int64_t I = lo + (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (I >= hi)
+        return;
+    const int32_t s = prp[I], e = prp[I + 1], o = grp[I];
+    for (int32_t k = s; k < e; k++) {
+        gc[o + (k - s)] = (double)pci[k];
+        gv[o + (k - s)] = pva[k];
+    }
+}
+
+// agg_loc: the rank's own aggregation of its n rows (local ids 0 .. nc_loc - 1, -1 = none).  On return L carries the transfer to the
+// gathered level (global ids) and C is that level.
+static int amg_gather_level1(fv_problem *p, AmgLevel *L, DevBuf<int32_t> &agg_loc, int64_t nc_loc, AmgLevel *C)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    const int64_t n = p->n, next = p->n + p->nhalo;
+    const int R = d->nranks;
+    // every rank's number of aggregates -> my offset, the size of the level
+    DevBuf<double> counts;
+    FV_TRY(counts.alloc(ctx, (size_t)R));
+    FV_TRY(counts.zero(ctx));
+    const double mine = (double)nc_loc;
+    FV_HIP(ctx, hipMemcpyAsync(counts.p + d->rank, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, counts.p, R, ctx->stream));
+    std::vector<double> hc((size_t)R);
+    FV_HIP(ctx, fv_memcpy_sync(ctx, hc.data(), counts.p, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
+    int64_t off = 0, ncg = 0;
+    for (int r = 0; r < R; r++) {
+        if (r < d->rank)
+            off += (int64_t)hc[(size_t)r];
+        ncg += (int64_t)hc[(size_t)r];
+    }
+    if (ncg <= 0 || ncg >= 0x7fffffffLL) {
+        fv_set_error(ctx, "gathered AMG level: %lld aggregates over all ranks", (long long)ncg);
+        return FV_ERR_STATE;
+    }
+    // global aggregate ids of my rows and, through the halo exchange, of my halo columns
+    DevBuf<double> gid;
+    DevBuf<int32_t> agg_ext;
+    FV_TRY(gid.alloc(ctx, (size_t)next + FV_VEC_PAD));
+    FV_TRY(agg_ext.alloc(ctx, (size_t)next));
+    hipLaunchKernelGGL(amg_global_ids_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, n, next, (const int32_t *)agg_loc.p, (double)off, gid.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_dist_exchange(p, gid.p));
+    hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, next, (const double *)gid.p, agg_ext.p);
+    FV_LAUNCH_CHECK(ctx);
+    gid.release();
+    // my rows of P^T A P, in the row space of the whole level (the rows of other ranks stay empty)
+    FV_TRY(amg_members(ctx, n, agg_ext.p, ncg, L->memptr, L->mem));
+    DevBuf<int32_t> prp, pci;
+    DevBuf<double> pva, pD;
+    int64_t pnnz = 0;
+    FV_TRY(amg_galerkin(ctx, n, p->nnz, p->rowptr.p, p->colind.p, p->vals.p, L->D, agg_ext.p, ncg, L->memptr.p, L->mem.p, prp, pci, pva, pD, &pnnz, next));
+    // row lengths of the whole level -> its row pointers
+    DevBuf<double> dcnt;
+    DevBuf<int32_t> icnt;
+    FV_TRY(dcnt.alloc(ctx, (size_t)ncg));
+    FV_TRY(icnt.alloc(ctx, (size_t)ncg));
+    hipLaunchKernelGGL(amg_row_counts_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const int32_t *)prp.p, dcnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, dcnt.p, (int)ncg, ctx->stream));
+    hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const double *)dcnt.p, icnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(C->o_rowptr.alloc(ctx, (size_t)ncg + 1));
+    int64_t gnnz = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, icnt.p, C->o_rowptr.p, ncg, &gnnz));
+    if (gnnz <= 0 || gnnz >= 0x7fffffffLL - 2) {
+        fv_set_error(ctx, "gathered AMG level: %lld entries", (long long)gnnz);
+        return FV_ERR_STATE;
+    }
+    dcnt.release();
+    icnt.release();
+    // entries: every rank writes its rows' segments, the sum over the ranks is the level
+    DevBuf<double> gc;
+    FV_TRY(gc.alloc(ctx, (size_t)gnnz));
+    FV_TRY(gc.zero(ctx));
+    FV_TRY(C->o_vals.alloc(ctx, (size_t)gnnz + 2));
+    FV_TRY(C->o_vals.zero(ctx));
+    if (nc_loc > 0)
+        hipLaunchKernelGGL(amg_scatter_piece_kernel, dim3(fv_blocks(nc_loc)), dim3(FV_BLOCK), 0, ctx->stream, off, off + nc_loc, (const int32_t *)prp.p,
+                           (const int32_t *)pci.p, (const double *)pva.p, (const int32_t *)C->o_rowptr.p, gc.p, C->o_vals.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, gc.p, (int)gnnz, ctx->stream));
+    FV_TRY(fv_comm_allreduce_sum(ctx, d, C->o_vals.p, (int)gnnz, ctx->stream));
+    FV_TRY(C->o_colind.alloc(ctx, (size_t)gnnz + 2));
+    FV_TRY(C->o_colind.zero(ctx));
+    hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(gnnz)), dim3(FV_BLOCK), 0, ctx->stream, gnnz, (const double *)gc.p, C->o_colind.p);
+    FV_LAUNCH_CHECK(ctx);
+    if (L->D) {
+        C->o_D.swap(pD); // (sums over my members; zero on the rows of other ranks)
+        FV_TRY(fv_comm_allreduce_sum(ctx, d, C->o_D.p, (int)ncg, ctx->stream));
+    }
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    C->n = ncg;
+    C->nnz = gnnz;
+    C->rowptr = C->o_rowptr.p;
+    C->colind = C->o_colind.p;
+    C->vals = C->o_vals.p;
+    C->D = L->D ? C->o_D.p : nullptr;
+    L->nc = ncg;
+    L->agg.swap(agg_ext);
+    if (amg_verbose())
+        fprintf(stderr, "[amg] rank %d: gathered level 1: %lld rows (mine %lld from %lld), %lld entries\n", d->rank, (long long)ncg, (long long)nc_loc,
+                (long long)off, (long long)gnnz);
+    return FV_OK;
+}
+
 static int amg_build_pooled(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
@@ -1205,9 +1354,12 @@ static int amg_build_pooled(fv_problem *p)
         L->vals = p->vals.p;
     }
     L->D = p->D.p; // may be null (steady solve before fv_transient_begin)
+    a->gathered = p->dist && p->dist->nranks > 1 && p->amg_gathered;
     for (int depth = 0; depth < 24; depth++) {
         L = a->lev.back();
-        if (L->n <= g_coarse_max)
+        // (gathered levels: whether there is a level 1 is not for one rank's block size to decide — every rank builds it)
+        const bool gather_here = a->gathered && depth == 0;
+        if (L->n <= g_coarse_max && !gather_here)
             break;
         // passes of pairwise aggregation, each on the Galerkin operator of the previous one
         DevBuf<int32_t> cur_rowptr, cur_colind, agg_total;
@@ -1228,7 +1380,12 @@ static int amg_build_pooled(fv_problem *p)
             if (amg_verbose())
                 fprintf(stderr, "[amg] level %zu pass %d: %lld rows -> %lld aggregates (matching %.3f s)\n", a->lev.size() - 1, pass, (long long)ncur,
                         (long long)nc, amg_now() - tp0);
-            if (nc == 0 || nc > (int64_t)(0.95 * (double)ncur)) {
+            if (gather_here && pass == 0 && (nc == 0 || ncur <= 1)) { // (a block without couplings: no aggregates of its own, the others' level all the same)
+                agg_total.swap(agg);
+                ncur = nc;
+                break;
+            }
+            if ((nc == 0 || nc > (int64_t)(0.95 * (double)ncur)) && !(gather_here && pass == 0)) {
                 stalled = pass == 0;
                 break;
             }
@@ -1257,6 +1414,15 @@ static int amg_build_pooled(fv_problem *p)
             nnz_cur = nnzc;
             if (ncur <= g_coarse_max)
                 break;
+        }
+        if (gather_here) {
+            AmgLevel *C = new AmgLevel();
+            a->lev.push_back(C); // (owned by the hierarchy whatever happens next)
+            FV_TRY(amg_gather_level1(p, L, agg_total, ncur, C));
+            FV_TRY(C->x.alloc(ctx, (size_t)C->n));
+            FV_TRY(C->b.alloc(ctx, (size_t)C->n));
+            FV_TRY(C->u.alloc(ctx, (size_t)C->n));
+            continue;
         }
         if (stalled || ncur == L->n || !agg_total.p)
             break; // cannot coarsen further: this level is the coarsest
@@ -1365,6 +1531,8 @@ int fv_amg_prepare(fv_problem *p, double sigma)
 // level 0 uses the problem's own SpMV; on a row block the product with the rank's diagonal block (x's halo slots are zero)
 static int amg_top_spmv(fv_problem *p, const double *x, double *t, double sigma)
 {
+    if (p->dist && p->amg->gathered) // the whole operator's rows: x's halo slots are fetched from their owners
+        return fv_dist_full_spmv(p, const_cast<double *>(x), t, sigma, p->amg->fold);
     if (p->dist)
         return fv_dist_local_spmv(p, const_cast<double *>(x), t, sigma, p->amg->fold);
     return fv_spmv_launch(p, x, t, sigma, nullptr, p->amg->fold);
@@ -1455,10 +1623,19 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     else
         FV_TRY(amg_level_spmv(ctx, L, u, L->t.p, sigma));
     // (4 lanes per aggregate: the aggregates of two pairwise passes have ~5 members)
+    const bool sum_ranks = l == 0 && a->gathered; // every rank has restricted its own rows: the level's right-hand side is their sum
     hipLaunchKernelGGL(amg_restrict_kernel<4>, dim3(fv_blocks(C->n, FV_BLOCK / 4)), blk, 0, ctx->stream, C->n, (const int32_t *)L->memptr.p,
                        (const int32_t *)L->mem.p, b, (const double *)L->t.p, C->b.p, (const double *)C->dinv.p, g_omega,
-                       c_last ? (double *)nullptr : C->u.p);
+                       (c_last || sum_ranks) ? (double *)nullptr : C->u.p);
     FV_LAUNCH_CHECK(ctx);
+    if (sum_ranks) {
+        FV_TRY(fv_comm_allreduce_sum(ctx, p->dist, C->b.p, (int)C->n, ctx->stream));
+        if (!c_last) {
+            hipLaunchKernelGGL(amg_smooth0_kernel, dim3(fv_blocks(C->n)), blk, 0, ctx->stream, C->n, (const double *)C->dinv.p, (const double *)C->b.p,
+                               g_omega, C->u.p);
+            FV_LAUNCH_CHECK(ctx);
+        }
+    }
     if (c_kcycle)
         FV_TRY(amg_kcycle(p, l + 1, C->b.p, C->x.p, sigma));
     else
@@ -1641,8 +1818,16 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
 // ------------------------------------------------------------------ C ABI
 extern "C" int fv_precond_set(fv_problem *p, int kind)
 {
-    if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG && kind != FV_PRECOND_AUTO))
+    if (!p || (kind != FV_PRECOND_JACOBI && kind != FV_PRECOND_AMG && kind != FV_PRECOND_AUTO && kind != FV_PRECOND_AMG_GATHERED))
         return FV_ERR_ARG;
+    const bool gathered = kind == FV_PRECOND_AMG_GATHERED;
+    if (gathered)
+        kind = FV_PRECOND_AMG; // (the same solver paths; the hierarchy differs: amg_build_pooled)
+    if (p->amg && p->amg_gathered != gathered) { // another hierarchy
+        fv_amg_free(p->amg);
+        p->amg = nullptr;
+    }
+    p->amg_gathered = gathered;
     if (kind != FV_PRECOND_JACOBI && p->nhalo && !p->dist) {
         fv_set_error(p->ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;

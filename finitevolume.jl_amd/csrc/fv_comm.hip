@@ -152,18 +152,22 @@ static int local_halo_exchange(fv_ctx *ctx, const fv_dist *d, const double *send
 static int local_allreduce(fv_ctx *ctx, const fv_dist *d, double *buf, int count, hipStream_t stream)
 {
     LocalGroup *g = static_cast<LocalGroup *>(ctx->local_group);
-    if (count > 8)
+    if (count < 0)
         return FV_ERR_ARG;
     std::vector<double> &mine = g->red[(size_t)d->rank];
+    if ((int)mine.size() < count) // (the few-double sums of the PCG fit the initial 8; the gathered AMG levels reduce whole coarse vectors)
+        mine.resize((size_t)count);
     FV_HIP(ctx, hipMemcpyAsync(mine.data(), buf, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, stream));
     FV_HIP(ctx, hipStreamSynchronize(stream));
     g->barrier();
-    double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = 0; q < d->nranks; q++) // rank order: every rank gets the same bits
+    std::vector<double> sum((size_t)count, 0.0);
+    for (int q = 0; q < d->nranks; q++) { // rank order: every rank gets the same bits
+        const double *theirs = g->red[(size_t)q].data();
         for (int k = 0; k < count; k++)
-            sum[k] += g->red[(size_t)q][(size_t)k];
-    g->barrier(); // everybody has read before anybody overwrites its slot in the next reduction
-    FV_HIP(ctx, hipMemcpyAsync(buf, sum, (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
+            sum[(size_t)k] += theirs[k];
+    }
+    g->barrier(); // everybody has read before anybody overwrites (or regrows) its slot in the next reduction
+    FV_HIP(ctx, hipMemcpyAsync(buf, sum.data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, stream));
     FV_HIP(ctx, hipStreamSynchronize(stream)); // `sum` is on this stack frame
     return FV_OK;
 }

@@ -331,6 +331,7 @@ struct fv_problem {
     // FV_PRECOND_AUTO in implicit steps: Jacobi until a step needs more than FV_AUTO_SWITCH_ITERS iterations, the AMG
     // V-cycle from then on (one V-cycle iteration costs ~3 Jacobi-PCG iterations, measured); reset by fv_precond_set.
     bool auto_steps_amg = false;
+    bool amg_gathered = false; // FV_PRECOND_AMG_GATHERED: row blocks share the coarse levels of the whole operator (fv_amg.hip)
     fv_amg *amg = nullptr;
 
     // PCG workspace
@@ -531,6 +532,8 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
 
 // y = (A_local + sigma D) x with the row block's own columns only: the caller keeps x's halo slots at zero (fv_pcg.hip)
 int fv_dist_local_spmv(fv_problem *p, double *x_with_zero_halo, double *y, double sigma, bool fold, bool want_dot = false);
+int fv_dist_full_spmv(fv_problem *p, double *xext, double *y, double sigma, bool fold); // with the halo exchange of xext
+int fv_dist_exchange(fv_problem *p, double *xext);
 // diagnostics (fv_comm_diag): record an event of category `cat` on `stream` (a pair = two consecutive calls)
 int fv_diag_mark(fv_ctx *ctx, int cat, hipStream_t stream);
 // ---- fv_comm.hip (RCCL); all are no-ops for a single rank

@@ -1878,6 +1878,24 @@ int fv_dist_local_spmv(fv_problem *p, double *x, double *y, double sigma, bool f
     return dist_spmv(p, x, y, folded ? 0.0 : sigma, folded, want_dot, false, true); // interior + boundary passes, no exchange
 }
 
+// the product with the whole operator's rows of this block: halo exchange of x, interior + boundary passes (the gathered AMG's level 0)
+int fv_dist_full_spmv(fv_problem *p, double *xext, double *y, double sigma, bool fold)
+{
+    const double *folded = nullptr;
+    if (fold && sigma != 0.0)
+        FV_TRY(ensure_folded(p, sigma, &folded));
+    return dist_spmv(p, xext, y, folded ? 0.0 : sigma, folded, false, false);
+}
+
+// halo slots of xext (n + nhalo doubles) filled from their owners; returns when they are in place
+int fv_dist_exchange(fv_problem *p, double *xext)
+{
+    FV_TRY(dist_exchange_begin(p, xext));
+    FV_TRY(dist_exchange_wait(p));
+    FV_HIP(p->ctx, hipStreamSynchronize(p->ctx->stream));
+    return FV_OK;
+}
+
 // ------------------------------------------------------------------ PCG with the block-Jacobi AMG V-cycle on row blocks
 // z = V_local(r) on every rank's diagonal block (fv_amg.hip; no communication), the PCG around it as on one GPU with its
 // three sums all-reduced: p.q, r.r (the stopping test, before the next V-cycle is spent) and r.z.

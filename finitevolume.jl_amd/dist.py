@@ -184,8 +184,10 @@ class RowBlock:
         return n.value, b.value, t.value
 
     def set_preconditioner(self, kind):
-        """"jacobi" (default) or "amg": block-Jacobi with the aggregation-AMG V-cycle of the rank's diagonal block as the
-        block solver (no communication inside the preconditioner).  Every rank must make the same choice."""
+        """"jacobi" (default); "amg": block-Jacobi with the aggregation-AMG cycle of the rank's diagonal block as the
+        block solver (no communication inside the preconditioner); "amg_gathered": the coarse levels of the whole operator,
+        gathered on every rank (two halo exchanges and one all-reduce per cycle; an iteration count that does not depend on
+        the rank count).  Every rank must make the same choice."""
         self.ctx.check(load().fv_precond_set(self.handle, Problem.PRECONDITIONERS[kind]))
         return self
 

@@ -228,13 +228,21 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * flexible variant), on row blocks with the rank's own inner products; fv_amg_apply applies the plain V(1,1) cycle, a fixed symmetric operator.  The hierarchy
  * is built on the device at the first solve after fv_assemble (and again after the next fv_assemble /
  * fv_transient_begin); it carries the storage term, so shifted solves (implicit steps) can use it as well.
- * Not available for row blocks of a distributed run. */
+ */
 #define FV_PRECOND_JACOBI 0
 #define FV_PRECOND_AMG 1
 /* steady solves: Jacobi-PCG for min(maxiter/4, 100) iterations, then AMG-PCG from that iterate for the rest — the
  * shape of the reference's defaultlinearsolver (transient.jl:50-58); implicit steps: Jacobi until one step needs more
  * than 50 iterations, the V-cycle from the next step on (large time steps). */
 #define FV_PRECOND_AUTO 2
+/* Row blocks of a distributed run (fv_dist_setup / fv_dist_setup_local): FV_PRECOND_AMG builds every rank's hierarchy on its own
+ * diagonal block — block-Jacobi, no communication inside the preconditioner, an iteration count that grows with the rank count.
+ * FV_PRECOND_AMG_GATHERED keeps the aggregation rank-local on level 0 but forms level 1 as the Galerkin product of the WHOLE
+ * operator (the role of the one global hierarchy of AlgebraicMultigrid.ruge_stuben at FiniteVolume.jl:159-161), gathered on every
+ * rank, and every rank builds and applies the levels below it for itself: two halo exchanges and one all-reduce of the level-1
+ * right-hand side per cycle, replicated coarse work, and an iteration count that does not depend on the rank count.  On a whole
+ * problem (one rank) it is FV_PRECOND_AMG.  Every rank must make the same choice. */
+#define FV_PRECOND_AMG_GATHERED 3
 int fv_precond_set(fv_problem *p, int kind);
 /* theta: strength threshold of the matching (0.10); omega: Jacobi damping of the smoother (0.85); passes: pairwise
  * passes per level (2 -> aggregates of ~4-5); rounds: handshake rounds per pass (10).  Process-wide. */
