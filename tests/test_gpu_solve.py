@@ -1679,6 +1679,70 @@ def test_rank_local_assembly_of_a_face_list_mesh(fv, case):
         want.close()
 
 
+def test_gathered_amg_on_rank_local_blocks_of_an_irregular_mesh(fv):
+    """FV_PRECOND_AMG_GATHERED where no rank ever holds the whole operator: a random multigraph (repeated faces, rows of very
+    different length, cells without a face), every rank assembling only the faces of its own rows (dist.partial_problem), 3 ranks.
+    The solution is the one-GPU solution; the iteration count stays near the one-GPU AMG's although most couplings of this graph cross
+    rank boundaries."""
+    import threading
+
+    from fvamd import dist
+
+    rng = np.random.default_rng(21)  # (the mesh of test_amg_on_a_random_multigraph_with_isolated_and_zero_rows)
+    N, F, nranks = 6000, 26000, 3
+    n1 = rng.integers(1, N - 30, F)  # the last 30 cells have no face at all
+    n2 = rng.integers(1, N - 30, F)
+    n2[::40] = n1[::40]
+    nb = np.stack([n1, n2], 1)
+    aol = np.exp(rng.uniform(-3, 3, F))
+    K = np.exp(rng.normal(0.0, 1.0, F))
+    dn = rng.choice(N - 30, 300, replace=False) + 1
+    dh = rng.uniform(0.0, 2.0, 300)
+    src = 1e-2 * rng.standard_normal(N)
+    src[dn - 1] = 0
+    src[N - 30 :] = 0
+    ref = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+    A, b = ref.csc().toscipy().tocsr(), ref.b()
+    live = A.diagonal() > 0
+    ref.set_preconditioner("amg")
+    _, x1, ch1 = ref.solve_steady(None, 1e-12, 400)
+    assert ch1.isconverged
+    out, errors = [None] * nranks, []
+
+    def worker(rank):
+        try:
+            ctx = fv.Context(0)
+            dist.comm_init_local(ctx, nranks, rank, 1490)
+            p, bounds, faces = dist.partial_problem(nb, aol, N, dn, nranks, rank, None, ctx)
+            p.assemble(K[faces], src, dh)
+            p.transient_begin(1.0, np.ones(N), np.zeros(N))
+            blk = dist.RowBlock(p, nranks, rank, bounds).set_preconditioner("amg_gathered")
+            p.close()
+            x, info = blk.solve_steady(None, 1e-12, 400)
+            out[rank] = (blk.lo, blk.hi, x, info.iters, info.converged)
+            blk.close()
+            fv.load().fv_comm_destroy(ctx.handle)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+    xs = np.empty(out[-1][1])
+    for lo, hi, x, it, conv in out:
+        xs[lo:hi] = x
+        assert conv and it == out[0][3]
+    r = A @ xs - b
+    assert np.linalg.norm(r[live]) <= 1e-10 * np.linalg.norm(b)
+    assert relerr(xs[live], x1[live]) < 1e-8
+    print("irregular mesh, AMG-PCG iterations: one GPU", ch1.iters, "; gathered levels on 3 rank-local blocks", out[0][3])
+    # (a random graph cut into row ranges: two thirds of a row's neighbours belong to other ranks and cannot be aggregated with it)
+    assert out[0][3] <= ch1.iters * 3 // 2
+
+
 def test_amg_on_a_random_multigraph_with_isolated_and_zero_rows(fv, oracle):
     """AMG set-up on an irregular operator: repeated faces, self-loops (zero contribution), rows of very different
     length, free nodes whose only neighbours are Dirichlet (no couplings: the smoother alone must solve them), a
