@@ -83,7 +83,7 @@ static int g_passes = 2;      // pairwise passes per level (aggregates of ~4: th
 static int g_rounds = 10;     // handshake rounds per pass
 static int g_coarse_max = 1024;
 static int g_coarse_sweeps = 12; // Jacobi sweeps on a coarsest level too large for the dense inverse
-int g_amg_stream = 65536;       // fv_tune key 53: coarse levels with at least this many rows use the wave-stream CSR kernel (0: never)
+int g_amg_stream = 65536;       // (frozen; round 3 measured it) coarse levels with at least this many rows use the wave-stream CSR kernel (0: never)
 int g_amg_kcycle = 2;            // fv_tune key 52: coarse levels 1 .. g_amg_kcycle are solved by two flexible-CG steps preconditioned by the cycle below them (K-cycle)
 
 extern "C" int fv_amg_configure(double theta, double omega, int passes, int rounds)

@@ -74,7 +74,7 @@ struct KfArgs {
     // scalars / control
     PcgScalars *scal;
     FusedSums in, out;
-    int nt;          // streaming-hint experiment (fv_tune key 45)
+    int nt;          // streaming hints (bit mask; frozen at the measured best since round 4)
     int xapply;      // MODE 1: apply the lagging x-update of the previous iteration, x += scal->alpha_last * p (p = a.v, the old direction)
     int mode;        // 0: scalars of this step already in scal (set-up finalised by an earlier launch); 1: merged boundary
     int chain_index; // index of this step in its burst

@@ -72,7 +72,7 @@ int fv_csr_stream_spmv(fv_ctx *ctx, int64_t n, const int32_t *rowptr, const int3
 
 #define FV_LAUNCH_CHECK(ctx) FV_HIP(ctx, hipGetLastError())
 
-// Large arrays are handed out at staggered offsets inside their allocations (fv_tune key 32: bytes per step of the
+// Large arrays are handed out at staggered offsets inside their allocations (an experiment of round 2, frozen at zero: bytes per step of the
 // stagger, 0 = off): the streaming kernels walk up to nine arrays at the same index at the same time, and when all of
 // them start at the same offset of their (2 MiB-aligned) allocations they land on the same HBM channels together.
 extern int g_alloc_skew_bytes;

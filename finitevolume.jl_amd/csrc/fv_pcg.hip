@@ -24,7 +24,7 @@
 
 extern int g_carry_refresh, g_carry_speculate, g_chain_steps, g_resume_runs; // fv_transient.hip
 int g_defer_reduce = 1; // fv_tune key 22: bursts of chained steps take a step's verdict and the next step's scalars in one launch; row-block runs also merge their two all-reduces (see dist_step)
-int g_sparse_b = 1; // fv_tune key 12: K2S leaves the b' stream out when b' is sparse
+int g_sparse_b = 1; // (frozen) K2S leaves the b' stream out when b' is sparse
 int g_chain_test_break = -1; // fv_tune key 14 (tests): the chained step with this index of every burst is treated as not converged
 
 // ------------------------------------------------------------------ PCG vector kernels
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_spec_kernel(int64_t n, co
     }
 }
 
-int g_k2s_nt = 3; // fv_tune key 26: streaming hints of K2S (see pcg_update_spec_kernel): the read-once streams bypass the caches, so that p' and x survive for the next K1 (-8 % per step at 216^3, -10 % on a 1.2e7-row block, -1.5 % at 464^3)
+int g_k2s_nt = 3; // (frozen at the measured best) streaming hints of K2S (see pcg_update_spec_kernel): the read-once streams bypass the caches, so that p' and x survive for the next K1 (-8 % per step at 216^3, -10 % on a 1.2e7-row block, -1.5 % at 464^3)
 int g_zform = 1; // fv_tune key 36: K2S in the z-form (see pcg_update_spec_kernel) where it applies
 static auto k2s_kernel(bool zf) -> decltype(&pcg_update_spec_kernel<0, false>)
 {

@@ -21,7 +21,7 @@
 #include "fv_device.h"
 #include <cstdlib>
 
-int g_reorder_blocks = 0; // fv_tune key 48 (experiment): blocks of the device walk, 0 = a sixteenth of the CUs, at most 16
+int g_reorder_blocks = 0; // (frozen) blocks of the device walk, 0 = a sixteenth of the CUs, at most 16
 
 namespace {
 

@@ -412,31 +412,29 @@ static int g_use_order = 1;
 static int g_nt = 1;
 int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 int g_use_dia = 1;
-static int g_sell_blocks = 8; // fv_tune key 58 (experiment): resident blocks per CU the SELL SpMV's grid is sized for
+static int g_sell_blocks = 8; // (frozen) resident blocks per CU the SELL SpMV's grid is sized for
 static int g_sell = 1; // fv_tune key 54: SELL-64 with 16-bit column offsets for the groups the CSR kernel would serve (0: always the CSR wave-stream)
-static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (fv_tune key 11; read when the DIA copy is built)
-static int g_march_dbg = 0; // diagnosis switches of the marching kernel (fv_tune key 17; results are wrong when set)
-static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (fv_tune key 18)
+static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (frozen; read when the DIA copy is built)
+static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (frozen)
 static int g_trace_spmv = getenv("FV_TRACE_SPMV") ? atoi(getenv("FV_TRACE_SPMV")) : 0;
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9): 0 never, 1 when x outgrows the last-level cache, 2 always
-static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (fv_tune key 19; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
-static int g_march_segs = 0; // segments per XCD of the marching kernel (fv_tune key 10; 0 = chosen per operator)
+static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (frozen; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
+static int g_march_segs = 0; // segments per XCD of the marching kernel (0 = chosen per operator; frozen)
 int g_fold_shift = 1;
 int g_chunk_ends = 1; // (part of fv_tune key 60: value 2 keeps the first / last plane's products with the slice-by-slice launch)
 static int g_symdia = 1; // fv_tune key 27 >= 3: symmetric plane-marching form where the marching kernel runs
 static int g_march_form = 1; // fv_tune key 27 >= 2: the plane-marching kernels at all (0: structured operators stay with the slice-by-slice kernel)
-static int g_symdia_dbg = 0; // fv_tune key 29: diagnosis switches of the symmetric kernel (bit 0: no in-plane x arm loads, bit 1: no in-plane lower-value loads, bit 2: no window shuffles); results are wrong when set
-static int g_tile_blocks = 2; // fv_tune key 39 (experiment): resident blocks per CU the tiled kernel's grid is sized for
-static int g_tile_segs = 0;   // fv_tune key 40 (experiment): segments of planes per tile column, 0 = chosen to fill whole rounds
-static int g_sym_tile = 1;   // fv_tune key 38: the tiled traversal of the symmetric form where the free rows are a regular box (spmv_symdia_tile_kernel)
+static int g_tile_blocks = 2; // (frozen) resident blocks per CU the tiled kernel's grid is sized for
+static int g_tile_segs = 0;   // (frozen) segments of planes per tile column, 0 = chosen to fill whole rounds
+static int g_sym_tile = 1;   // (fv_tune key 27 = 4) the tiled traversal of the symmetric form where the free rows are a regular box (spmv_symdia_tile_kernel)
 static int g_sym_rowsum = 1; // fv_tune key 37: 0 = the symmetric kernel always streams the diagonal (see symdia_rowsum_kernel)
-static int g_symdia_nt = 4; // fv_tune key 28: streaming hints of the symmetric kernel (see its template parameter)
+static int g_symdia_nt = 4; // (frozen) streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
 extern int g_chain_steps, g_resume_runs;        // fv_transient.hip
 
-int g_alloc_skew_bytes = 0, g_alloc_skew_count = 0; // fv_tune key 32 (fv_internal.h, DevBuf)
-static int g_blocks_per_cu = 8; // fv_tune key 30 (experiments): blocks per CU the SpMV grids are sized for
+int g_alloc_skew_bytes = 0, g_alloc_skew_count = 0; // (frozen at 0; fv_internal.h, DevBuf)
+static int g_blocks_per_cu = 8; // (frozen) blocks per CU the SpMV grids are sized for
 // blocks that are all resident at 8 waves per SIMD: 8 per CU (2048 on the 256-CU MI355X; fewer on a partitioned device)
 static int g_resident_blocks = FV_MAX_PARTIALS;
 static void set_resident_blocks(const fv_ctx *ctx)
@@ -964,7 +962,7 @@ __device__ inline double march_window_elem(double2 w, int j)
 
 template <bool DOT, bool NT, bool WIDE>
 __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int shift, int64_t stride,
-                                                                   int seglen, int segs_per_xcd, int dbg, int64_t win_lo, int64_t win_hi,
+                                                                   int seglen, int segs_per_xcd, int64_t win_lo, int64_t win_hi,
                                                                    const int32_t *__restrict__ dia_pos,
                                                                    const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
                                                                    const double *__restrict__ sval, const double *__restrict__ x,
@@ -1063,22 +1061,18 @@ __global__ __launch_bounds__(FV_BLOCK, 8) void spmv_dia_march_kernel(int64_t n, 
                             const double sh = __shfl(prevc, (lane - shift) & 63, 64);
                             int32_t c = lane < shift ? row - st32 : row - lane;
                             c = c < 0 ? 0 : c;
-                            const double ld = (dbg & 2) ? 0.0 : x[c];
+                            const double ld = x[c];
                             xv = lane < shift ? ld : sh;
                         } else if (!WIDE && off == st32 && have_next) {
                             const double sh = __shfl(nextc, (lane + shift) & 63, 64);
                             int32_t c = lane + shift >= 64 ? row + st32 : row - lane + 63;
                             c = c >= nc32 ? nc32 - 1 : c;
-                            const double ld = (dbg & 2) ? 0.0 : x[c];
+                            const double ld = x[c];
                             xv = lane + shift >= 64 ? ld : sh;
                         } else {
-                            if (dbg & 1) // diagnosis only (wrong results): what the in-plane arm loads cost
-                                xv = curc;
-                            else {
-                                int32_t c = row + off; // |off| <= stride < n/4: no overflow
-                                c = c < 0 ? 0 : (c >= nc32 ? nc32 - 1 : c);
-                                xv = x[c];
-                            }
+                            int32_t c = row + off; // |off| <= stride < n/4: no overflow
+                            c = c < 0 ? 0 : (c >= nc32 ? nc32 - 1 : c);
+                            xv = x[c];
                         }
                         sum += v * xv;
                     }
@@ -1178,13 +1172,13 @@ __device__ inline double wave_from_above(double v, double edge)
 // the derived diagonal, 1.086 against 1.011 with the streamed one — staging a step's loads the way this kernel does beats
 // having them all in flight at once.)  Taking the
 // diagonal stream out (sym_ok bit 1, below) removed 15 % of the HBM bytes for 4 % of the time; not loading the in-plane
-// arms at all (fv_tune key 29) removes 27 % of the L2->L1 bytes for 3.6 %.  No single resource is the limit.)
+// arms at all (a diagnosis build of round 2) removes 27 % of the L2->L1 bytes for 3.6 %.  No single resource is the limit.)
 // D1: the first in-plane offset is 1 (consecutive cells of a grid line are consecutive rows) — the +-1 arms of x and the
 // -1 matrix value are then the neighbouring lanes' centre x / U1 value (DPP wave shift) plus one scalar load for the lane at
 // the slice's edge: three vector loads fewer per step (-6 % at 464^3, and fewer lines for the L2 to keep).
 template <bool DOT, int NT, bool WIN, bool D1> // NT bit 0: diag / U3 streams non-temporal, bit 1: U1 / U2 too, bit 2: y store
 __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t n, int64_t ncols, int64_t nslices, int64_t step, int s, int32_t d1,
-                                                                          int32_t d2, int seglen, int segs_per_xcd, uint32_t front, int dbg,
+                                                                          int32_t d2, int seglen, int segs_per_xcd, uint32_t front,
                                                                           const uint8_t *__restrict__ sym_ok, const double *__restrict__ dg,
                                                                           const double *__restrict__ u1, const double *__restrict__ u2,
                                                                           const double *__restrict__ u3, const double *__restrict__ x,
@@ -1262,18 +1256,14 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
                     cd = dcode[(uint32_t)base + lane];
                 v1 = ld_off<NT & 2>(u1, fb + rb);
                 v2 = ld_off<NT & 2>(u2, fb + rb);
-                if (!(dbg & 2)) { // (diagnosis switches, fv_tune key 29: results are wrong when set)
-                    if (!D1)
-                        v1m = ld_off<0>(u1, fb + rb - d1b); // padded in front: rows < d read zeros
-                    v2m = ld_off<0>(u2, fb + rb - d2b);
-                }
-                if (!(dbg & 1)) {
-                    x2m = ld_off<0>(x, rb - d2b);
-                    x2p = ld_off<0>(x, rb + d2b);
-                    if (!D1) {
-                        x1m = ld_off<0>(x, rb - d1b);
-                        x1p = ld_off<0>(x, rb + d1b);
-                    }
+                if (!D1)
+                    v1m = ld_off<0>(u1, fb + rb - d1b); // padded in front: rows < d read zeros
+                v2m = ld_off<0>(u2, fb + rb - d2b);
+                x2m = ld_off<0>(x, rb - d2b);
+                x2p = ld_off<0>(x, rb + d2b);
+                if (!D1) {
+                    x1m = ld_off<0>(x, rb - d1b);
+                    x1p = ld_off<0>(x, rb + d1b);
                 }
             }
             double e1 = 0.0, exm = 0.0, exp_ = 0.0; // D1: the elements just outside the slice (wave-uniform addresses: scalar loads)
@@ -1285,25 +1275,14 @@ __global__ __launch_bounds__(FV_BLOCK, 6) void spmv_symdia_march_kernel(int64_t 
             if (WIN) {
                 if (base >= 32 && base <= wmax) { // always so where a slice of this round or the one before is computed
                     const double2 w = ld2_off<0>(x, rb + lane * 8u - 256u); // this slice's window: 16 bytes per lane from row - 32
-                    if (dbg & 4) { // no shuffles
-                        c = w.x;
-                        xp = w.y;
-                        xmn = w.x;
-                    } else {
-                        c = march_window_elem(w, jc);
-                        xp = march_window_elem(w, jp);
-                        xmn = march_window_elem(w, jm);
-                    }
+                    c = march_window_elem(w, jc);
+                    xp = march_window_elem(w, jp);
+                    xmn = march_window_elem(w, jm);
                 }
                 if (!fin) {
                     const double2 w3 = ld2_off<NT & 1>(u3, fb + rb + lane * 8u - 256u);
-                    if (dbg & 4) {
-                        a3 = w3.x;
-                        amn = w3.y;
-                    } else {
-                        a3 = march_window_elem(w3, jc);
-                        amn = march_window_elem(w3, jm);
-                    }
+                    a3 = march_window_elem(w3, jc);
+                    amn = march_window_elem(w3, jm);
                 }
             } else {
                 if (base + 64 <= ncols)
@@ -2498,7 +2477,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             // whole rounds, else the best filling one
             // the symmetric kernel runs best with 6 of the 8 blocks a CU could hold: fewer waves streaming at once leave the
             // lines its arm loads re-use in L2 a little longer (464^3: 1.157 ms at 8 per CU, 1.10 at 6 and 5, 1.18 at 4,
-            // profiles/r02_sym_ab.log); fv_tune key 30 overrides
+            // profiles/r02_sym_ab.log)
             const int resident = (sym && g_blocks_per_cu == 8) ? g_resident_blocks / 8 * 6 / 8 * 8 : g_resident_blocks;
             int segs_per_xcd = g_march_segs;
             if (segs_per_xcd <= 0) {
@@ -2526,7 +2505,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             GM = (int)g;
 #define FV_MARCH_W(D_, N_, W_)                                                                                                                 \
     hipLaunchKernelGGL((spmv_dia_march_kernel<D_, N_, W_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, p->order_stride, \
-                       seglen, segs_per_xcd, g_march_dbg, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
+                       seglen, segs_per_xcd, subset ? subset->win_lo : (int64_t)0, subset ? subset->win_hi : ns, (const int32_t *)p->dia_pos.p, (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p,        \
                        (const double *)p->dia_vals.p, x, y, shift, sigma, partials, scal)
 #define FV_MARCH(D_, N_)                                                                                                                      \
     do {                                                                                                                                      \
@@ -2539,11 +2518,11 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
                 const double *dg = p->sym_vals.p, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld; // array starts; row 0 is sym_front in
 #define FV_SYM1(D_, N_, W_, O_)                                                                                                               \
     hipLaunchKernelGGL((spmv_symdia_march_kernel<D_, N_, W_, O_>), dim3(GM), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->n + p->nhalo, ns, step, sh, \
-                       (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], seglen, segs_per_xcd, (uint32_t)p->sym_front, g_symdia_dbg, (const uint8_t *)p->sym_ok.p, dg, u1, u2, u3, x, y, \
+                       (int32_t)p->sym_d[0], (int32_t)p->sym_d[1], seglen, segs_per_xcd, (uint32_t)p->sym_front, (const uint8_t *)p->sym_ok.p, dg, u1, u2, u3, x, y, \
                        shift, sigma, partials, scal, (const uint8_t *)p->dcode.p, p->sym_shift, p->sym_shift_mode)
 #define FV_SYM(D_, N_, W_)                                                                                                                    \
     do {                                                                                                                                      \
-        if (p->sym_d[0] == 1 && !(g_symdia_dbg & 8))                                                                                          \
+        if (p->sym_d[0] == 1)                                                                                          \
             FV_SYM1(D_, N_, W_, true);                                                                                                        \
         else                                                                                                                                  \
             FV_SYM1(D_, N_, W_, false);                                                                                                       \
@@ -2557,7 +2536,7 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
         default: FV_SYM(D_, 0, W_); break;                                                                                                    \
         }                                                                                                                                     \
     } while (0)
-                if (tile) { // (fv_tune key 38)
+                if (tile) { // (fv_tune key 27 = 4)
                     const int64_t tnz = p->sym_d[1], td3 = p->sym_d[2];
                     // planes 1 .. nplanes - 1 can hold sym_ok slices; the last plane only in a row block whose +plane windows land in
                     // its halo slots (the last block of an operator: no +plane arm, no halo entry needed)
