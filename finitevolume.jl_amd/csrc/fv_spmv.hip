@@ -407,34 +407,34 @@ __global__ __launch_bounds__(FV_BLOCK) void spmv_sell_kernel(int64_t n, int64_t 
 // 3 = use the diagonal-folded shifted matrix copy in fixed-dt runs (0/1), 4 = non-temporal streaming loads (0/1),
 // 5 = fuse the PCG set-up of an implicit step into its first SpMV (0/1), 6 = sliced-DIA form for grid-like slices (0/1)
 int g_spmv_form = 2;
-static int g_spmv_unroll = 2;
-static int g_use_order = 1;
-static int g_nt = 1;
+static const int g_spmv_unroll = 2;
+static const int g_use_order = 1;
+static const int g_nt = 1;
 int g_fuse_init = 0; // measured: with the sliced-DIA SpMV the separate set-up kernel is ~3 % faster than the fused epilogue
 int g_use_dia = 1;
-static int g_sell_blocks = 8; // (frozen) resident blocks per CU the SELL SpMV's grid is sized for
+static const int g_sell_blocks = 8; // (frozen) resident blocks per CU the SELL SpMV's grid is sized for
 static int g_sell = 1; // fv_tune key 54: SELL-64 with 16-bit column offsets for the groups the CSR kernel would serve (0: always the CSR wave-stream)
-static int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (frozen; read when the DIA copy is built)
-static int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (frozen)
+static const int g_dia_packed = 1; // sliced-DIA values packed (sl_noff blocks per slice) or padded to DIA_K blocks (frozen; read when the DIA copy is built)
+static const int g_march_wide = 1; // marching kernel: 16-byte window accesses instead of centre + two edge loads when stride mod 64 <= 32 (frozen)
 static int g_trace_spmv = getenv("FV_TRACE_SPMV") ? atoi(getenv("FV_TRACE_SPMV")) : 0;
 static int g_march = 1;      // plane-marching sliced-DIA kernel on structured grids (fv_tune key 9): 0 never, 1 when x outgrows the last-level cache, 2 always
-static int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (frozen; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
-static int g_march_segs = 0; // segments per XCD of the marching kernel (0 = chosen per operator; frozen)
+static const int g_march_min_mb = 160; // ... i.e. when the x vector exceeds this many MiB (frozen; MI355X has 256 MB of infinity cache, which the step's other streams share: inside the stepping loop the crossover is at ~2e7 rows)
+static const int g_march_segs = 0; // segments per XCD of the marching kernel (0 = chosen per operator; frozen)
 int g_fold_shift = 1;
 int g_chunk_ends = 1; // (part of fv_tune key 60: value 2 keeps the first / last plane's products with the slice-by-slice launch)
 static int g_symdia = 1; // fv_tune key 27 >= 3: symmetric plane-marching form where the marching kernel runs
 static int g_march_form = 1; // fv_tune key 27 >= 2: the plane-marching kernels at all (0: structured operators stay with the slice-by-slice kernel)
-static int g_tile_blocks = 2; // (frozen) resident blocks per CU the tiled kernel's grid is sized for
-static int g_tile_segs = 0;   // (frozen) segments of planes per tile column, 0 = chosen to fill whole rounds
+static const int g_tile_blocks = 2; // (frozen) resident blocks per CU the tiled kernel's grid is sized for
+static const int g_tile_segs = 0;   // (frozen) segments of planes per tile column, 0 = chosen to fill whole rounds
 static int g_sym_tile = 1;   // (fv_tune key 27 = 4) the tiled traversal of the symmetric form where the free rows are a regular box (spmv_symdia_tile_kernel)
 static int g_sym_rowsum = 1; // fv_tune key 37: 0 = the symmetric kernel always streams the diagonal (see symdia_rowsum_kernel)
-static int g_symdia_nt = 4; // (frozen) streaming hints of the symmetric kernel (see its template parameter)
+static const int g_symdia_nt = 4; // (frozen) streaming hints of the symmetric kernel (see its template parameter)
 extern int g_carry_refresh, g_carry_speculate; // fv_transient.hip
 extern int g_sparse_b, g_chain_test_break;     // fv_pcg.hip
 extern int g_chain_steps, g_resume_runs;        // fv_transient.hip
 
 int g_alloc_skew_bytes = 0, g_alloc_skew_count = 0; // (frozen at 0; fv_internal.h, DevBuf)
-static int g_blocks_per_cu = 8; // (frozen) blocks per CU the SpMV grids are sized for
+static const int g_blocks_per_cu = 8; // (frozen) blocks per CU the SpMV grids are sized for
 // blocks that are all resident at 8 waves per SIMD: 8 per CU (2048 on the 256-CU MI355X; fewer on a partitioned device)
 static int g_resident_blocks = FV_MAX_PARTIALS;
 static void set_resident_blocks(const fv_ctx *ctx)
