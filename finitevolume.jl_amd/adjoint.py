@@ -523,12 +523,12 @@ def integratedfdplambda(u2, p, lambdas, ts_lambda, tspan, Ss, volumes, neighbors
     pK, ps, pd = pv[:nK], pv[nK : nK + N], pv[nK + N : nK + N + ndir]
     vols = Ss * af64(volumes)
     freenode, n2f = getfreenodes(N, dirichletnodes)
-    lam = LinearInterpolant(lambdas, ts_lambda)
     if complete and device and isinstance(u2, DeviceSolution):
         # u and lambda in HBM (keep="device" + the device-resident sweep): nothing crosses PCIe but the per-face results
         return devicegradientintegral(u2, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, True, scale="storage")
     if isinstance(u2, DeviceSolution) or isinstance(lambdas, DeviceStates):
         raise TypeError("device solutions / lambdas go through complete=True (the whole Jacobian integrated on the device)")
+    lam = LinearInterpolant(lambdas, ts_lambda)  # (host copies of every lambda state: only on the paths that need them)
     if complete and device and isinstance(u2, LinearInterpolant):
         # both factors piecewise linear: the device kernel integrates every face exactly (fv_param_gradient_integral)
         return devicegradientintegral(u2, lambdas, ts_lambda, tspan, Ss, volumes, neighbors, areasoverlengths, pK, ps, dirichletnodes, pd, metaindex, True, scale="storage")
