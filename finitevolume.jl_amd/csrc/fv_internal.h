@@ -158,6 +158,9 @@ struct PcgScalars {
     double alpha_last;
     const double *lag_p;
     int32_t xlag, pad_;
+    // the single-launch solver (fv_small.hip): the number of the launch that wrote this block — a launch that gave up at its grid
+    // barrier leaves the previous number, so one copy of the block tells the host both the result and that there is one
+    uint32_t small_seq, pad2_;
 };
 
 // Plan and buffers of a row block in a distributed run (built by fv_dist_setup).
@@ -381,6 +384,7 @@ struct fv_problem {
     DevBuf<double> small_part;     // the single-launch solver of small systems (fv_small.hip): per-block partial sums,
     DevBuf<uint32_t> small_bar;    // its grid barrier's arrival counter and failure flag,
     uint32_t small_bar_base = 0;   // ... the counter's value when the next launch begins
+    uint32_t small_seq = 0;        // number of the last launch (PcgScalars::small_seq)
     int64_t small_solves = 0;      // solves it has done
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
@@ -484,6 +488,9 @@ struct PcgSystem {
     // chain_more: another chained step follows in the same burst — this step's verdict and that step's scalars then come
     // from one launch (pcg_chain_boundary_kernel) and the next step skips its own set-up kernel
     bool chain_more = false;
+    // x0_src (implicit steps on systems the single-launch solver takes, fv_pcg_small_takes): the state the step starts from, when it
+    // is not yet in x — the kernel reads it there and writes x, which saves the copy launch in front of every solve of a stepper
+    const double *x0_src = nullptr;
 };
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
@@ -493,6 +500,7 @@ int fv_storage_form(fv_problem *p, StorageArg *out, int *bytes_saved, bool ignor
 int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *info, uint32_t *zero_mask = nullptr);
 // fv_small.hip: Jacobi-PCG of a small system in one persistent launch; *handled = false: not a case for it
 int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it, bool *handled);
+bool fv_pcg_small_takes(const fv_problem *p, const PcgSystem &sys); // whether fv_pcg_small will handle this solve
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
                    int *npartials = nullptr);

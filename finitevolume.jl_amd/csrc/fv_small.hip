@@ -30,6 +30,8 @@ struct SmallArgs {
     double sigma, dt, rtol;
     int implicit, b_times_D, x0_zero, G;
     double *x, *r, *pv, *q, *minv;
+    const double *x0; // the initial guess (= x, or the state a step starts from: the kernel then writes x without a copy in front of it)
+    uint32_t seq;
     double *part; // 4 x SM_MAXG: p.q | r.z | r.r | rhs.rhs
     PcgScalars *scal;
     int64_t maxiter;
@@ -117,12 +119,12 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
             double q0 = 0.0;
             const int32_t e = a.rowptr[i + 1];
             for (int32_t k = a.rowptr[i]; k < e; k++)
-                q0 += a.vals[k] * a.x[a.colind[k]];
-            const double rhsv = bi + di * (a.x[i] / a.dt);
+                q0 += a.vals[k] * a.x0[a.colind[k]];
+            const double rhsv = bi + di * (a.x0[i] / a.dt);
             ri = bi - q0;
             bi = rhsv;
         } else
-            ri = a.x0_zero ? bi : bi - product(a.x, i);
+            ri = a.x0_zero ? bi : bi - product(a.x0, i);
         const double d = shift ? a.diagA[i] + a.sigma * a.D[i] : a.diagA[i];
         const double mi = d > 0.0 ? 1.0 / d : 0.0; // (a free cell without any face has an empty row: left where it is)
         a.minv[i] = mi;
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
         // ---- K2: x += alpha p; r -= alpha q; sums r.M^-1 r, r.r
         arz = arr = 0.0;
         for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
-            a.x[i] += alpha * a.pv[i];
+            a.x[i] = (it == 0 ? (a.x0_zero ? 0.0 : a.x0[i]) : a.x[i]) + alpha * a.pv[i]; // (the first update reads the initial guess where it is)
             const double ri = a.r[i] - alpha * a.q[i];
             a.r[i] = ri;
             arz += ri * (a.minv[i] * ri);
@@ -210,8 +212,12 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
         if (gb.failed)
             return;
     }
+    if (it == 0 && (a.x0_zero || a.x0 != a.x)) // converged where it started: x is the initial guess
+        for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK)
+            a.x[i] = a.x0_zero ? 0.0 : a.x0[i];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         PcgScalars *s = a.scal;
+        s->small_seq = a.seq;
         s->rz[0] = s->rz[1] = rz;
         s->rr = rr;
         s->tol2 = tol2;
@@ -228,17 +234,28 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
 
 } // namespace
 
-// *handled = false: not a case for this kernel (the classic loop runs).  x: initial guess in, solution out.
+bool fv_pcg_small_takes(const fv_problem *p, const PcgSystem &sys)
+{
+    const int64_t n = p->n;
+    if (g_small_n <= 0 || n <= 0 || n > g_small_n || p->dist || p->nhalo > 0 || sys.x_next || sys.carry_prev || sys.speculate || sys.use_spec || sys.chain_index >= 0 ||
+        sys.resume_it > 0 || p->profile || !p->rowptr.p || !p->colind.p || !p->vals.p || !p->diagA.p)
+        return false;
+    return (sys.implicit_step ? fv_step_precond(p) : p->precond) != FV_PRECOND_AMG;
+}
+
+// *handled = false: not a case for this kernel (the classic loop runs).  x: initial guess in (or sys.x0_src), solution out.
 int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it, bool *handled)
 {
     fv_ctx *ctx = p->ctx;
     *handled = false;
     const int64_t n = p->n;
-    if (g_small_n <= 0 || n <= 0 || n > g_small_n || p->dist || p->nhalo > 0 || sys.x_next || sys.carry_prev || sys.speculate || sys.use_spec || sys.chain_index >= 0 ||
-        sys.resume_it > 0 || p->profile || !p->rowptr.p || !p->colind.p || !p->vals.p || !p->diagA.p)
+    if (!fv_pcg_small_takes(p, sys)) {
+        if (sys.x0_src) { // (step_impl asks the same predicate before it leaves the copy out)
+            fv_set_error(ctx, "internal: an implicit step left its copy to the single-launch solver, which does not take the system");
+            return FV_ERR_STATE;
+        }
         return FV_OK;
-    if ((sys.implicit_step ? fv_step_precond(p) : p->precond) == FV_PRECOND_AMG)
-        return FV_OK;
+    }
     if (!p->small_part.p) {
         FV_TRY(p->small_part.alloc(ctx, (size_t)4 * SM_MAXG));
         FV_TRY(p->small_bar.alloc(ctx, 2));
@@ -268,6 +285,8 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     a.b_times_D = sys.b_times_D ? 1 : 0;
     a.x0_zero = sys.x0_zero ? 1 : 0;
     a.x = x;
+    a.x0 = sys.x0_src ? sys.x0_src : x;
+    a.seq = ++p->small_seq;
     a.r = p->r.p;
     a.pv = p->pvec.p;
     a.q = p->q.p;
@@ -281,24 +300,22 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     a.bar_base = p->small_bar_base;
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (sys.x0_zero && !sys.implicit_step)
-        FV_HIP(ctx, hipMemsetAsync(x, 0, (size_t)n * sizeof(double), ctx->stream));
     hipLaunchKernelGGL(pcg_small_kernel, dim3(G), dim3(SM_BLOCK), 0, ctx->stream, a);
     FV_LAUNCH_CHECK(ctx);
     if (time_it)
         FV_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    // one copy back: the scalar block carries the launch's number (written last, by a launch that got through its barriers) and the
+    // barrier's count for the next launch
     PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
-    uint32_t *hbar = reinterpret_cast<uint32_t *>(static_cast<char *>(ctx->pinned) + 1024);
     FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
-    FV_HIP(ctx, hipMemcpyAsync(hbar, p->small_bar.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (hbar[1]) {
+    if (hs->small_seq != a.seq) {
         FV_HIP(ctx, hipMemsetAsync(p->small_bar.p, 0, 2 * sizeof(uint32_t), ctx->stream));
         p->small_bar_base = 0;
         fv_set_error(ctx, "fv_pcg_small: the blocks of the single-launch solver did not meet at their grid barrier");
         return FV_ERR_STATE;
     }
-    p->small_bar_base = hbar[0];
+    p->small_bar_base = (uint32_t)hs->pad_;
     // what the classic loop leaves behind it
     p->minv_valid = true;
     p->minv_sigma = sys.sigma;

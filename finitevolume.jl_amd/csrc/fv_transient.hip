@@ -330,8 +330,6 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
         fv_set_error(ctx, "time step must be positive"); // transient.jl:68-70
         return FV_ERR_DT;
     }
-    if (usrc != udst && resume_it == 0)
-        FV_HIP(ctx, hipMemcpyAsync(udst, usrc, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     PcgSystem sys;
     sys.sigma = 1.0 / dt;
     sys.dt = dt;
@@ -344,6 +342,14 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.chain_index = chain_index;
     sys.chain_more = chain_more;
     sys.resume_it = resume_it;
+    if (usrc != udst && resume_it == 0) {
+        // small systems: the single-launch solver reads the state where it is and writes udst (a copy launch less per solve; not in
+        // the adjoint's in-place scaling mode, which needs the state in udst first)
+        if (mode != FV_STEP_ADJOINT && fv_step_precond(p) != FV_PRECOND_AMG && fv_pcg_small_takes(p, sys))
+            sys.x0_src = usrc;
+        else
+            FV_HIP(ctx, hipMemcpyAsync(udst, usrc, (size_t)p->n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    }
     if (mode == FV_STEP_FORWARD) {
         sys.rhs = bhat_dev ? bhat_dev : p->b.p;
         sys.b_times_D = bhat_dev != nullptr;
