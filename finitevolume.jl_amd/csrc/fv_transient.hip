@@ -633,6 +633,7 @@ int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double
         double *E = p->slots[(size_t)scratch[0]], *S1 = p->slots[(size_t)scratch[1]], *S2 = p->slots[(size_t)scratch[2]],
                *S3 = p->slots[(size_t)scratch[3]];
         const size_t bytes = (size_t)p->n * sizeof(double);
+        double *const U0 = U; // the caller's slot
         double t = t0;
         double dt = dt0 < tfinal - t0 ? dt0 : tfinal - t0;
         if (ts_out && max_outer > 0)
@@ -689,7 +690,17 @@ int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double
             }
             if (rc != FV_OK)
                 break;
-            if (hipMemcpyAsync(U, unew, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+            // the accepted state becomes U by an exchange of buffers — the old state's buffer is scratch from here on — instead of a
+            // copy per outer step; the caller's slot receives the final state once, below
+            if (unew == S1)
+                std::swap(U, S1);
+            else if (unew == S2)
+                std::swap(U, S2);
+            else if (unew == S3)
+                std::swap(U, S3);
+            else if (unew == E)
+                std::swap(U, E);
+            else if (hipMemcpyAsync(U, unew, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
                 rc = FV_ERR_HIP;
                 break;
             }
@@ -706,6 +717,8 @@ int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double
             const double want = ts.increase ? 2 * ts.last : ts.last;
             dt = remaining < want ? remaining : want;
         }
+        if (U != U0 && rc != FV_ERR_HIP && hipMemcpyAsync(U0, U, bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) // (also after an error: the slot holds u(t))
+            rc = FV_ERR_HIP;
         if (rc == FV_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
             rc = FV_ERR_HIP;
         if (rc == FV_ERR_HIP)
