@@ -542,7 +542,7 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
         roof = {"bound": "hbm", "achieved": fbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
                 "kernel": ("fused_chunk_kernel<512, 5, 0>: " + what + "contiguous chunks of ~5100 rows of a plane (no column halos) marching through the planes, z' chunk "
                            "double-buffered and the 16-bit matrix words of two planes in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms "
-                           "(rows next to a Dirichlet cell: out of a table by a per-row code); first/last plane's products by spmv_dia_kernel") if chunks else
+                           "(rows next to a Dirichlet cell: out of a table by a per-row code); the first / last plane's products by the same launch where their rows' diagonals fit the table (the bench box), else by spmv_dia_kernel") if chunks else
                           ("fused_step_kernel<16, 0, %s>: " % ("true" if fbytes_row < 60 else "false") + what +
                            "2-D tiles of 16 lines x 128 columns marching through the planes, "
                            "z' tile and U1/U2 ring in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms; first/last plane's products by spmv_dia_kernel"),
