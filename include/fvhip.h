@@ -241,7 +241,8 @@ int fv_dot(fv_problem *p, const double *a_free, const double *b_free, double *ou
  * operator (the role of the one global hierarchy of AlgebraicMultigrid.ruge_stuben at FiniteVolume.jl:159-161), gathered on every
  * rank, and every rank builds and applies the levels below it for itself: two halo exchanges and one all-reduce of the level-1
  * right-hand side per cycle, replicated coarse work, and an iteration count that does not depend on the rank count.  On a whole
- * problem (one rank) it is FV_PRECOND_AMG.  Every rank must make the same choice. */
+ * problem (one rank) it is FV_PRECOND_AMG.  Every rank must make the same choice, and building the hierarchy is collective: it happens
+ * inside the first solve after fv_assemble / fv_transient_begin (or inside fv_amg_info), which every rank must then enter. */
 #define FV_PRECOND_AMG_GATHERED 3
 int fv_precond_set(fv_problem *p, int kind);
 /* theta: strength threshold of the matching (0.10); omega: Jacobi damping of the smoother (0.85); passes: pairwise
