@@ -441,6 +441,65 @@ def test_multi_rank_driver_loopback_marching_blocks_and_eight_ranks(fv):
         assert relerr(got, want) < 1e-11, (ns, nranks, "slabs")
 
 
+def test_gathered_amg_levels_at_a_million_cells_count_what_one_gpu_counts(fv):
+    """FV_PRECOND_AMG_GATHERED at 128 x 128 x 64 cells with the sigma = 3 field of the box_model configuration: the
+    steady AMG-PCG solve on 2 and on 8 loopback ranks takes the iterations of the one-GPU solve to within 2 (the aggregates that a
+    rank boundary forbids are a per-mille of them here); block-Jacobi AMG on the same blocks needs several times as many."""
+    import threading
+
+    from fvamd import dist
+
+    ns = [128, 128, 64]
+    mins, maxs = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+    dn, dh = workloads.box_model_dirichlet(ns)
+    logk = np.log(1e-5) + 3.0 * workloads.smooth_gaussian_field(ns, seed=0)
+
+    def build(ctx=None):
+        p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx) if ctx is not None else fv.Problem.regulargrid(mins, maxs, ns, dn)
+        n1, n2 = np.empty(p.F, np.int64), np.empty(p.F, np.int64)
+        p.check(fv.load().fv_problem_get_grid(p.handle, n1.ctypes.data, n2.ctypes.data, None, None))
+        return p.assemble(fv.nodehycos2neighborhycos((n1, n2), logk, True), np.zeros(p.N), dh, None, True)
+
+    p1 = build().set_preconditioner("amg")
+    _, x1, ch1 = p1.solve_steady(None, 1e-8, 400, want_head=False, want_resnorm=False)
+    assert ch1.isconverged
+    p1.close()
+    its = {}
+    for kind, nranks in (("amg_gathered", 2), ("amg_gathered", 8), ("amg", 8)):
+        out, errors = [None] * nranks, []
+
+        def worker(rank):
+            try:
+                ctx = fv.Context(0)
+                dist.comm_init_local(ctx, nranks, rank, 5200 + 10 * nranks + (kind == "amg"))
+                pg = build(ctx)
+                pg.transient_begin(0.1, None, np.zeros(pg.N))
+                blk = dist.RowBlock(pg, nranks, rank).set_preconditioner(kind)
+                pg.close()
+                x, info = blk.solve_steady(None, 1e-8, 2000)
+                out[rank] = (blk.lo, blk.hi, x, info.iters, info.converged)
+                blk.close()
+                fv.load().fv_comm_destroy(ctx.handle)
+            except BaseException as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(nranks)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not errors, errors
+        xs = np.empty(out[-1][1])
+        for lo, hi, x, it, conv in out:
+            xs[lo:hi] = x
+            assert conv and it == out[0][3]
+        assert np.abs(xs - x1).max() <= 1e-6 * np.abs(x1).max(), (kind, nranks)  # (two solves to rtol 1e-8 of an operator of condition ~1e6)
+        its[(kind, nranks)] = out[0][3]
+    print("AMG-PCG iterations at 1e6 cells: one GPU", ch1.iters, "; row blocks", its)
+    assert abs(its[("amg_gathered", 2)] - ch1.iters) <= 2 and abs(its[("amg_gathered", 8)] - ch1.iters) <= 2, (ch1.iters, its)
+    assert its[("amg", 8)] > 4 * ch1.iters, (ch1.iters, its)
+
+
 def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
     """`FV_BENCH_FORCE_DIST=1 python bench.py` (the multi-GPU driver with one rank: row block, pack, RCCL communicator of one,
     interior / boundary passes) against the plain loop running the same kernels (the fused step off): the distributed driver
