@@ -385,6 +385,7 @@ struct fv_problem {
     DevBuf<uint32_t> small_bar;    // its grid barrier's arrival counter and failure flag,
     uint32_t small_bar_base = 0;   // ... the counter's value when the next launch begins
     uint32_t small_seq = 0;        // number of the last launch (PcgScalars::small_seq)
+    DevBuf<PcgScalars> small_scal3; // the three solves of a step-doubling attempt in one launch (fv_small_twostep): their scalar blocks
     int64_t small_solves = 0;      // solves it has done
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
@@ -501,6 +502,9 @@ int fv_pcg_chain_poll(fv_problem *p, int nsteps, int *completed, fv_solve_info *
 // fv_small.hip: Jacobi-PCG of a small system in one persistent launch; *handled = false: not a case for it
 int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it, bool *handled);
 bool fv_pcg_small_takes(const fv_problem *p, const PcgSystem &sys); // whether fv_pcg_small will handle this solve
+bool fv_small_twostep_takes(const fv_problem *p, int mode, double dt);
+int fv_small_twostep(fv_problem *p, int mode, const double *const rhs[3], bool b_times_D, double *uk, double dt, double *onestep, bool have_onestep,
+                     double *two1, double *two, const double *weight, double rtol, int64_t maxiter, fv_solve_info *info, double *err, bool *handled);
 int fv_slot_new(fv_problem *p, int32_t *slot); // a state vector of n + nhalo + pad doubles (reuses freed slots)
 int fv_spmv_launch(fv_problem *p, const double *x, double *y, double sigma, double *partials_or_null, bool fold = false,
                    int *npartials = nullptr);
@@ -520,7 +524,9 @@ inline int fv_step_precond(const fv_problem *p)
 constexpr int FV_STEP_W = 2; // internal step mode: (D/dt + A) w+ = rhs + D w/dt with the caller's rhs as it is (the adjoint sweep's own state w = gamma / D)
 struct FvStepHooks {
     int mode = FV_STEP_FORWARD;
-    std::function<int(double t, const double **rhs_dev)> forcing;  // unset: the assembled b (forward) / none
+    // unset: the assembled b (forward) / none.  which = 0 .. 2: the buffer the forcing goes to — the three solves of a step-doubling
+    // attempt may be enqueued together (fv_small_twostep), their forcings then live side by side
+    std::function<int(double t, int which, const double **rhs_dev)> forcing;
     const double *norm_weight = nullptr;                          // step-doubling error = || weight .* (onestep - twostep) ||
     std::function<int(const double *state_dev, double t)> record; // sees the initial state and the state of every outer step
 };

@@ -92,10 +92,9 @@ __device__ inline double small_total(const double *part, int G)
     return s;
 }
 
-__global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
+// one solve; false: the blocks did not meet at a barrier (nothing of this solve's results may be used)
+__device__ __forceinline__ bool small_solve(const SmallArgs &a, GridBarrier &gb, double *smem)
 {
-    __shared__ double smem[SM_BLOCK / 64];
-    GridBarrier gb{a.bar, a.bar_base, a.G, false};
     const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block, hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
     double *part_pq = a.part, *part_rz = a.part + SM_MAXG, *part_rr = a.part + 2 * SM_MAXG, *part_bb = a.part + 3 * SM_MAXG;
     const bool shift = a.sigma != 0.0 && a.D != nullptr;
@@ -145,7 +144,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
     }
     gb.sync();
     if (gb.failed)
-        return;
+        return false;
     double rz = small_total(part_rz, a.G), rr = small_total(part_rr, a.G);
     const double bb = small_total(part_bb, a.G);
     const double tol2 = a.rtol * a.rtol * bb;
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
         }
         gb.sync();
         if (gb.failed)
-            return;
+            return false;
         pq = small_total(part_pq, a.G);
         if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
             done = 2;
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
         }
         gb.sync();
         if (gb.failed)
-            return;
+            return false;
         const double rzn = small_total(part_rz, a.G);
         rr = small_total(part_rr, a.G);
         if (blockIdx.x == 0 && threadIdx.x == 0 && a.hist && it < a.hist_cap)
@@ -210,7 +209,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
             a.pv[i] = a.minv[i] * a.r[i] + beta * a.pv[i];
         gb.sync(); // the next product reads the other blocks' p
         if (gb.failed)
-            return;
+            return false;
     }
     if (it == 0 && (a.x0_zero || a.x0 != a.x)) // converged where it started: x is the initial guess
         for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK)
@@ -229,6 +228,57 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
         s->zero_mask = 0;
         s->xlag = -1;
         s->pad_ = (int32_t)gb.target; // the barrier's count at the end of this launch: the next launch's base
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(SM_BLOCK) void pcg_small_kernel(SmallArgs a)
+{
+    __shared__ double smem[SM_BLOCK / 64];
+    GridBarrier gb{a.bar, a.bar_base, a.G, false};
+    small_solve(a, gb, smem);
+}
+
+// The step-doubling attempt of the adaptive stepper (transient.jl:72-91) as ONE launch: the full step, the two half steps — each the
+// solve above, the second half step starting from the first one's result — and the squared error norm || w .* (full - two halves) ||^2,
+// left in the last solve's scalar block (tol2x[0]).  first = 1: the full step is there already (the half step of a rejected attempt).
+struct Small3Args {
+    SmallArgs s[3];
+    int first;
+    const double *w; // weight of the error norm (null: none)
+};
+
+__global__ __launch_bounds__(SM_BLOCK) void pcg_small3_kernel(Small3Args a3)
+{
+    __shared__ double smem[SM_BLOCK / 64];
+    GridBarrier gb{a3.s[0].bar, a3.s[0].bar_base, a3.s[0].G, false};
+    for (int k = a3.first; k < 3; k++) {
+        if (!small_solve(a3.s[k], gb, smem))
+            return;
+        gb.sync(); // every block's rows of this solve's x are final (also where a solve converged at its start and copied its guess)
+        if (gb.failed)
+            return;
+    }
+    const SmallArgs &a = a3.s[2];
+    const int64_t lo = (int64_t)blockIdx.x * a.rows_per_block, hi = lo + a.rows_per_block < a.n ? lo + a.rows_per_block : a.n;
+    const double *one = a3.s[0].x, *two = a.x;
+    double acc = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
+        const double d = (a3.w ? a3.w[i] : 1.0) * (one[i] - two[i]);
+        acc += d * d;
+    }
+    const double t = small_block_sum(acc, smem);
+    if (threadIdx.x == 0)
+        a.part[blockIdx.x] = t;
+    gb.sync();
+    if (gb.failed)
+        return;
+    const double err2 = small_total(a.part, a.G);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.scal->tol2x[0] = err2;
+        a.scal->pad_ = (int32_t)gb.target;
+        __threadfence();
+        a.scal->small_seq = a.seq + 1u; // (the attempt as a whole got through: the host looks for this number)
     }
 }
 
@@ -343,6 +393,126 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     if (hs->done == 2)
         fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs->pq); // (reported like the classic loop: info->converged = 0)
+    *handled = true;
+    return FV_OK;
+}
+
+bool fv_small_twostep_takes(const fv_problem *p, int mode, double dt)
+{
+    const char *e = getenv("FV_SMALL_TWOSTEP"); // =0 (differential tests): the solves one by one
+    if ((e && atoi(e) == 0) || mode == FV_STEP_ADJOINT || !(dt > 0) || !p->D.p)
+        return false;
+    PcgSystem sys;
+    sys.implicit_step = true;
+    sys.sigma = 1.0 / dt;
+    sys.dt = dt;
+    return fv_pcg_small_takes(p, sys);
+}
+
+// The three solves and the error norm of one step-doubling attempt (adaptive_twostep, fv_transient.hip) in one launch, for the
+// systems fv_pcg_small takes.  rhs[k]: the forcing of solve k as step_impl would pass it (b' of an implicit step; null = none);
+// have_onestep: the full step is in `onestep` already.  *handled = false: not a case for it (the caller runs the three solves one by one).
+int fv_small_twostep(fv_problem *p, int mode, const double *const rhs[3], bool b_times_D, double *uk, double dt, double *onestep, bool have_onestep,
+                     double *two1, double *two, const double *weight, double rtol, int64_t maxiter, fv_solve_info *info, double *err, bool *handled)
+{
+    fv_ctx *ctx = p->ctx;
+    *handled = false;
+    if (!fv_small_twostep_takes(p, mode, dt))
+        return FV_OK;
+    FV_TRY(fv_pcg_prepare(p));
+    if (!p->small_part.p) {
+        FV_TRY(p->small_part.alloc(ctx, (size_t)4 * SM_MAXG));
+        FV_TRY(p->small_bar.alloc(ctx, 2));
+        FV_TRY(p->small_bar.zero(ctx));
+        p->small_bar_base = 0;
+    }
+    if (!p->small_scal3.p)
+        FV_TRY(p->small_scal3.alloc(ctx, 3));
+    const int64_t n = p->n;
+    int G = (int)((n + SM_BLOCK - 1) / SM_BLOCK);
+    G = G < 1 ? 1 : (G > SM_MAXG ? SM_MAXG : G);
+    if (G > ctx->num_cus)
+        G = ctx->num_cus;
+    Small3Args a3{};
+    const uint32_t seq = p->small_seq + 1;
+    p->small_seq += 2;
+    double *const xs[3] = {onestep, two1, two};
+    const double *const x0s[3] = {uk, uk, two1};
+    const double dts[3] = {dt, 0.5 * dt, 0.5 * dt};
+    for (int k = 0; k < 3; k++) {
+        SmallArgs &a = a3.s[k];
+        a.n = n;
+        a.G = G;
+        a.rows_per_block = (n + G - 1) / G;
+        a.rowptr = p->rowptr.p;
+        a.colind = p->colind.p;
+        a.vals = p->vals.p;
+        a.diagA = p->diagA.p;
+        a.D = p->D.p;
+        a.rhs = rhs[k];
+        a.sigma = 1.0 / dts[k];
+        a.dt = dts[k];
+        a.rtol = rtol;
+        a.implicit = 1;
+        a.b_times_D = b_times_D ? 1 : 0;
+        a.x0_zero = 0;
+        a.x = xs[k];
+        a.x0 = x0s[k];
+        a.seq = seq;
+        a.r = p->r.p;
+        a.pv = p->pvec.p;
+        a.q = p->q.p;
+        a.minv = p->minv.p;
+        a.part = p->small_part.p;
+        a.scal = p->small_scal3.p + k;
+        a.maxiter = maxiter;
+        a.hist = nullptr;
+        a.hist_cap = 0;
+        a.bar = p->small_bar.p;
+        a.bar_base = p->small_bar_base;
+    }
+    a3.first = have_onestep ? 1 : 0;
+    a3.w = weight;
+    hipLaunchKernelGGL(pcg_small3_kernel, dim3(G), dim3(SM_BLOCK), 0, ctx->stream, a3);
+    FV_LAUNCH_CHECK(ctx);
+    PcgScalars *hs = reinterpret_cast<PcgScalars *>(ctx->pinned);
+    static_assert(3 * sizeof(PcgScalars) <= 1024, "three scalar blocks fit the pinned page's first kilobyte");
+    FV_HIP(ctx, hipMemcpyAsync(hs, p->small_scal3.p, 3 * sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (hs[2].small_seq != seq + 1u) {
+        FV_HIP(ctx, hipMemsetAsync(p->small_bar.p, 0, 2 * sizeof(uint32_t), ctx->stream));
+        p->small_bar_base = 0;
+        fv_set_error(ctx, "fv_small_twostep: the blocks of the single-launch stepper did not meet at their grid barrier");
+        return FV_ERR_STATE;
+    }
+    p->small_bar_base = (uint32_t)hs[2].pad_;
+    // what three classic solves leave behind them
+    p->minv_valid = true;
+    p->minv_sigma = 1.0 / dts[2];
+    p->minv_epoch = p->assemble_epoch;
+    p->z_where = 0;
+    p->spec_valid = false;
+    p->vready = false;
+    p->last_iters = hs[2].iters;
+    p->loop_bytes = 0;
+    p->fused_chunked = false;
+    p->small_solves += 3 - a3.first;
+    p->resume.ok = false;
+    for (int k = a3.first; k < 3; k++) {
+        if (hs[k].done == 2)
+            fv_set_error(ctx, "PCG breakdown: p.Ap = %g is not positive (operator not SPD?)", hs[k].pq);
+        if (p->precond == FV_PRECOND_AUTO && !p->auto_steps_amg && hs[k].iters > FV_AUTO_SWITCH_ITERS)
+            p->auto_steps_amg = true; // (as step_impl after each solve: this operator wants the V-cycle from the next step on)
+    }
+    if (info) { // (of the last solve, as the one-by-one path leaves it)
+        info->converged = hs[2].done == 1;
+        info->iters = hs[2].iters;
+        info->bnorm = std::sqrt(hs[2].bnorm2);
+        info->relres = hs[2].bnorm2 > 0 ? std::sqrt(hs[2].rr / hs[2].bnorm2) : std::sqrt(hs[2].rr);
+        info->solve_ms = 0.0;
+        info->resnorm_len = 0;
+    }
+    *err = std::sqrt(hs[2].tol2x[0]);
     *handled = true;
     return FV_OK;
 }

@@ -538,8 +538,10 @@ extern "C" int fv_adjoint_run(fv_problem *p, fv_trajectory *u, fv_observation *o
     }
     FV_TRY(fv_pcg_prepare(p));
     // the forcing vector: zero except on the observation rows, which every solve's kernel rewrites
+    // (three of them: the solves of one step-doubling attempt may be enqueued together, fv_small_twostep)
+    const size_t flen = (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD;
     DevBuf<double> forcing;
-    FV_TRY(forcing.alloc(ctx, (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD));
+    FV_TRY(forcing.alloc(ctx, 3 * flen));
     FV_TRY(forcing.zero(ctx));
     int32_t slot = -1;
     FV_TRY(fv_slot_new(p, &slot));
@@ -549,7 +551,8 @@ extern "C" int fv_adjoint_run(fv_problem *p, fv_trajectory *u, fv_observation *o
     FvStepHooks h;
     h.mode = FV_STEP_W;
     h.norm_weight = p->D.p;
-    h.forcing = [&](double t, const double **rhs) -> int {
+    h.forcing = [&](double t, int which, const double **rhs) -> int {
+        double *const fbuf = forcing.p + (size_t)(which >= 0 && which < 3 ? which : 0) * flen;
         const double tau = T - t; // getdgdu(tspan[2] - t), :202
         int64_t k = 0, ko = 0;
         double w = 0.0, wo = 0.0;
@@ -559,10 +562,10 @@ extern "C" int fv_adjoint_run(fv_problem *p, fv_trajectory *u, fv_observation *o
             const double *oa = o->uobs.p + ko * o->nobs, *sa = o->has_sigma ? o->sigma.p + ko * o->nobs : nullptr;
             hipLaunchKernelGGL(adjoint_forcing_kernel, dim3(fv_blocks(o->nobs)), dim3(FV_BLOCK), 0, ctx->stream, o->nobs, (const int32_t *)o->idx.p,
                                (const double *)u->knots[(size_t)k], (const double *)u->knots[(size_t)k + 1], w, oa, oa + o->nobs, sa,
-                               sa ? sa + o->nobs : nullptr, wo, forcing.p);
+                               sa ? sa + o->nobs : nullptr, wo, fbuf);
             FV_LAUNCH_CHECK(ctx);
         }
-        *rhs = forcing.p;
+        *rhs = fbuf;
         return FV_OK;
     };
     h.record = [&](const double *state, double t) -> int { return fv_trajectory_push_device(gam, state, t, p->D.p); }; // gamma = D w

@@ -50,6 +50,7 @@ extern "C" {
  *   FV_TRACE_SPMV=N / FV_TRACE_FUSED=1 / FV_TRACE_REORDER=1  print kernel choices, fused-step eligibility, re-numbering decisions to stderr
  *   FV_TRACE_ALLOC=1     every device allocation / release that takes more than 0.1 ms, to stderr
  *   FV_AMG_VERBOSE=1     the AMG set-up phase by phase, to stderr
+ *   FV_SMALL_TWOSTEP=0   small systems: the three solves of a step-doubling attempt one by one instead of in one launch (the same bits: tested)
  *   FV_AMG_GALERKIN=sort the AMG's Galerkin products by the global stable sort instead of the row merge (the same bits: tested)
  *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments) */
 int fv_tune(int key, int value);

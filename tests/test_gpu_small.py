@@ -79,3 +79,43 @@ def test_single_launch_solver_reports_a_breakdown_like_the_classic_loop(fv):
     head, res, ch = p.solve_steady(None, 1e-12, 200, want_resnorm=False)
     assert not ch.isconverged
     p.close()
+
+
+def test_step_doubling_attempt_as_one_launch_is_the_three_solves_one_by_one(fv):
+    """The adaptive stepper on a small system: the full step, the two half steps and the error norm of an attempt enqueued as ONE
+    launch (fv_small_twostep) against the same attempt as three launches and a norm (FV_SMALL_TWOSTEP=0): the same accepted
+    times, the same number of solves and, bit for bit, the same states — forward with rejected attempts in it, and the
+    device-resident adjoint sweep (time-dependent forcing on the observation rows, weighted norm)."""
+    import os
+
+    nb, aol, vol, K, dn, dh, src = _box(fv, (17, 15, 6), seed=3)
+    N = len(vol)
+    out = {}
+    for how in ("1", "0"):
+        os.environ["FV_SMALL_TWOSTEP"] = how
+        try:
+            p = fv.Problem.create(nb, aol, N, dn).assemble(K, src, dh)
+            st = p.transient_begin(0.1, vol, np.zeros(N))
+            tr = p.new_trajectory()
+            p.record(tr)
+            ts, nsolves, info = p.run_adaptive(st, 0.0, 4.0e5, dt0=1.0e4, atol=1e-5, rtol=1e-12)  # (dt0 too large for atol: the first attempts are rejected)
+            p.record(None)
+            assert info.converged and nsolves > 3 * (len(ts) - 1)
+            rows = np.array([5, 40, 300, 700])
+            from fvamd.core import Observation
+
+            obs = Observation(p, rows, np.array([0.0, 4.0e5]), np.zeros((2, len(rows))))
+            lam, nout, nl, info_l = p.adjoint_run(tr, obs, 0.0, 4.0e5, dt0=5.0e4, atol=1e-3, rtol=1e-12)
+            assert nl > 3 * nout  # (rejected attempts here too)
+            tl = lam.ts
+            out[how] = (np.array(ts), nsolves, st.node_values(), np.array(tl), nl, lam.free_values(0), lam.free_values(len(tl) // 2))
+            for o in (tr, lam, obs):
+                o.close()
+            p.close()
+        finally:
+            os.environ.pop("FV_SMALL_TWOSTEP", None)
+    a, b = out["1"], out["0"]
+    assert len(a[0]) > 10 and np.array_equal(a[0], b[0]) and a[1] == b[1] and np.array_equal(a[2], b[2])
+    assert len(a[3]) > 10 and np.array_equal(a[3], b[3]) and a[4] == b[4] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+    assert np.abs(a[5]).max() > 0
+
