@@ -1071,6 +1071,420 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
     }
 }
 
+// ------------------------------------------------------------------ chunks of a plane with the matrix as DOUBLES (round 5)
+// A heterogeneous conductivity (one value per face: /root/reference/src/FiniteVolume.jl:75-108, every input the reference runs)
+// has no matrix codes, and the 2-D tiles that served it paid 13 % of extra traffic for their column halos.  The same chunk
+// traversal with the three upper diagonals streamed as doubles: what the 16-bit words did through the LDS ring is split three ways —
+//   U2 (the +line diagonal; the -line arm of a row is U2 of the row nz in front of it, another wave's): an LDS ring of doubles
+//      with two plane slots, [nz rows before | C own], written for plane p + 1 while plane p's is read, like z';
+//   U1 (+1; the -1 arm is U1 of the row in front, the neighbouring LANE's second row): registers + a DPP wave shift, the wave's
+//      edge element by a scalar load — no LDS;
+//   U3 (+plane; the -plane arm is the own row's value one plane step earlier): registers only, carried from step to step.
+// LDS per row: z' 2 x 8 + U2 2 x 8 = 32 B -> chunks of up to 4 400 rows at nz = 464 (49 per plane): halo rows 2 nz / C = 21 % of the
+// own rows at 16 B (z, v) + nz U2 values = 4.2 extra bytes per row of 73 (the tiles: 9.5).  U1 / U3 of a plane are loaded one plane
+// step ahead of their use (they are needed when the plane is the centre plane), z / v / x / U2 / the code byte two steps ahead (the
+// plane's z' must be in LDS one step before).  The code byte (chunk_code_stream_kernel): storage code | bit 4 the row's diagonal is
+// not minus the sum of its arms and is loaded from the stored diagonal (rows next to a Dirichlet cell: the first and the last line
+// of a plane, the end planes) | bit 5 this traversal forms the row's product.  Same arithmetic per row in the same order as the
+// tile kernel and the coded chunk kernel: the same bits per row; partial sums group differently.
+__device__ __forceinline__ double kd_from_below(double v, double edge) // v of the lane below (DPP wave_shr:1), lane 0 gets `edge`
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(edge), __double2loint(v), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(edge), __double2hiint(v), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int NT, int NP, int MODE>
+__global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
+{
+    constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
+    extern __shared__ __align__(16) unsigned char kc_lds[];
+    const int tid = (int)threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t nz = a.nz, d3 = a.d3, C = a.chunk;
+    const int ZL = C + 2 * nz, WL = C + nz;
+    double *zs = reinterpret_cast<double *>(kc_lds); // 2 x ZL: [nz rows before | C own | nz rows behind]
+    double *u2s = zs + 2 * ZL;                       // 2 x WL: [nz rows before | C own], slot = plane parity
+    double *tab = u2s + 2 * WL;                      // sigma D by the low nibble of a row's code byte
+    double *red = tab + FV_STORAGE_CODES;
+    PcgScalars *scal = a.scal;
+    double alpha = 0.0;
+    if (MODE == 1) { // K3's scalars, as in fused_step_kernel
+        if (*reinterpret_cast<volatile int32_t *>(&scal->done))
+            return;
+        const double rzn = kf_reduce<NT>(a.in.arz, a.in.nvec, red);
+        const double rrn = kf_reduce<NT>(a.in.arr, a.in.nvec, red);
+        const bool converged = rrn <= scal->tol2;
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->rz[(a.chain_index + 1) & 1] = rzn;
+            scal->rr = rrn;
+            scal->iters = a.chain_index + 1;
+            if (a.hist && a.chain_index < a.hist_cap)
+                a.hist[a.chain_index] = sqrt(rrn);
+            if (converged)
+                scal->done = 1;
+        }
+        if (converged)
+            return;
+        alpha = rzn / scal->rz[a.chain_index & 1];
+    }
+    if (MODE == 0) {
+        if (!kf_step_prologue<NT>(a, red, alpha))
+            return;
+    }
+    const bool XU = MODE == 0 || a.xapply != 0;
+    double ax = MODE == 1 && a.xapply ? scal->alpha_last : 0.0;
+    if (MODE == 1) {
+        const long long ab = __double_as_longlong(ax);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
+        ax = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    {
+        const long long ab = __double_as_longlong(alpha);
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
+        alpha = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    if (tid < FV_STORAGE_CODES)
+        tab[tid] = a.sD.v[tid];
+    const int xcd = (int)(blockIdx.x & 7);
+    const int64_t items = (int64_t)a.tiles * a.nsegs, per_xcd = (items + 7) / 8;
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
+        const int64_t item = (int64_t)xcd * per_xcd + j;
+        if (item >= items)
+            break;
+        const int32_t seg = (int32_t)(item / a.tiles), chunk = (int32_t)(item % a.tiles);
+        const int32_t cs = chunk * C, Cl = (cs + C <= d3) ? C : d3 - cs; // the chunk's rows of a plane: [cs, cs + Cl)
+        const int32_t p0 = a.pfirst + seg * a.seglen, p1 = (p0 + a.seglen < a.nplanes) ? p0 + a.seglen : a.nplanes;
+        if (p0 >= p1 || Cl <= 0)
+            continue;
+        const bool vec_first = a.pfirst == 1 && p0 == 1, vec_last = a.pfirst == 1 && p1 == a.nplanes && a.nplanes == a.P - 1;
+        const int64_t nrows8 = (int64_t)a.n * 8; // a halo row outside the vectors (in front of plane 0, behind plane P - 1) is not read
+        bool own[NP];
+        uint32_t ob[NP];  // byte offset of the pair's doubles inside a plane
+        int32_t erow[NP]; // the row in front of the first row of this wave's pairs (wave-uniform; -1 in front of the plane: the arrays are padded)
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int lr = 2 * (tid + NT * k);
+            own[k] = lr < Cl;
+            ob[k] = (uint32_t)(cs + (own[k] ? lr : 0)) * 8u; // rows beyond the chunk read its first row: finite, never used
+            const int lr0 = 2 * (wave * 64 + NT * k);
+            erow[k] = cs + (lr0 < Cl ? lr0 : 0) - 1;
+        }
+        int32_t hb[HR];
+        int hs[HR];
+        bool hv[HR], hbefore[HR];
+#pragma unroll
+        for (int r = 0; r < HR; r++) {
+            const int h = tid + NT * r;
+            hv[r] = h < 2 * nz;
+            hbefore[r] = h < nz;
+            const int32_t grow = !hv[r] ? cs : (hbefore[r] ? cs - nz + h : cs + Cl + (h - nz));
+            hb[r] = grow * 8;
+            hs[r] = hbefore[r] ? h : nz + Cl + (h - nz);
+        }
+        auto PB = [&](const void *arr, int32_t pl, int esz) -> const char * {
+            return reinterpret_cast<const char *>(arr) + (uint64_t)((int64_t)pl * d3) * (uint64_t)esz;
+        };
+        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return *reinterpret_cast<const double2 *>(PB(arr, pl, 8) + ob[k]); };
+        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 {
+            const double *b = reinterpret_cast<const double *>(PB(arr, pl, 8) + ob[k]);
+            return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
+        };
+        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (uint32_t) * reinterpret_cast<const uint16_t *>(PB(a.kcode, pl, 1) + (ob[k] >> 3)); };
+        auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
+        auto E1L = [&](int32_t pl, int k) -> double { return *reinterpret_cast<const double *>(PB(a.u1, pl, 8) + (int64_t)erow[k] * 8); };
+        auto HIN = [&](int32_t pl, int r) -> bool {
+            const int64_t off = (int64_t)pl * d3 * 8 + (int64_t)hb[r];
+            return off >= 0 && off < nrows8;
+        };
+        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + (int64_t)hb[r]); };
+        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]) = val; };
+        auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
+            double *q = reinterpret_cast<double *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]);
+            __builtin_nontemporal_store(val.x, q);
+            __builtin_nontemporal_store(val.y, q + 1);
+        };
+        __syncthreads(); // the table; the previous item's last LDS reads
+        // ---------------- prologue: z' of plane p0 - 1 and its U3 (registers), plane p0 (z' and U2 in LDS with their halos, U1 / U3 in
+        // registers), the batch of plane p0 + 1 in flight
+        double2 Zm[NP], DX[NP], A3m[NP], A3c[NP], U1c[NP], Za[NP], Va[NP], Xa[NP], U2a[NP];
+        double E1[NP];
+        uint32_t Mc[NP], Ma[NP];
+        int zb = p0 & 1;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int32_t pm = p0 > 0 ? p0 - 1 : 0; // (p0 = 0: there is no plane before it; what is loaded here is not used)
+            const double2 vv = P2(a.v, pm, k), zz = P2(a.z, pm, k);
+            Zm[k] = p0 > 0 ? make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y) : make_double2(0.0, 0.0);
+            if (MODE == 1 && vec_first && own[k]) {
+                ST2(a.znext, 0, k, Zm[k]);
+                if (XU) {
+                    const double2 xi = P2(a.x, 0, k);
+                    ST2(a.xout, 0, k, make_double2(xi.x + ax * vv.x, xi.y + ax * vv.y));
+                }
+            }
+            if (MODE == 0 && vec_first && own[k]) { // plane 0: its whole vector part, with the stored diagonal
+                const double2 xi = P2(a.x, 0, k), dd = P2(a.dg, 0, k), ss = SD(C2(0, k));
+                const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
+                ST2(a.xout, 0, k, make_double2(ra.xn, rb.xn));
+                ST2(a.znext, 0, k, Zm[k]);
+                acc[0] += ra.r * (ra.mv * ra.r) + rb.r * (rb.mv * rb.r);
+                acc[1] += ra.r * ra.r + rb.r * rb.r;
+                acc[2] += ra.c * ra.zn + rb.c * rb.zn;
+                acc[3] += ra.c * ra.c + rb.c * rb.c;
+                acc[4] += ra.h * ra.h + rb.h * rb.h;
+            }
+            A3m[k] = P2nt(a.u3, p0 - 1, k); // (p0 = 0: the zero padding in front of the array)
+            const double2 v0 = P2(a.v, p0, k), z0 = P2(a.z, p0, k);
+            const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
+            const uint32_t c0 = C2(p0, k);
+            DX[k] = make_double2(0.0, 0.0);
+            if (MODE == 1 && own[k]) {
+                ST2(a.znext, p0, k, Zc0);
+                if (XU) {
+                    const double2 xi = P2(a.x, p0, k);
+                    ST2(a.xout, p0, k, make_double2(xi.x + ax * v0.x, xi.y + ax * v0.y));
+                }
+            }
+            if (MODE == 0) {
+                const double2 xi = P2(a.x, p0, k);
+                const double2 xn = make_double2(xi.x + alpha * z0.x, xi.y + alpha * z0.y);
+                DX[k] = make_double2(xn.x - xi.x, xn.y - xi.y);
+                if (own[k]) {
+                    const double2 ss = SD(c0);
+                    ST2(a.xout, p0, k, xn);
+                    ST2(a.znext, p0, k, Zc0);
+                    const double hx = ss.x * xn.x, hy = ss.y * xn.y;
+                    acc[4] += hx * hx + hy * hy;
+                }
+            }
+            if (own[k]) {
+                const int lr = 2 * (tid + NT * k);
+                *reinterpret_cast<double2 *>(zs + zb * ZL + nz + lr) = Zc0;
+                *reinterpret_cast<double2 *>(u2s + (p0 & 1) * WL + nz + lr) = P2nt(a.u2, p0, k);
+            }
+            U1c[k] = P2nt(a.u1, p0, k);
+            A3c[k] = P2nt(a.u3, p0, k);
+            E1[k] = E1L(p0, k);
+            Mc[k] = c0;
+        }
+#pragma unroll
+        for (int r = 0; r < HR; r++)
+            if (hv[r]) {
+                zs[zb * ZL + hs[r]] = HIN(p0, r) ? H1(a.z, p0, r) + alpha * H1(a.v, p0, r) : 0.0;
+                if (hbefore[r])
+                    u2s[(p0 & 1) * WL + hs[r]] = H1(a.u2, p0, r); // (in front of plane 0: the array's zero padding)
+            }
+        const int32_t pn = p0 + 1 < a.P ? p0 + 1 : p0; // (a one-plane segment at the very end: nothing behind it)
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            Za[k] = P2(a.z, pn, k);
+            Va[k] = P2nt(a.v, pn, k);
+            Xa[k] = XU ? P2nt(a.x, pn, k) : make_double2(0.0, 0.0);
+            U2a[k] = P2nt(a.u2, pn, k);
+            Ma[k] = C2(pn, k);
+        }
+        double hz[HR], hq[HR], hu[HR];
+#pragma unroll
+        for (int r = 0; r < HR; r++) {
+            hz[r] = hq[r] = hu[r] = 0.0;
+            if (hv[r] && p0 + 1 < p1) {
+                if (HIN(p0 + 1, r)) {
+                    hz[r] = H1(a.z, p0 + 1, r);
+                    hq[r] = H1(a.v, p0 + 1, r);
+                }
+                if (hbefore[r])
+                    hu[r] = H1(a.u2, p0 + 1, r);
+            }
+        }
+        __syncthreads();
+        for (int32_t p = p0; p < p1; p++) {
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+                asm volatile("" : "+v"(ob[k])); // (opaque: one 32-bit offset per pair beside the scalar plane bases, no 64-bit lane addresses kept alive)
+            const bool inseg = p + 1 < p1, more = p + 2 <= p1 && p + 2 < a.P;
+            const bool nextp = p + 1 < a.P;        // there is a plane behind the centre plane
+            const bool vec_n = inseg || vec_last; // plane p + 1's vector part is ours
+            const bool lastplane = vec_last && p + 1 == a.P - 1; // ... and it never becomes a centre plane: its diagonal terms now, from the stored diagonal
+            const double *zc = zs + zb * ZL + nz;
+            double *zn_ = zs + (zb ^ 1) * ZL + nz;
+            const double *u2c = u2s + (p & 1) * WL + nz;
+            double *u2n = u2s + ((p + 1) & 1) * WL + nz;
+#pragma unroll
+            for (int k = 0; k < NP; k++) {
+                const int lr = own[k] ? 2 * (tid + NT * k) : 0; // (pairs beyond the chunk compute on its first rows; nothing of theirs is kept)
+                // ---- (a) plane p + 1: z', x_out; its z' and U2 into the other LDS slots
+                const double2 Zn = nextp ? make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y) : make_double2(0.0, 0.0);
+                double2 dxn = make_double2(0.0, 0.0);
+                const uint32_t Mn = Ma[k];
+                if (MODE == 0) {
+                    const double2 xn = make_double2(Xa[k].x + alpha * Za[k].x, Xa[k].y + alpha * Za[k].y);
+                    dxn = make_double2(xn.x - Xa[k].x, xn.y - Xa[k].y);
+                    if (vec_n && own[k]) {
+                        if (a.nt & 8)
+                            ST2nt(a.xout, p + 1, k, xn);
+                        else
+                            ST2(a.xout, p + 1, k, xn);
+                        const double2 sa = SD(Mn);
+                        const double hx = sa.x * xn.x, hy = sa.y * xn.y;
+                        acc[4] += hx * hx + hy * hy;
+                        if (lastplane) {
+                            const double2 dd = P2(a.dg, p + 1, k);
+                            const double cx = dd.x * Zn.x, cy = dd.y * Zn.y;
+                            const double rx = cx - sa.x * dxn.x, ry = cy - sa.y * dxn.y;
+                            acc[0] += rx * ((1.0 / dd.x) * rx) + ry * ((1.0 / dd.y) * ry);
+                            acc[1] += rx * rx + ry * ry;
+                            acc[2] += cx * Zn.x + cy * Zn.y;
+                            acc[3] += cx * cx + cy * cy;
+                        }
+                    }
+                }
+                if (MODE == 1 && XU && vec_n && own[k]) // (p_old of plane p + 1 is Va)
+                    ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
+                if (vec_n && own[k]) {
+                    if (a.nt & 1)
+                        ST2nt(a.znext, p + 1, k, Zn);
+                    else
+                        ST2(a.znext, p + 1, k, Zn);
+                }
+                if (inseg && own[k]) {
+                    *reinterpret_cast<double2 *>(zn_ + lr) = Zn;
+                    *reinterpret_cast<double2 *>(u2n + lr) = U2a[k];
+                }
+                // ---- (c) centre plane p: its diagonal, the residual sums of its rows, its product
+                const double *zrow = zc + lr;
+                const double2 Zc = *reinterpret_cast<const double2 *>(zrow);
+                const double x1m0 = zrow[-1], x1p1 = zrow[2];
+                const double2 x2m = *reinterpret_cast<const double2 *>(zrow - nz), x2p = *reinterpret_cast<const double2 *>(zrow + nz);
+                const double2 V2c = *reinterpret_cast<const double2 *>(u2c + lr), V2m = *reinterpret_cast<const double2 *>(u2c + lr - nz);
+                const double2 V1c = U1c[k], A3k = A3c[k], A3p = A3m[k];
+                const double v1m0 = kd_from_below(V1c.y, E1[k]); // (outside every divergent branch: the DPP shift reads the neighbouring lane)
+                const uint32_t M = Mc[k];
+                const double2 Sc = SD(M);
+                // the diagonal: zero row sum — from the six arms, in the order the assembly added them (+ sigma D) —, or, on a row
+                // whose stored diagonal is something else (a Dirichlet neighbour), the stored one
+                double2 d;
+                {
+                    double so = A3p.x + V2m.x;
+                    so += v1m0;
+                    so += A3k.x;
+                    so += V2c.x;
+                    so += V1c.x;
+                    d.x = -so + Sc.x;
+                    so = A3p.y + V2m.y;
+                    so += V1c.x;
+                    so += A3k.y;
+                    so += V2c.y;
+                    so += V1c.y;
+                    d.y = -so + Sc.y;
+                    if (M & 0x1010u) {
+                        const double2 dd = P2(a.dg, p, k);
+                        if (M & 0x10u)
+                            d.x = dd.x;
+                        if (M & 0x1000u)
+                            d.y = dd.y;
+                    }
+                }
+                double t0 = A3p.x * Zm[k].x + d.x * Zc.x, t1 = A3p.y * Zm[k].y + d.y * Zc.y;
+                t0 += V2m.x * x2m.x;
+                t1 += V2m.y * x2m.y;
+                t0 += v1m0 * x1m0;
+                t1 += V1c.x * Zc.x;
+                t0 += V1c.x * Zc.y;
+                t1 += V1c.y * x1p1;
+                t0 += V2c.x * x2p.x;
+                t1 += V2c.y * x2p.y;
+                t0 += A3k.x * Zn.x;
+                t1 += A3k.y * Zn.y;
+                if (MODE == 1 && own[k] && (M & 0x20u)) {
+                    const double wx = 1.0 / d.x, wy = 1.0 / d.y;
+                    ST2nt(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
+                if (MODE == 0 && own[k]) {
+                    const double mx = 1.0 / d.x, my = 1.0 / d.y;
+                    if (M & 0x20u) {
+                        const double2 vn = make_double2(-(mx * (t0 - Sc.x * Zc.x)), -(my * (t1 - Sc.y * Zc.y)));
+                        if (a.nt & 2)
+                            ST2nt(a.vnext, p, k, vn);
+                        else
+                            ST2(a.vnext, p, k, vn);
+                        acc[5] += Zc.x * t0 + Zc.y * t1;
+                    }
+                    const double cx = d.x * Zc.x, cy = d.y * Zc.y;
+                    const double rx = cx - Sc.x * DX[k].x, ry = cy - Sc.y * DX[k].y;
+                    acc[0] += rx * (mx * rx) + ry * (my * ry);
+                    acc[1] += rx * rx + ry * ry;
+                    acc[2] += cx * Zc.x + cy * Zc.y;
+                    acc[3] += cx * cx + cy * cy;
+                }
+                // ---- the pair's state for the next step
+                Zm[k] = Zc;
+                DX[k] = dxn;
+                Mc[k] = Mn;
+                A3m[k] = A3k;
+                // ---- (b) U1 / U3 of plane p + 1 (needed when it is the centre plane), the batch of plane p + 2
+                if (inseg) {
+                    A3c[k] = P2nt(a.u3, p + 1, k);
+                    U1c[k] = P2nt(a.u1, p + 1, k);
+                    E1[k] = E1L(p + 1, k);
+                }
+                if (more) {
+                    Za[k] = P2(a.z, p + 2, k);
+                    Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
+                    if (XU)
+                        Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
+                    U2a[k] = P2nt(a.u2, p + 2, k);
+                    Ma[k] = C2(p + 2, k);
+                }
+            }
+            // ---- halo of plane p + 1 into the other slots; the halo of plane p + 2 in flight
+#pragma unroll
+            for (int r = 0; r < HR; r++) {
+                if (hv[r] && inseg) {
+                    zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
+                    if (hbefore[r])
+                        u2s[((p + 1) & 1) * WL + hs[r]] = hu[r];
+                }
+                if (hv[r] && p + 2 < p1) {
+                    hz[r] = hq[r] = 0.0;
+                    if (HIN(p + 2, r)) {
+                        hz[r] = H1(a.z, p + 2, r);
+                        hq[r] = H1(a.v, p + 2, r);
+                    }
+                    if (hbefore[r])
+                        hu[r] = H1(a.u2, p + 2, r);
+                }
+            }
+            __syncthreads();
+            zb ^= 1;
+        }
+    }
+    double sgather = 0.0;
+    if (MODE == 0 && a.bm > 0) { // the assembled b's share of |rhs|^2 over its support, as in fused_step_kernel
+        __syncthreads();
+        for (int64_t k = (int64_t)blockIdx.x * NT + tid; k < a.bm; k += (int64_t)gridDim.x * NT) {
+            const int32_t i = a.bidx[k];
+            const double bi = a.b[i];
+            const double xn = a.x[i] + alpha * a.z[i];
+            const double sd = a.code ? tab[a.code[i]] : tab[0];
+            sgather += bi * (2.0 * (sd * xn) + bi);
+        }
+    }
+    const int G = (int)gridDim.x;
+    for (int k = MODE == 1 ? KF_NSUM - 1 : 0; k < KF_NSUM; k++) {
+        const double t = kf_block_sum<NT>(acc[k], red);
+        if (tid == 0)
+            (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (MODE == 0 && a.bm > 0) {
+        const double t = kf_block_sum<NT>(sgather, red);
+        if (tid == 0)
+            a.out.sbb[G + blockIdx.x] = t;
+    }
+}
+
 // ------------------------------------------------------------------ the fused step on the SELL form (irregular meshes)
 // The same step (kf_step_prologue, vrow, the same six sums) for operators stored as SELL-64 with 16-bit column offsets
 // (fv_spmv.hip): one wave per 64-row group, a lane per row.  A neighbour's z' is z + alpha v of that row — two gathers that hit the
@@ -1394,20 +1808,24 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
     return true;
 }
 
-// ---- the chunk kernel's plan: variant (threads, pairs per thread), rows per chunk, chunks per plane, segments of planes, grid, LDS
+// ---- the chunk kernels' plan: variant (threads, pairs per thread), rows per chunk, chunks per plane, segments of planes, grid, LDS
 constexpr size_t KC_LDS_MAX = 160 * 1024;
 struct KcPlan {
     int nt, np, grid;
     size_t lds;
+    bool doubles; // fused_chunkd_kernel (the matrix as doubles) instead of fused_chunk_kernel (as 16-bit codes)
 };
-static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt)
+int g_chunkd_np = 5; // (experiment, FV_CHUNKD_NP in the environment) pairs of rows per thread of fused_chunkd_kernel: 4 or 5
+static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt, bool doubles)
 {
+    if (doubles) // z' and U2 double-buffered, the storage table, the reduction scratch
+        return (size_t)(16 * (C + 2 * nz) + 16 * (C + nz) + 8 * (FV_STORAGE_CODES + nt / 64));
     return (size_t)(16 * (C + 2 * nz) + 4 * (C + nz) + 8 * (2 * FV_STORAGE_CODES + 3 * FV_MATRIX_CODES + nt / 64));
 }
-// false: the 2-D tiles serve the launch (no codes, lines longer than the block, chunks that would not fit the LDS)
-static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
+// false: the 2-D tiles serve the launch (lines longer than the block, chunks that would not fit the LDS, no code bytes)
+static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
 {
-    if (!g_fused_chunk || !a.mcode || p->kc_state != 1 || !p->kc_code.p)
+    if (!g_fused_chunk || !p->kc_code.p || p->kc_state != (coded ? 1 : 2) || (coded && !a.mcode))
         return false;
     a.kcode = p->kc_code.p;
     a.kdiag = p->kc_dtab;
@@ -1419,12 +1837,12 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
     // 512 threads x 5 pairs of rows per thread: the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD.
     // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
-    const int nt = 512, np = 5;
+    const int nt = 512, np = coded ? 5 : (g_chunkd_np == 4 ? 4 : 5);
     const int64_t nz = a.nz, d3 = a.d3;
     if (nz > nt) // the 2 nz halo rows are covered in two rounds of the block: longer lines stay with the tiles
         return false;
-    const int64_t fixed = (int64_t)kc_lds_bytes(0, nz, nt);
-    int64_t cmax = ((int64_t)KC_LDS_MAX - fixed) / 20 / 16 * 16;
+    const int64_t fixed = (int64_t)kc_lds_bytes(0, nz, nt, !coded);
+    int64_t cmax = ((int64_t)KC_LDS_MAX - fixed) / (coded ? 20 : 32) / 16 * 16;
     if (cmax > 2 * (int64_t)nt * np)
         cmax = 2 * (int64_t)nt * np;
     if (cmax < 2048 || cmax < 2 * nz) // (a chunk shorter than two lines: the halo would outweigh it)
@@ -1473,24 +1891,32 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl)
     pl.nt = nt;
     pl.np = np;
     pl.grid = (int)g;
-    pl.lds = kc_lds_bytes(bestC, nz, nt);
+    pl.lds = kc_lds_bytes(bestC, nz, nt, !coded);
+    pl.doubles = !coded;
     return true;
 }
-template <int NT, int NP, int MODE>
+template <int NT, int NP, int MODE, bool DOUBLES>
 static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
+    void (*kern)(KfArgs);
+    if constexpr (DOUBLES)
+        kern = &fused_chunkd_kernel<NT, NP, MODE>;
+    else
+        kern = &fused_chunk_kernel<NT, NP, MODE>;
     if (!raised) {
-        FV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&fused_chunk_kernel<NT, NP, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KC_LDS_MAX));
+        FV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KC_LDS_MAX));
         raised = true;
     }
-    hipLaunchKernelGGL((fused_chunk_kernel<NT, NP, MODE>), dim3(pl.grid), dim3(NT), pl.lds, ctx->stream, a);
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(NT), pl.lds, ctx->stream, a);
     return FV_OK;
 }
 template <int MODE>
 static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
-    return kc_launch_one<512, 5, MODE>(ctx, a, pl);
+    if (pl.doubles)
+        return pl.np == 4 ? kc_launch_one<512, 4, MODE, true>(ctx, a, pl) : kc_launch_one<512, 5, MODE, true>(ctx, a, pl);
+    return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
 }
 
 // the SELL variant of fv_fused_step (same contract)
@@ -1609,7 +2035,7 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
     a.out = out;
     const bool coded = kf_codes(p, a);
     KcPlan kc{};
-    const bool chunks = coded && kc_plan(p, a, kc);
+    const bool chunks = kc_plan(p, a, kc, coded);
     if (chunks) {
         out.nvec = kc.grid; // (the plan has its own grid: one partial sum of each kind per block)
         out.nbb = a.bm > 0 ? 2 * kc.grid : kc.grid;
@@ -1644,6 +2070,8 @@ int fv_fused_step(fv_problem *p, const double *x, double *x_next, double sigma, 
         const int mb = coded ? 2 : 24;
         p->fused_bytes = (nder * 2 >= nok ? 73 : 81) - 24 + mb;
         p->fused_bytes_launch = (48 + (a.code ? 1 : 0)) * p->n + mb * 64 * nok + 8 * 64 * (nok - nder);
+        if (chunks && kc.doubles) // the code byte on every row, the stored diagonal on the rows that do not derive theirs
+            p->fused_bytes_launch = 49 * p->n + 24 * 64 * nok + 8 * p->kc_nstream;
     }
     return FV_OK;
 }
@@ -1725,7 +2153,7 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
     a.n = p->n;
     const bool coded = kf_codes(p, a);
     KcPlan kc{};
-    const bool chunks = coded && kc_plan(p, a, kc);
+    const bool chunks = kc_plan(p, a, kc, coded);
     if (chunks)
         FV_TRY(kc_launch<1>(ctx, a, kc));
     else if (TLr == 16) {

@@ -289,7 +289,8 @@ struct fv_problem {
     int kc_ends_switch = -1;       // fv_tune key 60's end-plane choice as it was when the codes were built
     DevBuf<uint8_t> kc_code;
     StorageTable kc_dtab = {};
-    int kc_state = 0, kc_ndiag = 0;
+    int kc_state = 0, kc_ndiag = 0; // kc_state 2: the matrix as doubles — bit 4 = diagonal from its stream, bit 5 = product formed by the traversal (chunk_code_stream_kernel)
+    int64_t kc_nstream = 0;         // ... rows whose diagonal that traversal loads from the stored diagonal
     int sym_state = -1; // -1 not looked at yet, 0 not applicable (no such structure, or not symmetric), 1 built
 
     // numeric

@@ -452,7 +452,7 @@ extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
 extern int g_small_n; // fv_small.hip
-extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk; // fv_fused.hip
+extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk, g_chunkd_np; // fv_fused.hip
 
 // The selectors that are left after round 4's pruning (csrc/fv_tune.h): every value of every key gives correct
 // results — each names an alternative kernel or policy that the tests compare with the default — and the launch-shape / streaming-hint /
@@ -518,6 +518,8 @@ extern "C" int fv_tune(int key, int value)
     }
     else if (key == 61 && value >= 0)
         g_small_n = value;
+    else if (key == 62 && (value == 4 || value == 5))
+        g_chunkd_np = value;
     else
         return FV_ERR_ARG;
     return FV_OK;
@@ -1891,14 +1893,72 @@ __global__ __launch_bounds__(FV_BLOCK) void chunk_code_kernel(int64_t n, int32_t
     }
 }
 
+// The code byte of the chunk traversal that streams the matrix as doubles (a heterogeneous conductivity: fused_chunkd_kernel,
+// fv_fused.hip; kc_state = 2).  Bits 0-3: the row's storage code; bit 4: the row's diagonal is NOT minus the sum of its six arms
+// (+ the folded sigma D) — a row next to a Dirichlet cell, a row of an irregular slice — and is loaded from the stored diagonal;
+// bit 5: this traversal forms the row's product (what bit 15 of the matrix word says where the matrix comes as codes).  No table:
+// any number of distinct diagonals.  count: rows with bit 4 (their 8 bytes are part of the launch's byte model).
+__global__ __launch_bounds__(FV_BLOCK) void chunk_code_stream_kernel(int64_t n, int32_t d1, int32_t d2, int32_t d3, const double *__restrict__ dg,
+                                                                      const double *__restrict__ u1, const double *__restrict__ u2,
+                                                                      const double *__restrict__ u3, const uint8_t *__restrict__ dcode, StorageTable tshift,
+                                                                      int shift_mode, const uint8_t *__restrict__ ok, const uint8_t *__restrict__ reg,
+                                                                      uint8_t *__restrict__ code, int32_t *__restrict__ count)
+{
+    int mine = 0;
+    for (int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * FV_BLOCK) {
+        const uint8_t sc = dcode ? dcode[r] : (uint8_t)0;
+        const bool formed = (ok[r >> 6] & 1) || (reg && reg[r >> 6]);
+        bool derived = false;
+        if (formed) {
+            double so = u3[r - d3] + u2[r - d2];
+            so += u1[r - d1];
+            so += u3[r];
+            so += u2[r];
+            so += u1[r];
+            double cand = -so;
+            if (shift_mode)
+                cand += tshift.v[shift_mode == 1 ? sc : 0];
+            derived = __double_as_longlong(cand) == __double_as_longlong(dg[r]);
+        }
+        code[r] = (uint8_t)((sc & 15) | (derived ? 0 : 16) | (formed ? 32 : 0));
+        mine += derived ? 0 : 1;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+        mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine)
+        atomicAdd(count, mine);
+}
+
 static int build_chunk_codes(fv_problem *p, const uint8_t *dcode, int shift_mode)
 {
     fv_ctx *ctx = p->ctx;
     p->kc_state = 0;
     p->kc_ends = false;
-    if (shift_mode < 0 || p->sym_mcode_n <= 0 || !p->sym_mcode.p || p->sym_d[0] != 1)
+    p->kc_nstream = 0;
+    if (shift_mode < 0 || p->sym_d[0] != 1)
         return FV_OK;
     const int64_t n = p->n;
+    if (p->sym_mcode_n <= 0 || !p->sym_mcode.p) { // the matrix as doubles: codes without a table
+        if (!p->kc_code.p)
+            FV_TRY(p->kc_code.alloc(ctx, (size_t)n + 64));
+        const double *dgs = p->sym_vals.p + p->sym_front;
+        DevBuf<int32_t> cnt;
+        FV_TRY(cnt.alloc(ctx, 1));
+        FV_TRY(cnt.zero(ctx));
+        const bool ends = !p->dist && p->sym_reg.p && g_chunk_ends;
+        int64_t gs = (n + FV_BLOCK - 1) / FV_BLOCK;
+        gs = gs < 1 ? 1 : (gs > 4096 ? 4096 : gs);
+        hipLaunchKernelGGL(chunk_code_stream_kernel, dim3((unsigned)gs), dim3(FV_BLOCK), 0, ctx->stream, n, (int32_t)p->sym_d[0], (int32_t)p->sym_d[1],
+                           (int32_t)p->sym_d[2], dgs, dgs + p->sym_ld, dgs + 2 * p->sym_ld, dgs + 3 * p->sym_ld, dcode, p->sym_shift, shift_mode,
+                           (const uint8_t *)p->sym_ok.p, ends ? (const uint8_t *)p->sym_reg.p : (const uint8_t *)nullptr, p->kc_code.p, cnt.p);
+        FV_LAUNCH_CHECK(ctx);
+        int32_t h = 0;
+        FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
+        p->kc_nstream = h;
+        p->kc_state = 2;
+        p->kc_ends = ends;
+        return FV_OK;
+    }
     if (!p->kc_code.p)
         FV_TRY(p->kc_code.alloc(ctx, (size_t)n + 64));
     const double *dg = p->sym_vals.p + p->sym_front;

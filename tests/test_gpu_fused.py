@@ -57,7 +57,7 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
     finally:
         lib.fv_tune(41, 1)
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 46: 1, 49: 1, 60: 1}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 46: 1, 49: 1, 60: 1, 62: 5}.get(k, 0))
     return out
 
 
@@ -241,6 +241,42 @@ def test_chunk_traversal_against_the_tiles_and_the_oracle(fv, oracle, ns, latera
                                                  dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
         u, t = ous[-1], ots[-1]
     print("chunks vs tiles %.2e, chunks vs oracle %.2e (change over the run %.2e)" % (relerr(chunks[0], tiles[0]), relerr(chunks[0], u), relerr(chunks[0] - u0, u - u0)))
+    assert relerr(chunks[0], u) < 1e-8
+
+
+@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True)])
+def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_oracle(fv, oracle, ns, lateral):
+    """Round 5: a heterogeneous conductivity (one value per face, /root/reference/src/FiniteVolume.jl:75-108) has no matrix codes; its
+    fused step / pass walks the same chunks with the three upper diagonals streamed as doubles (fused_chunkd_kernel: U2 through an
+    LDS ring, U1 by a wave shift, U3 carried in registers, the diagonal of a row next to a Dirichlet cell from the stored one).  Same
+    Jacobi-PCG step as the 2-D tiles: identical iteration counts, heads to rounding (partial sums group differently), 73 B per row —
+    one-iteration steps, the many-iteration loop, zero-iteration steps, an injected chain break; the oracle's heads within 1e-8."""
+    case = _problem(fv, ns, lateral=lateral, seed=31)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    sched = [(DT, 14, 1e-11), (40.0, 3, 1e-12), (DT, 9, 1e-11), (DT, 6, 1e-3), (DT, 7, 1e-12)]
+    tiles = _run(fv, case, True, sched, tune=((60, 0),))
+    assert tiles[4] == 0 and tiles[2][1] in (73, 81) and tiles[2][0] > 20
+    for variant in (1, 2):  # 1: the first / last plane's products formed by the chunk kernel too; 2: those planes by the slice-by-slice launch
+        for np_ in (5, 4):
+            got = _run(fv, case, True, sched, tune=((60, variant), (62, np_)))
+            assert got[4] == 1 and got[2][1] == tiles[2][1] and got[2][0] == tiles[2][0], (variant, got[2], got[4])
+            assert np.array_equal(got[1], tiles[1]), (variant, got[1], tiles[1])
+            assert relerr(got[0], tiles[0]) < 1e-12, (variant, relerr(got[0], tiles[0]))
+    chunks = _run(fv, case, True, sched)
+    assert chunks[4] == 1
+    for brk in (0, 5):
+        a = _run(fv, case, True, sched[:1], tune=((14, brk),))
+        b = _run(fv, case, True, sched[:1], tune=((14, brk), (60, 0)))
+        assert a[4] == 1 and b[4] == 0 and np.array_equal(a[1], b[1]) and (a[1] > 1).sum() >= 1 and relerr(a[0], b[0]) < 1e-11
+    la = _run(fv, case, True, [(300.0, 4, 1e-12)])
+    lb = _run(fv, case, True, [(300.0, 4, 1e-12)], tune=((60, 0),))
+    assert la[4] == 1 and lb[4] == 0 and la[5] == 105 and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
+    t, u = 0.0, u0
+    for dt, steps, _ in sched:
+        ous, ots = oracle.backwardeulerintegrate(u, (t, t + dt * steps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
+                                                 dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
+        u, t = ous[-1], ots[-1]
+    print("chunks (doubles) vs tiles %.2e, vs oracle %.2e (change over the run %.2e)" % (relerr(chunks[0], tiles[0]), relerr(chunks[0], u), relerr(chunks[0] - u0, u - u0)))
     assert relerr(chunks[0], u) < 1e-8
 
 
