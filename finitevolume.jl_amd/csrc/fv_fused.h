@@ -11,6 +11,7 @@ struct FusedSums {
     double *srz, *srr, *sbb; // the next step's set-up: rho.z, rho.rho (nvec), rhs.rhs (nbb)
     double *pq;              // z'.q' of the next step's product                 (npq)
     int nvec, nbb, npq;
+    double *t2;              // the one-launch PCG iteration (fv_ploop_pass): its seventh sum, q.q
 };
 
 extern int g_fused, g_fused_dist, g_fused_dist_spare, g_fused_sell;
@@ -37,3 +38,7 @@ int fv_spmv_rest(fv_problem *p, const double *x, double *y, const double *vals, 
 bool fv_fused_iteration_applicable(fv_problem *p, double sigma, bool folded);
 // x: the iterate, updated in place by x += alpha_last * p (the lagging update of the previous iteration) when xapply is set
 int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double *part_rz, const double *part_rr, int nvec, int *npq, double *x, bool xapply);
+// The one-launch PCG iteration (MODE 3 of the chunk kernels): see kf_ploop_prologue in fv_fused.hip
+bool fv_ploop_applicable(fv_problem *p, double sigma, bool folded);
+int fv_ploop_pass(fv_problem *p, int j, const double *folded, const double *z, const double *w, const double *pold, const double *xin, double *xout,
+                  double *znew, double *pnew, double *wnew);

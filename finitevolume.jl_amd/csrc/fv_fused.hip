@@ -55,6 +55,7 @@ struct KfArgs {
     // geometry: lines of nz rows, planes of d3 rows, nplanes = one past the last plane whose product this kernel forms
     int32_t nz, L, d3, nplanes, P, seglen, tilesC, tiles, nsegs;
     int32_t chunk; // fused_chunk_kernel: rows of a plane per work item (tiles = chunks per plane)
+    uint32_t front; // doubles of zero padding in front of row 0 of the symmetric arrays (dg, u1, u2, u3 point at row 0)
     int32_t pfirst; // ... its first product plane: 1, or 0 when the first and the last plane are centre planes too (kc_ends; nplanes is then P)
     // the symmetric arrays (row 0 pointers: zero-padded in front and behind), flags per 64-row slice, storage codes
     const double *dg, *u1, *u2, *u3;
@@ -67,6 +68,9 @@ struct KfArgs {
     // vectors
     const double *x, *z, *v;
     double *xout, *znext, *vnext;
+    const double *w; // MODE 3 (the whole PCG iteration in one launch): w = -M^-1 q of the previous launch; z' = z + ax w goes to zout
+    double *zout;
+    int first;       // MODE 3: the first pass of a solve — the direction is z itself, nothing but w' is stored
     // the assembled b on its support (sparse): share of |rhs|^2
     const int32_t *bidx;
     const double *b;
@@ -226,6 +230,64 @@ __device__ __forceinline__ bool kf_step_prologue(const KfArgs &a, double *red, d
             scal->pq = pq;
     } else if (blockIdx.x == 0 && tid == 0)
         scal->zero_mask |= 1u << a.chain_index; // the step counts 0 iterations: alpha = 0 hands the state over unchanged
+    return true;
+}
+
+// The scalar part of ONE-LAUNCH PCG iterations (MODE 3 of the chunk kernels; fv_ploop_pass; round 5).  Launch j >= 1 of a solve finds
+// what launch j - 1 left: the iterate's TRUE sums r.z and r.r (r = d z, formed where the diagonal is at hand) and five sums over that
+// launch's product q = (A + sigma D) p:  p.q,  z.q,  q.M^-1 q,  r.q,  q.q.  With the step length alpha = r.z / p.q the NEXT iterate's
+// sums are polynomials in alpha — z' = z - alpha M^-1 q, r' = r - alpha q:
+//     r'.z' = r.z - 2 alpha z.q + alpha^2 q.M^-1 q ,     r'.r' = r.r - 2 alpha r.q + alpha^2 q.q
+// — so this launch has the verdict on iterate j and beta = r'.z' / r.z BEFORE its pass, and the pass itself forms z' = z + alpha w
+// (w = -M^-1 q stored by the previous launch), x += alpha p, p' = z' + beta p and the next product: no vector-update launch, no
+// M^-1 stream, 89 B per row and iteration where the pass + update pair moved 105 (67 instead of 76 with the matrix as codes).
+// Same Jacobi-PCG iteration and stopping rule (/root/reference/src/transient.jl:50-58); every launch re-bases on the true sums of
+// the iterate it reads, so the polynomial's rounding (relative eps x r.r / r'.r': 1e-9 when an iteration gains four digits) never
+// accumulates.  a.first: the first pass of a solve (alpha = beta = 0: the direction is z itself; the set-up has given its verdict).
+// false: the launch stops here (converged, broken down, or already done).
+template <int NT>
+__device__ __forceinline__ bool kf_ploop_prologue(const KfArgs &a, double *red, double &ax, double &beta)
+{
+    const int tid = (int)threadIdx.x;
+    PcgScalars *scal = a.scal;
+    if (*reinterpret_cast<volatile int32_t *>(&scal->done))
+        return false;
+    ax = 0.0;
+    beta = 0.0;
+    if (a.first)
+        return true;
+    const int np = a.in.npq;
+    const double pq = kf_reduce<NT>(a.in.pq, np, red);
+    if (!(pq > 0.0)) { // breakdown: not positive definite, or NaN
+        if (blockIdx.x == 0 && tid == 0) {
+            scal->pq = pq;
+            scal->done = 2;
+        }
+        return false;
+    }
+    const double rzb = kf_reduce<NT>(a.in.arz, np, red), rrb = kf_reduce<NT>(a.in.arr, np, red);
+    const double s1 = kf_reduce<NT>(a.in.srz, np, red), s2 = kf_reduce<NT>(a.in.srr, np, red);
+    const double t1 = kf_reduce<NT>(a.in.sbb, np, red), t2 = kf_reduce<NT>(a.in.t2, np, red);
+    const double alpha = rzb / pq;
+    double rzn = rzb + alpha * (alpha * s2 - 2.0 * s1), rrn = rrb + alpha * (alpha * t2 - 2.0 * t1);
+    if (!(rrn > 0.0))
+        rrn = 0.0; // (cancellation to below the rounding of r.r: the iteration gained more than eight digits)
+    const bool converged = rrn <= scal->tol2;
+    if (blockIdx.x == 0 && tid == 0) {
+        scal->rz[(a.chain_index + 1) & 1] = rzn;
+        scal->rr = rrn;
+        scal->pq = pq;
+        scal->iters = a.chain_index + 1;
+        scal->alpha_last = alpha; // the update this launch applies (or, if it stops here, the flush kernel: fv_ploop_flush)
+        if (a.hist && a.chain_index < a.hist_cap)
+            a.hist[a.chain_index] = sqrt(rrn);
+        if (converged)
+            scal->done = 1;
+    }
+    if (converged)
+        return false;
+    ax = alpha;
+    beta = rzn > 0.0 ? rzn / rzb : 0.0; // (r'.z' lost to cancellation: restart the directions from z')
     return true;
 }
 
@@ -1094,10 +1156,14 @@ __device__ __forceinline__ double kd_from_below(double v, double edge) // v of t
     return __hiloint2double(hi, lo);
 }
 
-template <int NT, int NP, int MODE>
+template <int NT, int NP, int MODE, int PD, int PU, int FL>
 __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
 {
     constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
+    // Rolling prefetch: the loads a pair needs (its batch z, v, x, U2, code byte for step (a); U1, U3 and the edge element for (c))
+    // are issued PD pairs ahead of their use, across the step boundary — not a whole plane step ahead: PD + 1 pairs' worth of
+    // loaded-but-unused registers instead of NP pairs' worth, which is what lets 5 pairs of doubles fit 256 registers
+    static_assert(PD <= NP && PU <= PD, "prefetch distance");
     extern __shared__ __align__(16) unsigned char kc_lds[];
     const int tid = (int)threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1132,9 +1198,15 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
         if (!kf_step_prologue<NT>(a, red, alpha))
             return;
     }
-    const bool XU = MODE == 0 || a.xapply != 0;
-    double ax = MODE == 1 && a.xapply ? scal->alpha_last : 0.0;
-    if (MODE == 1) {
+    double ax3 = 0.0;
+    if (MODE == 3) { // the whole PCG iteration in this launch: see kf_ploop_prologue (alpha here plays beta's part, ax3 is the step length)
+        if (!kf_ploop_prologue<NT>(a, red, ax3, alpha))
+            return;
+    }
+    const bool XU = MODE == 0 || (MODE == 1 && a.xapply != 0) || (MODE == 3 && !a.first);
+    const bool LW = MODE == 3 && !a.first; // w and the old direction are read (not in the first pass of a solve: alpha = beta = 0, the direction is z itself)
+    double ax = MODE == 1 && a.xapply ? scal->alpha_last : (MODE == 3 ? ax3 : 0.0);
+    if (MODE == 1 || MODE == 3) {
         const long long ab = __double_as_longlong(ax);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
         ax = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
@@ -1148,7 +1220,7 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
         tab[tid] = a.sD.v[tid];
     const int xcd = (int)(blockIdx.x & 7);
     const int64_t items = (int64_t)a.tiles * a.nsegs, per_xcd = (items + 7) / 8;
-    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0}, acc6 = 0.0;
     for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
         const int64_t item = (int64_t)xcd * per_xcd + j;
         if (item >= items)
@@ -1183,39 +1255,73 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
             hb[r] = grow * 8;
             hs[r] = hbefore[r] ? h : nz + Cl + (h - nz);
         }
-        auto PB = [&](const void *arr, int32_t pl, int esz) -> const char * {
+        // Addressing: array base (a kernel argument: scalar registers) + ONE 32-bit byte offset per access = the pair's offset inside a
+        // plane + the plane's offset (a scalar) [+ the front padding of the symmetric arrays, whose rows -d3 .. -1 read zeros].  No
+        // per-plane 64-bit bases: eleven arrays x three planes of them cost ~90 spilled scalar registers.  Every vector is < 4 GiB (the
+        // host checks when it builds the symmetric copy); offsets are taken modulo 2^32, plane -1 of a padded array included.
+        const uint32_t d3b = (uint32_t)d3 * 8u, fb = a.front * 8u;
+        const char *u1f = reinterpret_cast<const char *>(a.u1 - a.front), *u2f = reinterpret_cast<const char *>(a.u2 - a.front),
+                   *u3f = reinterpret_cast<const char *>(a.u3 - a.front), *dgf = reinterpret_cast<const char *>(a.dg - a.front);
+        auto OFF = [&](int32_t pl) -> uint32_t { return (uint32_t)pl * d3b; };
+        auto PBX = [&](const void *arr, int32_t pl, int esz) -> const char * { // (FL & 1: a 64-bit scalar base per array and plane)
             return reinterpret_cast<const char *>(arr) + (uint64_t)((int64_t)pl * d3) * (uint64_t)esz;
         };
-        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return *reinterpret_cast<const double2 *>(PB(arr, pl, 8) + ob[k]); };
-        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 {
-            const double *b = reinterpret_cast<const double *>(PB(arr, pl, 8) + ob[k]);
+        auto LD2 = [&](const char *base, uint32_t off) -> double2 { return *reinterpret_cast<const double2 *>(base + off); };
+        auto LD2nt = [&](const char *base, uint32_t off) -> double2 {
+            const double *b = reinterpret_cast<const double *>(base + off);
             return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
         };
-        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (uint32_t) * reinterpret_cast<const uint16_t *>(PB(a.kcode, pl, 1) + (ob[k] >> 3)); };
+        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2(PBX(arr, pl, 8), ob[k]) : LD2(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
+        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2nt(PBX(arr, pl, 8), ob[k]) : LD2nt(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
+        auto PUL = [&](const char *basef, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2nt(PBX(basef + fb, pl, 8), ob[k]) : LD2nt(basef, fb + ob[k] + OFF(pl)); }; // a padded array (its start + front)
+        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (FL & 1) ? (uint32_t) * reinterpret_cast<const uint16_t *>(PBX(a.kcode, pl, 1) + (ob[k] >> 3)) : (uint32_t) * reinterpret_cast<const uint16_t *>(a.kcode + ((ob[k] + OFF(pl)) >> 3)); };
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
-        auto E1L = [&](int32_t pl, int k) -> double { return *reinterpret_cast<const double *>(PB(a.u1, pl, 8) + (int64_t)erow[k] * 8); };
+        auto E1L = [&](int32_t pl, int k) -> double { // (a wave-uniform address: a scalar load)
+            // (through the constant address space — the matrix is not written while the kernel runs —, or the compiler issues a vector
+            // load for it: one more entry in the vector-memory queue per pair and two registers held until it returns)
+            const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fb + OFF(pl) + (uint32_t)erow[k] * 8u));
+            if (FL & 2)
+                return *reinterpret_cast<const double *>(u1f + off);
+            return *reinterpret_cast<const __attribute__((address_space(4))) double *>((const __attribute__((address_space(4))) char *)(u1f) + off);
+        };
         auto HIN = [&](int32_t pl, int r) -> bool {
             const int64_t off = (int64_t)pl * d3 * 8 + (int64_t)hb[r];
             return off >= 0 && off < nrows8;
         };
-        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + (int64_t)hb[r]); };
-        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]) = val; };
+        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(arr) + ((uint32_t)hb[r] + OFF(pl))); };
+        auto HZ = [&](int32_t pl, int r) -> double { // the direction on a halo row, formed from its streams (the row exists)
+            if (MODE == 3)
+                return LW ? (H1(a.z, pl, r) + ax * H1(a.w, pl, r)) + alpha * H1(a.v, pl, r) : H1(a.z, pl, r);
+            return H1(a.z, pl, r) + alpha * H1(a.v, pl, r);
+        };
+        auto HU = [&](int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(u2f + (fb + (uint32_t)hb[r] + OFF(pl))); };
+        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) {
+            if (FL & 1)
+                *reinterpret_cast<double2 *>(const_cast<char *>(PBX(arr, pl, 8)) + ob[k]) = val;
+            else
+                *reinterpret_cast<double2 *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl))) = val;
+        };
         auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
-            double *q = reinterpret_cast<double *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]);
+            double *q = (FL & 1) ? reinterpret_cast<double *>(const_cast<char *>(PBX(arr, pl, 8)) + ob[k]) : reinterpret_cast<double *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl)));
             __builtin_nontemporal_store(val.x, q);
             __builtin_nontemporal_store(val.y, q + 1);
         };
         __syncthreads(); // the table; the previous item's last LDS reads
         // ---------------- prologue: z' of plane p0 - 1 and its U3 (registers), plane p0 (z' and U2 in LDS with their halos, U1 / U3 in
         // registers), the batch of plane p0 + 1 in flight
-        double2 Zm[NP], DX[NP], A3m[NP], A3c[NP], U1c[NP], Za[NP], Va[NP], Xa[NP], U2a[NP];
+        double2 Zm[NP], DX[NP], A3m[NP], A3c[NP], U1c[NP], Za[NP], Va[NP], Xa[NP], U2a[NP], Wa[NP]; // (MODE 3: DX carries z' of the plane that is the centre plane next, Wa is the batch's w)
         double E1[NP];
         uint32_t Mc[NP], Ma[NP];
         int zb = p0 & 1;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int32_t pm = p0 > 0 ? p0 - 1 : 0; // (p0 = 0: there is no plane before it; what is loaded here is not used)
-            const double2 vv = P2(a.v, pm, k), zz = P2(a.z, pm, k);
+            double2 zz = P2(a.z, pm, k);
+            const double2 vv = (MODE == 3 && !LW) ? make_double2(0.0, 0.0) : P2(a.v, pm, k);
+            if (LW) { // z' = z + ax w first, then the direction
+                const double2 ww = P2(a.w, pm, k);
+                zz = make_double2(zz.x + ax * ww.x, zz.y + ax * ww.y);
+            }
             Zm[k] = p0 > 0 ? make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y) : make_double2(0.0, 0.0);
             if (MODE == 1 && vec_first && own[k]) {
                 ST2(a.znext, 0, k, Zm[k]);
@@ -1225,7 +1331,7 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                 }
             }
             if (MODE == 0 && vec_first && own[k]) { // plane 0: its whole vector part, with the stored diagonal
-                const double2 xi = P2(a.x, 0, k), dd = P2(a.dg, 0, k), ss = SD(C2(0, k));
+                const double2 xi = P2(a.x, 0, k), dd = LD2(dgf, fb + ob[k]), ss = SD(C2(0, k));
                 const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
                 ST2(a.xout, 0, k, make_double2(ra.xn, rb.xn));
                 ST2(a.znext, 0, k, Zm[k]);
@@ -1235,11 +1341,22 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                 acc[3] += ra.c * ra.c + rb.c * rb.c;
                 acc[4] += ra.h * ra.h + rb.h * rb.h;
             }
-            A3m[k] = P2nt(a.u3, p0 - 1, k); // (p0 = 0: the zero padding in front of the array)
-            const double2 v0 = P2(a.v, p0, k), z0 = P2(a.z, p0, k);
+            A3m[k] = PUL(u3f, p0 - 1, k); // (p0 = 0: the zero padding in front of the array)
+            const double2 v0 = (MODE == 3 && !LW) ? make_double2(0.0, 0.0) : P2(a.v, p0, k);
+            double2 z0 = P2(a.z, p0, k);
+            if (LW) {
+                const double2 w0 = P2(a.w, p0, k);
+                z0 = make_double2(z0.x + ax * w0.x, z0.y + ax * w0.y);
+            }
             const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
             const uint32_t c0 = C2(p0, k);
-            DX[k] = make_double2(0.0, 0.0);
+            DX[k] = MODE == 3 ? z0 : make_double2(0.0, 0.0);
+            if (LW && own[k]) { // (the first pass of a solve stores neither: z' is z, the direction is z)
+                ST2(a.zout, p0, k, z0);
+                ST2(a.znext, p0, k, Zc0);
+                const double2 xi = P2(a.x, p0, k);
+                ST2(a.xout, p0, k, make_double2(xi.x + ax * v0.x, xi.y + ax * v0.y));
+            }
             if (MODE == 1 && own[k]) {
                 ST2(a.znext, p0, k, Zc0);
                 if (XU) {
@@ -1262,42 +1379,68 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
             if (own[k]) {
                 const int lr = 2 * (tid + NT * k);
                 *reinterpret_cast<double2 *>(zs + zb * ZL + nz + lr) = Zc0;
-                *reinterpret_cast<double2 *>(u2s + (p0 & 1) * WL + nz + lr) = P2nt(a.u2, p0, k);
+                *reinterpret_cast<double2 *>(u2s + (p0 & 1) * WL + nz + lr) = PUL(u2f, p0, k);
             }
-            U1c[k] = P2nt(a.u1, p0, k);
-            A3c[k] = P2nt(a.u3, p0, k);
-            E1[k] = E1L(p0, k);
+            if (k < PU) { // (the other pairs' by the rolling prefetch of the first step)
+                U1c[k] = PUL(u1f, p0, k);
+                A3c[k] = PUL(u3f, p0, k);
+                E1[k] = E1L(p0, k);
+            }
             Mc[k] = c0;
         }
 #pragma unroll
         for (int r = 0; r < HR; r++)
             if (hv[r]) {
-                zs[zb * ZL + hs[r]] = HIN(p0, r) ? H1(a.z, p0, r) + alpha * H1(a.v, p0, r) : 0.0;
+                zs[zb * ZL + hs[r]] = HIN(p0, r) ? HZ(p0, r) : 0.0;
                 if (hbefore[r])
-                    u2s[(p0 & 1) * WL + hs[r]] = H1(a.u2, p0, r); // (in front of plane 0: the array's zero padding)
+                    u2s[(p0 & 1) * WL + hs[r]] = HU(p0, r); // (in front of plane 0: the array's zero padding)
             }
         const int32_t pn = p0 + 1 < a.P ? p0 + 1 : p0; // (a one-plane segment at the very end: nothing behind it)
+        auto issue_batch = [&](int k, int32_t pl) {
+            Za[k] = P2(a.z, pl, k);
+            if (MODE == 3) { // (w and the old direction are read by the neighbouring chunks' halo rows as well: cacheable)
+                if (LW) {
+                    Va[k] = P2(a.v, pl, k);
+                    Wa[k] = P2(a.w, pl, k);
+                }
+            } else
+                Va[k] = P2nt(a.v, pl, k); // (read once: streaming loads; z stays cacheable for the halo rows of the neighbouring chunks)
+            if (XU)
+                Xa[k] = P2nt(a.x, pl, k);
+            U2a[k] = PUL(u2f, pl, k);
+            Ma[k] = C2(pl, k);
+        };
+        auto issue_u13 = [&](int k, int32_t pl) {
+            A3c[k] = PUL(u3f, pl, k);
+            U1c[k] = PUL(u1f, pl, k);
+            E1[k] = E1L(pl, k);
+        };
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            Za[k] = P2(a.z, pn, k);
-            Va[k] = P2nt(a.v, pn, k);
-            Xa[k] = XU ? P2nt(a.x, pn, k) : make_double2(0.0, 0.0);
-            U2a[k] = P2nt(a.u2, pn, k);
-            Ma[k] = C2(pn, k);
+            Xa[k] = Va[k] = Wa[k] = make_double2(0.0, 0.0);
+            if (k < PD)
+                issue_batch(k, pn);
         }
         double hz[HR], hq[HR], hu[HR];
+        constexpr int KH = NP >= 3 ? NP - 3 : 0; // the pair behind whose section a step issues the halo loads of the plane after next
+        auto issue_halo = [&](int32_t pl) { // consumed at the end of the step in which plane pl - 1 is the centre plane
 #pragma unroll
-        for (int r = 0; r < HR; r++) {
-            hz[r] = hq[r] = hu[r] = 0.0;
-            if (hv[r] && p0 + 1 < p1) {
-                if (HIN(p0 + 1, r)) {
-                    hz[r] = H1(a.z, p0 + 1, r);
-                    hq[r] = H1(a.v, p0 + 1, r);
+            for (int r = 0; r < HR; r++) {
+                hz[r] = hq[r] = hu[r] = 0.0;
+                if (hv[r] && pl < p1) {
+                    if (HIN(pl, r)) {
+                        hz[r] = H1(a.z, pl, r);
+                        if (MODE != 3 || LW)
+                            hq[r] = H1(a.v, pl, r);
+                        if (LW)
+                            hz[r] += ax * H1(a.w, pl, r); // (z' of the row: one register for both)
+                    }
+                    if (hbefore[r])
+                        hu[r] = HU(pl, r);
                 }
-                if (hbefore[r])
-                    hu[r] = H1(a.u2, p0 + 1, r);
             }
-        }
+        };
+        issue_halo(p0 + 1);
         __syncthreads();
         for (int32_t p = p0; p < p1; p++) {
 #pragma unroll
@@ -1315,22 +1458,25 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
             for (int k = 0; k < NP; k++) {
                 const int lr = own[k] ? 2 * (tid + NT * k) : 0; // (pairs beyond the chunk compute on its first rows; nothing of theirs is kept)
                 // ---- (a) plane p + 1: z', x_out; its z' and U2 into the other LDS slots
+                if (LW)
+                    Za[k] = make_double2(Za[k].x + ax * Wa[k].x, Za[k].y + ax * Wa[k].y); // z' = z + ax w
                 const double2 Zn = nextp ? make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y) : make_double2(0.0, 0.0);
-                double2 dxn = make_double2(0.0, 0.0);
+                double2 dxn = MODE == 3 ? Za[k] : make_double2(0.0, 0.0);
                 const uint32_t Mn = Ma[k];
+                if (LW && inseg && own[k]) {
+                    ST2(a.zout, p + 1, k, Za[k]);
+                    ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
+                }
                 if (MODE == 0) {
                     const double2 xn = make_double2(Xa[k].x + alpha * Za[k].x, Xa[k].y + alpha * Za[k].y);
                     dxn = make_double2(xn.x - Xa[k].x, xn.y - Xa[k].y);
                     if (vec_n && own[k]) {
-                        if (a.nt & 8)
-                            ST2nt(a.xout, p + 1, k, xn);
-                        else
-                            ST2(a.xout, p + 1, k, xn);
+                        ST2(a.xout, p + 1, k, xn);
                         const double2 sa = SD(Mn);
                         const double hx = sa.x * xn.x, hy = sa.y * xn.y;
                         acc[4] += hx * hx + hy * hy;
                         if (lastplane) {
-                            const double2 dd = P2(a.dg, p + 1, k);
+                            const double2 dd = LD2(dgf, fb + ob[k] + OFF(p + 1));
                             const double cx = dd.x * Zn.x, cy = dd.y * Zn.y;
                             const double rx = cx - sa.x * dxn.x, ry = cy - sa.y * dxn.y;
                             acc[0] += rx * ((1.0 / dd.x) * rx) + ry * ((1.0 / dd.y) * ry);
@@ -1342,12 +1488,8 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                 }
                 if (MODE == 1 && XU && vec_n && own[k]) // (p_old of plane p + 1 is Va)
                     ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
-                if (vec_n && own[k]) {
-                    if (a.nt & 1)
-                        ST2nt(a.znext, p + 1, k, Zn);
-                    else
-                        ST2(a.znext, p + 1, k, Zn);
-                }
+                if (vec_n && own[k] && (MODE != 3 || LW))
+                    ST2(a.znext, p + 1, k, Zn);
                 if (inseg && own[k]) {
                     *reinterpret_cast<double2 *>(zn_ + lr) = Zn;
                     *reinterpret_cast<double2 *>(u2n + lr) = U2a[k];
@@ -1379,7 +1521,7 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                     so += V1c.y;
                     d.y = -so + Sc.y;
                     if (M & 0x1010u) {
-                        const double2 dd = P2(a.dg, p, k);
+                        const double2 dd = LD2(dgf, fb + ob[k] + OFF(p));
                         if (M & 0x10u)
                             d.x = dd.x;
                         if (M & 0x1000u)
@@ -1402,14 +1544,24 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                     ST2nt(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
+                if (MODE == 3 && own[k]) { // (every row's product is this kernel's: the host runs the mode on whole regular boxes only)
+                    const double wx = 1.0 / d.x, wy = 1.0 / d.y;
+                    const double2 zo = DX[k];
+                    ST2(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w' = -M^-1 q' (the next launch's halo rows read it too: cacheable)
+                    const double rx = d.x * zo.x, ry = d.y * zo.y; // the residual of the row
+                    acc[0] += rx * zo.x + ry * zo.y;               // r.z and r.r of the iterate this launch formed: the next launch's base
+                    acc[1] += rx * rx + ry * ry;
+                    acc[2] += zo.x * t0 + zo.y * t1;               // z.q, q.M^-1 q, r.q, q.q: the next iterate's r.z and r.r as polynomials in the step length
+                    acc[3] += t0 * (wx * t0) + t1 * (wy * t1);
+                    acc[4] += rx * t0 + ry * t1;
+                    acc6 += t0 * t0 + t1 * t1;
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
                 if (MODE == 0 && own[k]) {
                     const double mx = 1.0 / d.x, my = 1.0 / d.y;
                     if (M & 0x20u) {
                         const double2 vn = make_double2(-(mx * (t0 - Sc.x * Zc.x)), -(my * (t1 - Sc.y * Zc.y)));
-                        if (a.nt & 2)
-                            ST2nt(a.vnext, p, k, vn);
-                        else
-                            ST2(a.vnext, p, k, vn);
+                        ST2(a.vnext, p, k, vn);
                         acc[5] += Zc.x * t0 + Zc.y * t1;
                     }
                     const double cx = d.x * Zc.x, cy = d.y * Zc.y;
@@ -1424,38 +1576,37 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                 DX[k] = dxn;
                 Mc[k] = Mn;
                 A3m[k] = A3k;
-                // ---- (b) U1 / U3 of plane p + 1 (needed when it is the centre plane), the batch of plane p + 2
-                if (inseg) {
-                    A3c[k] = P2nt(a.u3, p + 1, k);
-                    U1c[k] = P2nt(a.u1, p + 1, k);
-                    E1[k] = E1L(p + 1, k);
-                }
-                if (more) {
-                    Za[k] = P2(a.z, p + 2, k);
-                    Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
-                    if (XU)
-                        Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
-                    U2a[k] = P2nt(a.u2, p + 2, k);
-                    Ma[k] = C2(p + 2, k);
-                }
-            }
-            // ---- halo of plane p + 1 into the other slots; the halo of plane p + 2 in flight
+                // ---- (b) the loads of the pair PD positions ahead: U1 / U3 of its centre plane, the batch of the plane behind that
+                if (k + PU < NP)
+                    issue_u13(k + PU, p); // ... a pair of this same step
+                else if (inseg)
+                    issue_u13(k + PU - NP, p + 1); // ... of the next step
+                if (k + PD < NP) {
+                    if (nextp)
+                        issue_batch(k + PD, p + 1);
+                } else if (more)
+                    issue_batch(k + PD - NP, p + 2);
+                if (!(FL & 4) && k == KH) { // the halo of plane p + 1 into the other slots (nobody reads those before the barrier), then the halo of plane p + 2 in flight
 #pragma unroll
-            for (int r = 0; r < HR; r++) {
-                if (hv[r] && inseg) {
-                    zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
-                    if (hbefore[r])
-                        u2s[((p + 1) & 1) * WL + hs[r]] = hu[r];
+                    for (int r = 0; r < HR; r++)
+                        if (hv[r] && inseg) {
+                            zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
+                            if (hbefore[r])
+                                u2s[((p + 1) & 1) * WL + hs[r]] = hu[r];
+                        }
+                    issue_halo(p + 2);
                 }
-                if (hv[r] && p + 2 < p1) {
-                    hz[r] = hq[r] = 0.0;
-                    if (HIN(p + 2, r)) {
-                        hz[r] = H1(a.z, p + 2, r);
-                        hq[r] = H1(a.v, p + 2, r);
+                __builtin_amdgcn_sched_barrier(0); // (the scheduler must not hoist these loads further up: their registers are the point)
+            }
+            if (FL & 4) {
+#pragma unroll
+                for (int r = 0; r < HR; r++)
+                    if (hv[r] && inseg) {
+                        zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
+                        if (hbefore[r])
+                            u2s[((p + 1) & 1) * WL + hs[r]] = hu[r];
                     }
-                    if (hbefore[r])
-                        hu[r] = H1(a.u2, p + 2, r);
-                }
+                issue_halo(p + 2);
             }
             __syncthreads();
             zb ^= 1;
@@ -1477,6 +1628,11 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
         const double t = kf_block_sum<NT>(acc[k], red);
         if (tid == 0)
             (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (MODE == 3) {
+        const double t = kf_block_sum<NT>(acc6, red);
+        if (tid == 0)
+            a.out.t2[blockIdx.x] = t;
     }
     if (MODE == 0 && a.bm > 0) {
         const double t = kf_block_sum<NT>(sgather, red);
@@ -1791,6 +1947,7 @@ static int kf_setup(fv_problem *p, KfArgs &a)
     const int GF = (int)g;
     const double *dg = p->sym_vals.p + p->sym_front;
     a.dg = dg;
+    a.front = (uint32_t)p->sym_front;
     a.u1 = dg + p->sym_ld;
     a.u2 = dg + 2 * p->sym_ld;
     a.u3 = dg + 3 * p->sym_ld;
@@ -1815,7 +1972,7 @@ struct KcPlan {
     size_t lds;
     bool doubles; // fused_chunkd_kernel (the matrix as doubles) instead of fused_chunk_kernel (as 16-bit codes)
 };
-int g_chunkd_np = 5; // (experiment, FV_CHUNKD_NP in the environment) pairs of rows per thread of fused_chunkd_kernel: 4 or 5
+int g_chunkd_np = 4; // (experiment: fv_tune key 62) pairs of rows per thread of fused_chunkd_kernel: 4 or 5
 static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt, bool doubles)
 {
     if (doubles) // z' and U2 double-buffered, the storage table, the reduction scratch
@@ -1895,13 +2052,13 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     pl.doubles = !coded;
     return true;
 }
-template <int NT, int NP, int MODE, bool DOUBLES>
+template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2, int FL = 0>
 static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
     void (*kern)(KfArgs);
     if constexpr (DOUBLES)
-        kern = &fused_chunkd_kernel<NT, NP, MODE>;
+        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU, FL>;
     else
         kern = &fused_chunk_kernel<NT, NP, MODE>;
     if (!raised) {
@@ -1911,12 +2068,23 @@ static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
     hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(NT), pl.lds, ctx->stream, a);
     return FV_OK;
 }
+int g_chunkd_variant = 0; // (experiment: fv_tune key 62, tens digit) prefetch distances of fused_chunkd_kernel
 template <int MODE>
 static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
-    if (pl.doubles)
-        return pl.np == 4 ? kc_launch_one<512, 4, MODE, true>(ctx, a, pl) : kc_launch_one<512, 5, MODE, true>(ctx, a, pl);
-    return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
+    if (pl.doubles) {
+        // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two: measured 464^3, one process, ms per step (tiles 1.531): (2,2) 1.376,
+        // (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane): 1.384-1.477
+        if (pl.np == 5)
+            return kc_launch_one<512, 5, MODE, true, 2, 1, 2>(ctx, a, pl);
+        if (g_chunkd_variant == 1)
+            return kc_launch_one<512, 4, MODE, true, 2, 1, 2>(ctx, a, pl);
+        return kc_launch_one<512, 4, MODE, true, 3, 2, 2>(ctx, a, pl);
+    }
+    if constexpr (MODE == 3)
+        return FV_ERR_STATE; // (the coded chunk kernel has no one-launch iteration yet)
+    else
+        return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
 }
 
 // the SELL variant of fv_fused_step (same contract)
@@ -2178,6 +2346,72 @@ int fv_fused_iteration(fv_problem *p, int it, const double *folded, const double
         FV_TRY(fv_spmv_rest(p, p->pnext.p, p->q.p, folded ? folded : p->vals.p, p->part_pq.p + GK, &GR, true, 0.0, true, ends)); // (stored as w as well)
     *npq = GK + GR;
     p->fused_chunked = chunks;
+    return FV_OK;
+}
+
+// ---- the one-launch PCG iteration (MODE 3 of the chunk kernels; kf_ploop_prologue)
+int g_ploop = 1; // fv_tune key 63: the many-iteration PCG loop as one launch per iteration where it applies (0: the pass + vector update pair)
+// Whole regular boxes only: every plane a centre plane of the chunk traversal (kc_ends), no slice left to the slice-by-slice kernel
+// — the five sums over the product must come from ONE kernel — and a chunk plan that fits.
+bool fv_ploop_applicable(fv_problem *p, double sigma, bool folded)
+{
+    if (!g_ploop || !fv_fused_iteration_applicable(p, sigma, folded) || !p->kc_ends || p->sym_nrest_irr > 0 || p->kc_state != 2)
+        return false;
+    KfArgs a{};
+    kf_setup(p, a);
+    KcPlan kc{};
+    return kc_plan(p, a, kc, kf_codes(p, a)) && a.pfirst == 0;
+}
+
+// Launch j of a solve's loop (j = 0: the first pass, direction = z, nothing but w' stored).  z, w, pold: iterate j - 1's scaled residual,
+// the previous launch's w = -M^-1 q and direction; xin -> xout: x += alpha p (may be the same array); znew, pnew, wnew receive iterate
+// j's.  Sums: the previous launch's (set j - 1 & 1) in, this launch's out.
+int fv_ploop_pass(fv_problem *p, int j, const double *folded, const double *z, const double *w, const double *pold, const double *xin, double *xout,
+                  double *znew, double *pnew, double *wnew)
+{
+    fv_ctx *ctx = p->ctx;
+    FV_TRY(fv_fused_prepare(p));
+    KfArgs a{};
+    kf_setup(p, a);
+    a.code = nullptr;
+    for (int k = 0; k < FV_STORAGE_CODES; k++)
+        a.sD.v[k] = 0.0;
+    if (p->sym_shift_mode) { // the diagonal a row re-derives carries the folded shift by the row's storage code (as in fv_fused_iteration)
+        a.sD = p->sym_shift;
+        a.code = p->sym_shift_mode == 1 ? p->dcode.p : nullptr;
+    }
+    a.first = j == 0 ? 1 : 0;
+    a.z = z;
+    a.w = w;
+    a.v = pold;
+    a.x = xin;
+    a.xout = xout;
+    a.zout = znew;
+    a.znext = pnew;
+    a.vnext = wnew;
+    a.scal = p->scal.p;
+    a.chain_index = j - 1;
+    a.hist = p->hist.p;
+    a.hist_cap = p->hist_cap;
+    a.n = p->n;
+    const bool coded = kf_codes(p, a);
+    KcPlan kc{};
+    if (!kc_plan(p, a, kc, coded) || a.pfirst != 0 || !kc.doubles) {
+        fv_set_error(ctx, "internal: the one-launch PCG iteration on an operator it does not serve");
+        return FV_ERR_STATE;
+    }
+    FusedSums in = fv_fused_sums(p, (j + 1) & 1), out = fv_fused_sums(p, j & 1);
+    in.t2 = in.sbb + FV_FUSED_PARTS;
+    out.t2 = out.sbb + FV_FUSED_PARTS;
+    in.npq = in.nvec = kc.grid;
+    a.in = in;
+    a.out = out;
+    FV_TRY(kc_launch<3>(ctx, a, kc));
+    FV_LAUNCH_CHECK(ctx);
+    (void)folded;
+    p->loop_bytes = 89; // z, w, p, x in and z', p', w', x out (64) + the three upper diagonals (24) + the code byte
+    p->fused_chunked = true;
+    p->ploop_grid = kc.grid;
     return FV_OK;
 }
 

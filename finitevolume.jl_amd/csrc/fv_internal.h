@@ -388,6 +388,9 @@ struct fv_problem {
     uint32_t small_seq = 0;        // number of the last launch (PcgScalars::small_seq)
     DevBuf<PcgScalars> small_scal3; // the three solves of a step-doubling attempt in one launch (fv_small_twostep): their scalar blocks
     int64_t small_solves = 0;      // solves it has done
+    DevBuf<double> zalt, walt; // the one-launch PCG iteration (fv_ploop_pass): the second scaled-residual and w vectors (z and w ping-pong: halo rows of other blocks read them)
+    int ploop_grid = 0;        // ... its grid (= partial sums per quantity)
+    int64_t ploop_solves = 0;  // solves whose loop ran that way
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;

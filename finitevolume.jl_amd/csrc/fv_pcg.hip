@@ -400,6 +400,66 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_xflush_kernel(int64_t n, double 
 }
 __global__ void pcg_xflush_clear_kernel(PcgScalars *__restrict__ scal) { scal->xlag = -1; }
 
+// The end of a loop of one-launch iterations (fv_ploop_pass; kf_ploop_prologue in fv_fused.hip): the one update that is still pending —
+// z' = z + alpha w, x' = x + alpha p.  have_alpha: the launch that found the iterate converged has left alpha in the scalar block
+// (it stopped before its pass); else the loop ran out of iterations: alpha, the iterate's r.z and r.r (as polynomials in alpha) and
+// the verdict on it from the last launch's sums, as the next launch's prologue would have taken them.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_ploop_flush_kernel(int64_t n, const double *z, const double *__restrict__ w, const double *__restrict__ pv,
+                                                                    const double *xin, double *xout, double *zout, PcgScalars *__restrict__ scal,
+                                                                    FusedSums in, int have_alpha, int it, double *__restrict__ hist, int64_t hist_cap)
+{
+    __shared__ double smem[4];
+    double alpha;
+    if (have_alpha)
+        alpha = scal->alpha_last;
+    else {
+        if (scal->done)
+            return;
+        const int np = in.npq;
+        const double pq = reduce_partials(in.pq, np, smem);
+        if (!(pq > 0.0)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                scal->pq = pq;
+                scal->done = 2;
+            }
+            return;
+        }
+        const double rzb = reduce_partials(in.arz, np, smem), rrb = reduce_partials(in.arr, np, smem);
+        const double s1 = reduce_partials(in.srz, np, smem), s2 = reduce_partials(in.srr, np, smem);
+        const double t1 = reduce_partials(in.sbb, np, smem), t2 = reduce_partials(in.t2, np, smem);
+        alpha = rzb / pq;
+        const double rzn = rzb + alpha * (alpha * s2 - 2.0 * s1);
+        double rrn = rrb + alpha * (alpha * t2 - 2.0 * t1);
+        if (!(rrn > 0.0))
+            rrn = 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            scal->rz[it & 1] = rzn;
+            scal->rr = rrn;
+            scal->pq = pq;
+            scal->iters = it;
+            scal->alpha_last = alpha;
+            if (hist && it - 1 < hist_cap)
+                hist[it - 1] = sqrt(rrn);
+            if (rrn <= scal->tol2)
+                scal->done = 1;
+        }
+    }
+    const int64_t n2 = n >> 1;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z), *w2 = reinterpret_cast<const double2 *>(w), *p2 = reinterpret_cast<const double2 *>(pv);
+    const double2 *xi2 = reinterpret_cast<const double2 *>(xin);
+    double2 *xo2 = reinterpret_cast<double2 *>(xout), *zo2 = reinterpret_cast<double2 *>(zout);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        const double2 zv = z2[i], wv = nt_load2(w2 + i), pvv = nt_load2(p2 + i), xv = xi2[i];
+        zo2[i] = make_double2(zv.x + alpha * wv.x, zv.y + alpha * wv.y);
+        xo2[i] = make_double2(xv.x + alpha * pvv.x, xv.y + alpha * pvv.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        zout[i] = z[i] + alpha * w[i];
+        xout[i] = xin[i] + alpha * pv[i];
+    }
+}
+
 // K3's scalars alone (the verdict on iteration `it`), for the end of a chunk of that loop: the next pass's prologue would
 // take it, but the host polls first.  The pass that follows repeats the same values.
 __global__ __launch_bounds__(FV_BLOCK) void pcg_verdict_kernel(int it, const double *__restrict__ part_rz, const double *__restrict__ part_rr, int nparts,
@@ -1343,6 +1403,88 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
 #define FV_PROF(idx)                                                                                            \
     if (p->profile && ((idx) < 2 || p->profile_level == 1))                                                     \
     FV_HIP(ctx, hipEventRecord(p->prof_ev[(size_t)(6 * (k + kprof) + (idx))], ctx->stream))
+    // ---- the many-iteration loop as ONE launch per iteration (fv_ploop_pass, fv_fused.hip) on operators it serves: launch j takes the
+    // verdict on iterate j and alpha, beta from the sums launch j - 1 left, applies the update of iteration j - 1 and forms the next
+    // direction and product; the last update is flushed when the loop has stopped.  z_j in zb[j & 1] (z_0: the set-up's pvec), p_j in
+    // pb[j & 1], w_j in wb[j & 1]; x in place (its first update reads the old state and writes x_next where the state ping-pongs).
+    bool ploop = false;
+    if (!resume && !use_spec && !speculate && !chained && maxiter > 0 && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && !p->dist && !sys.x0_src) {
+        bool mpos = false;
+        FV_TRY(minv_positive(p, &mpos));
+        ploop = mpos && fv_ploop_applicable(p, sigma, folded != nullptr);
+    }
+    if (ploop) {
+        const size_t nv = (size_t)n + (size_t)p->nhalo + FV_VEC_PAD;
+        if (!p->pnext.p)
+            FV_TRY(p->pnext.alloc(ctx, nv));
+        if (!p->zalt.p) {
+            FV_TRY(p->zalt.alloc(ctx, nv));
+            FV_TRY(p->zalt.zero(ctx));
+        }
+        if (!p->walt.p) {
+            FV_TRY(p->walt.alloc(ctx, nv));
+            FV_TRY(p->walt.zero(ctx));
+        }
+        double *zb[2] = {p->r.p, p->zalt.p}, *pb[2] = {p->pvec.p, p->pnext.p}, *wb[2] = {p->q.p, p->walt.p};
+        double *xdst = sys.x_next ? sys.x_next : x;
+        auto zof = [&](int64_t j) -> double * { return j == 0 ? pb[0] : zb[j & 1]; };
+        int64_t j = 0; // the next launch
+        while (j < maxiter) {
+            int64_t m = chunk + (j == 0 ? 1 : 0); // (the launch that finds the last iterate converged does no pass: one more than the iterations expected)
+            if (m > MAX_CHUNK)
+                m = MAX_CHUNK;
+            if (m > maxiter - j)
+                m = maxiter - j;
+            for (int64_t k = 0; k < m; k++, j++) {
+                FV_PROF(0);
+                if (j == 0)
+                    FV_TRY(fv_ploop_pass(p, 0, folded, pb[0], nullptr, nullptr, x, xdst, nullptr, nullptr, wb[0]));
+                else
+                    FV_TRY(fv_ploop_pass(p, (int)j, folded, zof(j - 1), wb[(j - 1) & 1], pb[(j - 1) & 1], j == 1 ? x : xdst, xdst, zb[j & 1], pb[j & 1], wb[j & 1]));
+                FV_PROF(1);
+            }
+            FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+            FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            polled = true;
+            if (p->profile) { // only launches that did real work
+                const int64_t live = hs->done == 1 ? (int64_t)hs->iters - (j - m) : m;
+                for (int64_t k = 0; k < m && k < live; k++) {
+                    float ms = 0.f;
+                    FV_HIP(ctx, hipEventElapsedTime(&ms, p->prof_ev[(size_t)(6 * k)], p->prof_ev[(size_t)(6 * k + 1)]));
+                    p->prof_ms[0] += ms;
+                    p->prof_launches[0]++;
+                }
+            }
+            if (hs->done)
+                break;
+            if (chunk < MAX_CHUNK)
+                chunk *= 2;
+        }
+        // the pending update: iterate `it` = z_{it-1} + alpha w_{it-1}, x likewise
+        int64_t itf = -1;
+        int have_alpha = 0;
+        if (hs->done == 1 && hs->iters >= 1) {
+            itf = hs->iters;
+            have_alpha = 1;
+        } else if (hs->done == 0 && j >= 1)
+            itf = j; // out of iterations: every launch ran its pass
+        if (itf >= 1) {
+            FusedSums fin2 = fv_fused_sums(p, (int)((itf - 1) & 1));
+            fin2.t2 = fin2.sbb + FV_FUSED_PARTS;
+            fin2.npq = p->ploop_grid;
+            hipLaunchKernelGGL(pcg_ploop_flush_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)zof(itf - 1), (const double *)wb[(itf - 1) & 1],
+                               (const double *)pb[(itf - 1) & 1], (const double *)(itf == 1 ? x : xdst), xdst, p->r.p, p->scal.p, fin2, have_alpha, (int)itf,
+                               p->hist.p, p->hist_cap);
+            FV_LAUNCH_CHECK(ctx);
+            if (!have_alpha) {
+                FV_HIP(ctx, hipMemcpyAsync(hs, p->scal.p, sizeof(PcgScalars), hipMemcpyDeviceToHost, ctx->stream));
+                FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
+        p->ploop_solves++;
+        p->loop_minv_coded = false;
+        maxiter = 0; // (skip the loop below)
+    }
     int zloop = 0, zr_is_z = 0; // the many-iteration loop through the fused kernel: 0 no, 1 to be decided after the first product, 2 yes
     bool wloop_first = true, wloop_lag = false; // ... its first vector update is the classic one; afterwards x lags one pass behind
     while (it < maxiter) {
@@ -1530,9 +1672,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
-    if (zloop != 2)
+    if (zloop != 2 && !ploop)
         p->loop_bytes = 0; // (else what fv_fused_iteration reported: 113, or 91 with the matrix as codes)
-    if (zloop == 2 && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)
+    if ((zloop == 2 || ploop) && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)
         p->z_where = 4; // the array r holds M^-1 r (residual_to_r / the next step's carried set-up take it from there)
     p->spec_valid = speculate && hs->done == 1 && hs->iters == 1; // the K2S ran and the step converged in it
     if (speculate && zf && hs->iters >= 1)

@@ -57,7 +57,7 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
     finally:
         lib.fv_tune(41, 1)
         for k, v in tune:
-            lib.fv_tune(k, {14: -1, 13: 8, 46: 1, 49: 1, 60: 1, 62: 5}.get(k, 0))
+            lib.fv_tune(k, {14: -1, 13: 8, 46: 1, 49: 1, 60: 1, 62: 4, 63: 1}.get(k, 0))
     return out
 
 
@@ -257,7 +257,7 @@ def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_or
     tiles = _run(fv, case, True, sched, tune=((60, 0),))
     assert tiles[4] == 0 and tiles[2][1] in (73, 81) and tiles[2][0] > 20
     for variant in (1, 2):  # 1: the first / last plane's products formed by the chunk kernel too; 2: those planes by the slice-by-slice launch
-        for np_ in (5, 4):
+        for np_ in (4, 14, 5):
             got = _run(fv, case, True, sched, tune=((60, variant), (62, np_)))
             assert got[4] == 1 and got[2][1] == tiles[2][1] and got[2][0] == tiles[2][0], (variant, got[2], got[4])
             assert np.array_equal(got[1], tiles[1]), (variant, got[1], tiles[1])
@@ -270,7 +270,7 @@ def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_or
         assert a[4] == 1 and b[4] == 0 and np.array_equal(a[1], b[1]) and (a[1] > 1).sum() >= 1 and relerr(a[0], b[0]) < 1e-11
     la = _run(fv, case, True, [(300.0, 4, 1e-12)])
     lb = _run(fv, case, True, [(300.0, 4, 1e-12)], tune=((60, 0),))
-    assert la[4] == 1 and lb[4] == 0 and la[5] == 105 and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
+    assert la[4] == 1 and lb[4] == 0 and la[5] == 89 and lb[5] == 105 and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
     t, u = 0.0, u0
     for dt, steps, _ in sched:
         ous, ots = oracle.backwardeulerintegrate(u, (t, t + dt * steps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
@@ -278,6 +278,50 @@ def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_or
         u, t = ous[-1], ots[-1]
     print("chunks (doubles) vs tiles %.2e, vs oracle %.2e (change over the run %.2e)" % (relerr(chunks[0], tiles[0]), relerr(chunks[0], u), relerr(chunks[0] - u0, u - u0)))
     assert relerr(chunks[0], u) < 1e-8
+
+
+@pytest.mark.parametrize("lateral", [False, True])
+def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(fv, oracle, lateral):
+    """Round 5 (fv_tune key 63): on whole regular boxes a PCG iteration of the many-iteration loop is ONE launch — the launch takes the
+    verdict on the iterate and alpha, beta from sums the previous launch left (the next iterate's r.z and r.r as polynomials in the
+    step length), applies z' = z + alpha w and x += alpha p and forms the next direction and product; the last update is flushed when the
+    loop has stopped.  Same Jacobi-PCG iteration and stopping rule (/root/reference/src/transient.jl:50-58): iteration counts within one of
+    the pass + update pair's, heads to rounding, the oracle's heads within 1e-8; a steady solve with its residual history, a solve that
+    runs out of iterations and a warm restart; steps that are converged at their set-up."""
+    case = _problem(fv, BOX3 if lateral else BOX, lateral=lateral, seed=41)
+    mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
+    sched = [(40.0, 6, 1e-12), (DT, 5, 1e-11), (300.0, 4, 1e-12), (40.0, 3, 1e-3), (3.0, 5, 1e-10)]
+    on = _run(fv, case, True, sched)
+    off = _run(fv, case, True, sched, tune=((63, 0),))
+    assert on[5] == 89 and off[5] == 105, (on[5], off[5])
+    assert (on[1][:6] > 3).all() and np.abs(on[1].astype(int) - off[1].astype(int)).max() <= 1, (on[1], off[1])
+    assert relerr(on[0], off[0]) < 1e-11, relerr(on[0], off[0])
+    t, u = 0.0, u0
+    for dt, steps, _ in sched[:3]:
+        ous, ots = oracle.backwardeulerintegrate(u, (t, t + dt * steps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
+                                                 dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
+        u, t = ous[-1], ots[-1]
+    tight = _run(fv, case, True, sched[:3])
+    assert relerr(tight[0], u) < 1e-8 and relerr(tight[0] - u0, u - u0) < 1e-6
+    lib = fv.load()
+    out = {}
+    try:
+        for key in (1, 0):
+            assert lib.fv_tune(63, key) == 0
+            p = fv.Problem.create(nb, aol, len(vol), dn).assemble(K, src, dh)
+            p.solve_steady(None, 1e-10, 3)  # (the first product of a problem establishes the storage form the loop asks for)
+            head, res, ch = p.solve_steady(None, 1e-10, 150, want_resnorm=True)
+            assert not ch.isconverged and ch.iters == 150
+            head2, res2, ch2 = p.solve_steady(res, 1e-10, 20000, want_resnorm=False)
+            assert ch2.isconverged
+            out[key] = (np.asarray(ch.data["resnorm"]), head2, ch2.iters, p.loop_form())
+            p.close()
+    finally:
+        lib.fv_tune(63, 1)
+    assert out[1][3] == 89 and out[0][3] == 105 and len(out[1][0]) == 150
+    assert np.allclose(out[1][0], out[0][0], rtol=1e-6, atol=0), np.abs(out[1][0] / out[0][0] - 1).max()
+    assert abs(out[1][2] - out[0][2]) <= max(3, out[0][2] // 50)
+    assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6 * np.abs(out[0][1]).max()  # both are rtol 1e-10 solves
 
 
 def test_many_iteration_loop_leaves_a_row_with_a_zero_diagonal_alone(fv):
