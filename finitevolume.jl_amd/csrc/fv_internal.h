@@ -390,6 +390,15 @@ struct fv_problem {
     int64_t small_solves = 0;      // solves it has done
     DevBuf<double> zalt, walt; // the one-launch PCG iteration (fv_ploop_pass): the second scaled-residual and w vectors (z and w ping-pong: halo rows of other blocks read them)
     int ploop_grid = 0;        // ... its grid (= partial sums per quantity)
+    // ... and, inside a fixed-dt run, the last update of a step's loop left pending for the next step's set-up to apply
+    // (pcg_carry_flush_kernel): z_m = z + alpha w, x_m = x + alpha pp with alpha in the scalar block.  Whoever else comes first flushes it.
+    struct PlPending {
+        bool valid = false;
+        const double *z = nullptr, *w = nullptr, *pp = nullptr, *xin = nullptr;
+        double *x = nullptr;
+    } pl_pending;
+    DevBuf<uint8_t> vcode; // pcg_carry_flush_kernel's code byte: storage code | bit 7 (b is not zero), for (vcode_sepoch, vcode_aepoch) = (storage, assembly)
+    int64_t vcode_sepoch = -1, vcode_aepoch = -1;
     int64_t ploop_solves = 0;  // solves whose loop ran that way
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
@@ -496,7 +505,11 @@ struct PcgSystem {
     // x0_src (implicit steps on systems the single-launch solver takes, fv_pcg_small_takes): the state the step starts from, when it
     // is not yet in x — the kernel reads it there and writes x, which saves the copy launch in front of every solve of a stepper
     const double *x0_src = nullptr;
+    // fixed-dt runs: the next call is the carried step that follows this one — a loop of one-launch iterations may leave its last
+    // update pending for that step's set-up (fv_problem::pl_pending)
+    bool defer_flush = false;
 };
+int fv_ploop_flush_pending(fv_problem *p); // applies a pending update (no-op when there is none)
 // x holds the initial guess on entry and the solution on return.
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it);
 // how K2S (and the symmetric K1, for the shift folded into a diagonal it re-derives) is handed the storage term D: see

@@ -400,6 +400,78 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_xflush_kernel(int64_t n, double 
 }
 __global__ void pcg_xflush_clear_kernel(PcgScalars *__restrict__ scal) { scal->xlag = -1; }
 
+// The code byte of pcg_carry_flush_kernel: the row's storage code (0 where D takes one value) | bit 7: the assembled b is not zero there
+__global__ __launch_bounds__(FV_BLOCK) void carry_code_kernel(int64_t n, const uint8_t *__restrict__ dcode, const double *__restrict__ b, uint8_t *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
+        out[i] = (uint8_t)((dcode ? (dcode[i] & 15) : 0) | ((b && b[i] != 0.0) ? 0x80 : 0));
+}
+
+// K0' for a step that follows a loop of one-launch iterations in the same fixed-dt run (fv_ploop_pass): the previous step's last update
+// is still pending — z_m = z + alpha w, x_m = x + alpha p, alpha in the scalar block — and is applied HERE, in the pass that forms the
+// new step's set-up the way pcg_carry_init_kernel does (same arithmetic): r0 = z_m / M^-1 + D (x_m - x_prev) / dt, z0 = M^-1 r0, the
+// sums r0.z0, r0.r0, rhs.rhs with rhs = b + D x_m / dt.  z, w, p, x, x_prev, M^-1 in (48) + a code byte (the storage code; bit 7: b is
+// not zero on the row, where it is then read), x_m and z0 out (16): 65 B per row where the flush (48) and K0' (64) moved 112.
+__global__ __launch_bounds__(FV_BLOCK) void pcg_carry_flush_kernel(int64_t n, const double *z, const double *w, const double *pp, double *x,
+                                                                    const double *__restrict__ xprev, const double *__restrict__ minv,
+                                                                    const uint8_t *__restrict__ code, StorageTable dtab, const double *__restrict__ b, double dt,
+                                                                    const PcgScalars *__restrict__ scal, double *pv, double *__restrict__ part_rz,
+                                                                    double *__restrict__ part_rr, double *__restrict__ part_bb)
+{
+    __shared__ double smem[4];
+    __shared__ double tab[FV_STORAGE_CODES];
+    if (threadIdx.x < FV_STORAGE_CODES)
+        tab[threadIdx.x] = dtab.v[threadIdx.x];
+    __syncthreads();
+    const double alpha = scal->alpha_last;
+    double arz = 0.0, arr = 0.0, abb = 0.0;
+    const int64_t n2 = n >> 1;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z), *w2 = reinterpret_cast<const double2 *>(w), *q2 = reinterpret_cast<const double2 *>(pp);
+    const double2 *o2 = reinterpret_cast<const double2 *>(xprev), *m2 = reinterpret_cast<const double2 *>(minv);
+    double2 *x2 = reinterpret_cast<double2 *>(x), *p2 = reinterpret_cast<double2 *>(pv);
+    for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n2; i += vec_stride()) {
+        const double2 zv0 = z2[i], wv = nt_load2(w2 + i), pvv = q2[i], xv0 = x2[i], ov = nt_load2(o2 + i), mv = nt_load2(m2 + i);
+        const uint32_t c = reinterpret_cast<const uint16_t *>(code)[i];
+        const double2 dv = make_double2(tab[c & 15u], tab[(c >> 8) & 15u]);
+        double2 bv = make_double2(0.0, 0.0);
+        if (c & 0x8080u)
+            bv = reinterpret_cast<const double2 *>(b)[i];
+        const double2 zv = make_double2(zv0.x + alpha * wv.x, zv0.y + alpha * wv.y);
+        const double2 xv = make_double2(xv0.x + alpha * pvv.x, xv0.y + alpha * pvv.y);
+        double2 rv = make_double2(zv.x / mv.x, zv.y / mv.y);
+        rv.x += dv.x * ((xv.x - ov.x) / dt);
+        rv.y += dv.y * ((xv.y - ov.y) / dt);
+        const double hx = bv.x + dv.x * (xv.x / dt), hy = bv.y + dv.y * (xv.y / dt);
+        const double zx = mv.x * rv.x, zy = mv.y * rv.y;
+        x2[i] = xv;
+        p2[i] = make_double2(zx, zy);
+        arz += rv.x * zx + rv.y * zy;
+        arr += rv.x * rv.x + rv.y * rv.y;
+        abb += hx * hx + hy * hy;
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        const double di = tab[code[i] & 15u];
+        const double zi0 = z[i] + alpha * w[i], xi = x[i] + alpha * pp[i];
+        const double ri = zi0 / minv[i] + di * ((xi - xprev[i]) / dt);
+        const double hi = ((code[i] & 0x80u) ? b[i] : 0.0) + di * (xi / dt);
+        const double zi = minv[i] * ri;
+        x[i] = xi;
+        pv[i] = zi;
+        arz += ri * zi;
+        arr += ri * ri;
+        abb += hi * hi;
+    }
+    const double t0 = block_sum(arz, smem);
+    const double t1 = block_sum(arr, smem);
+    const double t2 = block_sum(abb, smem);
+    if (threadIdx.x == 0) {
+        part_rz[blockIdx.x] = t0;
+        part_rr[blockIdx.x] = t1;
+        part_bb[blockIdx.x] = t2;
+    }
+}
+
 // The end of a loop of one-launch iterations (fv_ploop_pass; kf_ploop_prologue in fv_fused.hip): the one update that is still pending —
 // z' = z + alpha w, x' = x + alpha p.  have_alpha: the launch that found the iterate converged has left alpha in the scalar block
 // (it stopped before its pass); else the loop ran out of iterations: alpha, the iterate's r.z and r.r (as polynomials in alpha) and
@@ -1211,6 +1283,42 @@ int fv_pcg_prepare(fv_problem *p)
 
 static inline int fv_step_precond_of(const fv_problem *p, const PcgSystem &sys) { return sys.implicit_step ? fv_step_precond(p) : p->precond; }
 
+int fv_ploop_flush_pending(fv_problem *p)
+{
+    fv_problem::PlPending &pd = p->pl_pending;
+    if (!pd.valid)
+        return FV_OK;
+    fv_ctx *ctx = p->ctx;
+    pd.valid = false;
+    hipLaunchKernelGGL(pcg_ploop_flush_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, pd.z, pd.w, pd.pp, pd.xin, pd.x, p->r.p, p->scal.p,
+                       FusedSums{}, 1, 0, (double *)nullptr, (int64_t)0);
+    FV_LAUNCH_CHECK(ctx);
+    p->z_where = 4;
+    return FV_OK;
+}
+
+// the code byte of pcg_carry_flush_kernel (cached per storage and assembly epoch); *ok = false: D has too many distinct values
+static int ensure_carry_codes(fv_problem *p, bool *ok, StorageTable *tab)
+{
+    fv_ctx *ctx = p->ctx;
+    StorageArg sa{};
+    int saved = 0;
+    FV_TRY(fv_storage_form(p, &sa, &saved, true));
+    *ok = sa.D == nullptr;
+    if (!*ok)
+        return FV_OK;
+    *tab = sa.tab;
+    if (p->vcode_sepoch != p->storage_epoch || p->vcode_aepoch != p->assemble_epoch || !p->vcode.p) {
+        if (!p->vcode.p)
+            FV_TRY(p->vcode.alloc(ctx, (size_t)p->n + 16));
+        hipLaunchKernelGGL(carry_code_kernel, dim3(vec_grid(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, sa.code, (const double *)p->b.p, p->vcode.p);
+        FV_LAUNCH_CHECK(ctx);
+        p->vcode_sepoch = p->storage_epoch;
+        p->vcode_aepoch = p->assemble_epoch;
+    }
+    return FV_OK;
+}
+
 int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, int64_t maxiter, fv_solve_info *info, bool time_it)
 {
     fv_ctx *ctx = p->ctx;
@@ -1301,6 +1409,18 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     }
     const double *in_rz = p->part_rz.p, *in_rr = p->part_rr.p, *in_bb = p->part_bb.p;
     int in_nbb = -1;
+    // a pending update of the previous step's loop (fv_problem::pl_pending): this step's carried set-up applies it, anything else flushes it first
+    bool take_pending = false;
+    StorageTable vtab{};
+    if (p->pl_pending.valid) {
+        bool codes = false;
+        if (!resume && !use_spec && sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D && x == p->pl_pending.x && maxiter > 0 &&
+            (sys.rhs == p->b.p || !sys.rhs) && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && fv_ploop_applicable(p, sigma, folded != nullptr))
+            FV_TRY(ensure_carry_codes(p, &codes, &vtab));
+        take_pending = codes;
+        if (!take_pending)
+            FV_TRY(fv_ploop_flush_pending(p));
+    }
     if (resume) {
         // nothing to set up: r, p and the scalars are those of the interrupted solve
     } else if (use_spec) {
@@ -1320,6 +1440,15 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         }
         if (!zf)
             FV_TRY(residual_to_r(p)); // the first K2 of this step reads r
+    } else if (take_pending) {
+        // the previous step's last update and this step's carried set-up in one pass; only z0 (pvec) is written: the loop that follows
+        // is the one-launch kind (it reads nothing else)
+        const fv_problem::PlPending pd = p->pl_pending;
+        p->pl_pending.valid = false;
+        hipLaunchKernelGGL(pcg_carry_flush_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, pd.z, pd.w, pd.pp, x, sys.carry_prev, (const double *)p->minv.p,
+                           (const uint8_t *)p->vcode.p, vtab, (const double *)p->b.p, sys.dt, (const PcgScalars *)p->scal.p, p->pvec.p, p->part_rz.p,
+                           p->part_rr.p, p->part_bb.p);
+        p->z_where = 0;
     } else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) {
         const double *zsrc = p->z_where == 1 ? p->pvec.p : p->z_where == 2 ? p->pnext.p : p->z_where == 4 ? p->r.p : nullptr;
         hipLaunchKernelGGL(pcg_carry_init_kernel, dim3(Gv), dim3(FV_BLOCK), 0, ctx->stream, n, sys.rhs, (const double *)p->D.p, sys.dt,
@@ -1413,6 +1542,10 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_TRY(minv_positive(p, &mpos));
         ploop = mpos && fv_ploop_applicable(p, sigma, folded != nullptr);
     }
+    if (take_pending && !ploop) {
+        fv_set_error(ctx, "internal: a pending update was taken by a set-up whose loop cannot use it");
+        return FV_ERR_STATE;
+    }
     if (ploop) {
         const size_t nv = (size_t)n + (size_t)p->nhalo + FV_VEC_PAD;
         if (!p->pnext.p)
@@ -1468,7 +1601,26 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             have_alpha = 1;
         } else if (hs->done == 0 && j >= 1)
             itf = j; // out of iterations: every launch ran its pass
-        if (itf >= 1) {
+        bool deferred = false;
+        if (itf >= 1 && have_alpha && sys.defer_flush && sys.implicit_step && xdst != x && (sys.rhs == p->b.p || !sys.rhs) && !sys.b_times_D) {
+            // the next call is the carried step behind this one: its set-up applies the update (pcg_carry_flush_kernel)
+            bool codes = false;
+            StorageTable tmp{};
+            FV_TRY(ensure_carry_codes(p, &codes, &tmp));
+            if (codes) {
+                fv_problem::PlPending &pd = p->pl_pending;
+                pd.valid = true;
+                pd.z = zof(itf - 1);
+                pd.w = wb[(itf - 1) & 1];
+                pd.pp = pb[(itf - 1) & 1];
+                pd.xin = itf == 1 ? x : xdst;
+                pd.x = xdst;
+                deferred = itf >= 2; // (a one-iteration step's update reads the old state and writes the other vector: not an in-place update, flush it)
+                if (!deferred)
+                    pd.valid = false;
+            }
+        }
+        if (itf >= 1 && !deferred) {
             FusedSums fin2 = fv_fused_sums(p, (int)((itf - 1) & 1));
             fin2.t2 = fin2.sbb + FV_FUSED_PARTS;
             fin2.npq = p->ploop_grid;

@@ -323,7 +323,7 @@ int g_resume_runs = 1;     // fv_tune key 33: a fixed-dt run goes on from the re
 static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const double *bhat_dev, int mode, double rtol,
                      int64_t maxiter, fv_solve_info *info, bool time_it, bool fold_shift = false, double *x_next = nullptr,
                      const double *carry_prev = nullptr, bool speculate = false, int chain_index = -1, int resume_it = 0,
-                     bool chain_more = false)
+                     bool chain_more = false, bool defer_flush = false)
 {
     fv_ctx *ctx = p->ctx;
     if (!(dt > 0)) {
@@ -342,6 +342,7 @@ static int step_impl(fv_problem *p, double *usrc, double *udst, double dt, const
     sys.chain_index = chain_index;
     sys.chain_more = chain_more;
     sys.resume_it = resume_it;
+    sys.defer_flush = defer_flush;
     if (usrc != udst && resume_it == 0) {
         // small systems: the single-launch solver reads the state where it is and writes udst (a copy launch less per solve; not in
         // the adjoint's in-place scaling mode, which needs the state in udst first)
@@ -498,8 +499,10 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             continue;
         }
         const bool carry = prev != nullptr && ((s_base + s) % refresh) != 0;
+        // (the step behind this one is a carried step of this same call: a loop of one-launch iterations may leave its last update to that step's set-up)
+        const bool next_carried = pingpong && !p->recording && s + 1 < nsteps && ((s_base + s + 1) % refresh) != 0;
         rc = step_impl(p, u, u, dt, nullptr, FV_STEP_FORWARD, rtol, maxiter, &inf, false, nsteps >= 2, alt, carry ? prev : nullptr,
-                       pingpong && g_carry_speculate); // also on the last step: a 2-step warm-up then runs every kernel of the loop
+                       pingpong && g_carry_speculate, -1, 0, false, next_carried); // also on the last step: a 2-step warm-up then runs every kernel of the loop
         if (iters_per_step)
             iters_per_step[s] = inf.iters;
         if (pingpong && rc == FV_OK) {
@@ -515,6 +518,11 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
             p->record_t += dt;
             rc = fv_trajectory_push_device(p->recording, u, p->record_t, nullptr);
         }
+    }
+    if (p->pl_pending.valid) { // (only after a failed step: the last step of a call never leaves its update pending)
+        const int rcf = fv_ploop_flush_pending(p);
+        if (rc == FV_OK)
+            rc = rcf;
     }
     if (pingpong && alt) { // hand the buffers back: the caller's slot owns the current state — also after a failed step, where
         // u is the last state a step completed from (the failed step wrote, if anything, into alt)

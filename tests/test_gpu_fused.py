@@ -563,4 +563,4 @@ def test_minv_as_codes_in_the_many_iteration_loop_gives_the_same_bits(fv):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
     hetero = _problem(fv, BOX, seed=17)
     c, d = run(hetero, 1), run(hetero, 0)
-    assert c[2] == 105 and d[2] == 105 and np.array_equal(c[0], d[0])
+    assert c[2] == 89 and d[2] == 89 and np.array_equal(c[0], d[0])  # (round 5: the one-launch iteration, which reads no M^-1 at all)
