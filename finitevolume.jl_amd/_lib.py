@@ -53,7 +53,7 @@ _i64p = C.c_void_p  # arrays are passed as raw addresses (host or device)
 _f64p = C.c_void_p
 
 # name -> (restype, argtypes): every symbol include/fvhip.h declares
-ABI_VERSION = 3  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
+ABI_VERSION = 4  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
 FV_OPT_REORDER = 1
 # the experimenter's panel (finitevolume.jl_amd/csrc/fv_tune.h): exported, but not part of include/fvhip.h
 PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int])}
@@ -108,6 +108,7 @@ SIGNATURES = {
     "fv_spmv_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64)]),
     "fv_update_form": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_loop_form": (C.c_int, [c_prob, P(C.c_int32)]),
+    "fv_step_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64)]),
     "fv_fused_form": (C.c_int, [c_prob, P(C.c_int64), P(C.c_int32), P(C.c_int64)]),
     "fv_fused_traversal": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_problem_reorder_info": (C.c_int, [c_prob, P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double)]),

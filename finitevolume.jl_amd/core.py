@@ -314,6 +314,14 @@ class Problem:
         self.check(load().fv_loop_form(self.handle, C.byref(b)))
         return b.value
 
+    def step_form(self):
+        """((set-up, first pass, flush) bytes per row outside the loop iterations, solves so far) of the most recent solve whose loop ran
+        as one launch per iteration (fv_step_form; loop_form() 89 / 67)."""
+        b = (C.c_int32 * 3)()
+        n = C.c_int64()
+        self.check(load().fv_step_form(self.handle, b, C.byref(n)))
+        return (int(b[0]), int(b[1]), int(b[2])), n.value
+
     def fused_form(self):
         """(launches so far, bytes per row of its storage form, bytes per launch) of the fused step of the one-iteration regime
         (fv_fused_form)."""
@@ -494,7 +502,9 @@ class Trajectory:
         return self
 
     def close(self):
-        if getattr(self, "handle", None) and getattr(self.problem, "handle", None):
+        # (safe in either order with the problem's own close: fv_problem_destroy detaches what is still alive — its HBM released, its
+        # problem pointer cleared — and fv_trajectory_destroy then frees the handle alone)
+        if getattr(self, "handle", None):
             load().fv_trajectory_destroy(self.handle)
         self.handle = None
 
@@ -526,7 +536,7 @@ class Observation:
         return G.value
 
     def close(self):
-        if getattr(self, "handle", None) and getattr(self.problem, "handle", None):
+        if getattr(self, "handle", None):  # (in either order with the problem's close, as Trajectory.close)
             load().fv_observation_destroy(self.handle)
         self.handle = None
 

@@ -857,6 +857,7 @@ extern "C" void fv_problem_destroy(fv_problem *p)
         return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipDeviceSynchronize();
+    fv_detach_dependents(p);
     delete p;
 }
 

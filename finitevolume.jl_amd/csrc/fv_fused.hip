@@ -767,10 +767,16 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         if (!kf_step_prologue<NT>(a, red, alpha))
             return;
     }
+    double ax3 = 0.0;
+    if (MODE == 3) { // the whole PCG iteration in this launch (kf_ploop_prologue): alpha here plays beta's part, ax3 is the step length
+        if (!kf_ploop_prologue<NT>(a, red, ax3, alpha))
+            return;
+    }
     // MODE 1: x += ax * p_old, the x-update of the previous iteration, which lags one pass behind (its direction is this pass's a.v)
-    const bool XU = MODE == 0 || a.xapply != 0;
-    double ax = MODE == 1 && a.xapply ? scal->alpha_last : 0.0;
-    if (MODE == 1) {
+    const bool XU = MODE == 0 || (MODE == 1 && a.xapply != 0) || (MODE == 3 && !a.first);
+    const bool LW = MODE == 3 && !a.first; // MODE 3: w and the old direction are read (not in the first pass of a solve: the direction is z itself)
+    double ax = MODE == 1 && a.xapply ? scal->alpha_last : (MODE == 3 ? ax3 : 0.0);
+    if (MODE == 1 || MODE == 3) {
         const long long ab = __double_as_longlong(ax);
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)ab), hi = __builtin_amdgcn_readfirstlane((uint32_t)((unsigned long long)ab >> 32));
         ax = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
     const double *T1 = mtab, *T2 = mtab + FV_MATRIX_CODES, *T3 = mtab + 2 * FV_MATRIX_CODES;
     const int xcd = (int)(blockIdx.x & 7);
     const int64_t items = (int64_t)a.tiles * a.nsegs, per_xcd = (items + 7) / 8;
-    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0};
+    double acc[KF_NSUM] = {0, 0, 0, 0, 0, 0}, acc6 = 0.0;
     for (int64_t j = (int64_t)(blockIdx.x >> 3); j < per_xcd; j += (int64_t)(gridDim.x >> 3)) {
         const int64_t item = (int64_t)xcd * per_xcd + j;
         if (item >= items)
@@ -842,6 +848,11 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             return off >= 0 && off < nrows8;
         };
         auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(PB(arr, pl, 8) + (int64_t)hb[r]); };
+        auto HZ = [&](int32_t pl, int r) -> double { // the direction on a halo row, formed from its streams (the row exists)
+            if (MODE == 3)
+                return LW ? (H1(a.z, pl, r) + ax * H1(a.w, pl, r)) + alpha * H1(a.v, pl, r) : H1(a.z, pl, r);
+            return H1(a.z, pl, r) + alpha * H1(a.v, pl, r);
+        };
         auto HW = [&](int32_t pl, int r) -> uint16_t { return *reinterpret_cast<const uint16_t *>(PB(a.mcode, pl, 2) + (int64_t)(hb[r] >> 2)); };
         auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(const_cast<char *>(PB(arr, pl, 8)) + ob[k]) = val; };
         auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
@@ -851,13 +862,18 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         };
         __syncthreads(); // the tables; the previous item's last LDS reads
         // ---------------- prologue: z' of plane p0 - 1 (registers), plane p0 (LDS, with halo and codes), batch p0 + 1 in flight
-        double2 Zm[NP], DX[NP], Za[NP], Va[NP], Xa[NP];
+        double2 Zm[NP], DX[NP], Za[NP], Va[NP], Xa[NP], Qa[NP]; // (MODE 3: DX carries z' of the plane that is the centre plane next, Qa is the batch's w)
         uint32_t Mc[NP], Ma[NP], Wa[NP]; // M: the pair's code bytes | (centre plane only) U3 codes of the plane before << 18; W: its matrix words (bit 15: this kernel forms the row's product)
         int zb = p0 & 1;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int32_t pm = p0 > 0 ? p0 - 1 : 0; // (p0 = 0: there is no plane before it; what is loaded here is not used)
-            const double2 vv = P2(a.v, pm, k), zz = P2(a.z, pm, k);
+            double2 zz = P2(a.z, pm, k);
+            const double2 vv = (MODE == 3 && !LW) ? make_double2(0.0, 0.0) : P2(a.v, pm, k);
+            if (LW) { // z' = z + ax w first, then the direction
+                const double2 ww = P2(a.w, pm, k);
+                zz = make_double2(zz.x + ax * ww.x, zz.y + ax * ww.y);
+            }
             Zm[k] = p0 > 0 ? make_double2(zz.x + alpha * vv.x, zz.y + alpha * vv.y) : make_double2(0.0, 0.0);
             if (MODE == 1 && vec_first && own[k]) {
                 ST2(a.znext, 0, k, Zm[k]);
@@ -879,10 +895,21 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             }
             const uint32_t wm = MW(pm, k);
             const uint32_t u3m = ((wm >> 10) & 31u) | (((wm >> 26) & 31u) << 5);
-            const double2 v0 = P2(a.v, p0, k), z0 = P2(a.z, p0, k);
+            const double2 v0 = (MODE == 3 && !LW) ? make_double2(0.0, 0.0) : P2(a.v, p0, k);
+            double2 z0 = P2(a.z, p0, k);
+            if (LW) {
+                const double2 w0 = P2(a.w, p0, k);
+                z0 = make_double2(z0.x + ax * w0.x, z0.y + ax * w0.y);
+            }
             const double2 Zc0 = make_double2(z0.x + alpha * v0.x, z0.y + alpha * v0.y);
             const uint32_t c0 = C2(p0, k);
-            DX[k] = make_double2(0.0, 0.0);
+            DX[k] = MODE == 3 ? z0 : make_double2(0.0, 0.0);
+            if (LW && own[k]) { // (the first pass of a solve stores neither: z' is z, the direction is z)
+                ST2(a.zout, p0, k, z0);
+                ST2(a.znext, p0, k, Zc0);
+                const double2 xi = P2(a.x, p0, k);
+                ST2(a.xout, p0, k, make_double2(xi.x + ax * v0.x, xi.y + ax * v0.y));
+            }
             if (MODE == 1 && own[k]) {
                 ST2(a.znext, p0, k, Zc0);
                 if (XU) {
@@ -913,7 +940,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         for (int r = 0; r < HR; r++)
             if (hv[r]) {
                 const bool in = HIN(p0, r);
-                zs[zb * ZL + hs[r]] = in ? H1(a.z, p0, r) + alpha * H1(a.v, p0, r) : 0.0;
+                zs[zb * ZL + hs[r]] = in ? HZ(p0, r) : 0.0;
                 if (hbefore[r])
                     ws[(p0 & 1) * WL + hs[r]] = in ? HW(p0, r) : (uint16_t)0;
             }
@@ -921,7 +948,8 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             Za[k] = P2(a.z, pn, k);
-            Va[k] = P2nt(a.v, pn, k);
+            Va[k] = MODE == 3 ? (LW ? P2(a.v, pn, k) : make_double2(0.0, 0.0)) : P2nt(a.v, pn, k);
+            Qa[k] = LW ? P2(a.w, pn, k) : make_double2(0.0, 0.0);
             Xa[k] = XU ? P2nt(a.x, pn, k) : make_double2(0.0, 0.0);
             Wa[k] = MW(pn, k);
             Ma[k] = C2(pn, k);
@@ -934,7 +962,10 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             hw[r] = 0;
             if (hv[r] && p0 + 1 < p1 && HIN(p0 + 1, r)) {
                 hz[r] = H1(a.z, p0 + 1, r);
-                hq[r] = H1(a.v, p0 + 1, r);
+                if (MODE != 3 || LW)
+                    hq[r] = H1(a.v, p0 + 1, r);
+                if (LW)
+                    hz[r] += ax * H1(a.w, p0 + 1, r); // (z' of the row: one register for both)
                 if (hbefore[r])
                     hw[r] = HW(p0 + 1, r);
             }
@@ -956,9 +987,15 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
             for (int k = 0; k < NP; k++) {
                 const int lr = own[k] ? 2 * (tid + NT * k) : 0; // (pairs beyond the chunk compute on its first rows; nothing of theirs is kept)
                 // ---- (a) plane p + 1: z', x_out; its z' and codes into the other LDS slots
+                if (LW)
+                    Za[k] = make_double2(Za[k].x + ax * Qa[k].x, Za[k].y + ax * Qa[k].y); // z' = z + ax w
                 const double2 Zn = nextp ? make_double2(Za[k].x + alpha * Va[k].x, Za[k].y + alpha * Va[k].y) : make_double2(0.0, 0.0);
-                double2 dxn = make_double2(0.0, 0.0);
+                double2 dxn = MODE == 3 ? Za[k] : make_double2(0.0, 0.0);
                 const uint32_t Mn = Ma[k];
+                if (LW && inseg && own[k]) {
+                    ST2(a.zout, p + 1, k, Za[k]);
+                    ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
+                }
                 if (MODE == 0) {
                     const double2 xn = make_double2(Xa[k].x + alpha * Za[k].x, Xa[k].y + alpha * Za[k].y);
                     dxn = make_double2(xn.x - Xa[k].x, xn.y - Xa[k].y);
@@ -983,7 +1020,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 }
                 if (MODE == 1 && XU && vec_n && own[k]) // (before (b) refills the registers: p_old of plane p + 1 is Va)
                     ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
-                if (vec_n && own[k]) {
+                if (vec_n && own[k] && (MODE != 3 || LW)) {
                     if (a.nt & 1)
                         ST2nt(a.znext, p + 1, k, Zn);
                     else
@@ -996,7 +1033,13 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 // ---- (b) the batch of plane p + 2 into the registers (a) has just emptied
                 if (more) {
                     Za[k] = P2(a.z, p + 2, k);
-                    Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
+                    if (MODE == 3) { // (w and the old direction are read by the neighbouring chunks' halo rows as well: cacheable)
+                        if (LW) {
+                            Va[k] = P2(a.v, p + 2, k);
+                            Qa[k] = P2(a.w, p + 2, k);
+                        }
+                    } else
+                        Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
                     if (XU)
                         Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
                     Wa[k] = MW(p + 2, k);
@@ -1059,6 +1102,22 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                     ST2nt(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w = -M^-1 q: the vector pass reads it once (z' = z + alpha w)
                     acc[5] += Zc.x * t0 + Zc.y * t1;
                 }
+                if (MODE == 3 && own[k]) { // (every row's product is this kernel's: the host runs the mode on whole regular boxes only)
+                    const double wx = 1.0 / d.x;
+                    double wy = wx;
+                    if (__double_as_longlong(d.y) != __double_as_longlong(d.x))
+                        wy = 1.0 / d.y;
+                    const double2 zo = DX[k];
+                    ST2(a.vnext, p, k, make_double2(-(wx * t0), -(wy * t1))); // w' = -M^-1 q' (the next launch's halo rows read it too: cacheable)
+                    const double rx = d.x * zo.x, ry = d.y * zo.y; // the residual of the row
+                    acc[0] += rx * zo.x + ry * zo.y;               // r.z and r.r of the iterate this launch formed: the next launch's base
+                    acc[1] += rx * rx + ry * ry;
+                    acc[2] += zo.x * t0 + zo.y * t1;               // z.q, q.M^-1 q, r.q, q.q: the next iterate's r.z and r.r as polynomials in the step length
+                    acc[3] += t0 * (wx * t0) + t1 * (wy * t1);
+                    acc[4] += rx * t0 + ry * t1;
+                    acc6 += t0 * t0 + t1 * t1;
+                    acc[5] += Zc.x * t0 + Zc.y * t1;
+                }
                 if (MODE == 0 && own[k]) {
                     // (the two rows of a pair almost always share their diagonal — one conductivity, interior rows —: one division then)
                     const double mx = 1.0 / d.x;
@@ -1099,7 +1158,10 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                     hw[r] = 0;
                     if (in) {
                     hz[r] = H1(a.z, p + 2, r);
-                    hq[r] = H1(a.v, p + 2, r);
+                    if (MODE != 3 || LW)
+                        hq[r] = H1(a.v, p + 2, r);
+                    if (LW)
+                        hz[r] += ax * H1(a.w, p + 2, r);
                     if (hbefore[r])
                         hw[r] = HW(p + 2, r);
                     }
@@ -1125,6 +1187,11 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
         const double t = kf_block_sum<NT>(acc[k], red);
         if (tid == 0)
             (k == 0 ? a.out.arz : k == 1 ? a.out.arr : k == 2 ? a.out.srz : k == 3 ? a.out.srr : k == 4 ? a.out.sbb : a.out.pq)[blockIdx.x] = t;
+    }
+    if (MODE == 3) {
+        const double t = kf_block_sum<NT>(acc6, red);
+        if (tid == 0)
+            a.out.t2[blockIdx.x] = t;
     }
     if (MODE == 0 && a.bm > 0) {
         const double t = kf_block_sum<NT>(sgather, red);
@@ -2081,10 +2148,7 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
             return kc_launch_one<512, 4, MODE, true, 2, 1, 2>(ctx, a, pl);
         return kc_launch_one<512, 4, MODE, true, 3, 2, 2>(ctx, a, pl);
     }
-    if constexpr (MODE == 3)
-        return FV_ERR_STATE; // (the coded chunk kernel has no one-launch iteration yet)
-    else
-        return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
+    return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
 }
 
 // the SELL variant of fv_fused_step (same contract)
@@ -2355,7 +2419,7 @@ int g_ploop = 1; // fv_tune key 63: the many-iteration PCG loop as one launch pe
 // — the five sums over the product must come from ONE kernel — and a chunk plan that fits.
 bool fv_ploop_applicable(fv_problem *p, double sigma, bool folded)
 {
-    if (!g_ploop || !fv_fused_iteration_applicable(p, sigma, folded) || !p->kc_ends || p->sym_nrest_irr > 0 || p->kc_state != 2)
+    if (!g_ploop || !fv_fused_iteration_applicable(p, sigma, folded) || !p->kc_ends || p->sym_nrest_irr > 0 || (p->kc_state != 1 && p->kc_state != 2))
         return false;
     KfArgs a{};
     kf_setup(p, a);
@@ -2396,7 +2460,7 @@ int fv_ploop_pass(fv_problem *p, int j, const double *folded, const double *z, c
     a.n = p->n;
     const bool coded = kf_codes(p, a);
     KcPlan kc{};
-    if (!kc_plan(p, a, kc, coded) || a.pfirst != 0 || !kc.doubles) {
+    if (!kc_plan(p, a, kc, coded) || a.pfirst != 0) {
         fv_set_error(ctx, "internal: the one-launch PCG iteration on an operator it does not serve");
         return FV_ERR_STATE;
     }
@@ -2409,7 +2473,7 @@ int fv_ploop_pass(fv_problem *p, int j, const double *folded, const double *z, c
     FV_TRY(kc_launch<3>(ctx, a, kc));
     FV_LAUNCH_CHECK(ctx);
     (void)folded;
-    p->loop_bytes = 89; // z, w, p, x in and z', p', w', x out (64) + the three upper diagonals (24) + the code byte
+    p->loop_bytes = coded ? 67 : 89; // z, w, p, x in and z', p', w', x out (64) + the three upper diagonals (24, or 2 as codes) + the code byte
     p->fused_chunked = true;
     p->ploop_grid = kc.grid;
     return FV_OK;

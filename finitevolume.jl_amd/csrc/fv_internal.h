@@ -380,6 +380,8 @@ struct fv_problem {
     int vready_counts[3] = {0, 0, 0}; // ... and how many pieces of each kind (vector sums, rhs.rhs, z.q)
     int32_t fused_bytes = 0; // bytes per row of the most recent fused launch's storage form (0: none ran)
     int64_t fused_launches = 0, fused_bytes_launch = 0;
+    std::vector<fv_trajectory *> trajectories;   // alive trajectories / observation series of this problem: detached (HBM released,
+    std::vector<fv_observation *> observations; // problem pointer cleared) by fv_problem_destroy if it comes first
     fv_trajectory *recording = nullptr; // fv_trajectory_record: fixed / adaptive runs push the state of every outer step here
     double record_t = 0.0;              // ... the time of the last recorded state of a fixed-dt run
     DevBuf<double> small_part;     // the single-launch solver of small systems (fv_small.hip): per-block partial sums,
@@ -400,6 +402,7 @@ struct fv_problem {
     DevBuf<uint8_t> vcode; // pcg_carry_flush_kernel's code byte: storage code | bit 7 (b is not zero), for (vcode_sepoch, vcode_aepoch) = (storage, assembly)
     int64_t vcode_sepoch = -1, vcode_aepoch = -1;
     int64_t ploop_solves = 0;  // solves whose loop ran that way
+    int32_t ploop_bytes[3] = {0, 0, 0}; // fv_step_form: set-up, first pass, flush of the most recent such solve (bytes per row)
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
     DevBuf<double> hist;
@@ -550,6 +553,7 @@ struct FvStepHooks {
 int fv_step_raw(fv_problem *p, double *usrc, double *udst, double dt, const double *rhs_dev, int mode, double rtol, int64_t maxiter, fv_solve_info *info);
 int fv_stepper_run(fv_problem *p, int32_t slot, double t0, double tfinal, double dt0, bool fixed, double atol, double rtol, int64_t maxiter, int64_t max_outer,
                    double *ts_out, int64_t *n_outer, int64_t *n_solves, fv_solve_info *last_info, const FvStepHooks &h);
+void fv_detach_dependents(fv_problem *p); // fv_trajectory.hip
 int fv_trajectory_push_device(fv_trajectory *tr, const double *state_dev, double t, const double *scale_dev); // knot = scale .* state (scale may be null)
 int fv_norm2_diff_weighted_device(fv_problem *p, const double *a, const double *b, const double *w, double *out_host);
 int fv_slot_new(fv_problem *p, int32_t *slot);

@@ -1081,6 +1081,17 @@ extern "C" int fv_loop_form(fv_problem *p, int32_t *bytes_per_row)
     return FV_OK;
 }
 
+extern "C" int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves)
+{
+    if (!p || !bytes)
+        return FV_ERR_ARG;
+    for (int k = 0; k < 3; k++)
+        bytes[k] = p->ploop_bytes[k];
+    if (solves)
+        *solves = p->ploop_solves;
+    return FV_OK;
+}
+
 extern "C" int fv_update_form(fv_problem *p, int32_t *bytes_per_row)
 {
     if (!p || !bytes_per_row)
@@ -1542,6 +1553,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_TRY(minv_positive(p, &mpos));
         ploop = mpos && fv_ploop_applicable(p, sigma, folded != nullptr);
     }
+    const bool took_pending = take_pending;
     if (take_pending && !ploop) {
         fv_set_error(ctx, "internal: a pending update was taken by a set-up whose loop cannot use it");
         return FV_ERR_STATE;
@@ -1634,6 +1646,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             }
         }
         p->ploop_solves++;
+        p->ploop_bytes[0] = took_pending ? 65 : ((sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) ? 64 : 0);
+        p->ploop_bytes[1] = p->loop_bytes == 67 ? 19 : 41;
+        p->ploop_bytes[2] = (itf >= 1 && !deferred) ? 48 : 0;
         p->loop_minv_coded = false;
         maxiter = 0; // (skip the loop below)
     }

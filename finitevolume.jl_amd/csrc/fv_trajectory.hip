@@ -238,8 +238,33 @@ extern "C" int fv_trajectory_create(fv_problem *p, fv_trajectory **out)
     }
     fv_trajectory *tr = new fv_trajectory;
     tr->p = p;
+    p->trajectories.push_back(tr); // (fv_problem_destroy detaches what is still alive: fv_detach_dependents)
     *out = tr;
     return FV_OK;
+}
+
+// A trajectory / an observation series whose problem is gone (fv_problem_destroy came first — Julia does not order finalizers):
+// its HBM has been released and its problem pointer cleared there; every entry point but destroy refuses it (check_traj).
+void fv_detach_dependents(fv_problem *p)
+{
+    for (fv_trajectory *tr : p->trajectories) {
+        for (void *b : tr->blocks)
+            (void)hipFree(b);
+        tr->blocks.clear();
+        tr->knots.clear();
+        tr->ts.clear();
+        tr->used_in_block = tr->block_knots = 0;
+        tr->p = nullptr;
+    }
+    p->trajectories.clear();
+    for (fv_observation *o : p->observations) {
+        o->idx.release();
+        o->uobs.release();
+        o->sigma.release();
+        o->p = nullptr;
+    }
+    p->observations.clear();
+    p->recording = nullptr;
 }
 
 extern "C" int fv_trajectory_clear(fv_trajectory *tr)
@@ -260,9 +285,13 @@ extern "C" int fv_trajectory_destroy(fv_trajectory *tr)
 {
     if (!tr)
         return FV_OK;
-    if (tr->p && tr->p->recording == tr)
-        tr->p->recording = nullptr;
-    fv_trajectory_clear(tr);
+    if (tr->p) {
+        if (tr->p->recording == tr)
+            tr->p->recording = nullptr;
+        std::vector<fv_trajectory *> &v = tr->p->trajectories;
+        v.erase(std::remove(v.begin(), v.end(), tr), v.end());
+        fv_trajectory_clear(tr);
+    }
     delete tr;
     return FV_OK;
 }
@@ -404,6 +433,7 @@ extern "C" int fv_observation_create(fv_problem *p, int64_t nobs, const int64_t 
     }
     fv_observation *o = new fv_observation;
     o->p = p;
+    p->observations.push_back(o);
     o->nobs = nobs;
     o->nt = nt;
     o->tobs.assign(tobs, tobs + nt);
@@ -431,8 +461,11 @@ extern "C" int fv_observation_create(fv_problem *p, int64_t nobs, const int64_t 
 extern "C" int fv_observation_destroy(fv_observation *o)
 {
     if (o) {
-        if (o->p)
+        if (o->p) {
             (void)hipSetDevice(o->p->ctx->device);
+            std::vector<fv_observation *> &v = o->p->observations;
+            v.erase(std::remove(v.begin(), v.end(), o), v.end());
+        }
         delete o;
     }
     return FV_OK;
@@ -443,7 +476,7 @@ extern "C" int fv_observation_destroy(fv_observation *o)
 // 6-point Gauss-Legendre rule per piece is exact.
 extern "C" int fv_observation_integral(fv_trajectory *u, fv_observation *o, double t0, double t1, double *G)
 {
-    if (!u || !o || !G || u->p != o->p || !(t1 >= t0))
+    if (!u || !o || !G || !u->p || u->p != o->p || !(t1 >= t0))
         return FV_ERR_ARG;
     fv_problem *p = u->p;
     fv_ctx *ctx = p->ctx;

@@ -19,7 +19,7 @@ import LinearAlgebra
 import SparseArrays
 
 const libfvhip = get(ENV, "FVHIP_LIB", joinpath(@__DIR__, "..", "libfvhip.so"))
-const FVHIP_ABI_VERSION = 3   # of include/fvhip.h this shim was written against
+const FVHIP_ABI_VERSION = 4   # of include/fvhip.h this shim was written against
 function __init__()
 	have = ccall((:fv_abi_version, libfvhip), Cint, ())
 	have == FVHIP_ABI_VERSION || error("libfvhip.so speaks ABI version $have, FiniteVolumeHIP.jl expects $FVHIP_ABI_VERSION: rebuild it (make -C finitevolume.jl_amd/csrc)")

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FVHIP_ABI_VERSION 3 /* 3: fv_fused_traversal, fv_trajectory_*, fv_observation_*, fv_adjoint_run, fv_param_gradient_integral_traj; 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
+#define FVHIP_ABI_VERSION 4 /* 4: fv_step_form (the one-launch PCG iteration); 3: fv_fused_traversal, fv_trajectory_*, fv_observation_*, fv_adjoint_run, fv_param_gradient_integral_traj; 2: fv_ctx_set_option, fv_fused_form; fv_tune left the public header; fv_transient_run_adaptive fails when max_outer runs out */
 
 enum {
     FV_OK = 0,
@@ -303,8 +303,18 @@ int fv_fused_form(fv_problem *p, int64_t *launches, int32_t *bytes_per_row, int6
 /* The PCG loop of the most recent solve with several iterations (cg! of src/transient.jl:52 / src/FiniteVolume.jl:161): 0 = K1 + K2 +
  * K3 per iteration (the SpMV form's bytes + 88 per row); 113 = the direction update and the product as one pass of the fused kernel
  * (z = M^-1 r and p in, p' and q out, three upper diagonals, a code byte: 57) + the vector update in the z-form (x, z, p, q, M^-1 in,
- * x, z out: 56); 91 with the matrix as codes, 7 fewer again where M^-1 takes few distinct values and comes as a code byte. */
+ * x, z out: 56); 91 with the matrix as codes, 7 fewer again where M^-1 takes few distinct values and comes as a code byte.
+ * Round 5: 89 (67 with the matrix as codes) = ONE launch per iteration on whole regular boxes — z, w, p, x in and z', p', w', x out (64), the
+ * three upper diagonals (24 or 2), a code byte; the launch takes the verdict on the iterate and alpha, beta from sums the previous launch
+ * left (the next iterate's r.z and r.r as polynomials in the step length), so that no vector-update launch and no M^-1 stream remain. */
 int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
+/* What the most recent solve with the one-launch loop (fv_loop_form 89 / 67) moved per row OUTSIDE its loop iterations: bytes[0] the
+ * set-up (65 = the previous step's pending update and the carried residual in one pass, pcg_carry_flush_kernel; 64 = the carried
+ * set-up K0' alone; 0 = another set-up), bytes[1] the first pass (direction = z: z, the matrix, a code byte in, w out: 41, or 19 with
+ * the matrix as codes), bytes[2] the flush of the last update (48: z, w, p, x in, z, x out; 0 when the next step's set-up applies it);
+ * *solves: solves on this problem whose loop ran that way.  A step of m iterations moves bytes[0] + bytes[1] + (m - 1) x fv_loop_form +
+ * bytes[2] per row.  A measurement aid: the step is backwardeuleronestep! / cg! of src/transient.jl:50-76 either way. */
+int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves);
 /* How the most recent fused launch (fv_fused_form / fv_loop_form) walked the planes of the operator: 0 = 2-D tiles of 16 lines x 128
  * columns (or it has not run), 1 = contiguous chunks of a plane's rows (no column halos; where the matrix comes as codes and the
  * rows whose diagonal does not follow from their arms share at most 15 values).  A measurement aid like the two above: the step it

@@ -26,9 +26,9 @@ def test_every_declared_symbol_is_exported_and_bound(fv):
         assert hasattr(lib, name), "libfvhip.so does not export %s" % name
         assert name in _lib.SIGNATURES, "python binding lacks %s" % name
     assert set(_lib.SIGNATURES) == set(declared)
-    assert fv.load().fv_abi_version() == _lib.ABI_VERSION == 3
+    assert fv.load().fv_abi_version() == _lib.ABI_VERSION == 4
     hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
-    assert "#define FVHIP_ABI_VERSION 3" in hdr
+    assert "#define FVHIP_ABI_VERSION 4" in hdr
     # the experimenter's panel is exported for the tools, but it is not part of the public header
     assert "fv_tune" not in declared and hasattr(lib, "fv_tune") and set(_lib.PRIVATE_SIGNATURES) == {"fv_tune"}
 
@@ -154,4 +154,4 @@ def test_julia_package_wrapper_has_the_reference_name_and_uuid():
     assert re.search(r"^module FiniteVolume\s*$", src, flags=re.M) and "FiniteVolumeHIP.jl" in src and "@eval const $name = FiniteVolumeHIP.$name" in src
     assert os.path.exists(os.path.normpath(os.path.join(pkg, "src", "..", "..", "FiniteVolumeHIP.jl")))
     shim = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
-    assert "FVHIP_ABI_VERSION = 3" in shim and ":fv_abi_version" in shim
+    assert "FVHIP_ABI_VERSION = 4" in shim and ":fv_abi_version" in shim

@@ -55,6 +55,35 @@ def test_trajectory_basics(fv):
     p.close()
 
 
+def test_a_problem_destroyed_before_its_trajectories_detaches_them(fv):
+    """Julia does not order finalizers, so fv_problem_destroy may come before fv_trajectory_destroy / fv_observation_destroy
+    of its dependents.  The library keeps a list of them: destroying the problem releases their HBM and clears their problem
+    pointer; every later call on them is refused (FV_ERR_ARG), and destroying them frees the handles without touching freed memory."""
+    import ctypes as C
+
+    lib = fv.load()
+    c = _case(fv)
+    p = fv.Problem.create(c["nb"], c["aol"], c["N"], c["dn"]).assemble(np.exp(c["K"]), c["src"], c["dh"])
+    st = p.transient_begin(c["Ss"], c["vol"], c["u0"])
+    tr, tr2 = p.new_trajectory(), p.new_trajectory()
+    tr.push(st, 0.0)
+    tr.push_free(np.zeros(p.n), 1.0)
+    from fvamd.core import Observation
+
+    ob = Observation(p, np.array([1, 2], dtype=np.int64), [0.0, 1.0], np.zeros((2, 2)))
+    assert ob.integral(tr, 0.0, 1.0) >= 0.0
+    tr2.close()  # (the usual order for one of them)
+    p.close()
+    n = C.c_int64()
+    assert lib.fv_trajectory_size(tr.handle, C.byref(n)) != 0  # refused: the problem is gone
+    G = C.c_double()
+    assert lib.fv_observation_integral(tr.handle, ob.handle, 0.0, 1.0, C.byref(G)) != 0
+    assert lib.fv_trajectory_clear(tr.handle) != 0
+    tr.close()
+    ob.close()
+    assert tr.handle is None and ob.handle is None
+
+
 @pytest.mark.parametrize("stepper", ["adaptive", "fixed"])
 def test_states_recorded_in_hbm_are_the_host_loop_s(fv, stepper):
     """backwardeulerintegrate(..., keep="device") against the loop that downloads every state: the same `ts`, the same states."""

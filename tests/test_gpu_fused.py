@@ -233,7 +233,7 @@ def test_chunk_traversal_against_the_tiles_and_the_oracle(fv, oracle, ns, latera
     # the many-iteration loop alone: a steady-ish long step from the start state
     la = _run(fv, case, True, [(300.0, 4, 1e-12)])
     lb = _run(fv, case, True, [(300.0, 4, 1e-12)], tune=((60, 0),))
-    assert la[4] == 1 and lb[4] == 0 and la[5] in (76, 83) and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
+    assert la[4] == 1 and lb[4] == 0 and la[5] == 67 and lb[5] in (76, 83) and np.abs(la[1].astype(int) - lb[1].astype(int)).max() <= 1 and relerr(la[0], lb[0]) < 1e-11
     # the oracle: the same schedule, its CG run to 1e-14 (every step its own solve)
     t, u = 0.0, u0
     for dt, steps, _ in sched:
@@ -280,20 +280,21 @@ def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_or
     assert relerr(chunks[0], u) < 1e-8
 
 
-@pytest.mark.parametrize("lateral", [False, True])
-def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(fv, oracle, lateral):
+@pytest.mark.parametrize("lateral,uniform_k", [(False, False), (True, False), (True, True)])
+def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(fv, oracle, lateral, uniform_k):
     """Round 5 (fv_tune key 63): on whole regular boxes a PCG iteration of the many-iteration loop is ONE launch — the launch takes the
     verdict on the iterate and alpha, beta from sums the previous launch left (the next iterate's r.z and r.r as polynomials in the
     step length), applies z' = z + alpha w and x += alpha p and forms the next direction and product; the last update is flushed when the
     loop has stopped.  Same Jacobi-PCG iteration and stopping rule (/root/reference/src/transient.jl:50-58): iteration counts within one of
     the pass + update pair's, heads to rounding, the oracle's heads within 1e-8; a steady solve with its residual history, a solve that
     runs out of iterations and a warm restart; steps that are converged at their set-up."""
-    case = _problem(fv, BOX3 if lateral else BOX, lateral=lateral, seed=41)
+    case = _problem(fv, BOX3 if lateral else BOX, lateral=lateral, seed=41, uniform_k=uniform_k)
+    want_on, want_off = (67, (76, 83)) if uniform_k else (89, (105,))  # (the matrix as 16-bit codes: 67 B per row and iteration)
     mins, maxs, coords, nb, aol, vol, K, dn, dh, src, u0 = case
     sched = [(40.0, 6, 1e-12), (DT, 5, 1e-11), (300.0, 4, 1e-12), (40.0, 3, 1e-3), (3.0, 5, 1e-10)]
     on = _run(fv, case, True, sched)
     off = _run(fv, case, True, sched, tune=((63, 0),))
-    assert on[5] == 89 and off[5] == 105, (on[5], off[5])
+    assert on[5] == want_on and off[5] in want_off, (on[5], off[5])
     assert (on[1][:6] > 3).all() and np.abs(on[1].astype(int) - off[1].astype(int)).max() <= 1, (on[1], off[1])
     assert relerr(on[0], off[0]) < 1e-11, relerr(on[0], off[0])
     t, u = 0.0, u0
@@ -318,7 +319,7 @@ def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(f
             p.close()
     finally:
         lib.fv_tune(63, 1)
-    assert out[1][3] == 89 and out[0][3] == 105 and len(out[1][0]) == 150
+    assert out[1][3] == want_on and out[0][3] in want_off and len(out[1][0]) == 150
     assert np.allclose(out[1][0], out[0][0], rtol=1e-6, atol=0), np.abs(out[1][0] / out[0][0] - 1).max()
     assert abs(out[1][2] - out[0][2]) <= max(3, out[0][2] // 50)
     assert np.abs(out[1][1] - out[0][1]).max() <= 1e-6 * np.abs(out[0][1]).max()  # both are rtol 1e-10 solves
