@@ -109,7 +109,35 @@ def cpu_baseline(dt, rtol):
         "kind": "port",
         "sample": "oracle (C restatement of the reference path, unpreconditioned CG rtol %.0e) on %dx%dx%d cells x %d steps, same cell size/K/Ss/dt/BCs; %.1f s; %.1f CG iters/step" % (rtol, ns[0], ns[1], ns[2], steps, sec, float(np.mean(iters))),
     }
-    del A, b, us
+    del us
+    try:  # the same steps on the host's cores (OpenMP; oracle/fv_oracle_mt.c): SURVEY 8(d) asks for both figures, core count printed
+        import ctypes as C
+
+        mt = C.CDLL(os.path.join(ROOT, "oracle", "_build", "libfvoracle_mt.so"))
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        nthreads = max(1, min(avail, int(os.environ.get("FV_BENCH_CPU_THREADS", "16"))))  # (a one-GPU box of this pool has a 16-core share)
+        _, n1, n2, aol, vol = o.regulargrid(*spacing_box(ns), ns, want_coords=False)
+        dn, src = box_setup(ns)
+        A0 = o.assembleA(n1, n2, aol, np.full(len(aol), 1e-5), src, dn, np.full(len(dn), 1e3))
+        _, n2f = o.getfreenodes(len(vol), dn)
+        dvol = np.ascontiguousarray((0.1 * vol)[np.asarray(o.freenodei2nodei(n2f)) - 1])
+        del n1, n2, aol
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        u = np.full(A0.n, 1e3)
+        itot = C.c_int64()
+        t0 = time.perf_counter()
+        rc = mt.fvo_mt_fixed_steps(C.c_int64(A0.n), vp(A0.colptr), vp(A0.rowval), vp(A0.nzval), vp(dvol), vp(b), vp(u), C.c_double(dt), C.c_int64(steps),
+                                   C.c_double(rtol), C.c_int64(1000), C.byref(itot), C.c_int(nthreads))
+        secm = time.perf_counter() - t0
+        if rc != 0:
+            raise RuntimeError("fvo_mt_fixed_steps returned %d" % rc)
+        out["all_cores"] = {"value": N * steps / secm, "unit": "DoF-updates/s", "cores": nthreads, "cores_available": os.cpu_count(), "kind": "port-threaded",
+                            "sample": "the same %dx%dx%d cells x %d steps, the same CG with OpenMP over the rows (gather product on the symmetric matrix, dot products summed "
+                                      "per thread: oracle/fv_oracle_mt.c); %.1f s; %.1f CG iters/step; the reference itself runs on one thread" % (ns[0], ns[1], ns[2], steps, secm, itot.value / steps)}
+        del A0, u, dvol
+    except Exception as e:
+        out["all_cores"] = "failed: %r" % (e,)
+    del A, b
     try:  # the backslash path: one sparse LU per step (the reference factorises the shifted matrix anew in every step)
         nsd, stepsd = [32, 32, 32], 3
         A, b, Nd = problem(nsd)
@@ -149,8 +177,16 @@ def other_baseline_configs(fv, ctx):
     levels = p.amg_info()
     head, res, ch = p.solve_steady(None, 1e-8, 400, want_head=False, want_resnorm=False)
     ctx.synchronize()
-    row("box_model 256^3 steady, sigma=3 field, AMG-PCG rtol 1e-8 (hierarchy set-up included)", p.N, 1, time.perf_counter() - t0,
-        pcg_iters=int(ch.iters), converged=bool(ch.isconverged), amg_levels=int(len(levels[0])))
+    sec_amg = time.perf_counter() - t0
+    ms0 = p.bench_spmv(0.0, 20)
+    _, form_name0, form_bytes0 = p.spmv_form()
+    row("box_model 256^3 steady, sigma=3 field, AMG-PCG rtol 1e-8 (hierarchy set-up included)", p.N, 1, sec_amg,
+        pcg_iters=int(ch.iters), converged=bool(ch.isconverged), amg_levels=int(len(levels[0])),
+        roofline={"bound": "hbm", "kernel": "the level-0 product of the cycle and of the PCG (%s)" % form_name0, "achieved": form_bytes0 / (ms0 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                  "unit": "GB/s", "frac": form_bytes0 / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms0, "launches": 20,
+                  "bytes_per_row": form_bytes0 / max(p.n, 1),
+                  "note": "a V-cycle iteration is ~100 launches over six levels (DESIGN 4a: 1.0 of its 2.55 ms are level-0 kernels at this rate, the rest coarse-level products "
+                          "within a fifth of their byte bounds); no single byte model covers the solve, so the figure is the dominant kernel's"})
     p.close()
     # configs[2]: watertable-like 10 M cells, 100 implicit steps
     ns = [216, 216, 216]
@@ -161,10 +197,30 @@ def other_baseline_configs(fv, ctx):
     p.run_fixed(st, 60.0, 3, 1e-10)
     ctx.synchronize()
     t0 = time.perf_counter()
+    f0 = p.fused_form()[0]
     iters, info, _ = p.run_fixed(st, 60.0, 100, 1e-10)
     ctx.synchronize()
-    row("watertable-like 216^3 transient, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, time.perf_counter() - t0,
-        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged))
+    sec = time.perf_counter() - t0
+    launches, brow, bl = p.fused_form()
+    row("watertable-like 216^3 transient, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, sec,
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl))
+    p.close()
+    # ... "plus the same field at sigma = 1" (SURVEY 8d): node log K = log(1e-5) + g, the Gaussian field of the 256^3 case at this size
+    p = fv.Problem.regulargrid([0.0, 0.0, 0.0], [1000.0, 1000.0, 100.0], ns, dn, ctx)
+    Kf, _ = gaussian_face_logK(fv, p, ns, 1.0, seed=0)
+    p.assemble(Kf, src, np.full(len(dn), 1e3), None, True)
+    del Kf
+    st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    p.run_fixed(st, 60.0, 3, 1e-10)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    f0 = p.fused_form()[0]
+    iters, info, _ = p.run_fixed(st, 60.0, 100, 1e-10)
+    ctx.synchronize()
+    sec = time.perf_counter() - t0
+    launches, brow, bl = p.fused_form()
+    row("watertable-like 216^3 transient, sigma=1 Gaussian log-K field, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, sec,
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl))
     p.close()
     # configs[3]: fractures-like 5 M cells, irregular CSR (cells numbered at random inside each fracture), 100 implicit steps.
     # The mesh is handed over as it is numbered; fv_problem_create re-numbers the free cells for locality by itself
@@ -185,15 +241,18 @@ def other_baseline_configs(fv, ctx):
         p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
         ctx.synchronize()
         t0 = time.perf_counter()
+        f0 = p.fused_form()[0]
         iters, sinfo, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
         ctx.synchronize()
         sec = time.perf_counter() - t0
+        launches, brow, bl = p.fused_form()
+        regime = step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl)
         ms = p.bench_spmv(1.0, 20)
         form_id, form_name, form_bytes = p.spmv_form()
         row("fractures-like 5M cells (irregular CSR, %s), transient, 100 steps, dt=1s, Jacobi-PCG rtol 1e-10" % label, p.N, 100, sec,
             pcg_iters_per_step=float(iters.mean()), converged=bool(sinfo.converged), problem_create_s=t_create,
             renumbered=info["reordered"], renumbering_s=info["seconds"], mean_face_distance=[info["mean_before"], info["mean_after"]],
-            spmv={"form": form_name, "ms": ms, "GB/s": form_bytes / (ms * 1e-3) / 1e9, "frac_of_peak": form_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+            spmv={"form": form_name, "ms": ms, "GB/s": form_bytes / (ms * 1e-3) / 1e9, "frac_of_peak": form_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}, roofline=regime)
         p.close()
     return rows
 
@@ -402,6 +461,50 @@ def main():
     print(json.dumps(out))
 
 
+def device_smooth_gaussian_field(fv, ns, seed=0, radius_cells=(10, 10, 10), passes=3):
+    """fv.workloads.smooth_gaussian_field (SURVEY 8d's stand-in for the reference's Matern field: separable box smoothing of N(0,1)
+    noise, unit variance) evaluated on the GPU through torch where there is one — the same noise (host generator, seed), the same
+    running-sum windows; the sums run in another order, so the field agrees with the host routine to rounding, not bit for bit.  29 s on
+    the host at 464^3, ~2 s here.  Falls back to the host routine."""
+    try:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no device")
+        n1, n2, n3 = ns
+        g = torch.from_numpy(np.random.default_rng(seed).standard_normal((n1, n2, n3))).to("cuda")
+        for axis, r in enumerate(radius_cells):
+            r = int(max(1, min(r, ns[axis] // 2)))
+            n = ns[axis]
+            for _ in range(passes):
+                c = torch.cumsum(g, dim=axis)
+                first, last = c.narrow(axis, 0, 1), c.narrow(axis, n - 1, 1)
+                cp = torch.cat([first.expand(*[r + 1 if d == axis else -1 for d in range(3)]), c, last.expand(*[r if d == axis else -1 for d in range(3)])], dim=axis)
+                del c
+                g = (cp.narrow(axis, 2 * r + 1, n) - cp.narrow(axis, 0, n)) / (2 * r + 1)
+                del cp
+        g -= g.mean()
+        g /= g.std(unbiased=False)
+        out = g.reshape(-1).cpu().numpy()
+        del g
+        torch.cuda.empty_cache()
+        return out, "device (torch)"
+    except Exception:
+        return fv.workloads.smooth_gaussian_field(ns, seed=seed, radius_cells=radius_cells, passes=passes), "host"
+
+
+def gaussian_face_logK(fv, p, ns, sigma, seed=0):
+    """Face log-conductivities of SURVEY 8d's heterogeneous inputs: node log K = log(1e-5) + sigma g, g the unit-variance Gaussian field;
+    face value = arithmetic mean of the two node values (grid.jl:27, logtransform = true)."""
+    g, where = device_smooth_gaussian_field(fv, ns, seed)
+    logk = np.log(1e-5) + sigma * g
+    del g
+    n1, n2 = np.empty(p.F, np.int64), np.empty(p.F, np.int64)
+    p.check(fv.load().fv_problem_get_grid(p.handle, n1.ctypes.data, n2.ctypes.data, None, None))
+    Kf = fv.nodehycos2neighborhycos((n1, n2), logk, True)
+    return Kf, where
+
+
 def hetero_face_K(ns, F, N):
     """The bench's heterogeneous conductivity, one value per face: K = 1e-5 exp(g), g a smooth field of unit variance (sums of
     sines of the cell indices), evaluated from the cell the face list reaches the face in (regulargrid emits up to three faces
@@ -437,7 +540,15 @@ def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes
     else:
         form_id, form_name, form_bytes = p.spmv_form()
         loop = p.loop_form()
-        if loop:
+        if loop in (89, 67):  # one launch per PCG iteration (fv_step_form says what the step moved outside its loop iterations)
+            (b_setup, b_first, b_flush), _ = p.step_form()
+            bytes_step = float(np.mean(np.where(its >= 1, b_setup + b_first + np.maximum(its - 1, 0) * loop + b_flush, b_setup))) * n
+            model = ("per step: set-up %d n (%s) + first pass %d n (direction = z: z, the matrix, a code byte in, w out) + per further iteration ONE launch of %d n "
+                     "(z, w, p, x in; z', p', w', x out; the three upper diagonals%s; a code byte — verdict, alpha, beta from the previous launch's sums) + flush %d n; "
+                     "weighted with the iteration count of every step" %
+                     (b_setup, "the previous step's pending update + the carried residual in one pass" if b_setup == 65 else "carried residual K0'" if b_setup == 64 else "a fresh residual",
+                      b_first, loop, " as 16-bit codes" if loop == 67 else "", b_flush))
+        elif loop:
             first_upd = 49 if loop in (76, 98) else 56  # (the loop's first vector update is the classic one: x, z, p, q, M^-1 in, x, z out)
             per_it = loop * n
             first = 64 * n + form_bytes + first_upd * n
@@ -463,8 +574,10 @@ def hetero_block(fv, ctx, args):
     mins, maxs = spacing_box(ns)
     dn, src = box_setup(ns)
     p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
-    K = hetero_face_K(ns, p.F, p.N)
-    p.assemble(K, src, np.full(len(dn), 1e3))
+    t0 = time.perf_counter()
+    K, where = gaussian_face_logK(fv, p, ns, 1.0, seed=0)
+    t_field = time.perf_counter() - t0
+    p.assemble(K, src, np.full(len(dn), 1e3), None, True)
     del K
     st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
     p.run_fixed(st, args.dt, max(args.warmup, 3), args.rtol, args.maxiter)
@@ -478,7 +591,8 @@ def hetero_block(fv, ctx, args):
         secs.append(time.perf_counter() - t0)
     sec = float(np.median(secs))
     launches, brow, bl = p.fused_form()
-    out = {"workload": "same %d^3 box, K = 1e-5 exp(g) per face with g a smooth field of unit variance (sums of sines of the cell indices), %d steps x 3 regions" % (args.ns, args.steps),
+    out = {"workload": "same %d^3 box, node log K = log(1e-5) + 1.0 g with g SURVEY 8d's unit-variance Gaussian field (separable box smoothing of N(0,1) noise, radius 10 cells, 3 passes, seed 0; "
+                       "generated on the %s in %.1f s), face K = exp(arithmetic mean of the node values) (grid.jl:27), %d steps x 3 regions" % (args.ns, where, t_field, args.steps),
            "dof_updates_per_s": p.N * args.steps / sec, "ms_per_step": sec / args.steps * 1e3, "ms_per_step_each": [s / args.steps * 1e3 for s in secs],
            "pcg_iters_per_step": float(iters.mean()), "converged": bool(info.converged), "last_relres": info.relres,
            "fused_launches": launches - f0}
@@ -540,7 +654,10 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
         what = ("x_out = x + alpha z, z' = z + alpha v, the convergence and set-up sums of step k, then q' = (A + D/dt) z' with z'.q' of step k + 1, "
                 "stored as v' = -M^-1 (q' - D z'/dt); ")
         roof = {"bound": "hbm", "achieved": fbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                "kernel": ("fused_chunk_kernel<512, 5, 0>: " + what + "contiguous chunks of ~5100 rows of a plane (no column halos) marching through the planes, z' chunk "
+                "kernel": ("fused_chunkd_kernel<512, 4, 0, 3, 2, 2>: " + what + "contiguous chunks of ~3400 rows of a plane (no column halos) marching through the planes, the matrix streamed as doubles: "
+                           "z' chunk and the +line diagonal double-buffered in LDS, the +1 diagonal by a wave shift, the +plane diagonal carried in registers, loads issued two to three row pairs ahead; "
+                           "diagonal and M^-1 re-derived from the arms (rows next to a Dirichlet cell: the stored diagonal)") if chunks and fbytes_row >= 60 else
+                          ("fused_chunk_kernel<512, 5, 0>: " + what + "contiguous chunks of ~5100 rows of a plane (no column halos) marching through the planes, z' chunk "
                            "double-buffered and the 16-bit matrix words of two planes in LDS, +-plane arms in registers, diagonal and M^-1 re-derived from the arms "
                            "(rows next to a Dirichlet cell: out of a table by a per-row code); the first / last plane's products by the same launch where their rows' diagonals fit the table (the bench box), else by spmv_dia_kernel") if chunks else
                           ("fused_step_kernel<16, 0, %s>: " % ("true" if fbytes_row < 60 else "false") + what +
@@ -619,22 +736,24 @@ def multi_iteration_block(p, args):
     del st
     form_id, form_name, form_bytes = p.spmv_form()
     nit = int(np.sum(iters))
-    loop = p.loop_form()  # 105: direction update, lagging x-update and product in one pass of the fused kernel (73) + the slim vector update z' = z + alpha w (32);
-    upd = 25 if loop in (76, 98) else 32  # 83 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
+    loop = p.loop_form()  # 89 / 67: ONE launch per iteration (round 5); 105: fused pass (73) + slim vector update z' = z + alpha w (32);
+    upd = 0 if loop in (89, 67) else (25 if loop in (76, 98) else 32)  # 83 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
     per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
     regime = step_regime_roofline(p, iters, sec / steps, 0, 0, 0)  # every launch of a step: carried set-up, first product and update, the loop
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)), "roofline": regime,
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,
-           "bytes_model": ("fused pass x += alpha p, p' = z + beta p, w = -M^-1 (A + D/dt) p' (%d n: z, p, x in, p', w, x out, the 3 upper diagonals%s, storage codes) + vector update z' = z + alpha w (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 60 else "", upd, ": M^-1 as a code byte" if upd == 25 else "") if loop
+           "bytes_model": (("one launch per iteration: z' = z + alpha w, x += alpha p, p' = z' + beta p, w' = -M^-1 (A + D/dt) p' with the verdict, alpha and beta taken in the launch's "
+                            "prologue from the previous launch's sums (%d n: z, w, p, x in, z', p', w', x out, the 3 upper diagonals%s, a code byte); no vector-update launch" % (loop, " as 16-bit codes" if loop == 67 else "")) if upd == 0 else
+                           "fused pass x += alpha p, p' = z + beta p, w = -M^-1 (A + D/dt) p' (%d n: z, p, x in, p', w, x out, the 3 upper diagonals%s, storage codes) + vector update z' = z + alpha w (%d n%s)" % (loop - upd, " as 16-bit codes" if loop - upd < 60 else "", upd, ": M^-1 as a code byte" if upd == 25 else "") if loop
                            else "K1 storage form (%s) + 88 n for K2 + K3" % form_name),
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "frac_note": "frac_of_peak charges one loop iteration's bytes against wall time / iterations, i.e. it leaves the step's set-up, first product and first update (~170 B per row and step) unaccounted; `roofline` counts every launch of a step",
+           "frac_note": "frac_of_peak charges one loop iteration's bytes against wall time / iterations, i.e. it leaves the step's set-up and first pass unaccounted; `roofline` counts every launch of a step",
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
     for k, bytes_ in ((("spmv_dot", (loop - upd) * p.n), ("update", upd * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]
-        if kc:
+        if kc and bytes_:
             out["kernels"]["fused_pass" if (loop and k == "spmv_dot") else k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
     return out
 

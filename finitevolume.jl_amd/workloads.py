@@ -12,14 +12,22 @@ def smooth_gaussian_field(ns, seed=0, radius_cells=(10, 10, 10), passes=3):
     g = rng.standard_normal((n1, n2, n3)).astype(np.float64)
     for axis, r in enumerate(radius_cells):
         r = int(max(1, min(r, ns[axis] // 2)))
+        n = ns[axis]
         for _ in range(passes):
+            # running sums, padded with their edge values: window sum of cells [i - r, i + r] = cp[i + 2 r + 1] - cp[i] (windows
+            # clipped at the box's faces count the face cell repeatedly, as np.pad(mode="edge") of the sums implies)
             c = np.cumsum(g, axis=axis)
             pad = [(0, 0)] * 3
             pad[axis] = (r + 1, r)
             cp = np.pad(c, pad, mode="edge")
-            hi = np.take(cp, np.arange(2 * r + 1, 2 * r + 1 + ns[axis]), axis=axis)
-            lo = np.take(cp, np.arange(0, ns[axis]), axis=axis)
-            g = (hi - lo) / (2 * r + 1)
+            del c
+            hi = [slice(None)] * 3
+            lo = [slice(None)] * 3
+            hi[axis] = slice(2 * r + 1, 2 * r + 1 + n)
+            lo[axis] = slice(0, n)
+            g = cp[tuple(hi)] - cp[tuple(lo)]
+            del cp
+            g /= 2 * r + 1
     g -= g.mean()
     g /= g.std()
     return g.reshape(-1)  # C order of (n1,n2,n3) == node order i3 + n3*(i2 + n2*i1)

@@ -155,3 +155,177 @@ def test_julia_package_wrapper_has_the_reference_name_and_uuid():
     assert os.path.exists(os.path.normpath(os.path.join(pkg, "src", "..", "..", "FiniteVolumeHIP.jl")))
     shim = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
     assert "FVHIP_ABI_VERSION = 4" in shim and ":fv_abi_version" in shim
+
+
+# ------------------------------------------------------------------ round 5: static checks beyond arity
+def _split_top(s):
+    """split at commas that are not inside (), [] or {}"""
+    out, cur, depth = [], "", 0
+    for c in s:
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+        if c == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += c
+    if cur.strip():
+        out.append(cur)
+    return [t.strip() for t in out if t.strip()]
+
+
+def _c_class(decl):
+    """A C parameter / return type of include/fvhip.h -> the class a Julia ccall type must belong to."""
+    d = re.sub(r"\b(const|struct)\b", " ", decl)
+    d = re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*(\[[^\]]*\])?\s*$", lambda m: "*" if m.group(1) else "", d.strip()) if not re.fullmatch(r"\s*(void|int|double|int32_t|int64_t|char)\s*\**\s*", d) else d
+    d = d.replace(" ", "")
+    if "*" in d:
+        return "ptr"
+    return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "void": "void", "uint32_t": "i32"}.get(d, "?" + d)
+
+
+def _julia_class(t):
+    t = t.strip()
+    if re.match(r"^(Ptr|Ref)\{", t) or t in ("Cstring", "Ptr{Cvoid}"):
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Cuint": "i32", "UInt32": "i32", "Int64": "i64", "Clonglong": "i64", "Float64": "f64", "Cdouble": "f64", "Cvoid": "void"}.get(t, "?" + t)
+
+
+def test_julia_shim_ccall_types_match_the_header():
+    """Every ccall of the shim against the C declaration it binds: return type and every argument type belong to the class of the
+    header's C type (Int64 <-> int64_t, Cint / Int32 <-> int / int32_t, Float64 <-> double, Ptr / Ref / Cstring <-> pointers and
+    arrays).  The shim has never met a Julia parser; a width mismatch here would corrupt the call frame silently."""
+    hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    decls = {}
+    for ret, name, params in re.findall(r"^\s*((?:const\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**)\s*\b(fv_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S | re.M):
+        params = params.strip()
+        decls[name] = (_c_class(ret + " x") if "*" in ret else _c_class(ret), [] if params in ("", "void") else [_c_class(p) for p in _split_top(params)])
+    src = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
+    calls = re.findall(r"ccall\(\(:(\w+),\s*libfvhip\),\s*(\w+(?:\{[^}]*\})?),\s*\(([^)]*)\)", src)
+    assert len(calls) >= 40
+    bad = []
+    for name, ret, types in calls:
+        cret, cparams = decls[name]
+        jparams = [_julia_class(t) for t in _split_top(types)]
+        if _julia_class(ret) != cret:
+            bad.append((name, "return", ret, cret))
+        for k, (jt, ct) in enumerate(zip(jparams, cparams)):
+            if jt != ct:
+                bad.append((name, k, _split_top(types)[k], ct))
+    assert not bad, bad
+    assert all(not c.startswith("?") for _, (r, ps) in decls.items() for c in [r] + ps), [(n, d) for n, d in decls.items() if any(c.startswith("?") for c in [d[0]] + d[1])]
+
+
+def test_julia_solveinfo_mirrors_fv_solve_info_field_by_field():
+    hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
+    body = re.search(r"typedef struct fv_solve_info \{(.*?)\} fv_solve_info;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    cfields = [(m.group(2), {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64"}[m.group(1)]) for m in re.finditer(r"(int32_t|int64_t|double)\s+(\w+)\s*;", body)]
+    src = open(os.path.join(ROOT, "finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl")).read()
+    jbody = re.search(r"^struct SolveInfo[^\n]*\n(.*?)^end", src, flags=re.S | re.M).group(1)
+    jfields = [(m.group(1), m.group(2)) for m in re.finditer(r"^\s*(\w+)::(\w+)", jbody, flags=re.M)]
+    assert len(cfields) == 6 and jfields == cfields, (jfields, cfields)
+
+
+def _julia_lex(src):
+    """A small lexer for the subset of Julia the shim uses: strips comments (#, #= =#), strings ("...", \"\"\"...\"\"\", with $(...)
+    interpolation skipped by bracket depth), character literals; yields (kind, text, line) for identifiers / keywords and brackets.
+    Raises on an unterminated string or block comment."""
+    toks, i, n, line = [], 0, len(src), 1
+    while i < n:
+        c = src[i]
+        if c == "\n":
+            line += 1
+            toks.append(("nl", "\n", line))
+            i += 1
+        elif src.startswith("#=", i):
+            j = src.find("=#", i + 2)
+            assert j >= 0, "unterminated block comment at line %d" % line
+            line += src.count("\n", i, j)
+            i = j + 2
+        elif c == "#":
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith('"""', i) or c == '"':
+            q = '"""' if src.startswith('"""', i) else '"'
+            j = i + len(q)
+            while True:
+                assert j < n, "unterminated string starting at line %d" % line
+                if src[j] == "\\":
+                    j += 2
+                    continue
+                if src.startswith("$(", j):  # interpolation: skip to the matching parenthesis
+                    depth, j = 1, j + 2
+                    while depth:
+                        assert j < n, "unterminated interpolation at line %d" % line
+                        depth += src[j] == "("
+                        depth -= src[j] == ")"
+                        j += 1
+                    continue
+                if src.startswith(q, j):
+                    break
+                j += 1
+            line += src.count("\n", i, j)
+            toks.append(("str", src[i:j + len(q)], line))
+            i = j + len(q)
+        elif c == "'" and re.match(r"'(\\.|[^\\'])'", src[i:i + 4]):
+            i += len(re.match(r"'(\\.|[^\\'])'", src[i:i + 4]).group(0))
+        elif c in "()[]{}":
+            toks.append(("br", c, line))
+            i += 1
+        elif re.match(r"[A-Za-z_@]", c):
+            m = re.match(r"@?[A-Za-z_][A-Za-z0-9_!]*", src[i:])
+            if m is None:  # (a lone @, e.g. `@.`)
+                i += 1
+                continue
+            toks.append(("id", m.group(0), line))
+            i += m.end()
+        elif c == ":" and i + 1 < n and re.match(r"[A-Za-z_]", src[i + 1]) and (i == 0 or not re.match(r"[A-Za-z0-9_\)\]]", src[i - 1])):
+            m = re.match(r":[A-Za-z_][A-Za-z0-9_!]*", src[i:])  # a symbol (:end, :resnorm): not a keyword
+            i += m.end()
+        else:
+            i += 1
+    return toks
+
+
+def test_julia_shim_blocks_brackets_and_strings_balance():
+    """No Julia runtime has ever parsed the shim.  A lexer pass over it and over the package wrapper: every string and block comment
+    terminates, every bracket closes in order, and the block openers (module, function, struct, if, for, while, let, do, begin, try,
+    quote, macro; `end` inside [] is an index, `for` / `if` inside brackets are comprehension parts) are matched by exactly as many `end`s."""
+    for rel in (("finitevolume.jl_amd", "julia", "FiniteVolumeHIP.jl"), ("finitevolume.jl_amd", "julia", "FiniteVolume", "src", "FiniteVolume.jl")):
+        src = open(os.path.join(ROOT, *rel)).read()
+        toks = _julia_lex(src)
+        stack, blocks = [], []
+        openers = {"module", "baremodule", "function", "struct", "if", "for", "while", "let", "do", "begin", "try", "quote", "macro"}
+        prev = None
+        for kind, text, line in toks:
+            if kind == "br":
+                if text in "([{":
+                    stack.append((text, line))
+                else:
+                    assert stack, "%s: closing %s at line %d without an opener" % (rel[-1], text, line)
+                    o, ol = stack.pop()
+                    assert {"(": ")", "[": "]", "{": "}"}[o] == text, "%s: %s (line %d) closed by %s (line %d)" % (rel[-1], o, ol, text, line)
+            elif kind == "id":
+                inside = [b for b, _ in stack]
+                if text == "mutable" or (text == "struct" and prev == "mutable"):
+                    if text == "struct":
+                        blocks.append((text, line))
+                elif text in openers:
+                    if text in ("for", "if") and inside and inside[-1] in "([":  # a comprehension / generator part
+                        pass
+                    elif not (text == "if" and prev == "else"):  # `elseif` is one word in Julia; `else if` would open a block and is not used
+                        blocks.append((text, line))
+                elif text == "end":
+                    if inside and inside[-1] == "[":
+                        pass  # a[end]
+                    else:
+                        assert blocks, "%s: `end` at line %d closes nothing" % (rel[-1], line)
+                        blocks.pop()
+            if kind != "nl":
+                prev = text
+        assert not stack, "%s: unclosed %s" % (rel[-1], stack[-3:])
+        assert not blocks, "%s: blocks never closed: %s" % (rel[-1], blocks[-5:])

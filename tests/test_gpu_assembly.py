@@ -246,3 +246,28 @@ def test_empty_and_all_dirichlet(fv):
     assert A.n == 3 and A.colptr.tolist() == [1, 1, 1, 1]
     head, freenode, n2f = fv.freenodes2nodes(np.array([5.0]), np.zeros(3), [1, 3], [7.0, 9.0])
     assert head.tolist() == [7.0, 5.0, 9.0] and freenode.tolist() == [False, True, False] and n2f.tolist() == [-1, 1, -1]
+
+
+@pytest.mark.parametrize("name", ["oracle_box_3x4x5.npz", "oracle_box_10x10x10.npz"])
+def test_committed_oracle_fixtures_grid_maps_assembly_and_heads(fv, name):
+    """The device against the COMMITTED oracle fixtures (tests/golden/make_oracle_fixtures.py) — no oracle call: the
+    files are the numbers a session with a Julia runtime will diff the real package against.  Grid, free maps, colptr / rowval /
+    nzval / b bit for bit; the heads of the 10^3 box within 1e-8 of the fixture's direct solve."""
+    g = np.load(os.path.join(GOLDEN, name))
+    coords, nb, aol, vol = fv.regulargrid(list(g["mins"]), list(g["maxs"]), [int(v) for v in g["ns"]])
+    assert np.array_equal(coords, g["coords"]) and np.array_equal(nb[:, 0], g["node1"]) and np.array_equal(nb[:, 1], g["node2"])
+    assert np.array_equal(aol, g["areasoverlengths"]) and np.array_equal(vol, g["volumes"])
+    f, n2f = fv.getfreenodes(len(vol), g["dirichletnodes"])
+    assert np.array_equal(f, g["freenode"]) and np.array_equal(n2f, g["nodei2freenodei"])
+    args = (nb, aol, g["conductivities"], g["sources"], g["dirichletnodes"], g["dirichletheads"])
+    A = fv.assembleA(*args)
+    assert np.array_equal(A.colptr, g["colptr"]) and np.array_equal(A.rowval, g["rowval"]) and np.array_equal(A.nzval, g["nzval"])
+    assert np.array_equal(fv.assembleb(*args), g["b"])
+    if "head_direct" in g.files:
+        head, ch, A2, b2, freenode = fv.solvediffusion(*args)
+        assert ch.isconverged
+        p = fv.Problem.create(nb, aol, len(vol), g["dirichletnodes"]).assemble(g["conductivities"], g["sources"], g["dirichletheads"])
+        tight, _, ch2 = p.solve_steady(None, 1e-13, 5000)
+        p.close()
+        assert np.linalg.norm(tight - g["head_direct"]) <= 1e-8 * np.linalg.norm(g["head_direct"])
+        assert np.linalg.norm(head - g["head_direct"]) <= 1e-6 * np.linalg.norm(g["head_direct"])  # (the reference's default tolerance, sqrt(eps))

@@ -294,7 +294,6 @@ def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(f
     sched = [(40.0, 6, 1e-12), (DT, 5, 1e-11), (300.0, 4, 1e-12), (40.0, 3, 1e-3), (3.0, 5, 1e-10)]
     on = _run(fv, case, True, sched)
     off = _run(fv, case, True, sched, tune=((63, 0),))
-    assert on[5] == want_on and off[5] in want_off, (on[5], off[5])
     assert (on[1][:6] > 3).all() and np.abs(on[1].astype(int) - off[1].astype(int)).max() <= 1, (on[1], off[1])
     assert relerr(on[0], off[0]) < 1e-11, relerr(on[0], off[0])
     t, u = 0.0, u0
@@ -304,6 +303,8 @@ def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(f
         u, t = ous[-1], ots[-1]
     tight = _run(fv, case, True, sched[:3])
     assert relerr(tight[0], u) < 1e-8 and relerr(tight[0] - u0, u - u0) < 1e-6
+    tight_off = _run(fv, case, True, sched[:3], tune=((63, 0),))  # (the loop forms of a schedule that ends with many-iteration steps)
+    assert tight[5] == want_on and tight_off[5] in want_off, (tight[5], tight_off[5])
     lib = fv.load()
     out = {}
     try:
@@ -548,7 +549,7 @@ def test_minv_as_codes_in_the_many_iteration_loop_gives_the_same_bits(fv):
 
     def run(case, key):
         lib = fv.load()
-        assert lib.fv_tune(59, key) == 0
+        assert lib.fv_tune(59, key) == 0 and lib.fv_tune(63, 0) == 0  # (the pass + vector update pair: the one-launch iteration of round 5 reads no M^-1 at all)
         try:
             p = fv.Problem.create(case[3], case[4], len(case[5]), case[7]).assemble(case[6], case[9], case[8])
             st = p.transient_begin(0.1, case[5], case[10])
@@ -557,6 +558,7 @@ def test_minv_as_codes_in_the_many_iteration_loop_gives_the_same_bits(fv):
             p.close()
         finally:
             lib.fv_tune(59, 1)
+            lib.fv_tune(63, 1)
         return out
 
     a, b = run(case, 1), run(case, 0)
@@ -564,4 +566,4 @@ def test_minv_as_codes_in_the_many_iteration_loop_gives_the_same_bits(fv):
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
     hetero = _problem(fv, BOX, seed=17)
     c, d = run(hetero, 1), run(hetero, 0)
-    assert c[2] == 89 and d[2] == 89 and np.array_equal(c[0], d[0])  # (round 5: the one-launch iteration, which reads no M^-1 at all)
+    assert c[2] == 105 and d[2] == 105 and np.array_equal(c[0], d[0])
