@@ -197,13 +197,13 @@ def other_baseline_configs(fv, ctx):
     p.run_fixed(st, 60.0, 3, 1e-10)
     ctx.synchronize()
     t0 = time.perf_counter()
-    f0 = p.fused_form()[0]
+    f0, m0 = p.fused_form()[0], p.bytes_moved()
     iters, info, _ = p.run_fixed(st, 60.0, 100, 1e-10)
     ctx.synchronize()
     sec = time.perf_counter() - t0
     launches, brow, bl = p.fused_form()
     row("watertable-like 216^3 transient, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, sec,
-        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl))
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl, p.bytes_moved() - m0))
     p.close()
     # ... "plus the same field at sigma = 1" (SURVEY 8d): node log K = log(1e-5) + g, the Gaussian field of the 256^3 case at this size
     p = fv.Problem.regulargrid([0.0, 0.0, 0.0], [1000.0, 1000.0, 100.0], ns, dn, ctx)
@@ -214,13 +214,13 @@ def other_baseline_configs(fv, ctx):
     p.run_fixed(st, 60.0, 3, 1e-10)
     ctx.synchronize()
     t0 = time.perf_counter()
-    f0 = p.fused_form()[0]
+    f0, m0 = p.fused_form()[0], p.bytes_moved()
     iters, info, _ = p.run_fixed(st, 60.0, 100, 1e-10)
     ctx.synchronize()
     sec = time.perf_counter() - t0
     launches, brow, bl = p.fused_form()
     row("watertable-like 216^3 transient, sigma=1 Gaussian log-K field, 100 steps, dt=60s, Jacobi-PCG rtol 1e-10", p.N, 100, sec,
-        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl))
+        pcg_iters_per_step=float(iters.mean()), converged=bool(info.converged), roofline=step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl, p.bytes_moved() - m0))
     p.close()
     # configs[3]: fractures-like 5 M cells, irregular CSR (cells numbered at random inside each fracture), 100 implicit steps.
     # The mesh is handed over as it is numbered; fv_problem_create re-numbers the free cells for locality by itself
@@ -241,12 +241,12 @@ def other_baseline_configs(fv, ctx):
         p.run_fixed(st, 1.0, 3, 1e-10, maxiter=5000)
         ctx.synchronize()
         t0 = time.perf_counter()
-        f0 = p.fused_form()[0]
+        f0, m0 = p.fused_form()[0], p.bytes_moved()
         iters, sinfo, _ = p.run_fixed(st, 1.0, 100, 1e-10, maxiter=5000)
         ctx.synchronize()
         sec = time.perf_counter() - t0
         launches, brow, bl = p.fused_form()
-        regime = step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl)
+        regime = step_regime_roofline(p, iters, sec / 100, launches - f0, brow, bl, p.bytes_moved() - m0)
         ms = p.bench_spmv(1.0, 20)
         form_id, form_name, form_bytes = p.spmv_form()
         row("fractures-like 5M cells (irregular CSR, %s), transient, 100 steps, dt=1s, Jacobi-PCG rtol 1e-10" % label, p.N, 100, sec,
@@ -461,42 +461,10 @@ def main():
     print(json.dumps(out))
 
 
-def device_smooth_gaussian_field(fv, ns, seed=0, radius_cells=(10, 10, 10), passes=3):
-    """fv.workloads.smooth_gaussian_field (SURVEY 8d's stand-in for the reference's Matern field: separable box smoothing of N(0,1)
-    noise, unit variance) evaluated on the GPU through torch where there is one — the same noise (host generator, seed), the same
-    running-sum windows; the sums run in another order, so the field agrees with the host routine to rounding, not bit for bit.  29 s on
-    the host at 464^3, ~2 s here.  Falls back to the host routine."""
-    try:
-        import torch
-
-        if not torch.cuda.is_available():
-            raise RuntimeError("no device")
-        n1, n2, n3 = ns
-        g = torch.from_numpy(np.random.default_rng(seed).standard_normal((n1, n2, n3))).to("cuda")
-        for axis, r in enumerate(radius_cells):
-            r = int(max(1, min(r, ns[axis] // 2)))
-            n = ns[axis]
-            for _ in range(passes):
-                c = torch.cumsum(g, dim=axis)
-                first, last = c.narrow(axis, 0, 1), c.narrow(axis, n - 1, 1)
-                cp = torch.cat([first.expand(*[r + 1 if d == axis else -1 for d in range(3)]), c, last.expand(*[r if d == axis else -1 for d in range(3)])], dim=axis)
-                del c
-                g = (cp.narrow(axis, 2 * r + 1, n) - cp.narrow(axis, 0, n)) / (2 * r + 1)
-                del cp
-        g -= g.mean()
-        g /= g.std(unbiased=False)
-        out = g.reshape(-1).cpu().numpy()
-        del g
-        torch.cuda.empty_cache()
-        return out, "device (torch)"
-    except Exception:
-        return fv.workloads.smooth_gaussian_field(ns, seed=seed, radius_cells=radius_cells, passes=passes), "host"
-
-
 def gaussian_face_logK(fv, p, ns, sigma, seed=0):
     """Face log-conductivities of SURVEY 8d's heterogeneous inputs: node log K = log(1e-5) + sigma g, g the unit-variance Gaussian field;
     face value = arithmetic mean of the two node values (grid.jl:27, logtransform = true)."""
-    g, where = device_smooth_gaussian_field(fv, ns, seed)
+    g, where = fv.workloads.smooth_gaussian_field(ns, seed=seed), "host"
     logk = np.log(1e-5) + sigma * g
     del g
     n1, n2 = np.empty(p.F, np.int64), np.empty(p.F, np.int64)
@@ -523,7 +491,7 @@ def hetero_face_K(ns, F, N):
     return K
 
 
-def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes, fused_launch_bytes):
+def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes, fused_launch_bytes, moved=None):
     """A roofline-shaped object for the regime a block of fixed-dt steps ran in: the bytes one step must move with
     every array of every launch touched once, over the wall time of a step.
     One-iteration steps through the fused launch: fv_fused_form's bytes.  Steps of several PCG iterations (the carried residual, then
@@ -560,8 +528,13 @@ def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes
             per_it = form_bytes + 88 * n
             bytes_step = float(np.mean(64 * n + its * per_it))
             model = "per step: carried set-up 64 n + per iteration K1 (%s) + 88 n for K2 + K3" % form_name
+    source = "the regime's byte model (below)"
+    if moved is not None and moved > 0:  # the library's own running total over the timed steps (fv_step_form): every launch that ran, by the iterations that ran
+        model_bytes = bytes_step
+        bytes_step = float(moved) / max(len(its), 1)
+        source = "fv_step_form's running total over the timed steps (the model below gives %.4g B per row and step)" % (model_bytes / max(n, 1))
     gbs = bytes_step / sec_per_step / 1e9
-    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_from": source,
             "algorithmic_bytes_per_step": bytes_step, "bytes_per_row_per_step": bytes_step / max(n, 1), "pcg_iters_per_step": mean_it,
             "measured": "wall time of the stepping loop / steps (all launches of a step, polls included)", "bytes_model": model}
 
@@ -582,13 +555,15 @@ def hetero_block(fv, ctx, args):
     st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
     p.run_fixed(st, args.dt, max(args.warmup, 3), args.rtol, args.maxiter)
     f0 = p.fused_form()[0]
-    secs = []
+    secs, moved = [], []
     for rep in range(3):
         ctx.synchronize()
+        m0 = p.bytes_moved()
         t0 = time.perf_counter()
         iters, info, _ = p.run_fixed(st, args.dt, args.steps, args.rtol, args.maxiter)
         ctx.synchronize()
         secs.append(time.perf_counter() - t0)
+        moved.append(p.bytes_moved() - m0)
     sec = float(np.median(secs))
     launches, brow, bl = p.fused_form()
     out = {"workload": "same %d^3 box, node log K = log(1e-5) + 1.0 g with g SURVEY 8d's unit-variance Gaussian field (separable box smoothing of N(0,1) noise, radius 10 cells, 3 passes, seed 0; "
@@ -596,7 +571,7 @@ def hetero_block(fv, ctx, args):
            "dof_updates_per_s": p.N * args.steps / sec, "ms_per_step": sec / args.steps * 1e3, "ms_per_step_each": [s / args.steps * 1e3 for s in secs],
            "pcg_iters_per_step": float(iters.mean()), "converged": bool(info.converged), "last_relres": info.relres,
            "fused_launches": launches - f0}
-    out["roofline"] = step_regime_roofline(p, iters, sec / args.steps, launches - f0, brow, bl)
+    out["roofline"] = step_regime_roofline(p, iters, sec / args.steps, launches - f0, brow, bl, moved[int(np.argsort(secs)[1])])
     # ... and at a time step short enough for this field's stiffest cells to converge in one PCG iteration: the regime of the
     # headline, where the fused step streams the matrix as doubles
     if out["pcg_iters_per_step"] > 1.0:
@@ -604,20 +579,22 @@ def hetero_block(fv, ctx, args):
         st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
         p.run_fixed(st, dt1, 8, args.rtol, args.maxiter)
         f1 = p.fused_form()[0]
-        secs1, its1 = [], []
+        secs1, its1, moved1 = [], [], []
         for rep in range(3):
             ctx.synchronize()
+            m0 = p.bytes_moved()
             t0 = time.perf_counter()
             it1, info1, _ = p.run_fixed(st, dt1, n1s, args.rtol, args.maxiter)
             ctx.synchronize()
             secs1.append(time.perf_counter() - t0)
+            moved1.append(p.bytes_moved() - m0)
             its1.append(float(it1.mean()))
         sec1 = float(np.median(secs1))
         l1, brow1, bl1 = p.fused_form()
         out["one_iteration_regime"] = {"dt": dt1, "steps": n1s, "dof_updates_per_s": p.N * n1s / sec1, "ms_per_step": sec1 / n1s * 1e3,
                                        "ms_per_step_each": [s / n1s * 1e3 for s in secs1], "pcg_iters_per_step": float(np.mean(its1)),
                                        "converged": bool(info1.converged), "fused_launches": l1 - f1,
-                                       "roofline": step_regime_roofline(p, it1, sec1 / n1s, (l1 - f1) / 3.0, brow1, bl1)}
+                                       "roofline": step_regime_roofline(p, it1, sec1 / n1s, (l1 - f1) / 3.0, brow1, bl1, moved1[int(np.argsort(secs1)[1])])}
     p.close()
     return out
 
@@ -727,10 +704,12 @@ def multi_iteration_block(p, args):
     p.run_fixed(st, dt, 2, args.rtol, args.maxiter)
     p.profile(True)
     p.ctx.synchronize()
+    m0 = p.bytes_moved()
     t0 = time.perf_counter()
     iters, info, _ = p.run_fixed(st, dt, steps, args.rtol, args.maxiter)
     p.ctx.synchronize()
     sec = time.perf_counter() - t0
+    moved = p.bytes_moved() - m0
     prof = p.profile_get()
     p.profile(False)
     del st
@@ -740,7 +719,7 @@ def multi_iteration_block(p, args):
     upd = 0 if loop in (89, 67) else (25 if loop in (76, 98) else 32)  # 83 with the matrix as codes; 7 fewer again with M^-1 as a code byte in the vector update
     per_it_bytes = loop * p.n if loop else form_bytes + 88 * p.n
     ms_it = sec / max(nit, 1) * 1e3
-    regime = step_regime_roofline(p, iters, sec / steps, 0, 0, 0)  # every launch of a step: carried set-up, first product and update, the loop
+    regime = step_regime_roofline(p, iters, sec / steps, 0, 0, 0, moved)  # every launch of a step: set-up, first pass, the loop
     out = {"workload": "same %d^3 operator, dt=%gs, %d steps" % (args.ns, dt, steps), "pcg_iters_per_step": float(np.mean(iters)), "roofline": regime,
            "converged": bool(info.converged), "ms_per_step": sec / steps * 1e3, "dof_updates_per_s": p.N * steps / sec,
            "ms_per_iteration": ms_it, "bytes_per_iteration": per_it_bytes,

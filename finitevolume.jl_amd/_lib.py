@@ -108,7 +108,7 @@ SIGNATURES = {
     "fv_spmv_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64)]),
     "fv_update_form": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_loop_form": (C.c_int, [c_prob, P(C.c_int32)]),
-    "fv_step_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64)]),
+    "fv_step_form": (C.c_int, [c_prob, P(C.c_int32), P(C.c_int64), P(C.c_int64)]),
     "fv_fused_form": (C.c_int, [c_prob, P(C.c_int64), P(C.c_int32), P(C.c_int64)]),
     "fv_fused_traversal": (C.c_int, [c_prob, P(C.c_int32)]),
     "fv_problem_reorder_info": (C.c_int, [c_prob, P(C.c_int32), P(C.c_double), P(C.c_double), P(C.c_double)]),

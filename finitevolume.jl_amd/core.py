@@ -318,9 +318,15 @@ class Problem:
         """((set-up, first pass, flush) bytes per row outside the loop iterations, solves so far) of the most recent solve whose loop ran
         as one launch per iteration (fv_step_form; loop_form() 89 / 67)."""
         b = (C.c_int32 * 3)()
-        n = C.c_int64()
-        self.check(load().fv_step_form(self.handle, b, C.byref(n)))
+        n, tot = C.c_int64(), C.c_int64()
+        self.check(load().fv_step_form(self.handle, b, C.byref(n), C.byref(tot)))
+        self.bytes_total = tot.value  # running total of the bytes every Jacobi-PCG solve's launches had to move (differences over a run: its algorithmic bytes)
         return (int(b[0]), int(b[1]), int(b[2])), n.value
+
+    def bytes_moved(self):
+        """Running total of the algorithmic bytes of every Jacobi-PCG solve on this problem (fv_step_form's bytes_total)."""
+        self.step_form()
+        return self.bytes_total
 
     def fused_form(self):
         """(launches so far, bytes per row of its storage form, bytes per launch) of the fused step of the one-iteration regime

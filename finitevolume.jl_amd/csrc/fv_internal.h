@@ -402,6 +402,7 @@ struct fv_problem {
     DevBuf<uint8_t> vcode; // pcg_carry_flush_kernel's code byte: storage code | bit 7 (b is not zero), for (vcode_sepoch, vcode_aepoch) = (storage, assembly)
     int64_t vcode_sepoch = -1, vcode_aepoch = -1;
     int64_t ploop_solves = 0;  // solves whose loop ran that way
+    int64_t bytes_total = 0;   // fv_step_form: bytes the launches of every Jacobi-PCG solve on this problem had to move (every array of every launch once), running total
     int32_t ploop_bytes[3] = {0, 0, 0}; // fv_step_form: set-up, first pass, flush of the most recent such solve (bytes per row)
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)

@@ -1081,7 +1081,7 @@ extern "C" int fv_loop_form(fv_problem *p, int32_t *bytes_per_row)
     return FV_OK;
 }
 
-extern "C" int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves)
+extern "C" int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves, int64_t *bytes_total)
 {
     if (!p || !bytes)
         return FV_ERR_ARG;
@@ -1089,6 +1089,8 @@ extern "C" int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves)
         bytes[k] = p->ploop_bytes[k];
     if (solves)
         *solves = p->ploop_solves;
+    if (bytes_total)
+        *bytes_total = p->bytes_total;
     return FV_OK;
 }
 
@@ -1294,6 +1296,14 @@ int fv_pcg_prepare(fv_problem *p)
 
 static inline int fv_step_precond_of(const fv_problem *p, const PcgSystem &sys) { return sys.implicit_step ? fv_step_precond(p) : p->precond; }
 
+// Bytes the most recent product's storage form moves per launch (fv_spmv_form), for fv_problem::bytes_total
+static int64_t k1_form_bytes(fv_problem *p)
+{
+    int32_t form = 0;
+    int64_t b = 0;
+    return fv_spmv_form(p, &form, &b) == FV_OK ? b : 0;
+}
+
 int fv_ploop_flush_pending(fv_problem *p)
 {
     fv_problem::PlPending &pd = p->pl_pending;
@@ -1429,9 +1439,12 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             (sys.rhs == p->b.p || !sys.rhs) && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && fv_ploop_applicable(p, sigma, folded != nullptr))
             FV_TRY(ensure_carry_codes(p, &codes, &vtab));
         take_pending = codes;
-        if (!take_pending)
+        if (!take_pending) {
             FV_TRY(fv_ploop_flush_pending(p));
+            p->bytes_total += 48 * n;
+        }
     }
+    const bool take_pending_acct = take_pending;
     if (resume) {
         // nothing to set up: r, p and the scalars are those of the interrupted solve
     } else if (use_spec) {
@@ -1504,6 +1517,19 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            p->part_rr.p, p->part_bb.p);
     }
     FV_LAUNCH_CHECK(ctx);
+    // fv_step_form's running total: the bytes this solve's launches must move with every array of every launch touched once — the
+    // carried set-ups by their streams (64 / 65 n), any other set-up as a product of the form that ran + a 56 n vector pass
+    int64_t acct = 0;
+    if (resume || use_spec)
+        acct = 0;
+    else if (take_pending_acct)
+        acct = 65 * n;
+    else if (sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D)
+        acct = 64 * n;
+    else if (sys.x0_zero && !sys.implicit_step)
+        acct = 48 * n;
+    else
+        acct = k1_form_bytes(p) + 56 * n;
     if (!resume && !use_spec)
         p->z_where = 0; // every other set-up has written r
     if (!resume)
@@ -1645,6 +1671,10 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
         }
+        if (hs->iters >= 1 || j >= 1) {
+            const int64_t full = hs->done == 1 ? (int64_t)hs->iters - 1 : j - 1; // launches beyond the first that ran their pass
+            acct += (int64_t)(p->loop_bytes == 67 ? 19 : 41) * n + (full > 0 ? full : 0) * (int64_t)p->loop_bytes * n + ((itf >= 1 && !deferred) ? 48 * n : 0);
+        }
         p->ploop_solves++;
         p->ploop_bytes[0] = took_pending ? 65 : ((sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D) ? 64 : 0);
         p->ploop_bytes[1] = p->loop_bytes == 67 ? 19 : 41;
@@ -1699,6 +1729,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
             p->vready_counts[1] = fout.nbb;
             p->vready_counts[2] = fout.npq;
             p->fused_launches++;
+            p->bytes_total += acct + p->fused_bytes_launch + (was_vready ? 0 : k1_form_bytes(p) + 32 * n);
             p->last_iters = 1;
             p->spec_valid = true;
             p->z_where = 2;
@@ -1803,6 +1834,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_LAUNCH_CHECK(ctx);
         it += m;
         if (chained) { // the caller polls once per burst (fv_pcg_chain_poll)
+            p->bytes_total += acct + k1_form_bytes(p) + (int64_t)p->k2s_bytes * n;
             p->last_iters = 1;
             p->spec_valid = true;
             p->z_where = zf ? 2 : 0; // unless the chain stops on the device (the poll then says so)
@@ -1839,6 +1871,17 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     p->last_iters = hs->iters;
+    if (!ploop && fv_step_precond_of(p, sys) != FV_PRECOND_AMG) { // (the V-cycle's launches are not modelled: fv_step_form's total leaves AMG solves out)
+        const int64_t its = hs->iters - (resume ? sys.resume_it : 0), k1b = k1_form_bytes(p);
+        if (its > 0) {
+            if (zloop == 2) {
+                const int64_t lb = p->loop_bytes - (p->loop_minv_coded ? 7 : 0);
+                acct += k1b + (p->loop_minv_coded ? 49 : 56) * n + (its - 1) * lb * n + (wloop_lag ? 24 * n : 0);
+            } else
+                acct += its * (k1b + 56 * n) + (its - 1) * 32 * n + ((speculate && !resume) ? ((int64_t)p->k2s_bytes - 56) * n : 0);
+        }
+    }
+    p->bytes_total += acct;
     if (zloop != 2 && !ploop)
         p->loop_bytes = 0; // (else what fv_fused_iteration reported: 113, or 91 with the matrix as codes)
     if ((zloop == 2 || ploop) && hs->iters >= 1) // (a solve that was converged at its set-up has launched no-ops only: r is still r)

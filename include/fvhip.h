@@ -313,8 +313,11 @@ int fv_loop_form(fv_problem *p, int32_t *bytes_per_row);
  * set-up K0' alone; 0 = another set-up), bytes[1] the first pass (direction = z: z, the matrix, a code byte in, w out: 41, or 19 with
  * the matrix as codes), bytes[2] the flush of the last update (48: z, w, p, x in, z, x out; 0 when the next step's set-up applies it);
  * *solves: solves on this problem whose loop ran that way.  A step of m iterations moves bytes[0] + bytes[1] + (m - 1) x fv_loop_form +
- * bytes[2] per row.  A measurement aid: the step is backwardeuleronestep! / cg! of src/transient.jl:50-76 either way. */
-int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves);
+ * bytes[2] per row.  *bytes_total: a running total over EVERY Jacobi-PCG solve on this problem, whatever its regime — the bytes its launches had to
+ * move with every array of every launch touched once (set-ups, products by their storage form, vector updates, fused steps, loop launches by
+ * the iterations that ran); differences of it over a timed run give that run's algorithmic bytes (bench.py's regime rooflines).  AMG solves and
+ * row blocks are not counted.  A measurement aid: the step is backwardeuleronestep! / cg! of src/transient.jl:50-76 either way. */
+int fv_step_form(fv_problem *p, int32_t bytes[3], int64_t *solves, int64_t *bytes_total);
 /* How the most recent fused launch (fv_fused_form / fv_loop_form) walked the planes of the operator: 0 = 2-D tiles of 16 lines x 128
  * columns (or it has not run), 1 = contiguous chunks of a plane's rows (no column halos; where the matrix comes as codes and the
  * rows whose diagonal does not follow from their arms share at most 15 values).  A measurement aid like the two above: the step it
