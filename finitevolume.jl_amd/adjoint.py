@@ -110,6 +110,10 @@ def adjointintegrate(*args, **kwargs):
         forcing, tspan = args[0], args[1]
         uc = forcing.uc
         p = uc.trajectory.problem
+        # the reference re-assembles A from these arguments (transient.jl:189-193); here the sweep runs on the forward run's problem, so they
+        # must be what that problem was built from (fingerprints recorded by Problem.create / assemble / transient_begin)
+        names = ("Ss", "volumes", "neighbors", "areasoverlengths", "conductivities", "sources", "dirichletnodes", "dirichletheads", "metaindex", "logtransformconductivity")
+        p.check_inputs(**dict(zip(names, args[2:])))
         stepper = kwargs.pop("stepper", kwargs.pop("stepper_", adaptivebackwardeulerstep))
         if stepper not in (adaptivebackwardeulerstep, fixedbackwardeulerstep) or any(k in kwargs for k in ("linearsolver", "callback")):
             raise ValueError("the device-resident adjoint sweep runs the adaptive or the fixed stepper with the device PCG")

@@ -143,6 +143,18 @@ def getnodei2dirichleti(sources, dirichletnodes, ctx=None):
 
 
 # ------------------------------------------------------------------ device problem
+def _checksum(x):
+    """(size, sum, strided sum) of an input array: a cheap fingerprint by which the device-resident adjoint workflow recognises that the
+    arguments it is handed are the ones its problem was built from (adjoint.adjointintegrate)."""
+    if x is None:
+        return None
+    a = np.asarray(x)
+    if a.dtype == object or a.size == 0:
+        return (int(a.size), 0.0, 0.0)
+    a = a.reshape(-1)
+    return (int(a.size), float(a.sum(dtype=np.float64)), float(a[:: max(1, a.size // 997)].sum(dtype=np.float64)))
+
+
 class Problem:
     """fv_problem: the mesh + Dirichlet set resident on the GPU (symbolic CSR built once)."""
 
@@ -163,7 +175,9 @@ class Problem:
             raise FVError(_lib.FV_ERR_INDEX, "BoundsError: %d areasoverlengths for %d neighbors" % (len(aol), len(n1)))
         h = _lib.c_prob()
         ctx.check(load().fv_problem_create(ctx.handle, int(N), len(n1), ptr(n1), ptr(n2), ptr(aol), len(d), ptr(d), C.byref(h)))
-        return cls(h, ctx)
+        p = cls(h, ctx)
+        p.inputs = {"neighbors": (_checksum(n1), _checksum(n2)), "areasoverlengths": _checksum(aol), "dirichletnodes": _checksum(d)}
+        return p
 
     @classmethod
     def regulargrid(cls, mins, maxs, ns, dirichletnodes, ctx=None):
@@ -213,6 +227,10 @@ class Problem:
         mi = _metaindex_array(metaindex, self.F)
         bad = C.c_int64()
         self.check(load().fv_assemble(self.handle, len(K), ptr(K), ptr(mi), int(bool(logtransformconductivity)), ptr(s), ptr(dh), C.byref(bad)))
+        if not hasattr(self, "inputs"):
+            self.inputs = {}
+        self.inputs.update(conductivities=_checksum(K), sources=_checksum(s), dirichletheads=_checksum(dh), metaindex=_checksum(mi),
+                           logtransformconductivity=bool(logtransformconductivity))
         return self
 
     def csc(self):
@@ -359,7 +377,32 @@ class Problem:
         v = af64(volumes) if volumes is not None else None
         u = af64(u0_nodes) if u0_nodes is not None else None
         self.check(load().fv_transient_begin(self.handle, float(Ss), ptr(v), ptr(u)))
+        if not hasattr(self, "inputs"):
+            self.inputs = {}
+        self.inputs.update(Ss=float(Ss), volumes=_checksum(v))
         return DeviceVector(self, 0, owned=False)
+
+    def check_inputs(self, **given):
+        """Raise if an argument differs from what this problem was built / assembled / started from (fingerprints recorded by create,
+        assemble and transient_begin); arguments the problem has no record of (a regulargrid problem's mesh) are not checked."""
+        rec = getattr(self, "inputs", {})
+        for name, val in given.items():
+            if name not in rec or val is None:
+                continue
+            if name == "neighbors":
+                n1, n2 = _split_neighbors(val)
+                got = (_checksum(n1), _checksum(n2))
+            elif name in ("Ss", "logtransformconductivity"):
+                got = type(rec[name])(val)
+            elif name == "metaindex":
+                got = _checksum(_metaindex_array(val, self.F))
+            elif name == "dirichletnodes":
+                got = _checksum(ai64(val))
+            else:
+                got = _checksum(af64(val))
+            if got != rec[name]:
+                raise FVError(_lib.FV_ERR_ARG, "%s differs from what the forward run's problem was built from: the device-resident adjoint sweep runs on that "
+                                               "problem (re-assemble it, or use the host-closure path)" % name)
 
     def param_gradient_integral(self, ts, x_knots, lam_knots, scale_by_storage=False, logtransformconductivity=False):
         """fv_param_gradient_integral: exact time integral of (b_p - A_p u)' w for piecewise-linear u, w given at the

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_w_kernel(int64_t n, int i
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             scal->pq = pq;
             scal->done = 2;
+            scal->xlag = -1; // (the pass in front of this launch has applied the update that was lagging: pcg_xflush_kernel must not apply it again)
         }
         return;
     }

@@ -139,6 +139,9 @@ def test_device_adjoint_sweep_against_the_host_closure_path_and_the_oracle(fv, o
     lam_h, ts_h = fv.adjointintegrate(lambda t: dgdu(uc, t), c["tspan"], *mesh_fv, c["K"], *rest, **kw)
     lam_d, ts_d = fv.adjointintegrate(dgdu.bind(duc), c["tspan"], *mesh_fv, c["K"], *rest, **kw)
     assert ts_d == ts_h and len(lam_d) == len(lam_h) > 5
+    # the device sweep runs on the forward run's problem: arguments that are not the ones it was built from are refused, not ignored
+    with pytest.raises(fv.FVError, match="conductivities differs"):
+        fv.adjointintegrate(dgdu.bind(duc), c["tspan"], *mesh_fv, c["K"] + 0.01, *rest, **kw)
     scale = max(np.abs(np.asarray(l)).max() for l in lam_h)
     worst = max(np.abs(lam_d[k] - np.asarray(lam_h[k])).max() for k in range(len(lam_h)))
     assert worst <= 1e-10 * scale, worst / scale

@@ -131,7 +131,10 @@ def _check(tag, dev, sysm, sched, rtol, t_setup, want_fused=None):
            relerr(draw, sdraw), relerr(draw, rdraw), relerr(sdraw, rdraw)))
     assert rdraw.max() > 1e-4
     assert its_flat == sit  # the same algorithm at the same tolerance: the same iteration count on every step
-    assert relerr(head, shead) < HEAD_RTOL and relerr(draw, sdraw) < DRAW_RTOL
+    # (the drawdown is a difference of heads near 1e3, each good to a few units in the last place — 1.1e-13 — at best: over N cells that is
+    # a floor of a few ulp sqrt(N) / ||drawdown|| under any comparison of two runs, 1e-6 at 320^3 with four iterations per step)
+    floor = 8 * np.spacing(1e3) * np.sqrt(len(head)) / np.linalg.norm(sdraw)
+    assert relerr(head, shead) < HEAD_RTOL and relerr(draw, sdraw) < max(DRAW_RTOL, floor), (relerr(draw, sdraw), floor)
     assert relerr(head, rhead) < HEAD_RTOL
     # against the exact discrete solution the drawdown is as good as the tolerance the workload states — for the device and for
     # the CPU run of the same algorithm alike (their distance to (R) is the same to 1e-3 of itself)
