@@ -534,9 +534,43 @@ def step_regime_roofline(p, iters, sec_per_step, fused_launches, fused_row_bytes
         bytes_step = float(moved) / max(len(its), 1)
         source = "fv_step_form's running total over the timed steps (the model below gives %.4g B per row and step)" % (model_bytes / max(n, 1))
     gbs = bytes_step / sec_per_step / 1e9
-    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_from": source,
+    stamp = regime_traffic_stamp(p, fused_launches >= 0.8 * len(its) and mean_it <= 1.0, fused_launch_bytes)
+    out_extra = {}
+    if stamp and stamp.get("whole_step"):  # one launch per step: the PMC bytes of that launch are the step's
+        out_extra = {"traffic": stamp["bytes"], "traffic_source": stamp["source"], "frac_traffic": stamp["bytes"] / sec_per_step / 1e9 / HBM_PEAK_GBS}
+    elif stamp:
+        out_extra = {"loop_launch": {"kernel": stamp["kernel"], "form_bytes": stamp["form_bytes"], "traffic": stamp["bytes"], "traffic_source": stamp["source"],
+                                     "ratio": stamp["bytes"] / stamp["form_bytes"]}}
+    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None, "bytes_from": source,
             "algorithmic_bytes_per_step": bytes_step, "bytes_per_row_per_step": bytes_step / max(n, 1), "pcg_iters_per_step": mean_it,
             "measured": "wall time of the stepping loop / steps (all launches of a step, polls included)", "bytes_model": model}
+    roof.update(out_extra)
+    return roof
+
+
+def regime_traffic_stamp(p, one_launch_steps, fused_launch_bytes):
+    """The PMC stamp under profiles/ (spmv_traffic.json) for the launch that dominates a regime, when kernel, form and size match: the fused
+    step on chunks with the matrix as doubles (one launch per step), or the one-launch PCG iteration (doubles / codes)."""
+    tfile = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    if not os.path.exists(tfile):
+        return None
+    try:
+        tj = json.load(open(tfile))
+        if one_launch_steps:
+            if p.fused_traversal() != 1:
+                return None
+            for key in ("fused_doubles_464", "fused_464"):
+                t = tj.get(key)
+                if t and abs(t["form_bytes"] - fused_launch_bytes) <= 0.005 * fused_launch_bytes:
+                    return dict(t, whole_step=True)
+            return None
+        loop = p.loop_form()
+        t = tj.get({89: "ploop_doubles_464", 67: "ploop_coded_464"}.get(loop, ""))
+        if t and abs(t["form_bytes"] - loop * p.n) <= 0.005 * loop * p.n:
+            return t
+    except Exception:
+        pass
+    return None
 
 
 def hetero_block(fv, ctx, args):

@@ -56,7 +56,8 @@ _f64p = C.c_void_p
 ABI_VERSION = 4  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
 FV_OPT_REORDER = 1
 # the experimenter's panel (finitevolume.jl_amd/csrc/fv_tune.h): exported, but not part of include/fvhip.h
-PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int])}
+PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int]),
+                      "fv_comm_init_local": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int])}  # the loopback transport of the multi-rank rehearsals (tests)
 SIGNATURES = {
     "fv_abi_version": (C.c_int, []),
     "fv_ctx_set_option": (C.c_int, [c_ctx, C.c_int, C.c_int]),
@@ -118,7 +119,6 @@ SIGNATURES = {
     "fv_comm_selftest": (C.c_int, [c_ctx, C.c_int64, P(C.c_int)]),
     "fv_comm_diag": (C.c_int, [c_ctx, C.c_int]),
     "fv_comm_diag_get": (C.c_int, [c_ctx, P(C.c_double), P(C.c_int64)]),
-    "fv_comm_init_local": (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     "fv_dist_setup": (C.c_int, [c_prob, C.c_int, C.c_int, P(c_prob)]),
     "fv_param_gradient_integral": (C.c_int, [c_prob, C.c_int64, _f64p, _f64p, _f64p, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
     "fv_trajectory_create": (C.c_int, [c_prob, P(C.c_void_p)]),

@@ -734,6 +734,8 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
     constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
     extern __shared__ __align__(16) unsigned char kc_lds[];
     const int tid = (int)threadIdx.x;
+    constexpr int NTB = 0; // the streaming hints (KfArgs::nt's bits) at their frozen values, as compile-time constants: with run-time tests the compiler split every
+                           // 16-byte store into two 8-byte ones (round 5: 0.8965 -> 0.8702 ms per step at 464^3, profiles/r05_step_ab_coded_addressing.log)
     const int32_t nz = a.nz, d3 = a.d3, C = a.chunk;
     const int ZL = C + 2 * nz, WL = C + nz;
     double *zs = reinterpret_cast<double *>(kc_lds);          // 2 x ZL: [nz rows before | C own | nz rows behind]
@@ -1000,7 +1002,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                     const double2 xn = make_double2(Xa[k].x + alpha * Za[k].x, Xa[k].y + alpha * Za[k].y);
                     dxn = make_double2(xn.x - Xa[k].x, xn.y - Xa[k].y);
                     if (vec_n && own[k]) {
-                        if (a.nt & 8) // (plain stores of x_out measure 3.6 % faster here than the streaming ones the tile kernel prefers:
+                        if (NTB & 8) // (plain stores of x_out measure 3.6 % faster here than the streaming ones the tile kernel prefers:
                             ST2nt(a.xout, p + 1, k, xn); // 0.949 against 0.984 ms per step, profiles/r04_step_ab_chunk_hints.log)
                         else
                             ST2(a.xout, p + 1, k, xn);
@@ -1021,7 +1023,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                 if (MODE == 1 && XU && vec_n && own[k]) // (before (b) refills the registers: p_old of plane p + 1 is Va)
                     ST2(a.xout, p + 1, k, make_double2(Xa[k].x + ax * Va[k].x, Xa[k].y + ax * Va[k].y));
                 if (vec_n && own[k] && (MODE != 3 || LW)) {
-                    if (a.nt & 1)
+                    if (NTB & 1)
                         ST2nt(a.znext, p + 1, k, Zn);
                     else
                         ST2(a.znext, p + 1, k, Zn);
@@ -1039,9 +1041,9 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                             Qa[k] = P2(a.w, p + 2, k);
                         }
                     } else
-                        Va[k] = (a.nt & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
+                        Va[k] = (NTB & 4) ? P2(a.v, p + 2, k) : P2nt(a.v, p + 2, k);
                     if (XU)
-                        Xa[k] = (a.nt & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
+                        Xa[k] = (NTB & 4) ? P2(a.x, p + 2, k) : P2nt(a.x, p + 2, k);
                     Wa[k] = MW(p + 2, k);
                     Ma[k] = C2(p + 2, k);
                 }
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
                         my = 1.0 / d.y;
                     if (wc & 0x8000u) {
                         const double2 vn = make_double2(-(mx * (t0 - Sc.x * Zc.x)), -(my * (t1 - Sc.y * Zc.y)));
-                        if (a.nt & 2)
+                        if (NTB & 2)
                             ST2nt(a.vnext, p, k, vn);
                         else
                             ST2(a.vnext, p, k, vn);
@@ -1223,7 +1225,7 @@ __device__ __forceinline__ double kd_from_below(double v, double edge) // v of t
     return __hiloint2double(hi, lo);
 }
 
-template <int NT, int NP, int MODE, int PD, int PU, int FL>
+template <int NT, int NP, int MODE, int PD, int PU>
 __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
 {
     constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
@@ -1330,26 +1332,21 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
         const char *u1f = reinterpret_cast<const char *>(a.u1 - a.front), *u2f = reinterpret_cast<const char *>(a.u2 - a.front),
                    *u3f = reinterpret_cast<const char *>(a.u3 - a.front), *dgf = reinterpret_cast<const char *>(a.dg - a.front);
         auto OFF = [&](int32_t pl) -> uint32_t { return (uint32_t)pl * d3b; };
-        auto PBX = [&](const void *arr, int32_t pl, int esz) -> const char * { // (FL & 1: a 64-bit scalar base per array and plane)
-            return reinterpret_cast<const char *>(arr) + (uint64_t)((int64_t)pl * d3) * (uint64_t)esz;
-        };
         auto LD2 = [&](const char *base, uint32_t off) -> double2 { return *reinterpret_cast<const double2 *>(base + off); };
         auto LD2nt = [&](const char *base, uint32_t off) -> double2 {
             const double *b = reinterpret_cast<const double *>(base + off);
             return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
         };
-        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2(PBX(arr, pl, 8), ob[k]) : LD2(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
-        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2nt(PBX(arr, pl, 8), ob[k]) : LD2nt(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
-        auto PUL = [&](const char *basef, int32_t pl, int k) -> double2 { return (FL & 1) ? LD2nt(PBX(basef + fb, pl, 8), ob[k]) : LD2nt(basef, fb + ob[k] + OFF(pl)); }; // a padded array (its start + front)
-        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (FL & 1) ? (uint32_t) * reinterpret_cast<const uint16_t *>(PBX(a.kcode, pl, 1) + (ob[k] >> 3)) : (uint32_t) * reinterpret_cast<const uint16_t *>(a.kcode + ((ob[k] + OFF(pl)) >> 3)); };
+        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
+        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2nt(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
+        auto PUL = [&](const char *basef, int32_t pl, int k) -> double2 { return LD2nt(basef, fb + ob[k] + OFF(pl)); }; // a padded array (its start + front)
+        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (uint32_t) * reinterpret_cast<const uint16_t *>(a.kcode + ((ob[k] + OFF(pl)) >> 3)); };
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
-        auto E1L = [&](int32_t pl, int k) -> double { // (a wave-uniform address: a scalar load)
-            // (through the constant address space — the matrix is not written while the kernel runs —, or the compiler issues a vector
-            // load for it: one more entry in the vector-memory queue per pair and two registers held until it returns)
+        auto E1L = [&](int32_t pl, int k) -> double {
+            // (a wave-uniform address, loaded as a vector all the same: through the constant address space — a scalar load — the launch measured
+            // 1.8 % SLOWER: scalar loads return out of order, so the wait for it also waits for every LDS operation in flight)
             const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fb + OFF(pl) + (uint32_t)erow[k] * 8u));
-            if (FL & 2)
-                return *reinterpret_cast<const double *>(u1f + off);
-            return *reinterpret_cast<const __attribute__((address_space(4))) double *>((const __attribute__((address_space(4))) char *)(u1f) + off);
+            return *reinterpret_cast<const double *>(u1f + off);
         };
         auto HIN = [&](int32_t pl, int r) -> bool {
             const int64_t off = (int64_t)pl * d3 * 8 + (int64_t)hb[r];
@@ -1362,14 +1359,9 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
             return H1(a.z, pl, r) + alpha * H1(a.v, pl, r);
         };
         auto HU = [&](int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(u2f + (fb + (uint32_t)hb[r] + OFF(pl))); };
-        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) {
-            if (FL & 1)
-                *reinterpret_cast<double2 *>(const_cast<char *>(PBX(arr, pl, 8)) + ob[k]) = val;
-            else
-                *reinterpret_cast<double2 *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl))) = val;
-        };
+        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl))) = val; };
         auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
-            double *q = (FL & 1) ? reinterpret_cast<double *>(const_cast<char *>(PBX(arr, pl, 8)) + ob[k]) : reinterpret_cast<double *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl)));
+            double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl)));
             __builtin_nontemporal_store(val.x, q);
             __builtin_nontemporal_store(val.y, q + 1);
         };
@@ -1653,7 +1645,7 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                         issue_batch(k + PD, p + 1);
                 } else if (more)
                     issue_batch(k + PD - NP, p + 2);
-                if (!(FL & 4) && k == KH) { // the halo of plane p + 1 into the other slots (nobody reads those before the barrier), then the halo of plane p + 2 in flight
+                if (k == KH) { // the halo of plane p + 1 into the other slots (nobody reads those before the barrier), then the halo of plane p + 2 in flight
 #pragma unroll
                     for (int r = 0; r < HR; r++)
                         if (hv[r] && inseg) {
@@ -1664,16 +1656,6 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                     issue_halo(p + 2);
                 }
                 __builtin_amdgcn_sched_barrier(0); // (the scheduler must not hoist these loads further up: their registers are the point)
-            }
-            if (FL & 4) {
-#pragma unroll
-                for (int r = 0; r < HR; r++)
-                    if (hv[r] && inseg) {
-                        zs[(zb ^ 1) * ZL + hs[r]] = hz[r] + alpha * hq[r];
-                        if (hbefore[r])
-                            u2s[((p + 1) & 1) * WL + hs[r]] = hu[r];
-                    }
-                issue_halo(p + 2);
             }
             __syncthreads();
             zb ^= 1;
@@ -2039,7 +2021,6 @@ struct KcPlan {
     size_t lds;
     bool doubles; // fused_chunkd_kernel (the matrix as doubles) instead of fused_chunk_kernel (as 16-bit codes)
 };
-int g_chunkd_np = 4; // (experiment: fv_tune key 62) pairs of rows per thread of fused_chunkd_kernel: 4 or 5
 static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt, bool doubles)
 {
     if (doubles) // z' and U2 double-buffered, the storage table, the reduction scratch
@@ -2061,7 +2042,7 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     // 512 threads x 5 pairs of rows per thread: the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD.
     // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
-    const int nt = 512, np = coded ? 5 : (g_chunkd_np == 4 ? 4 : 5);
+    const int nt = 512, np = coded ? 5 : 4; // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill)
     const int64_t nz = a.nz, d3 = a.d3;
     if (nz > nt) // the 2 nz halo rows are covered in two rounds of the block: longer lines stay with the tiles
         return false;
@@ -2119,13 +2100,13 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     pl.doubles = !coded;
     return true;
 }
-template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2, int FL = 0>
+template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2>
 static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
     void (*kern)(KfArgs);
     if constexpr (DOUBLES)
-        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU, FL>;
+        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU>;
     else
         kern = &fused_chunk_kernel<NT, NP, MODE>;
     if (!raised) {
@@ -2135,19 +2116,18 @@ static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
     hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(NT), pl.lds, ctx->stream, a);
     return FV_OK;
 }
-int g_chunkd_variant = 0; // (experiment: fv_tune key 62, tens digit) prefetch distances of fused_chunkd_kernel
 template <int MODE>
 static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     if (pl.doubles) {
-        // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two: measured 464^3, one process, ms per step (tiles 1.531): (2,2) 1.376,
-        // (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane): 1.384-1.477
-        if (pl.np == 5)
-            return kc_launch_one<512, 5, MODE, true, 2, 1, 2>(ctx, a, pl);
-        if (g_chunkd_variant == 1)
-            return kc_launch_one<512, 4, MODE, true, 2, 1, 2>(ctx, a, pl);
-        return kc_launch_one<512, 4, MODE, true, 3, 2, 2>(ctx, a, pl);
+        // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two, the wave's edge element by a vector load: measured 464^3, one process, ms
+        // per step (tiles 1.531): (2,2) 1.376, (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane):
+        // 1.384-1.477; the edge element by a scalar load (constant address space): +1.8 %; 64-bit plane bases: +0.1 % (profiles/r05_hetero_ab_*.log)
+        return kc_launch_one<512, 4, MODE, true, 3, 2>(ctx, a, pl);
     }
+    // the coded kernel: streaming hints as compile-time constants (stores stay 16-byte instructions): 464^3, one process, ms per step 0.8965 -> 0.8702;
+    // with 32-bit offsets instead of 64-bit plane bases on top the median of five rounds was WORSE (0.965 / 0.941, minimum 0.893 / 0.874: two
+    // modes), so its bases stay (profiles/r05_step_ab_coded_addressing.log)
     return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
 }
 

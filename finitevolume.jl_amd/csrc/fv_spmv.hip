@@ -452,7 +452,7 @@ extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
 extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
 extern int g_small_n; // fv_small.hip
-extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk, g_chunkd_np, g_chunkd_variant, g_ploop; // fv_fused.hip
+extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk, g_ploop; // fv_fused.hip
 
 // The selectors that are left after round 4's pruning (csrc/fv_tune.h): every value of every key gives correct
 // results — each names an alternative kernel or policy that the tests compare with the default — and the launch-shape / streaming-hint /
@@ -520,10 +520,6 @@ extern "C" int fv_tune(int key, int value)
         g_small_n = value;
     else if (key == 63 && (value == 0 || value == 1))
         g_ploop = value;
-    else if (key == 62 && (value % 10 == 4 || value % 10 == 5) && value / 10 <= 7) {
-        g_chunkd_np = value % 10;
-        g_chunkd_variant = value / 10;
-    }
     else
         return FV_ERR_ARG;
     return FV_OK;

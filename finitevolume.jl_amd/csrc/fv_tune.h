@@ -1,4 +1,4 @@
-// Private entry point of libfvhip.so: exported for the tools and tests of this repository, not declared in include/fvhip.h and not
+// Private entry points of libfvhip.so: exported for the tools and tests of this repository, not declared in include/fvhip.h and not
 // part of the drop-in boundary.
 #pragma once
 #ifdef __cplusplus
@@ -54,6 +54,13 @@ extern "C" {
  *   FV_AMG_GALERKIN=sort the AMG's Galerkin products by the global stable sort instead of the row merge (the same bits: tested)
  *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments) */
 int fv_tune(int key, int value);
+/* Test infrastructure, like fv_tune: the loopback transport for rehearsals of the row-block driver on ONE device (RCCL refuses two ranks on one
+ * GPU).  nranks host threads of one process, each with its own context on the same device, join the group `group_id`; halos then move by
+ * device-to-device copies and the reductions are summed on the host in rank order.  Same plan, kernels and call sequence as the RCCL path
+ * (fv_comm_init in include/fvhip.h).  Every rank's thread must make the same sequence of distributed calls.  Not part of the drop-in boundary
+ * (round 5: moved out of the public header). */
+struct fv_ctx;
+int fv_comm_init_local(struct fv_ctx *ctx, int nranks, int rank, int group_id);
 #ifdef __cplusplus
 }
 #endif

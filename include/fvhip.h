@@ -386,11 +386,6 @@ int fv_comm_diag_get(fv_ctx *ctx, double total_ms[5], int64_t counts[5]);
 /* Health check of the RCCL transport, to run once after fv_comm_init on every rank: a ring of ncclSend/ncclRecv (the halo
  * exchange's call pattern, on the halo stream) and an ncclAllReduce of `count` doubles; *ok = 1 when the data arrived. */
 int fv_comm_selftest(fv_ctx *ctx, int64_t count, int *ok);
-/* Loopback transport for rehearsals on ONE device (RCCL refuses two ranks on one GPU): nranks host threads of one
- * process, each with its own context on the same device, join the group `group_id`; halos then move by device-to-device
- * copies and the reductions are summed on the host in rank order.  Same plan, kernels and call sequence as the RCCL
- * path.  Every rank's thread must make the same sequence of distributed calls. */
-int fv_comm_init_local(fv_ctx *ctx, int nranks, int rank, int group_id);
 
 /* Row-block partition for one-process-per-GPU runs (no reference counterpart:
  * FiniteVolume.jl is single-process).  Call on a global problem after fv_assemble

@@ -30,7 +30,8 @@ def test_every_declared_symbol_is_exported_and_bound(fv):
     hdr = open(os.path.join(ROOT, "include", "fvhip.h")).read()
     assert "#define FVHIP_ABI_VERSION 4" in hdr
     # the experimenter's panel is exported for the tools, but it is not part of the public header
-    assert "fv_tune" not in declared and hasattr(lib, "fv_tune") and set(_lib.PRIVATE_SIGNATURES) == {"fv_tune"}
+    assert "fv_tune" not in declared and hasattr(lib, "fv_tune") and set(_lib.PRIVATE_SIGNATURES) == {"fv_tune", "fv_comm_init_local"}
+    assert "fv_comm_init_local" not in declared  # (round 5: the loopback transport of the rehearsals left the public header)
 
 
 def test_product_never_imports_the_oracle():
