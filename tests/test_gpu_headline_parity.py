@@ -131,10 +131,12 @@ def _check(tag, dev, sysm, sched, rtol, t_setup, want_fused=None):
            relerr(draw, sdraw), relerr(draw, rdraw), relerr(sdraw, rdraw)))
     assert rdraw.max() > 1e-4
     assert its_flat == sit  # the same algorithm at the same tolerance: the same iteration count on every step
-    # (the drawdown is a difference of heads near 1e3, each good to a few units in the last place — 1.1e-13 — at best: over N cells that is
-    # a floor of a few ulp sqrt(N) / ||drawdown|| under any comparison of two runs, 1e-6 at 320^3 with four iterations per step)
-    floor = 8 * np.spacing(1e3) * np.sqrt(len(head)) / np.linalg.norm(sdraw)
-    assert relerr(head, shead) < HEAD_RTOL and relerr(draw, sdraw) < max(DRAW_RTOL, floor), (relerr(draw, sdraw), floor)
+    # Device against (S), the same algorithm at the same tolerance: identical iteration counts, heads to rounding, and the drawdown to 1e-6 —
+    # or, on steps of several iterations, to 1e-3 of what that tolerance leaves undone ((S) against (R)): the one-launch iteration takes beta from
+    # r'.z' evaluated as a polynomial in the step length (kf_ploop_prologue), an equally valid realisation of the same iteration whose iterates
+    # differ from (S)'s by ~1e-9 of a step's change, far inside the solver's tolerance (the heads still agree to 4e-14)
+    bound = max(DRAW_RTOL, 1e-3 * relerr(sdraw, rdraw)) if max(its_flat) > 1 else DRAW_RTOL
+    assert relerr(head, shead) < HEAD_RTOL and relerr(draw, sdraw) < bound, (relerr(draw, sdraw), bound)
     assert relerr(head, rhead) < HEAD_RTOL
     # against the exact discrete solution the drawdown is as good as the tolerance the workload states — for the device and for
     # the CPU run of the same algorithm alike (their distance to (R) is the same to 1e-3 of itself)
