@@ -764,7 +764,11 @@ def multi_iteration_block(p, args):
            "GB/s": per_it_bytes / (ms_it * 1e-3) / 1e9, "frac_of_peak": per_it_bytes / (ms_it * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "frac_note": "frac_of_peak charges one loop iteration's bytes against wall time / iterations, i.e. it leaves the step's set-up and first pass unaccounted; `roofline` counts every launch of a step",
            "effective_csr_bytes_per_iteration": 12 * p.nnz + 20 * p.n + 88 * p.n, "kernels": {}}
-    for k, bytes_ in ((("spmv_dot", (loop - upd) * p.n), ("update", upd * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
+    pass_bytes = (loop - upd) * p.n
+    if upd == 0 and loop:  # the one-launch loop's live launches: per step one first pass (fv_step_form's bytes[1]) and iterations - 1 whole ones
+        b_first = p.step_form()[0][1]
+        pass_bytes = float(np.mean((b_first + np.maximum(np.asarray(iters, dtype=np.float64) - 1, 0) * loop) / np.maximum(iters, 1))) * p.n
+    for k, bytes_ in ((("spmv_dot", pass_bytes), ("update", upd * p.n)) if loop else (("spmv_dot", form_bytes), ("update", 56 * p.n), ("pupdate", 32 * p.n))):
         kms, kc = prof[k]
         if kc and bytes_:
             out["kernels"]["fused_pass" if (loop and k == "spmv_dot") else k] = {"avg_ms": kms / kc, "launches": kc, "GB/s": bytes_ / (kms / kc * 1e-3) / 1e9}
