@@ -158,6 +158,39 @@ SIGNATURES = {
 _lib = None
 
 
+def legacy_tune(raw):
+    """The library's panel has 18 keys since round 5 (csrc/fv_tune.h): families became bits of one key.  Tests and tools still name the members
+    by the numbers they had as keys of their own; this wrapper keeps the current masks (process-wide, like the panel itself) and translates
+        36, 37 -> bits 2, 4 of key 35 (35 itself: bit 1);   46, 49, 50, 55, 59, 63 -> bits 2, 4, 8, 16, 32, 64 of key 41 (41 itself: bit 1);
+        47 -> the tens digit of key 31 (31 itself: the units digit).
+    Every other key goes through unchanged; 52 (the AMG K-cycle) is the environment variable FV_AMG_KCYCLE now."""
+    state = {35: 7, 41: 127, 31: 1}
+    bits = {35: (35, 1), 36: (35, 2), 37: (35, 4), 41: (41, 1), 46: (41, 2), 49: (41, 4), 50: (41, 8), 55: (41, 16), 59: (41, 32), 63: (41, 64)}
+
+    def tune(key, value):
+        key, value = int(key), int(value)
+        if key in bits:
+            if value not in (0, 1):
+                return FV_ERR_ARG
+            k, b = bits[key]
+            new = (state[k] | b) if value else (state[k] & ~b)
+            rc = raw(k, new)
+            if rc == 0:
+                state[k] = new
+            return rc
+        if key in (31, 47):
+            if key == 31 and not 0 <= value <= 2 or key == 47 and value not in (0, 1):
+                return FV_ERR_ARG
+            new = (state[31] // 10) * 10 + value if key == 31 else (1 - value) * 10 + state[31] % 10
+            rc = raw(31, new)
+            if rc == 0:
+                state[31] = new
+            return rc
+        return raw(key, value)
+
+    return tune
+
+
 def load():
     """Load libfvhip.so (no GPU is touched until a context is created)."""
     global _lib
@@ -173,6 +206,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
+    lib.fv_tune_raw = lib.fv_tune
+    lib.fv_tune = legacy_tune(lib.fv_tune_raw)
     have = lib.fv_abi_version()
     if have != ABI_VERSION:  # a stale libfvhip.so (or a newer one): the signatures above would not match
         raise ImportError("libfvhip.so speaks ABI version %d, this binding expects %d: rebuild it (make -C finitevolume.jl_amd/csrc)" % (have, ABI_VERSION))

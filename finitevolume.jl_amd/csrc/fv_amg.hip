@@ -84,7 +84,13 @@ static int g_rounds = 10;     // handshake rounds per pass
 static int g_coarse_max = 1024;
 static int g_coarse_sweeps = 12; // Jacobi sweeps on a coarsest level too large for the dense inverse
 int g_amg_stream = 65536;       // (frozen; round 3 measured it) coarse levels with at least this many rows use the wave-stream CSR kernel (0: never)
-int g_amg_kcycle = 2;            // fv_tune key 52: coarse levels 1 .. g_amg_kcycle are solved by two flexible-CG steps preconditioned by the cycle below them (K-cycle)
+// FV_AMG_KCYCLE in the environment (round 5: was fv_tune key 52; read at every use, so a sweep may change it between solves): coarse levels
+// 1 .. k are solved by two flexible-CG steps preconditioned by the cycle below them (K-cycle; 0 = V-cycle) [2]
+static int amg_kcycle_levels()
+{
+    const char *e = getenv("FV_AMG_KCYCLE");
+    return e ? atoi(e) : 2;
+}
 
 extern "C" int fv_amg_configure(double theta, double omega, int passes, int rounds)
 {
@@ -1612,7 +1618,7 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
     }
     AmgLevel *C = a->lev[l + 1];
     const bool c_last = l + 2 == a->lev.size();
-    const bool c_kcycle = a->kcycle && (int)(l + 1) <= g_amg_kcycle && !c_last;
+    const bool c_kcycle = a->kcycle && (int)(l + 1) <= amg_kcycle_levels() && !c_last;
     double *u = l == 0 ? x : L->u.p; // the iterate before the last smoothing pass
     if (!first_ready) {
         hipLaunchKernelGGL(amg_smooth0_kernel, g, blk, 0, ctx->stream, L->n, (const double *)L->dinv.p, b, g_omega, u);
@@ -1662,12 +1668,12 @@ static int amg_cycle(fv_problem *p, size_t l, const double *b, double *x, double
 }
 
 // kcycle: the caller's PCG is flexible (row blocks: dist_amg_loop); fv_amg_apply keeps the fixed linear V-cycle
-bool fv_amg_kcycle_available(fv_problem *p) { return g_amg_kcycle > 0; }
+bool fv_amg_kcycle_available(fv_problem *p) { return amg_kcycle_levels() > 0; }
 int fv_amg_apply_device(fv_problem *p, const double *r, double *z, double sigma, bool kcycle)
 {
     FV_TRY(fv_amg_prepare(p, sigma));
     p->amg->fold = false;
-    p->amg->kcycle = kcycle && g_amg_kcycle > 0 && p->amg->lev.size() > 2;
+    p->amg->kcycle = kcycle && amg_kcycle_levels() > 0 && p->amg->lev.size() > 2;
     return amg_cycle(p, 0, r, z, sigma);
 }
 
@@ -1782,7 +1788,7 @@ int fv_amg_pcg_loop(fv_problem *p, double *x, double sigma, bool fold, int64_t m
     if (hs->done || maxiter <= 0)
         return FV_OK;
     const bool fused_dot = a->lev.size() > 1; // a single-level "hierarchy" (tiny problem) ends in the dense solve, not in a smoothing pass
-    a->kcycle = g_amg_kcycle > 0 && a->lev.size() > 2;
+    a->kcycle = amg_kcycle_levels() > 0 && a->lev.size() > 2;
     const bool flexible = a->kcycle && fused_dot;
     FV_TRY(amg_cycle(p, 0, p->r.p, a->z.p, sigma, fused_dot ? p->part_rz.p : nullptr));
     if (!fused_dot)

@@ -2066,7 +2066,7 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     double best = -1.0;
     int64_t bestK = kmin, bestC = cmax;
     int bestm = 1;
-    for (int64_t K = kmin; K <= kmin + 8; K++) {
+    for (int64_t K = kmin; K <= 4 * kmin + 8; K++) { // (small operators: more, shorter chunks leave segments of more planes — fewer prologue steps per product plane)
         const int64_t Cr = ((d3 + K - 1) / K + 15) / 16 * 16;
         if (Cr > cmax || Cr < 2 * nz)
             continue;

@@ -450,7 +450,6 @@ extern int g_comm_single_rank_collectives; // fv_comm.hip
 extern int g_defer_reduce, g_k2s_nt, g_cg_one_reduction, g_uniform_storage, g_zform, g_minv_codes; // fv_pcg.hip
 extern int g_reorder, g_reorder_device;     // fv_assembly.hip
 extern int g_reorder_blocks;                // fv_reorder.hip
-extern int g_amg_kcycle, g_amg_stream; // fv_amg.hip
 extern int g_small_n; // fv_small.hip
 extern int g_fused, g_fused_iter, g_fused_codes, g_fused_dist, g_fused_sell, g_fused_chunk, g_ploop; // fv_fused.hip
 
@@ -482,44 +481,33 @@ extern "C" int fv_tune(int key, int value)
         g_march_form = value >= 2;
         g_symdia = value >= 3;
         g_sym_tile = value >= 4;
-    } else if (key == 31 && value >= 0 && value <= 2)
-        g_reorder = value;
-    else if (key == 33 && (value == 0 || value == 1))
+    } else if (key == 31 && value >= 0 && value % 10 <= 2 && value / 10 <= 1) { // units: the re-numbering policy; tens: 1 = computed by the host routine
+        g_reorder = value % 10;
+        g_reorder_device = value / 10 == 0;
+    } else if (key == 33 && (value == 0 || value == 1))
         g_resume_runs = value;
     else if (key == 34 && (value == 0 || value == 1))
         g_cg_one_reduction = value;
-    else if (key == 35 && (value == 0 || value == 1))
-        g_uniform_storage = value;
-    else if (key == 36 && (value == 0 || value == 1))
-        g_zform = value;
-    else if (key == 37 && (value == 0 || value == 1))
-        g_sym_rowsum = value;
-    else if (key == 41 && (value == 0 || value == 1))
-        g_fused = value;
-    else if (key == 46 && (value == 0 || value == 1))
-        g_fused_iter = value;
-    else if (key == 47 && (value == 0 || value == 1))
-        g_reorder_device = value;
-    else if (key == 49 && (value == 0 || value == 1))
-        g_fused_codes = value;
-    else if (key == 50 && (value == 0 || value == 1))
-        g_fused_dist = value;
-    else if (key == 52 && value >= 0 && value <= 8)
-        g_amg_kcycle = value;
-    else if (key == 54 && (value == 0 || value == 1))
+    else if (key == 35 && value >= 0 && value <= 7) { // bit 0: the storage term as codes, bit 1: K2S in the z-form, bit 2: zero row sum (the diagonal from the arms)
+        g_uniform_storage = value & 1;
+        g_zform = (value >> 1) & 1;
+        g_sym_rowsum = (value >> 2) & 1;
+    } else if (key == 41 && value >= 0 && value <= 127) { // the fused family, one bit per member (fv_tune.h)
+        g_fused = value & 1;
+        g_fused_iter = (value >> 1) & 1;
+        g_fused_codes = (value >> 2) & 1;
+        g_fused_dist = (value >> 3) & 1;
+        g_fused_sell = (value >> 4) & 1;
+        g_minv_codes = (value >> 5) & 1;
+        g_ploop = (value >> 6) & 1;
+    } else if (key == 54 && (value == 0 || value == 1))
         g_sell = value;
-    else if (key == 55 && (value == 0 || value == 1))
-        g_fused_sell = value;
-    else if (key == 59 && (value == 0 || value == 1))
-        g_minv_codes = value;
     else if (key == 60 && value >= 0 && value <= 2) { // 1: chunks, the first / last plane's products included; 2: chunks, those planes by the slice-by-slice launch; 0: tiles
         g_fused_chunk = value != 0;
         g_chunk_ends = value == 1;
     }
     else if (key == 61 && value >= 0)
         g_small_n = value;
-    else if (key == 63 && (value == 0 || value == 1))
-        g_ploop = value;
     else
         return FV_ERR_ARG;
     return FV_OK;

@@ -4,8 +4,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* Process-wide selectors for differential tests and A/B measurements (defaults in brackets).  Round 4 pruned the panel (VERDICT r3
- * item 7): of the 55 keys of round 3 the launch-shape, streaming-hint and diagnosis experiments are gone — frozen at their measured
+/* Process-wide selectors for differential tests and A/B measurements (defaults in brackets).  Round 5 folded the panel into 18 keys (the
+ * members of a family are bits of one key); round 4 had pruned it: of the 55 keys of round 3 the launch-shape, streaming-hint and diagnosis experiments are gone — frozen at their measured
  * best, the tools that drove them deleted, their logs kept under profiles/ — among them the two keys whose settings gave wrong
  * results by design (17, 29).  EVERY value of EVERY key below gives correct results: each names an alternative kernel, storage form
  * or policy that a test compares with the default.  Not synchronised: set it while no call of the library is in flight; tests and
@@ -25,32 +25,32 @@ extern "C" {
  *  25: print the next N choices between the SpMV kernels to stderr (also FV_TRACE_SPMV=N in the environment) [0]
  *  27: the richest SpMV form a structured operator may take: 0 CSR wave-stream, 1 + sliced-DIA slice by slice, 2 + plane-marching
  *      sliced-DIA, 3 + symmetric plane-marching (diagonal + three upper diagonals), 4 + its tiled traversal [4]
- *  31: process-wide default of FV_OPT_REORDER (fv_ctx_set_option) for contexts that have not set it: 0 never, 1 when the mesh is
- *      numbered far worse than its size needs and the new order at least halves the mean face distance, 2 always [1]
+ *  31: the locality re-numbering of face-list meshes — units digit: process-wide default of FV_OPT_REORDER (fv_ctx_set_option) for contexts that
+ *      have not set it: 0 never, 1 when the mesh is numbered far worse than its size needs and the new order at least halves the mean face
+ *      distance, 2 always; tens digit: 1 = computed by the host routine instead of fv_reorder.hip (the same order) [1]
  *  33: a fixed-dt run goes on from the residual, the prepared set-up and the refresh count the previous call on the same slot left [1]
  *  34: PCG of the row-block driver: 0 = the classic two-reduction form north_star names, 1 = Chronopoulos-Gear's one-reduction form [0]
- *  35: the storage term Ss * volumes as one-byte codes (at most 16 distinct values) or one double instead of its stream [1]
- *  36: K2S in the z-form (only z = M^-1 r kept between two one-iteration steps) [1]
- *  37: zero row sum: slices whose stored diagonal is, bit for bit, minus the sum of the row's six arms (+ the folded sigma D by the
- *      row's storage code) are computed without the diagonal stream [1]
- *  41: the fused step (fv_fused_form) in bursts of one-iteration steps where it applies; 0 = K1 + K2S [1]
- *  46: the many-iteration PCG loop through the fused kernel (fv_loop_form); 0 = K1 + K2 + K3 [1]
- *  47: the locality re-numbering computed on the device (fv_reorder.hip) [1]; 0 = by the host routine (the same order)
- *  49: the three upper diagonals as one 16-bit word of codes per row where each takes at most 32 distinct values [1]; 0 = doubles
- *  50: the fused step on row blocks (fv_dist_run_fixed) [1]; 0 = row blocks keep the K1 + K2S pair
- *  52: AMG K-cycle on the coarse levels 1 .. value (the PCG around it becomes flexible) [2]; 0 = V-cycle
+ *  35: bits [7] — 1: the storage term Ss * volumes as one-byte codes (at most 16 distinct values) or one double instead of its stream;
+ *      2: K2S in the z-form (only z = M^-1 r kept between two one-iteration steps); 4: zero row sum — slices whose stored diagonal is, bit for
+ *      bit, minus the sum of the row's six arms (+ the folded sigma D by the row's storage code) are computed without the diagonal stream
+ *  41: the fused family, bits [127] — 1: the fused step (fv_fused_form) in bursts of one-iteration steps (0 = K1 + K2S); 2: the many-iteration PCG
+ *      loop through the fused kernel (fv_loop_form; 0 = K1 + K2 + K3); 4: the three upper diagonals as one 16-bit word of codes per row where each
+ *      takes at most 32 distinct values (0 = doubles); 8: the fused step on row blocks (fv_dist_run_fixed); 16: the fused step on the SELL form
+ *      (irregular meshes); 32: M^-1 as one-byte codes in the vector pass of the many-iteration loop; 64: a PCG iteration as ONE launch on whole
+ *      regular boxes (round 5, fv_loop_form 89 / 67; 0 = the pass + vector-update pair)
  *  54: SELL-64 with 16-bit column offsets (FV_SPMV_SELL) for the groups the CSR wave-stream kernel would serve [1]
- *  55: the fused step on the SELL form (irregular meshes) [1]
- *  59: M^-1 as one-byte codes in the vector pass of the many-iteration loop where it takes at most 16 distinct values [1]
- *  60: the coded fused step / pass on contiguous chunks of a plane (fused_chunk_kernel): 1 = with the first / last plane's products formed by it
- *      too [1], 2 = those planes by the slice-by-slice launch, 0 = the 2-D tiles
+ *  60: the fused step / pass on contiguous chunks of a plane (fused_chunk_kernel, fused_chunkd_kernel): 1 = with the first / last plane's products
+ *      formed by it too [1], 2 = those planes by the slice-by-slice launch, 0 = the 2-D tiles
  *  61: systems of at most this many rows are solved by the single-launch kernel of fv_small.hip [32768]; 0 = never
+ * 18 keys (round 4: 27; round 3: 55).  The tests and tools still name the members of keys 31 / 35 / 41 by the numbers they had as keys of their own
+ * (36, 37, 46, 47, 49, 50, 55, 59, 63): the Python binding translates them into the bits above (finitevolume.jl_amd/_lib.py, legacy_tune).
  *
  * Environment variables the library reads besides FV_TUNE (diagnostics and one differential switch, none changes a result):
  *   FV_TRACE_SPMV=N / FV_TRACE_FUSED=1 / FV_TRACE_REORDER=1  print kernel choices, fused-step eligibility, re-numbering decisions to stderr
  *   FV_TRACE_ALLOC=1     every device allocation / release that takes more than 0.1 ms, to stderr
  *   FV_AMG_VERBOSE=1     the AMG set-up phase by phase, to stderr
  *   FV_SMALL_TWOSTEP=0   small systems: the three solves of a step-doubling attempt one by one instead of in one launch (the same bits: tested)
+ *   FV_AMG_KCYCLE=k      AMG K-cycle on the coarse levels 1 .. k (the PCG around it becomes flexible) [2]; 0 = V-cycle (round 5: was fv_tune key 52)
  *   FV_AMG_GALERKIN=sort the AMG's Galerkin products by the global stable sort instead of the row merge (the same bits: tested)
  *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments) */
 int fv_tune(int key, int value);

@@ -38,7 +38,7 @@ if os.environ.get("FV_AMG_SWEEP") == "5":  # round 4 (rows without a candidate l
 for cfg in configs:
     theta, omega, passes, rounds = cfg[:4]
     kc = cfg[4] if len(cfg) > 4 else 0
-    lib.fv_tune(52, kc)
+    os.environ["FV_AMG_KCYCLE"] = str(kc)  # (round 5: the K-cycle's depth is an environment variable, read at every use)
     lib.fv_amg_configure(theta, omega, passes, rounds)
     p.assemble(Kf, np.zeros(p.N), dh, None, True)  # (a new assembly epoch: the hierarchy is rebuilt with the new parameters)
     p.set_preconditioner("amg")
