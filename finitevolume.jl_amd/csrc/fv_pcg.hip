@@ -169,6 +169,9 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_init_finalize_kernel(const doubl
         scal->pq = 0.0;
         scal->iters = 0;
         scal->done = (rr <= scal->tol2) ? 1 : 0;
+        scal->xlag = -1; // no x-update is pending at a set-up.  (A freshly zeroed block says 0 = "iteration 0's update is pending": a solve that is converged
+                         // at its set-up while its chunk of launches enqueued a w-form update then sent pcg_xflush_kernel through a null lag_p — a fault
+                         // tools/ploop_fuzz.py found in round 5, in the pair path of round 4)
     }
 }
 
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(FV_BLOCK) void pcg_update_w_kernel(int64_t n, int i
 // down — the host cannot know at which launch), then pcg_xflush_clear_kernel marks it done.
 __global__ __launch_bounds__(FV_BLOCK) void pcg_xflush_kernel(int64_t n, double *__restrict__ x, const PcgScalars *__restrict__ scal)
 {
-    if (scal->xlag < 0)
+    if (scal->xlag < 0 || !scal->lag_p)
         return;
     const double alpha = scal->alpha_last;
     const double *__restrict__ pv = scal->lag_p;
@@ -1533,6 +1536,9 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         acct = k1_form_bytes(p) + 56 * n;
     if (!resume && !use_spec)
         p->z_where = 0; // every other set-up has written r
+    if (take_pending_acct)
+        p->z_where = 1; // ... but pcg_carry_flush_kernel writes z0 = M^-1 r0 (pvec) alone: should the step be converged at its set-up, the next
+                        // carried set-up finds the residual there (found by tools/ploop_fuzz.py: loose steps behind a several-iteration step read a stale r)
     if (!resume)
         if (!(chained && sys.chain_index > 0 && (g_defer_reduce || was_vready))) // ... unless the previous chained step's boundary launch wrote them (or this step's fused launch will)
             hipLaunchKernelGGL(pcg_init_finalize_kernel, dim3(1), dim3(FV_BLOCK), 0, ctx->stream, in_rz, in_rr, in_bb, Ginit, rtol, p->scal.p,

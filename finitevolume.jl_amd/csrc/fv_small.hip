@@ -55,7 +55,7 @@ struct GridBarrier {
             atomicAdd(bar, 1u);
             long spins = 0;
             while ((int32_t)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > 200000000L) {
+                if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || ++spins > 4000000L) {
                     atomicExch(bar + 1, 1u);
                     break;
                 }
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small3_kernel(Small3Args a3)
     const double *one = a3.s[0].x, *two = a.x;
     double acc = 0.0;
     for (int64_t i = lo + threadIdx.x; i < hi; i += SM_BLOCK) {
-        const double d = (a3.w ? a3.w[i] : 1.0) * (one[i] - two[i]);
+        const double d = a3.w ? a3.w[i] * one[i] - a3.w[i] * two[i] : one[i] - two[i]; // (the expression of wdiff_kernel / diff2_kernel: the same accept / reject decisions)
         acc += d * d;
     }
     const double t = small_block_sum(acc, smem);
@@ -283,6 +283,17 @@ __global__ __launch_bounds__(SM_BLOCK) void pcg_small3_kernel(Small3Args a3)
 }
 
 } // namespace
+
+// Blocks of the single-launch kernels that can be resident at once: what the occupancy query says the kernel's own registers and LDS allow per
+// CU (the CU count alone says nothing about that), times the CUs; the grid barrier needs every block resident.  A GPU shared with
+// other processes can still fall short: the barrier's spin is bounded (~0.2 s) and the launch then reports FV_ERR_STATE.
+static int small_resident_blocks(fv_ctx *ctx, const void *kernel)
+{
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, SM_BLOCK, 0) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    return per_cu * ctx->num_cus;
+}
 
 bool fv_pcg_small_takes(const fv_problem *p, const PcgSystem &sys)
 {
@@ -318,8 +329,8 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     // loads (row pointer, column, vector entry) — with eight rows per thread a pass over 15 650 rows took 16 us, the whole solve 46
     int G = (int)((n + SM_BLOCK - 1) / SM_BLOCK);
     G = G < 1 ? 1 : (G > SM_MAXG ? SM_MAXG : G);
-    if (G > ctx->num_cus) // (every block must be resident for the barrier)
-        G = ctx->num_cus;
+    if (G > small_resident_blocks(ctx, reinterpret_cast<const void *>(&pcg_small_kernel))) // (every block must be resident for the barrier)
+        G = small_resident_blocks(ctx, reinterpret_cast<const void *>(&pcg_small_kernel));
     a.G = G;
     a.rows_per_block = (n + G - 1) / G;
     a.rowptr = p->rowptr.p;
@@ -399,7 +410,9 @@ int fv_pcg_small(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
 
 bool fv_small_twostep_takes(const fv_problem *p, int mode, double dt)
 {
-    const char *e = getenv("FV_SMALL_TWOSTEP"); // =0 (differential tests): the solves one by one
+    // =0 (differential tests): the solves one by one.  Read at every attempt on purpose — the test flips it inside one process —; a getenv is ~0.1 us
+    // beside an attempt of ~100 (ADVICE r4 asked for a cache: it would freeze the switch)
+    const char *e = getenv("FV_SMALL_TWOSTEP");
     if ((e && atoi(e) == 0) || mode == FV_STEP_ADJOINT || !(dt > 0) || !p->D.p)
         return false;
     PcgSystem sys;
@@ -431,8 +444,8 @@ int fv_small_twostep(fv_problem *p, int mode, const double *const rhs[3], bool b
     const int64_t n = p->n;
     int G = (int)((n + SM_BLOCK - 1) / SM_BLOCK);
     G = G < 1 ? 1 : (G > SM_MAXG ? SM_MAXG : G);
-    if (G > ctx->num_cus)
-        G = ctx->num_cus;
+    if (G > small_resident_blocks(ctx, reinterpret_cast<const void *>(&pcg_small3_kernel)))
+        G = small_resident_blocks(ctx, reinterpret_cast<const void *>(&pcg_small3_kernel));
     Small3Args a3{};
     const uint32_t seq = p->small_seq + 1;
     p->small_seq += 2;

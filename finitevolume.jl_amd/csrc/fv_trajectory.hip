@@ -41,8 +41,8 @@ struct fv_observation {
 
 namespace {
 
-__global__ __launch_bounds__(FV_BLOCK) void traj_copy_kernel(int64_t n, const double *__restrict__ src, const double *__restrict__ scale,
-                                                              double *__restrict__ dst)
+__global__ __launch_bounds__(FV_BLOCK) void traj_copy_kernel(int64_t n, const double *src, const double *__restrict__ scale,
+                                                              double *dst) // (src may be dst: fv_adjoint_run scales a knot in place)
 {
     for (int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x; i < n; i += vec_stride())
         dst[i] = scale ? scale[i] * src[i] : src[i];

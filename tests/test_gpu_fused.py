@@ -300,6 +300,12 @@ def test_one_launch_iterations_against_the_pass_and_update_pair_and_the_oracle(f
         ous, ots = oracle.backwardeulerintegrate(u, (t, t + dt * steps), 0.1, vol, nb[:, 0], nb[:, 1], aol, K, src, dn, dh, stepper=oracle.fixedbackwardeulerstep,
                                                  dt0=dt, linearsolver=oracle.tightcgsolver(1e-14))
         u, t = ous[-1], ots[-1]
+    # loose steps behind several-iteration steps: the step after a deferred flush is converged at its set-up, and the one after that must find the
+    # residual where the flush + set-up kernel left it (tools/ploop_fuzz.py, seed 7)
+    loose = [(600.0, 8, 1e-3), (1.0, 5, 1e-8), (DT, 6, 1e-12), (60.0, 8, 1e-3), (4000.0, 3, 1e-12)]
+    lon = _run(fv, case, True, loose)
+    loff = _run(fv, case, True, loose, tune=((63, 0),))
+    assert np.abs(lon[1].astype(int) - loff[1].astype(int)).max() <= 1 and relerr(lon[0], loff[0]) < 1e-10, (lon[1], loff[1], relerr(lon[0], loff[0]))
     tight = _run(fv, case, True, sched[:3])
     assert relerr(tight[0], u) < 1e-8 and relerr(tight[0] - u0, u - u0) < 1e-6
     tight_off = _run(fv, case, True, sched[:3], tune=((63, 0),))  # (the loop forms of a schedule that ends with many-iteration steps)

@@ -15,10 +15,10 @@ from __graft_entry__ import load_package  # noqa: E402
 import bench  # noqa: E402
 
 
-def run(fv, nseeds=12, verbose=True):
+def run(fv, nseeds=12, verbose=True, first=0, trace=False):
     lib = fv.load()
     bad = 0
-    for seed in range(nseeds):
+    for seed in range(first, first + nseeds):
         rng = np.random.default_rng(1000 + seed)
         ns = [int(rng.integers(36, 50)), int(rng.integers(184, 200)), 2 * int(rng.integers(93, 105))]
         mins, maxs = bench.spacing_box(ns)
@@ -44,6 +44,8 @@ def run(fv, nseeds=12, verbose=True):
                 p.record(tr)
             its, forms = [], []
             for dt, k, rtol in schedule:
+                if trace:
+                    print("  seed %d %s: %d steps of dt %g at rtol %g ..." % (seed, name, k, dt, rtol), flush=True)
                 it, info, _ = p.run_fixed(st, dt, k, rtol, maxiter=5000)
                 assert info.converged
                 its.append(it.copy())
@@ -74,4 +76,5 @@ def run(fv, nseeds=12, verbose=True):
 if __name__ == "__main__":
     fv_ = load_package()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    print("mismatches:", run(fv_, n))
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # usage: ploop_fuzz.py [nseeds [first seed [trace]]]
+    print("mismatches:", run(fv_, n, first=first, trace=len(sys.argv) > 3))
