@@ -51,7 +51,11 @@ def run(fv, nseeds=12, tight=False, verbose=True):
         loose = float(os.environ.get("FV_FUZZ_RTOL", "1e-11")) if os.environ.get("FV_FUZZ_TILE") else 0.0
         for name, (state, its) in out.items():
             same = np.array_equal(state, ref[0]) if loose == 0.0 else np.abs(state - ref[0]).max() <= loose * np.abs(ref[0]).max()
-            if not (same and np.array_equal(its, ref[1])):
+            # (tile-sized boxes since round 5: steps of several iterations run as one launch per iteration, whose verdict uses r'.r' as a polynomial in
+            # the step length — at rtol 1e-13, where the residual sits at the rounding of the heads, two runs whose states differ in the last bits may
+            # stop one iteration apart)
+            same_its = np.array_equal(its, ref[1]) if loose == 0.0 else (np.abs(its.astype(int) - ref[1].astype(int)) <= (ref[1] >= 2)).all()
+            if not (same and same_its):
                 bad += 1
                 d = np.nonzero(its != ref[1])[0]
                 print("seed %d %s: MISMATCH max |diff| %.3e, first differing step %s, schedule %s" % (seed, name, np.abs(state - ref[0]).max(), d[:3], schedule), flush=True)
