@@ -1829,11 +1829,7 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
     const bool gathered = kind == FV_PRECOND_AMG_GATHERED;
     if (gathered)
         kind = FV_PRECOND_AMG; // (the same solver paths; the hierarchy differs: amg_build_pooled)
-    if (p->amg && p->amg_gathered != gathered) { // another hierarchy
-        fv_amg_free(p->amg);
-        p->amg = nullptr;
-    }
-    p->amg_gathered = gathered;
+    // (validation first, state afterwards: a refused call leaves the problem's preconditioner and hierarchy as they were — ADVICE r4)
     if (kind != FV_PRECOND_JACOBI && p->nhalo && !p->dist) {
         fv_set_error(p->ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;
@@ -1842,6 +1838,11 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
         fv_set_error(p->ctx, "row blocks take FV_PRECOND_JACOBI or FV_PRECOND_AMG (every rank must make the same choice: no automatic switch)");
         return FV_ERR_ARG;
     }
+    if (p->amg && p->amg_gathered != gathered) { // another hierarchy
+        fv_amg_free(p->amg);
+        p->amg = nullptr;
+    }
+    p->amg_gathered = gathered;
     p->precond = kind;
     p->auto_steps_amg = false;
     return FV_OK;

@@ -1440,7 +1440,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (p->pl_pending.valid) {
         bool codes = false;
         if (!resume && !use_spec && sys.implicit_step && sys.carry_prev && !compute_minv && !sys.b_times_D && x == p->pl_pending.x && maxiter > 0 &&
-            (sys.rhs == p->b.p || !sys.rhs) && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && fv_ploop_applicable(p, sigma, folded != nullptr))
+            sys.rhs == p->b.p && fv_step_precond_of(p, sys) != FV_PRECOND_AMG && fv_ploop_applicable(p, sigma, folded != nullptr))
             FV_TRY(ensure_carry_codes(p, &codes, &vtab));
         take_pending = codes;
         if (!take_pending) {
@@ -1647,7 +1647,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         } else if (hs->done == 0 && j >= 1)
             itf = j; // out of iterations: every launch ran its pass
         bool deferred = false;
-        if (itf >= 1 && have_alpha && sys.defer_flush && sys.implicit_step && xdst != x && (sys.rhs == p->b.p || !sys.rhs) && !sys.b_times_D) {
+        if (itf >= 1 && have_alpha && sys.defer_flush && sys.implicit_step && xdst != x && sys.rhs == p->b.p && !sys.b_times_D // (the flush + set-up kernel reads the assembled b by its support)) {
             // the next call is the carried step behind this one: its set-up applies the update (pcg_carry_flush_kernel)
             bool codes = false;
             StorageTable tmp{};
