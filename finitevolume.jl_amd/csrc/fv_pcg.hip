@@ -1647,7 +1647,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
         } else if (hs->done == 0 && j >= 1)
             itf = j; // out of iterations: every launch ran its pass
         bool deferred = false;
-        if (itf >= 1 && have_alpha && sys.defer_flush && sys.implicit_step && xdst != x && sys.rhs == p->b.p && !sys.b_times_D // (the flush + set-up kernel reads the assembled b by its support)) {
+        if (itf >= 1 && have_alpha && sys.defer_flush && sys.implicit_step && xdst != x && sys.rhs == p->b.p && !sys.b_times_D) { // (the flush + set-up kernel reads the assembled b by its support)
             // the next call is the carried step behind this one: its set-up applies the update (pcg_carry_flush_kernel)
             bool codes = false;
             StorageTable tmp{};
