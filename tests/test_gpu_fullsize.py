@@ -194,6 +194,50 @@ def test_synthetic_464_cubed_transient_properties(fv):
     assert nodes[c1, c2].min() == nodes.min() and nodes[c1, c2].max() < 1e3 - 0.4
 
 
+def test_synthetic_464_cubed_heterogeneous_properties(fv):
+    """Round 5: the 10^8-cell transient with a conductivity per face (what every input of the reference has: src/FiniteVolume.jl:75-108) through the
+    kernels of this round at full size — the fused step on chunks with the matrix as doubles (dt = 7.5 s, one iteration per step) and the one-launch
+    PCG iteration with the flush deferred into the next step's set-up (dt = 60 s, several iterations per step).  Size-independent properties: without
+    pumping the initial state is a fixed point; the drawdowns of Q and 2Q scale by exactly 2 to the solver tolerance; pumping only lowers heads; and
+    the one-launch loop gives the pass + update pair's heads (1e-10) with iteration counts within one."""
+    ns = [464, 464, 464]
+    mins, maxs = bench.spacing_box(ns)
+    dn, src = bench.box_setup(ns)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    K = bench.hetero_face_K(ns, p.F, p.N)  # (a smooth unit-variance field evaluated from the cell indices: no 5 GB of face ends on the host)
+    dh = np.full(len(dn), 1e3)
+    u0 = np.full(p.N, 1e3)
+    lib = fv.load()
+    p.assemble(K, np.zeros(p.N), dh)
+    st = p.transient_begin(0.1, None, u0)
+    iters, info, _ = p.run_fixed(st, 60.0, 3, 1e-10)
+    assert info.converged and np.abs(st.free_values() - 1e3).max() < 1e-9
+    draw, its, forms = [], [], []
+    for q, key in ((1.0, 1), (2.0, 1), (1.0, 0)):
+        assert lib.fv_tune(63, key) == 0
+        try:
+            p.assemble(K, q * src, dh)
+            st = p.transient_begin(0.1, None, u0)
+            f0 = p.fused_form()[0]
+            i1, info1, _ = p.run_fixed(st, 7.5, 12, 1e-10)
+            fused = (p.fused_form()[0] - f0, p.fused_form()[1], p.fused_traversal())
+            i2, info2, _ = p.run_fixed(st, 60.0, 6, 1e-10)
+        finally:
+            lib.fv_tune(63, 1)
+        assert info1.converged and info2.converged and p.spmv_form()[0] == 4
+        its.append((i1.copy(), i2.copy()))
+        forms.append((fused, p.loop_form()))
+        draw.append(1e3 - st.free_values())
+    assert (its[0][0] == 1).all() and forms[0][0][0] >= 9 and forms[0][0][1] == 73 and forms[0][0][2] == 1, forms[0]  # the fused step, doubles, on chunks
+    assert (its[0][1] >= 2).all() and forms[0][1] == 89 and forms[2][1] == 105, forms  # one launch per iteration / the pair
+    assert draw[0].max() > 1e-4 and draw[0].min() > -2.5e-6
+    assert np.linalg.norm(draw[1] - 2 * draw[0]) / (1e3 * np.sqrt(p.n)) < 1e-8
+    assert np.linalg.norm(draw[1] - 2 * draw[0]) / np.linalg.norm(draw[1]) < 1e-3
+    assert np.abs(its[0][1].astype(int) - its[2][1].astype(int)).max() <= 1
+    assert np.abs(draw[0] - draw[2]).max() <= 1e-10 * 1e3, np.abs(draw[0] - draw[2]).max()
+    p.close()
+
+
 def test_bench_decomposition_eight_slab_assembled_ranks(fv):
     """bench.py --gpus 8 in small: 464 x 232 x 232 cells cut into the bench's eight x-slabs of 58 planes, every rank
     assembling only its own planes, the row-block driver with the merged 6-double all-reduce over the loopback transport
