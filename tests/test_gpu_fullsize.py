@@ -232,7 +232,9 @@ def test_synthetic_464_cubed_heterogeneous_properties(fv):
     assert (its[0][1] >= 2).all() and forms[0][1] == 89 and forms[2][1] == 105, forms  # one launch per iteration / the pair
     assert draw[0].max() > 1e-4 and draw[0].min() > -2.5e-6
     assert np.linalg.norm(draw[1] - 2 * draw[0]) / (1e3 * np.sqrt(p.n)) < 1e-8
-    assert np.linalg.norm(draw[1] - 2 * draw[0]) / np.linalg.norm(draw[1]) < 1e-3
+    # (relative to the drawdown itself the bar is the solver's tolerance: rtol 1e-10 is relative to ||rhs|| ~ D 1e3 / dt, which does not scale with Q, and
+    # leaves ~1e-2 of a step's change undone on this field — tests/test_gpu_headline_parity.py measures 9e-3 against the exact discrete solution)
+    assert np.linalg.norm(draw[1] - 2 * draw[0]) / np.linalg.norm(draw[1]) < 5e-2
     assert np.abs(its[0][1].astype(int) - its[2][1].astype(int)).max() <= 1
     assert np.abs(draw[0] - draw[2]).max() <= 1e-10 * 1e3, np.abs(draw[0] - draw[2]).max()
     p.close()
