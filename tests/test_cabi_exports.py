@@ -330,3 +330,34 @@ def test_julia_shim_blocks_brackets_and_strings_balance():
                 prev = text
         assert not stack, "%s: unclosed %s" % (rel[-1], stack[-3:])
         assert not blocks, "%s: blocks never closed: %s" % (rel[-1], blocks[-5:])
+
+
+def test_legacy_tune_translates_the_historical_key_numbers_into_the_panel_s_bits(fv):
+    """csrc/fv_tune.h has 18 keys since round 5: the members of a family are bits of one key (41: the fused family, 35: storage codes / z-form /
+    zero row sum, 31: the re-numbering's policy and where it is computed).  Tests and tools still name the members by the numbers they had as keys
+    of their own; `_lib.legacy_tune` keeps the masks and translates.  Checked against a recording stand-in for the library's entry point."""
+    from fvamd import _lib
+
+    calls = []
+
+    def raw(k, v):
+        calls.append((k, v))
+        return 0 if (k, v) != (41, -1) else 1
+
+    t = _lib.legacy_tune(raw)
+    assert t(46, 0) == 0 and calls[-1] == (41, 127 & ~2)
+    assert t(63, 0) == 0 and calls[-1] == (41, 127 & ~2 & ~64)
+    assert t(46, 1) == 0 and calls[-1] == (41, 127 & ~64)
+    assert t(41, 0) == 0 and calls[-1] == (41, 127 & ~64 & ~1)
+    assert t(49, 0) == 0 and t(50, 0) == 0 and t(55, 0) == 0 and t(59, 0) == 0 and calls[-1] == (41, 2)  # (bit 2, the fused-pass loop, was switched on again above)
+    assert t(36, 0) == 0 and calls[-1] == (35, 5) and t(37, 0) == 0 and calls[-1] == (35, 1) and t(35, 0) == 0 and calls[-1] == (35, 0)
+    assert t(47, 0) == 0 and calls[-1] == (31, 11) and t(31, 2) == 0 and calls[-1] == (31, 12) and t(47, 1) == 0 and calls[-1] == (31, 2)
+    assert t(13, 3) == 0 and calls[-1] == (13, 3)  # every other key goes through unchanged
+    assert t(46, 2) == _lib.FV_ERR_ARG and t(31, 5) == _lib.FV_ERR_ARG  # members take 0 / 1, the policy 0 .. 2
+    # the panel's documentation names exactly the keys the library accepts
+    hdr = open(os.path.join(ROOT, "finitevolume.jl_amd", "csrc", "fv_tune.h")).read()
+    documented = sorted(int(k) for k in re.findall(r"^ \*\s+(\d+): ", hdr, flags=re.M))
+    src = open(os.path.join(ROOT, "finitevolume.jl_amd", "csrc", "fv_spmv.hip")).read()
+    body = src[src.index('extern "C" int fv_tune(int key, int value)'):src.index("// lanes per row from the mean row length")]
+    accepted = sorted(set(int(k) for k in re.findall(r"key == (\d+)", body)))
+    assert documented == accepted and len(accepted) == 18, (documented, accepted)
