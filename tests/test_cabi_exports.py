@@ -356,7 +356,7 @@ def test_legacy_tune_translates_the_historical_key_numbers_into_the_panel_s_bits
     assert t(46, 2) == _lib.FV_ERR_ARG and t(31, 5) == _lib.FV_ERR_ARG  # members take 0 / 1, the policy 0 .. 2
     # the panel's documentation names exactly the keys the library accepts
     hdr = open(os.path.join(ROOT, "finitevolume.jl_amd", "csrc", "fv_tune.h")).read()
-    documented = sorted(int(k) for k in re.findall(r"^ \*\s+(\d+): ", hdr, flags=re.M))
+    documented = sorted(int(k) for k in re.findall(r"^ \* {2,3}(\d+): ", hdr, flags=re.M))
     src = open(os.path.join(ROOT, "finitevolume.jl_amd", "csrc", "fv_spmv.hip")).read()
     body = src[src.index('extern "C" int fv_tune(int key, int value)'):src.index("// lanes per row from the mean row length")]
     accepted = sorted(set(int(k) for k in re.findall(r"key == (\d+)", body)))
