@@ -728,10 +728,9 @@ __global__ __launch_bounds__(TL * 64, 4) void fused_step_kernel(KfArgs a)
 // (3) Slices whose diagonal is streamed (rows next to a Dirichlet cell) get it prefetched one plane step ahead.
 // LDS: z' double-buffered 2 x (C + 2 nz) doubles, code ring 2 x (C + nz) words, tables: 139 KB at nz = 464, C = 6128.
 // Results: the same arithmetic per row in the same order as the tile kernel; partial sums group differently (other blocks).
-template <int NT, int NP, int MODE>
+template <int NT, int NP, int MODE, int HR = 2> // HR: rounds in which the block's NT threads cover the 2 nz halo rows (2 nz <= HR x NT; 2: lines of up to 512 rows, 3: 768)
 __global__ __launch_bounds__(NT) void fused_chunk_kernel(KfArgs a)
 {
-    constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
     extern __shared__ __align__(16) unsigned char kc_lds[];
     const int tid = (int)threadIdx.x;
     constexpr int NTB = 0; // the streaming hints (KfArgs::nt's bits) at their frozen values, as compile-time constants: with run-time tests the compiler split every
@@ -1225,10 +1224,9 @@ __device__ __forceinline__ double kd_from_below(double v, double edge) // v of t
     return __hiloint2double(hi, lo);
 }
 
-template <int NT, int NP, int MODE, int PD, int PU>
+template <int NT, int NP, int MODE, int PD, int PU, int HR = 2> // (HR as in fused_chunk_kernel)
 __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
 {
-    constexpr int HR = 2; // rounds in which NT threads cover the 2 nz halo rows (nz <= NT)
     // Rolling prefetch: the loads a pair needs (its batch z, v, x, U2, code byte for step (a); U1, U3 and the edge element for (c))
     // are issued PD pairs ahead of their use, across the step boundary — not a whole plane step ahead: PD + 1 pairs' worth of
     // loaded-but-unused registers instead of NP pairs' worth, which is what lets 5 pairs of doubles fit 256 registers
@@ -2019,7 +2017,7 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
 // ---- the chunk kernels' plan: variant (threads, pairs per thread), rows per chunk, chunks per plane, segments of planes, grid, LDS
 constexpr size_t KC_LDS_MAX = 160 * 1024;
 struct KcPlan {
-    int nt, np, grid;
+    int nt, np, grid, hr;
     size_t lds;
     bool doubles; // fused_chunkd_kernel (the matrix as doubles) instead of fused_chunk_kernel (as 16-bit codes)
 };
@@ -2046,7 +2044,12 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
     const int nt = 512, np = coded ? 5 : 4; // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill)
     const int64_t nz = a.nz, d3 = a.d3;
-    if (nz > nt) // the 2 nz halo rows are covered in two rounds of the block: longer lines stay with the tiles
+    // the 2 nz halo rows are covered in two rounds of the block (three for the coded kernel on lines of 513 .. 768 rows: 640^3, the largest box one
+    // GPU holds with 32-bit indices); longer lines stay with the tiles
+    pl.hr = (int)((2 * nz + nt - 1) / nt);
+    if (pl.hr < 2)
+        pl.hr = 2;
+    if (pl.hr > 3)
         return false;
     const int64_t fixed = (int64_t)kc_lds_bytes(0, nz, nt, !coded);
     int64_t cmax = ((int64_t)KC_LDS_MAX - fixed) / (coded ? 20 : 32) / 16 * 16;
@@ -2104,15 +2107,15 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     pl.doubles = !coded;
     return true;
 }
-template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2>
+template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2, int HR = 2>
 static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
     void (*kern)(KfArgs);
     if constexpr (DOUBLES)
-        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU>;
+        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU, HR>;
     else
-        kern = &fused_chunk_kernel<NT, NP, MODE>;
+        kern = &fused_chunk_kernel<NT, NP, MODE, HR>;
     if (!raised) {
         FV_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KC_LDS_MAX));
         raised = true;
@@ -2127,11 +2130,15 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
         // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two, the wave's edge element by a vector load: measured 464^3, one process, ms
         // per step (tiles 1.531): (2,2) 1.376, (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane):
         // 1.384-1.477; the edge element by a scalar load (constant address space): +1.8 %; 64-bit plane bases: +0.1 % (profiles/r05_hetero_ab_*.log)
+        if (pl.hr == 3)
+            return kc_launch_one<512, 4, MODE, true, 3, 2, 3>(ctx, a, pl);
         return kc_launch_one<512, 4, MODE, true, 3, 2>(ctx, a, pl);
     }
     // the coded kernel: streaming hints as compile-time constants (stores stay 16-byte instructions): 464^3, one process, ms per step 0.8965 -> 0.8702;
     // with 32-bit offsets instead of 64-bit plane bases on top the median of five rounds was WORSE (0.965 / 0.941, minimum 0.893 / 0.874: two
     // modes), so its bases stay (profiles/r05_step_ab_coded_addressing.log)
+    if (pl.hr == 3)
+        return kc_launch_one<512, 5, MODE, false, 2, 2, 3>(ctx, a, pl);
     return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
 }
 
