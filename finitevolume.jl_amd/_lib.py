@@ -55,6 +55,7 @@ _f64p = C.c_void_p
 # name -> (restype, argtypes): every symbol include/fvhip.h declares
 ABI_VERSION = 4  # FVHIP_ABI_VERSION of include/fvhip.h this binding was written against
 FV_OPT_REORDER = 1
+FV_OPT_LEAN_SETUP = 2
 # the experimenter's panel (finitevolume.jl_amd/csrc/fv_tune.h): exported, but not part of include/fvhip.h
 PRIVATE_SIGNATURES = {"fv_tune": (C.c_int, [C.c_int, C.c_int]),
                       "fv_comm_init_local": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int])}  # the loopback transport of the multi-rank rehearsals (tests)
@@ -258,7 +259,8 @@ class Context:
         self.check(load().fv_ctx_synchronize(self.handle))
 
     def set_option(self, option, value):
-        """fv_ctx_set_option: per-context options (FV_OPT_REORDER: 0 never / 1 auto / 2 always re-number face-list meshes)."""
+        """fv_ctx_set_option: per-context options (FV_OPT_REORDER: 0 never / 1 auto / 2 always re-number face-list meshes; FV_OPT_LEAN_SETUP:
+        regular-grid problems without faces and CSR in HBM — 0 never / 1 always / 2 where the CSR would not fit int32 offsets)."""
         self.check(load().fv_ctx_set_option(self.handle, int(option), int(value)))
 
     def get_option(self, option):

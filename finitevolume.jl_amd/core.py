@@ -180,11 +180,19 @@ class Problem:
         return p
 
     @classmethod
-    def regulargrid(cls, mins, maxs, ns, dirichletnodes, ctx=None):
+    def regulargrid(cls, mins, maxs, ns, dirichletnodes, ctx=None, lean=None):
+        """fv_problem_create_regulargrid.  lean: FV_OPT_LEAN_SETUP for this problem (True / False; None: the context's setting, by default
+        lean only where the CSR's int32 offsets would not hold the operator) — no face arrays, incident lists or CSR in HBM."""
         ctx = ctx or default_context()
         mins_, maxs_, ns_, d = af64(mins), af64(maxs), ai64(ns), ai64(dirichletnodes)
         h = _lib.c_prob()
-        ctx.check(load().fv_problem_create_regulargrid(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), len(d), ptr(d), C.byref(h)))
+        before = ctx.get_option(_lib.FV_OPT_LEAN_SETUP)
+        if lean is not None:
+            ctx.set_option(_lib.FV_OPT_LEAN_SETUP, 1 if lean else 0)
+        try:
+            ctx.check(load().fv_problem_create_regulargrid(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), len(d), ptr(d), C.byref(h)))
+        finally:
+            ctx.set_option(_lib.FV_OPT_LEAN_SETUP, before)
         return cls(h, ctx)
 
     @classmethod

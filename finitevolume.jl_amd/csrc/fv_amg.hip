@@ -1529,6 +1529,7 @@ static int amg_set_sigma(fv_problem *p, double sigma)
 
 int fv_amg_prepare(fv_problem *p, double sigma)
 {
+    FV_TRY(fv_require_csr(p, "the AMG hierarchy"));
     if (!p->amg || p->amg->epoch != p->assemble_epoch || p->amg->storage_epoch != p->storage_epoch)
         FV_TRY(amg_build(p));
     return amg_set_sigma(p, sigma);
@@ -1830,6 +1831,8 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
     if (gathered)
         kind = FV_PRECOND_AMG; // (the same solver paths; the hierarchy differs: amg_build_pooled)
     // (validation first, state afterwards: a refused call leaves the problem's preconditioner and hierarchy as they were — ADVICE r4)
+    if (kind != FV_PRECOND_JACOBI)
+        FV_TRY(fv_require_csr(p, "the AMG preconditioner"));
     if (kind != FV_PRECOND_JACOBI && p->nhalo && !p->dist) {
         fv_set_error(p->ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;

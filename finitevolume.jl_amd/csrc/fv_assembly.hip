@@ -606,6 +606,62 @@ __global__ __launch_bounds__(FV_BLOCK) void assemble_rows_kernel(
     b[r] = bacc;
 }
 
+// metaindex entries outside 1:nK?
+__global__ __launch_bounds__(FV_BLOCK) void meta_range_kernel(int64_t F, int64_t nK, const int64_t *__restrict__ metaindex, int *__restrict__ bad)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i < F && (metaindex[i] < 1 || metaindex[i] > nK))
+        *bad = 1;
+}
+
+// fv_assemble of a lean problem: the conductivities stay as handed over (the rows are formed from them whenever a storage form
+// is filled), b and the diagonal come from one pass over the rows (fv_lean.hip)
+static int lean_assemble(fv_problem *p, int64_t nK, const double *conductivities, const int64_t *metaindex, int logtransformconductivity,
+                         const double *sources, const double *dirichletheads, int64_t *badnode)
+{
+    fv_ctx *ctx = p->ctx;
+    if (nK < 1) {
+        fv_set_error(ctx, "BoundsError: no conductivities");
+        return FV_ERR_INDEX;
+    }
+    DevBuf<double> dsrc;
+    FV_TRY(dsrc.alloc(ctx, (size_t)p->N));
+    FV_HIP(ctx, hipMemcpyAsync(dsrc.p, sources, (size_t)p->N * sizeof(double), hipMemcpyDefault, ctx->stream));
+    if (p->ndir > 0)
+        FV_HIP(ctx, hipMemcpyAsync(p->dheads.p, dirichletheads, (size_t)p->ndir * sizeof(double), hipMemcpyDefault, ctx->stream));
+    FV_TRY(check_sources(ctx, p->dnodes0.p, p->ndir, dsrc.p, badnode));
+    const int64_t keep = (metaindex || nK == 1) ? nK : p->F; // (without a metaindex the first F entries are the faces')
+    if ((int64_t)p->lean_K.n != keep)
+        FV_TRY(p->lean_K.alloc(ctx, (size_t)keep));
+    FV_HIP(ctx, hipMemcpyAsync(p->lean_K.p, conductivities, (size_t)keep * sizeof(double), hipMemcpyDefault, ctx->stream));
+    if (metaindex) {
+        if ((int64_t)p->lean_meta.n != p->F)
+            FV_TRY(p->lean_meta.alloc(ctx, (size_t)p->F));
+        FV_HIP(ctx, hipMemcpyAsync(p->lean_meta.p, metaindex, (size_t)p->F * sizeof(int64_t), hipMemcpyDefault, ctx->stream));
+        DevBuf<int> dbad;
+        FV_TRY(dbad.alloc(ctx, 1));
+        FV_TRY(dbad.zero(ctx));
+        hipLaunchKernelGGL(meta_range_kernel, dim3(fv_blocks(p->F)), dim3(FV_BLOCK), 0, ctx->stream, p->F, nK, (const int64_t *)p->lean_meta.p, dbad.p);
+        FV_LAUNCH_CHECK(ctx);
+        int bad = 0;
+        FV_TRY(fv_copy(ctx, &bad, dbad.p, sizeof bad));
+        if (bad) {
+            p->lean_meta.release();
+            p->assembled = false;
+            fv_set_error(ctx, "BoundsError: metaindex outside 1:%lld", (long long)nK);
+            return FV_ERR_INDEX;
+        }
+    } else
+        p->lean_meta.release();
+    p->lean_nK = nK;
+    p->lean_logt = logtransformconductivity ? 1 : 0;
+    FV_TRY(fv_lean_assemble(p, dsrc.p));
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->assembled = true;
+    p->assemble_epoch++;
+    return FV_OK;
+}
+
 extern "C" int fv_assemble(fv_problem *p, int64_t nK, const double *conductivities, const int64_t *metaindex,
                            int logtransformconductivity, const double *sources, const double *dirichletheads, int64_t *badnode)
 {
@@ -621,6 +677,8 @@ extern "C" int fv_assemble(fv_problem *p, int64_t nK, const double *conductiviti
         fv_set_error(ctx, "BoundsError: %lld conductivities for %lld faces", (long long)nK, (long long)p->F);
         return FV_ERR_INDEX;
     }
+    if (p->lean)
+        return lean_assemble(p, nK, conductivities, metaindex, logtransformconductivity, sources, dirichletheads, badnode);
     DevBuf<double> dK, dsrc;
     DevBuf<int64_t> dmeta;
     FV_TRY(dK.alloc(ctx, (size_t)nK));
@@ -756,7 +814,10 @@ extern "C" int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], 
     FV_HIP(ctx, hipSetDevice(ctx->device));
     int64_t N, F;
     FV_TRY(fv_regulargrid_sizes(ns, &N, &F));
-    if (F > 0x7fffffffLL) {
+    // FV_OPT_LEAN_SETUP: no face arrays, no incident lists, no CSR — the solver's storage forms come straight from the grid (fv_lean.hip).
+    // 1: wherever the sliced forms apply (>= 4096 cells); 2 [default]: where the CSR's int32 offsets would not hold the operator (nnz <= 7 N)
+    const bool lean = N >= 4096 && N <= 0x7fffffffLL && (ctx->opt_lean == 1 || (ctx->opt_lean == 2 && (F > 0x7fffffffLL || 7 * N > 0x7fffffffLL - 2)));
+    if (F > 0x7fffffffLL && !lean) {
         fv_set_error(ctx, "F=%lld exceeds the int32 device index range", (long long)F);
         return FV_ERR_TOO_LARGE;
     }
@@ -769,6 +830,17 @@ extern "C" int fv_problem_create_regulargrid(fv_ctx *ctx, const double mins[3], 
     for (int d = 0; d < 3; d++)
         p->ns[d] = ns[d];
     int rc;
+    if (lean) {
+        p->lean = true;
+        if ((rc = p->gridvol.alloc(ctx, (size_t)N)) ||
+            (rc = fv_grid_generate_device(ctx, mins, maxs, ns, nullptr, nullptr, nullptr, p->gridvol.p, nullptr)) ||
+            (rc = fv_lean_finish(p, dirichletnodes, mins, maxs))) {
+            delete p;
+            return rc;
+        }
+        *out = p;
+        return FV_OK;
+    }
     if ((rc = p->node1.alloc(ctx, (size_t)F)) || (rc = p->node2.alloc(ctx, (size_t)F)) || (rc = p->aol.alloc(ctx, (size_t)F)) ||
         (rc = p->gridvol.alloc(ctx, (size_t)N)) ||
         (rc = fv_grid_generate_device(ctx, mins, maxs, ns, p->node1.p, p->node2.p, p->aol.p, p->gridvol.p, nullptr)) ||
@@ -882,6 +954,8 @@ extern "C" int fv_problem_get_grid(fv_problem *p, int64_t *node1, int64_t *node2
         fv_set_error(ctx, "fv_problem_get_grid: problem has no faces");
         return FV_ERR_STATE;
     }
+    if (node1 || node2 || areasoverlengths)
+        FV_TRY(fv_require_csr(p, "fv_problem_get_grid (faces)"));
     if (node1 || node2) {
         DevBuf<int64_t> w;
         FV_TRY(w.alloc(ctx, (size_t)p->F));
@@ -992,6 +1066,7 @@ extern "C" int fv_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, doubl
         fv_set_error(ctx, "fv_get_csc: call fv_assemble first");
         return FV_ERR_STATE;
     }
+    FV_TRY(fv_require_csr(p, "fv_get_csc"));
     if (p->reordered)
         return get_csc_canonical(p, colptr, rowval, nzval);
     DevBuf<int64_t> w;

@@ -35,6 +35,7 @@ void fv_warm_dist(hipStream_t);
 void fv_warm_fused(hipStream_t);
 void fv_warm_gradient(hipStream_t);
 void fv_warm_grid(hipStream_t);
+void fv_warm_lean(hipStream_t);
 void fv_warm_pcg(hipStream_t);
 void fv_warm_reorder(hipStream_t);
 void fv_warm_small(hipStream_t);
@@ -58,6 +59,7 @@ static int fv_warm_modules(fv_ctx *ctx)
     fv_warm_fused(ctx->stream);
     fv_warm_gradient(ctx->stream);
     fv_warm_grid(ctx->stream);
+    fv_warm_lean(ctx->stream);
     fv_warm_pcg(ctx->stream);
     fv_warm_reorder(ctx->stream);
     fv_warm_small(ctx->stream);
@@ -101,6 +103,10 @@ extern "C" int fv_ctx_set_option(fv_ctx *ctx, int option, int value)
         ctx->opt_reorder = value;
         return FV_OK;
     }
+    if (option == FV_OPT_LEAN_SETUP && value >= 0 && value <= 2) {
+        ctx->opt_lean = value;
+        return FV_OK;
+    }
     fv_set_error(ctx, "fv_ctx_set_option: unknown option %d or value %d out of range", option, value);
     return FV_ERR_ARG;
 }
@@ -112,6 +118,10 @@ extern "C" int fv_ctx_get_option(fv_ctx *ctx, int option, int *value)
         return FV_ERR_ARG;
     if (option == FV_OPT_REORDER) {
         *value = ctx->opt_reorder >= 0 ? ctx->opt_reorder : g_reorder;
+        return FV_OK;
+    }
+    if (option == FV_OPT_LEAN_SETUP) {
+        *value = ctx->opt_lean;
         return FV_OK;
     }
     fv_set_error(ctx, "fv_ctx_get_option: unknown option %d", option);

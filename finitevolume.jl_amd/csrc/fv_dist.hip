@@ -257,6 +257,7 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
         fv_set_error(ctx, "fv_dist_setup: call fv_assemble and fv_transient_begin on the global problem first");
         return FV_ERR_STATE;
     }
+    FV_TRY(fv_require_csr(pg, "fv_dist_setup"));
     if (pg->dist || pg->nhalo) {
         fv_set_error(ctx, "fv_dist_setup: problem is already a row block");
         return FV_ERR_STATE;

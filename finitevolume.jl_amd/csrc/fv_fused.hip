@@ -2049,7 +2049,7 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     pl.hr = (int)((2 * nz + nt - 1) / nt);
     if (pl.hr < 2)
         pl.hr = 2;
-    if (pl.hr > 3)
+    if (pl.hr > 4)
         return false;
     const int64_t fixed = (int64_t)kc_lds_bytes(0, nz, nt, !coded);
     int64_t cmax = ((int64_t)KC_LDS_MAX - fixed) / (coded ? 20 : 32) / 16 * 16;
@@ -2130,6 +2130,8 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
         // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two, the wave's edge element by a vector load: measured 464^3, one process, ms
         // per step (tiles 1.531): (2,2) 1.376, (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane):
         // 1.384-1.477; the edge element by a scalar load (constant address space): +1.8 %; 64-bit plane bases: +0.1 % (profiles/r05_hetero_ab_*.log)
+        if (pl.hr == 4)
+            return kc_launch_one<512, 4, MODE, true, 3, 2, 4>(ctx, a, pl);
         if (pl.hr == 3)
             return kc_launch_one<512, 4, MODE, true, 3, 2, 3>(ctx, a, pl);
         return kc_launch_one<512, 4, MODE, true, 3, 2>(ctx, a, pl);
@@ -2137,6 +2139,8 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
     // the coded kernel: streaming hints as compile-time constants (stores stay 16-byte instructions): 464^3, one process, ms per step 0.8965 -> 0.8702;
     // with 32-bit offsets instead of 64-bit plane bases on top the median of five rounds was WORSE (0.965 / 0.941, minimum 0.893 / 0.874: two
     // modes), so its bases stay (profiles/r05_step_ab_coded_addressing.log)
+    if (pl.hr == 4)
+        return kc_launch_one<512, 5, MODE, false, 2, 2, 4>(ctx, a, pl);
     if (pl.hr == 3)
         return kc_launch_one<512, 5, MODE, false, 2, 2, 3>(ctx, a, pl);
     return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);

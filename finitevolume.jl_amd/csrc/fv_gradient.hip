@@ -147,6 +147,7 @@ extern "C" int fv_param_jacobian_apply(fv_problem *p, const double *x_free, cons
         fv_set_error(ctx, "fv_param_jacobian_apply: needs a mesh problem after fv_assemble (not a CSC import or a row block)");
         return FV_ERR_STATE;
     }
+    FV_TRY(fv_require_csr(p, "fv_param_jacobian_apply"));
     if (scale_by_storage && !p->transient_ready) {
         fv_set_error(ctx, "fv_param_jacobian_apply: the D^-1 scaling needs fv_transient_begin (Ss, volumes)");
         return FV_ERR_STATE;
@@ -180,6 +181,7 @@ int fv_param_gradient_integral_device(fv_problem *p, int64_t kc, const double *t
                                       int logtransform, int accumulate, double *gk, double *gd, double *gs)
 {
     fv_ctx *ctx = p->ctx;
+    FV_TRY(fv_require_csr(p, "the parameter gradient"));
     const int64_t n = p->n, F = p->F;
     if (F > 0)
         hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, ts_dev, X, L, D,
@@ -201,6 +203,7 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
         fv_set_error(ctx, "fv_param_gradient_integral: needs a mesh problem after fv_assemble (not a CSC import or a row block)");
         return FV_ERR_STATE;
     }
+    FV_TRY(fv_require_csr(p, "fv_param_gradient_integral"));
     if (scale_by_storage && !p->transient_ready) {
         fv_set_error(ctx, "fv_param_gradient_integral: the D^-1 scaling needs fv_transient_begin (Ss, volumes)");
         return FV_ERR_STATE;

@@ -41,6 +41,7 @@ struct fv_ctx {
     int nranks = 1, rank = 0;
     int64_t n_allreduce = 0, n_halo = 0; // collectives issued through this context (fv_comm_stats)
     int opt_reorder = -1; // FV_OPT_REORDER of this context; -1: the process-wide default (fv_tune key 31)
+    int opt_lean = 2;     // FV_OPT_LEAN_SETUP: 0 never, 1 every regular-grid problem that can, 2 those whose CSR would not fit int32 indices
     // fv_comm_diag: HIP event pairs around the pieces of a distributed step — [0] all-reduces, [1] the halo exchange on the second
     // stream, [2] the compute stream's stall at the wait for the halo, [3] interior SpMV pass, [4] boundary pass
     bool diag = false;
@@ -203,6 +204,21 @@ struct StorageArg {
     StorageTable tab;
 };
 
+// Rows of a regular-grid operator formed on the fly (fv_lean.h): geometry, node maps, the caller's conductivities, and the diagonal
+// as the assembly left it in diagA (+ sigma D where a shift is folded in)
+struct GridRows {
+    int64_t n1, n2, n3;
+    double dx, dy, dz;
+    const int32_t *nodemap, *f2n;
+    const double *K;
+    const int64_t *meta;
+    int64_t nK;
+    int logt;
+    const double *diagA, *D;
+    double sigma;
+};
+constexpr int DIA_K = 8; // distinct column offsets a 64-row slice of the sliced-DIA form can have
+
 struct fv_problem {
     fv_ctx *ctx = nullptr;
     int64_t N = 0, F = 0, n = 0, nnz = 0, ndir = 0, E = 0;
@@ -211,6 +227,15 @@ struct fv_problem {
     bool from_grid = false, from_csc = false, assembled = false, transient_ready = false;
     int64_t ns[3] = {0, 0, 0};
     int64_t slab_lo = -1, slab_hi = -1; // fv_problem_create_regulargrid_slab: the planes whose rows are complete
+    // FV_OPT_LEAN_SETUP: a regular-grid problem without face arrays, incident lists and CSR — the storage forms of the solver are
+    // filled from rows formed on the fly (fv_lean.hip); what needs the CSR or the faces (fv_get_csc, AMG, row blocks, gradients) fails loudly
+    bool lean = false;
+    double lean_d[3] = {0, 0, 0}; // grid spacing, as regulargrid_kernel forms it (axis[1] - axis[0])
+    DevBuf<double> lean_K;        // the conductivities of the last fv_assemble as handed over (1, or one per face / per metaindex target)
+    DevBuf<int64_t> lean_meta;    // ... and its metaindex (1-based), when one came
+    int64_t lean_nK = 0;
+    int lean_logt = 0;
+    int dia_alloc = 0;            // lean: dia_vals / dia_pos hold 0 nothing yet, 1 the symmetric form's rest slices only, 2 every DIA slice
 
     // mesh (0-based int32 on device)
     DevBuf<int32_t> node1, node2;
@@ -244,7 +269,7 @@ struct fv_problem {
     DevBuf<int32_t> sl_off, dia_list, csr_list, dia_pos;
     DevBuf<int32_t> dia_list_ord; // the DIA slices in traversal order (plane-blocked), when the operator has a plane stride
     DevBuf<double> dia_vals;
-    int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1;
+    int64_t ndia = 0, ncsr_groups = 0, dia_epoch = -1, dia_nblocks = 0; // (dia_nblocks: blocks of 64 values of all DIA slices)
     // SELL-64 copy of the 64-row groups the CSR kernel would serve (irregular meshes after the locality re-numbering): per group
     // `width` lane-major blocks of 64 values + 64 sixteen-bit column offsets relative to the row, the diagonal first (fv_spmv.hip)
     DevBuf<double> sell_vals;
@@ -460,6 +485,16 @@ int64_t fv_grid_face_offset(const int64_t ns[3], int64_t i1);
 // ---- fv_assembly.hip
 int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes_host_or_dev);
 int fv_build_symbolic(fv_problem *p);
+// fv_lean.hip: the set-up of a lean problem (no faces, no CSR) from rows formed on the fly
+GridRows fv_grid_rows(const fv_problem *p, double sigma);
+int fv_require_csr(fv_problem *p, const char *what); // FV_ERR_STATE with a message for a lean problem, FV_OK otherwise
+int fv_lean_finish(fv_problem *p, const int64_t *dirichletnodes, const double mins[3], const double maxs[3]);
+int fv_lean_assemble(fv_problem *p, const double *sources_dev);
+int fv_lean_plane_stride(fv_problem *p, int64_t *stride);
+int fv_lean_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree);
+int fv_lean_dia_pattern(fv_problem *p, uint8_t *sl_noff, int32_t *sl_off, int32_t *is_dia, int32_t *is_csr);
+int fv_lean_dia_fill(fv_problem *p, double sigma, int64_t count, const int32_t *list);
+int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int32_t d3, double *dg, double *u1, double *u2, double *u3);
 int fv_widen_indices(fv_ctx *ctx, const int32_t *src, int64_t *dst, int64_t n, int64_t add);
 int fv_narrow_indices(fv_ctx *ctx, const int64_t *src, int32_t *dst, int64_t n, int64_t lo, int64_t hi, int *bad);
 int fv_compact_flags(fv_ctx *ctx, const int32_t *flag, int64_t n, int32_t *out, int64_t *count); // ascending indices of the set flags

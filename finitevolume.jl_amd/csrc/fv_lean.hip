@@ -1,0 +1,359 @@
+// Lean regular-grid problems (FV_OPT_LEAN_SETUP): assembleA / assembleb and the set-up of the solver's storage forms without
+// face arrays, incident lists or a CSR in HBM.  A regulargrid mesh is a closed form (fv_grid.hip; /root/reference/src/grid.jl:56-110),
+// so row r of what assembleA would have built (/root/reference/src/FiniteVolume.jl:75-108) can be formed wherever it is needed
+// (fv_lean.h) — here: by the kernels that fill b and the diagonal, classify the 64-row slices and fill the sliced-DIA and the
+// symmetric copies.  Same doubles as the CSR route, bit for bit (tests/test_gpu_lean.py compares every array of the two).
+// Compiled without FMA contraction, like fv_grid.hip and fv_assembly.hip.
+#include "fv_lean.h"
+
+GridRows fv_grid_rows(const fv_problem *p, double sigma)
+{
+    GridRows g{};
+    g.n1 = p->ns[0];
+    g.n2 = p->ns[1];
+    g.n3 = p->ns[2];
+    g.dx = p->lean_d[0];
+    g.dy = p->lean_d[1];
+    g.dz = p->lean_d[2];
+    g.nodemap = p->nodemap.p;
+    g.f2n = p->f2n.p;
+    g.K = p->lean_K.p;
+    g.meta = p->lean_meta.p;
+    g.nK = p->lean_nK;
+    g.logt = p->lean_logt;
+    g.diagA = p->diagA.p;
+    g.D = p->D.p;
+    g.sigma = sigma;
+    return g;
+}
+
+int fv_require_csr(fv_problem *p, const char *what)
+{
+    if (!p->lean)
+        return FV_OK;
+    fv_set_error(p->ctx, "%s needs the face arrays / the CSR, which a lean problem (FV_OPT_LEAN_SETUP) does not keep: create the problem with the option at 0",
+                 what);
+    return FV_ERR_STATE;
+}
+
+// ------------------------------------------------------------------ structure
+__global__ __launch_bounds__(FV_BLOCK) void lean_count_kernel(GridRows g, int64_t n, unsigned long long *__restrict__ total)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    int len = 0;
+    if (r < n) {
+        GridRow e;
+        grid_row(g, r, e, false);
+        len = e.len;
+    }
+    __shared__ int wsum[FV_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1)
+        len += __shfl_xor(len, off, 64);
+    if ((threadIdx.x & 63) == 0)
+        wsum[threadIdx.x >> 6] = len;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w = 0; w < FV_BLOCK / 64; w++)
+            c += wsum[w];
+        if (c)
+            atomicAdd(total, (unsigned long long)c);
+    }
+}
+
+// maps, the kept Dirichlet nodes, b / diagA / dheads, the spacing, nnz (what fv_problem_sizes reports): finish_problem without faces
+int fv_lean_finish(fv_problem *p, const int64_t *dirichletnodes, const double mins[3], const double maxs[3])
+{
+    fv_ctx *ctx = p->ctx;
+    std::vector<double> ax[3];
+    if (fv_grid_axes(mins, maxs, p->ns, ax) != FV_OK) {
+        fv_set_error(ctx, "regulargrid needs ns[d] >= 2 in every dimension");
+        return FV_ERR_ARG;
+    }
+    for (int d = 0; d < 3; d++)
+        p->lean_d[d] = ax[d][1] - ax[d][0]; // grid.jl:65-67, as regulargrid_kernel forms it
+    FV_TRY(fv_build_maps(p, dirichletnodes));
+    FV_TRY(p->dnodes0.alloc(ctx, (size_t)p->ndir));
+    if (p->ndir > 0) {
+        DevBuf<int64_t> w;
+        FV_TRY(w.alloc(ctx, (size_t)p->ndir));
+        FV_HIP(ctx, hipMemcpyAsync(w.p, dirichletnodes, (size_t)p->ndir * sizeof(int64_t), hipMemcpyDefault, ctx->stream));
+        int bad = 0;
+        FV_TRY(fv_narrow_indices(ctx, w.p, p->dnodes0.p, p->ndir, 1, p->N, &bad));
+    }
+    FV_TRY(p->b.alloc(ctx, (size_t)p->n));
+    FV_TRY(p->diagA.alloc(ctx, (size_t)p->n));
+    FV_TRY(p->dheads.alloc(ctx, (size_t)p->ndir));
+    DevBuf<unsigned long long> cnt;
+    FV_TRY(cnt.alloc(ctx, 1));
+    FV_TRY(cnt.zero(ctx));
+    if (p->n > 0) {
+        hipLaunchKernelGGL(lean_count_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, 0.0), p->n, cnt.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    unsigned long long h = 0;
+    FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
+    p->nnz = (int64_t)h;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ assembleb and the diagonal of assembleA (assemble_rows_kernel without the lists)
+// One thread per free row; its faces in face order — (-x, -y, -z) emitted by the lower neighbours, then its own (+x, +y, +z) —, the
+// order sparse(I, J, V, n, n, +) and assembleb's `b[...] +=` statements fold contributions in (FiniteVolume.jl:96-103, :131-134).
+__global__ __launch_bounds__(FV_BLOCK) void lean_assemble_kernel(GridRows g, int64_t n, const double *__restrict__ sources,
+                                                                  const double *__restrict__ dheads, double *__restrict__ b, double *__restrict__ diagA)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    const int64_t n2 = g.n2, n3 = g.n3, plane = n2 * n3;
+    const int64_t c = g.f2n[r];
+    const int64_t i3 = c % n3, i2 = (c / n3) % n2, i1 = c / plane;
+    double dacc = 0.0, bacc = sources[c]; // FiniteVolume.jl:113-120
+    bool first = true;
+    auto face = [&](bool exists, int64_t nb, double cond) {
+        if (!exists)
+            return;
+        dacc = first ? cond : dacc + cond; // (row, row, +c): FiniteVolume.jl:96, 98, 101, 103
+        first = false;
+        const int32_t m = g.nodemap[nb];
+        if (m < 0) // the other end is a Dirichlet cell: FiniteVolume.jl:131-134
+            bacc += cond * dheads[-m - 1];
+    };
+    if (i1 > 0)
+        face(true, c - plane, grid_face_cond(g, c - plane, i1 - 1, i2, i3, 0));
+    if (i2 > 0)
+        face(true, c - n3, grid_face_cond(g, c - n3, i1, i2 - 1, i3, 1));
+    if (i3 > 0)
+        face(true, c - 1, grid_face_cond(g, c - 1, i1, i2, i3 - 1, 2));
+    if (i1 < g.n1 - 1)
+        face(true, c + plane, grid_face_cond(g, c, i1, i2, i3, 0));
+    if (i2 < n2 - 1)
+        face(true, c + n3, grid_face_cond(g, c, i1, i2, i3, 1));
+    if (i3 < n3 - 1)
+        face(true, c + 1, grid_face_cond(g, c, i1, i2, i3, 2));
+    diagA[r] = dacc;
+    b[r] = bacc;
+}
+
+int fv_lean_assemble(fv_problem *p, const double *sources_dev)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->n > 0) {
+        hipLaunchKernelGGL(lean_assemble_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, 0.0), p->n, sources_dev,
+                           (const double *)p->dheads.p, p->b.p, p->diagA.p);
+        FV_LAUNCH_CHECK(ctx);
+    }
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ the plane stride (build_group_order's estimate and vote)
+__global__ __launch_bounds__(FV_BLOCK) void lean_far_stride_kernel(GridRows g, int64_t n, int64_t stride, unsigned long long *__restrict__ count)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    bool hit = false;
+    if (r < n) {
+        GridRow e;
+        grid_row(g, r, e, false);
+        hit = (int64_t)e.off[e.len - 1] == stride; // (the diagonal is always stored: len >= 1)
+    }
+    __shared__ int wcount[FV_BLOCK / 64];
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0)
+        wcount[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w = 0; w < FV_BLOCK / 64; w++)
+            c += wcount[w];
+        if (c)
+            atomicAdd(count, (unsigned long long)c);
+    }
+}
+
+__global__ void lean_last_offset_kernel(GridRows g, int64_t r, int64_t *__restrict__ out)
+{
+    GridRow e;
+    grid_row(g, r, e, false);
+    *out = e.off[e.len - 1];
+}
+
+// the last stored offset of the middle row (0 when that is its diagonal)
+int fv_lean_plane_stride(fv_problem *p, int64_t *stride)
+{
+    fv_ctx *ctx = p->ctx;
+    DevBuf<int64_t> out;
+    FV_TRY(out.alloc(ctx, 1));
+    hipLaunchKernelGGL(lean_last_offset_kernel, dim3(1), dim3(1), 0, ctx->stream, fv_grid_rows(p, 0.0), p->n / 2, out.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_TRY(fv_copy(ctx, stride, out.p, sizeof(int64_t)));
+    return FV_OK;
+}
+
+int fv_lean_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree)
+{
+    fv_ctx *ctx = p->ctx;
+    DevBuf<unsigned long long> cnt;
+    FV_TRY(cnt.alloc(ctx, 1));
+    FV_TRY(cnt.zero(ctx));
+    hipLaunchKernelGGL(lean_far_stride_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, 0.0), p->n, stride, cnt.p);
+    FV_LAUNCH_CHECK(ctx);
+    unsigned long long h = 0;
+    FV_TRY(fv_copy(ctx, &h, cnt.p, sizeof h));
+    *agree = (int64_t)h;
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ sliced DIA: pattern and values (dia_pattern_kernel / dia_fill_kernel, fv_spmv.hip)
+__global__ __launch_bounds__(FV_BLOCK) void lean_dia_pattern_kernel(GridRows g, int64_t n, uint8_t *__restrict__ sl_noff, int32_t *__restrict__ sl_off,
+                                                                     int32_t *__restrict__ is_dia, int32_t *__restrict__ is_csr)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nslices = (n + 63) >> 6;
+    const int64_t sl = (int64_t)blockIdx.x * WPB + wave;
+    if (sl >= nslices)
+        return;
+    const int64_t row = (sl << 6) + lane;
+    int32_t o[DIA_K];
+#pragma unroll
+    for (int k = 0; k < DIA_K; k++)
+        o[k] = 0x7fffffff;
+    if (row < n) {
+        GridRow e;
+        grid_row(g, row, e, false);
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            if (k < e.len)
+                o[k] = e.off[k];
+    }
+    // the distinct offsets of the slice in ascending order (rows of a grid store at most seven entries: never too long for the form)
+    int32_t last = -0x7fffffff - 1;
+    int count = 0;
+    bool ok = true;
+    int32_t found[DIA_K];
+    while (ok) {
+        int32_t m = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (o[k] > last && o[k] < m)
+                m = o[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int32_t t = __shfl_xor(m, off, 64);
+            m = t < m ? t : m;
+        }
+        if (m == 0x7fffffff)
+            break;
+        if (count == DIA_K) {
+            ok = false;
+            break;
+        }
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (k == count)
+                found[k] = m;
+        count++;
+        last = m;
+    }
+    if (count == 0)
+        ok = false;
+    if (lane == 0) {
+        sl_noff[sl] = ok ? (uint8_t)count : 0;
+        is_dia[sl] = ok ? 1 : 0;
+        is_csr[sl] = ok ? 0 : 1;
+    }
+    if (ok && lane < DIA_K) {
+        int32_t v = 0;
+#pragma unroll
+        for (int k = 0; k < DIA_K; k++)
+            if (k == lane && k < count)
+                v = found[k];
+        sl_off[sl * DIA_K + lane] = v;
+    }
+}
+
+int fv_lean_dia_pattern(fv_problem *p, uint8_t *sl_noff, int32_t *sl_off, int32_t *is_dia, int32_t *is_csr)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t ns = (p->n + 63) >> 6;
+    hipLaunchKernelGGL(lean_dia_pattern_kernel, dim3(fv_blocks(ns, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, 0.0), p->n, sl_noff, sl_off,
+                       is_dia, is_csr);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void lean_dia_fill_kernel(GridRows g, int64_t n, int64_t ndia, const int32_t *__restrict__ dia_list,
+                                                                  const uint8_t *__restrict__ sl_noff, const int32_t *__restrict__ sl_off,
+                                                                  const int32_t *__restrict__ dia_pos, double *__restrict__ sval)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t pos = (int64_t)blockIdx.x * WPB + wave;
+    if (pos >= ndia)
+        return;
+    const int64_t sl = dia_list[pos];
+    const int64_t base = dia_pos[sl];
+    const int64_t row = (sl << 6) + lane;
+    const int noff = sl_noff[sl];
+    GridRow e;
+    e.len = 0;
+    if (row < n)
+        grid_row(g, row, e, true);
+    for (int k = 0; k < noff; k++) {
+        const int32_t off = sl_off[sl * DIA_K + k];
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            if (j < e.len && e.off[j] == off)
+                v = e.val[j];
+        sval[(base + k) * 64 + lane] = v;
+    }
+}
+
+int fv_lean_dia_fill(fv_problem *p, double sigma, int64_t count, const int32_t *list)
+{
+    fv_ctx *ctx = p->ctx;
+    if (count <= 0)
+        return FV_OK;
+    hipLaunchKernelGGL(lean_dia_fill_kernel, dim3(fv_blocks(count, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, sigma), p->n, count, list,
+                       (const uint8_t *)p->sl_noff.p, (const int32_t *)p->sl_off.p, (const int32_t *)p->dia_pos.p, p->dia_vals.p);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+// ------------------------------------------------------------------ the symmetric copy (symdia_fill_kernel, fv_spmv.hip); a(i, i - d) is the bits of
+// a(i - d, i) by construction — one face, one product —, so there is nothing for symdia_check_kernel to look at
+__global__ __launch_bounds__(FV_BLOCK) void lean_symdia_fill_kernel(GridRows g, int64_t n, int32_t d1, int32_t d2, int32_t d3, double *__restrict__ dg,
+                                                                     double *__restrict__ u1, double *__restrict__ u2, double *__restrict__ u3)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    GridRow e;
+    grid_row(g, r, e, true);
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        if (j < e.len) {
+            const int32_t off = e.off[j];
+            const double v = e.val[j];
+            if (off == 0)
+                dg[r] = v;
+            else if (off == d1)
+                u1[r] = v;
+            else if (off == d2)
+                u2[r] = v;
+            else if (off == d3)
+                u3[r] = v;
+        }
+}
+
+int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int32_t d3, double *dg, double *u1, double *u2, double *u3)
+{
+    fv_ctx *ctx = p->ctx;
+    hipLaunchKernelGGL(lean_symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, fv_grid_rows(p, sigma), p->n, d1, d2, d3, dg, u1, u2, u3);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
+FV_WARM_TU(lean)

@@ -1483,7 +1483,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                            (const double *)x, sys.carry_prev, (const double *)p->minv.p, p->r.p, p->pvec.p, p->part_rz.p, p->part_rr.p,
                            p->part_bb.p, zsrc);
         p->z_where = 0;
-    } else if (sys.implicit_step && g_fuse_init && g_spmv_form == 2) {
+    } else if (sys.implicit_step && g_fuse_init && g_spmv_form == 2 && !p->lean) { // (lean: the set-up epilogue runs in the seven-diagonal slices, whose values a lean problem does not fill)
         // the whole set-up in the epilogue of ONE SpMV: with the folded matrix q = (A + sigma D) x0 and
         // r0 = rhs - q; otherwise q = A x0 (plain) and r0 = b' - q (the D x0/dt terms cancel)
         StepInitEpilogue epi{};

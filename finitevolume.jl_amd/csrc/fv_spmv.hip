@@ -551,18 +551,26 @@ static int build_group_order(fv_problem *p)
     if (n < (1 << 20) || p->nnz == 0)
         return FV_OK; // small: x stays cache-resident anyway
     // estimate the far stride from the middle row, then count how many rows agree
-    int32_t rp[2] = {0, 0};
-    FV_HIP(ctx, fv_memcpy_sync(ctx, rp, p->rowptr.p + n / 2, sizeof rp, hipMemcpyDeviceToHost));
-    if (rp[1] <= rp[0])
-        return FV_OK;
-    int32_t lastcol = 0;
-    FV_HIP(ctx, fv_memcpy_sync(ctx, &lastcol, p->colind.p + (rp[1] - 1), sizeof lastcol, hipMemcpyDeviceToHost));
-    const int64_t stride = (int64_t)lastcol - n / 2;
+    int64_t stride = 0;
+    if (p->lean) // (rows formed on the fly: fv_lean.hip)
+        FV_TRY(fv_lean_plane_stride(p, &stride));
+    else {
+        int32_t rp[2] = {0, 0};
+        FV_HIP(ctx, fv_memcpy_sync(ctx, rp, p->rowptr.p + n / 2, sizeof rp, hipMemcpyDeviceToHost));
+        if (rp[1] <= rp[0])
+            return FV_OK;
+        int32_t lastcol = 0;
+        FV_HIP(ctx, fv_memcpy_sync(ctx, &lastcol, p->colind.p + (rp[1] - 1), sizeof lastcol, hipMemcpyDeviceToHost));
+        stride = (int64_t)lastcol - n / 2;
+    }
     if (stride < 32768 || stride > n / 4)
         return FV_OK; // near-diagonal band (natural order is fine) or no plane structure
     extern int fv_count_far_stride(fv_problem *, int64_t, int64_t *);
     int64_t agree = 0;
-    FV_TRY(fv_count_far_stride(p, stride, &agree));
+    if (p->lean)
+        FV_TRY(fv_lean_count_far_stride(p, stride, &agree));
+    else
+        FV_TRY(fv_count_far_stride(p, stride, &agree));
     if (agree < (n - stride) * 8 / 10)
         return FV_OK;
     if (p->dist) { // a row block is traversed by its interior / boundary lists; the stride lets its interior window march
@@ -646,6 +654,7 @@ static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double si
                             int64_t npos_override = -1, int *grid_out = nullptr)
 {
     fv_ctx *ctx = p->ctx;
+    FV_TRY(fv_require_csr(p, "the lanes-per-row CSR SpMV"));
     set_resident_blocks(ctx);
     if (!p->order_built)
         FV_TRY(build_group_order(p));
@@ -716,7 +725,6 @@ static int spmv_launch_impl(fv_problem *p, const double *x, double *y, double si
 // (irregular meshes, rows longer than DIA_K) stay with the CSR wave-stream kernel, which
 // then runs over the list of remaining 64-row groups.  The terms of a row are summed in
 // ascending column order, exactly like the CSR kernels.
-constexpr int DIA_K = 8;
 
 __global__ __launch_bounds__(FV_BLOCK) void dia_pattern_kernel(int64_t n, const int32_t *__restrict__ rowptr,
                                                                 const int32_t *__restrict__ colind, uint8_t *__restrict__ sl_noff,
@@ -2004,10 +2012,13 @@ static int ensure_symdia_vals(fv_problem *p, const double *src, double src_tag)
     p->kc_ends_switch = g_chunk_ends;
     double *dg = p->sym_vals.p + p->sym_front, *u1 = dg + p->sym_ld, *u2 = u1 + p->sym_ld, *u3 = u2 + p->sym_ld;
     const int32_t d1 = (int32_t)p->sym_d[0], d2 = (int32_t)p->sym_d[1], d3 = (int32_t)p->sym_d[2];
-    hipLaunchKernelGGL(symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
-                       (const int32_t *)p->colind.p, src, d1, d2, d3, dg, u1, u2, u3);
+    if (p->lean)
+        FV_TRY(fv_lean_symdia_fill(p, src_tag, d1, d2, d3, dg, u1, u2, u3));
+    else
+        hipLaunchKernelGGL(symdia_fill_kernel, dim3(fv_blocks(p->n)), dim3(FV_BLOCK), 0, ctx->stream, p->n, (const int32_t *)p->rowptr.p,
+                           (const int32_t *)p->colind.p, src, d1, d2, d3, dg, u1, u2, u3);
     FV_LAUNCH_CHECK(ctx);
-    if (p->sym_epoch != p->assemble_epoch) { // new values: the lower triangle must mirror the upper one exactly
+    if (p->sym_epoch != p->assemble_epoch && !p->lean) { // new values: the lower triangle must mirror the upper one exactly (a grid's rows do by construction)
         DevBuf<int> bad;
         FV_TRY(bad.alloc(ctx, 1));
         FV_TRY(bad.zero(ctx));
@@ -2116,6 +2127,36 @@ __global__ __launch_bounds__(FV_BLOCK) void dia_order_gather_kernel(int64_t m, c
         out[i] = order[idx[i]];
 }
 
+// positions and storage of the lane-major values of the listed DIA slices (what: 2 every DIA slice, 1 the symmetric form's rest slices)
+static int dia_alloc_values(fv_problem *p, const int32_t *list, int64_t count, int what) // (what = 0: only count the blocks of the listed slices)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t ns = (p->n + 63) >> 6;
+    DevBuf<int32_t> len, start;
+    FV_TRY(len.alloc(ctx, (size_t)count));
+    FV_TRY(start.alloc(ctx, (size_t)count + 1));
+    if (count > 0)
+        hipLaunchKernelGGL(dia_len_kernel, dim3(fv_blocks(count)), dim3(FV_BLOCK), 0, ctx->stream, count, list, (const uint8_t *)p->sl_noff.p,
+                           g_dia_packed ? 0 : DIA_K, len.p);
+    FV_LAUNCH_CHECK(ctx);
+    int64_t nblocks = 0; // blocks of 64 doubles in all
+    FV_TRY(fv_exclusive_scan_i32(ctx, len.p, start.p, count, &nblocks));
+    if (what == 0 || what == 2)
+        p->dia_nblocks = nblocks;
+    if (what == 0)
+        return FV_OK;
+    FV_TRY(p->dia_vals.alloc(ctx, (size_t)nblocks * 64 + 64));
+    if (!p->dia_pos.p)
+        FV_TRY(p->dia_pos.alloc(ctx, (size_t)ns));
+    if (count > 0)
+        hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(count)), dim3(FV_BLOCK), 0, ctx->stream, count, list, (const int32_t *)start.p, p->dia_pos.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    p->dia_alloc = what;
+    p->dia_epoch = -1;
+    return FV_OK;
+}
+
 int fv_build_dia(fv_problem *p)
 {
     fv_ctx *ctx = p->ctx;
@@ -2130,13 +2171,22 @@ int fv_build_dia(fv_problem *p)
     FV_TRY(p->sl_off.alloc(ctx, (size_t)ns * DIA_K));
     FV_TRY(fd.alloc(ctx, (size_t)ns));
     FV_TRY(fc.alloc(ctx, (size_t)ns));
-    hipLaunchKernelGGL(dia_pattern_kernel, dim3(fv_blocks(ns, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p,
-                       p->sl_noff.p, p->sl_off.p, fd.p, fc.p);
+    if (p->lean)
+        FV_TRY(fv_lean_dia_pattern(p, p->sl_noff.p, p->sl_off.p, fd.p, fc.p));
+    else
+        hipLaunchKernelGGL(dia_pattern_kernel, dim3(fv_blocks(ns, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p,
+                           p->sl_noff.p, p->sl_off.p, fd.p, fc.p);
     FV_LAUNCH_CHECK(ctx);
     FV_TRY(p->dia_list.alloc(ctx, (size_t)ns));
     FV_TRY(p->csr_list.alloc(ctx, (size_t)ns));
     FV_TRY(fv_compact_flags(ctx, fd.p, ns, p->dia_list.p, &p->ndia));
     FV_TRY(fv_compact_flags(ctx, fc.p, ns, p->csr_list.p, &p->ncsr_groups));
+    if (p->lean && p->ncsr_groups > 0) { // (Dirichlet cells scattered so that some 64-row slice sees more than 8 distinct column offsets)
+        p->dia_built = false;
+        fv_set_error(ctx, "lean set-up: %lld of %lld 64-row slices have more than %d distinct column offsets and would need the CSR, which a lean problem "
+                          "does not keep: create the problem with FV_OPT_LEAN_SETUP at 0", (long long)p->ncsr_groups, (long long)ns, DIA_K);
+        return FV_ERR_STATE;
+    }
     if (p->ndia * 2 < ns) { // mostly irregular: keep the pure CSR form
         p->ndia = 0;
         p->ncsr_groups = ns;
@@ -2146,22 +2196,9 @@ int fv_build_dia(fv_problem *p)
         p->sl_off.release();
         return FV_OK;
     }
-    {
-        DevBuf<int32_t> len, start;
-        FV_TRY(len.alloc(ctx, (size_t)p->ndia));
-        FV_TRY(start.alloc(ctx, (size_t)p->ndia + 1));
-        hipLaunchKernelGGL(dia_len_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, (const int32_t *)p->dia_list.p,
-                           (const uint8_t *)p->sl_noff.p, g_dia_packed ? 0 : DIA_K, len.p);
-        FV_LAUNCH_CHECK(ctx);
-        int64_t nblocks = 0; // blocks of 64 doubles in all
-        FV_TRY(fv_exclusive_scan_i32(ctx, len.p, start.p, p->ndia, &nblocks));
-        FV_TRY(p->dia_vals.alloc(ctx, (size_t)nblocks * 64 + 64));
-        FV_TRY(p->dia_pos.alloc(ctx, (size_t)ns));
-        hipLaunchKernelGGL(dia_pos_kernel, dim3(fv_blocks(p->ndia)), dim3(FV_BLOCK), 0, ctx->stream, p->ndia, (const int32_t *)p->dia_list.p,
-                           (const int32_t *)start.p, p->dia_pos.p);
-        FV_LAUNCH_CHECK(ctx);
-        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    }
+    p->dia_alloc = 0;
+    // (a lean problem allocates the lane-major values when a form first asks for them, and then only the slices it asks for)
+    FV_TRY(dia_alloc_values(p, p->dia_list.p, p->ndia, p->lean ? 0 : 2));
     p->dia_epoch = -1;
     if (p->group_order.p) { // walk the slices band by band, plane after plane: the +-plane x arms are then re-used while still in L2
         DevBuf<int32_t> flag, idx;
@@ -2192,7 +2229,11 @@ static int ensure_dia_vals(fv_problem *p, const double *src, double src_tag, boo
         return FV_OK;
     const int64_t cnt = only_rest ? p->sym_nrest : p->ndia;
     const int32_t *list = only_rest ? p->sym_rest.p : p->dia_list.p;
-    if (cnt > 0)
+    if (p->lean) {
+        if (p->dia_alloc < (only_rest ? 1 : 2))
+            FV_TRY(dia_alloc_values(p, list, cnt, only_rest ? 1 : 2));
+        FV_TRY(fv_lean_dia_fill(p, src_tag, cnt, list));
+    } else if (cnt > 0)
         hipLaunchKernelGGL(dia_fill_kernel, dim3(fv_blocks(cnt, FV_BLOCK / 64)), dim3(FV_BLOCK), 0, ctx->stream, p->n, cnt, list,
                            p->sl_noff.p, p->sl_off.p, p->rowptr.p, p->colind.p, src, (const int32_t *)p->dia_pos.p, p->dia_vals.p);
     FV_LAUNCH_CHECK(ctx);
@@ -2321,6 +2362,7 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
 {
     fv_ctx *ctx = p->ctx;
     *used_sell = false;
+    FV_TRY(fv_require_csr(p, "the SpMV of groups outside the sliced-DIA form"));
     // (a pure-CSR operator hands over its traversal order of ALL groups: the SELL form then covers every group, in ascending order)
     if (mode != SPMV_INIT && !p->dist && p->nhalo == 0)
         FV_TRY(ensure_sell(p, list == p->group_order.p ? nullptr : list, count, vals, vals_tag));
@@ -2389,6 +2431,7 @@ static int launch_wstream(fv_problem *p, int G, const double *vals, const double
                           int mode, double *partials, const PcgScalars *scal, const int32_t *order, int64_t npos, const StepInitEpilogue &epi)
 {
     fv_ctx *ctx = p->ctx;
+    FV_TRY(fv_require_csr(p, "the CSR wave-stream SpMV (an operator without the sliced-DIA structure)"));
 #define FV_WS(D_, N_, I_)                                                                                                            \
     hipLaunchKernelGGL((spmv_wstream_kernel<512, D_, N_, I_>), dim3(G), dim3(FV_BLOCK), 0, ctx->stream, p->n, p->rowptr.p, p->colind.p, \
                        vals, x, y, shift, sigma, partials, scal, order, npos, epi)
@@ -2782,7 +2825,7 @@ extern "C" int fv_spmv_form(fv_problem *p, int32_t *form, int64_t *bytes_per_lau
     const int64_t csr_all = 12 * p->nnz + 20 * n;
     int64_t bytes = csr_all;
     if (p->last_form > FV_SPMV_CSR && ns > 0 && p->ndia > 0) {
-        const int64_t blocks = p->dia_vals.n / 64;                           // lane-major blocks of all DIA slices
+        const int64_t blocks = p->dia_nblocks + 1;                           // lane-major blocks of all DIA slices (+ the pad block)
         const int64_t meta = 37;                                               // per slice: sl_noff 1, sl_off 32, dia_pos 4
         const int64_t dia_all = blocks * 512 + p->ndia * meta;                // matrix side of the sliced-DIA form
         const int64_t csr_part = csr_all / ns * p->ncsr_groups;               // the CSR groups' share, by group count
@@ -2839,6 +2882,13 @@ int ensure_folded(fv_problem *p, double sigma, const double **out)
     *out = nullptr;
     if (!g_fold_shift || p->fold_ok == 0 || p->nnz == 0)
         return FV_OK;
+    if (p->lean) { // no value array to fold into: the rows carry sigma D on their diagonal when a form is filled (fv_lean.h); the pointer is a token
+        p->fold_ok = 1;
+        p->shifted_sigma = sigma;
+        p->shifted_epoch = p->assemble_epoch;
+        *out = p->diagA.p;
+        return FV_OK;
+    }
     if (p->vals_shifted.p && p->shifted_sigma == sigma && p->shifted_epoch == p->assemble_epoch) {
         *out = p->vals_shifted.p;
         return FV_OK;

@@ -259,6 +259,16 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *                   mesh is numbered far worse than its size needs and the new order at least halves the mean distance between
  *                   the two cells of a face [default], 2 always.  Read when a problem is created in this context. */
 #define FV_OPT_REORDER 1
+/*   FV_OPT_LEAN_SETUP  fv_problem_create_regulargrid without face arrays, incident lists and canonical CSR in HBM: a regulargrid mesh is a
+ *                   closed form (src/grid.jl:56-110), so fv_assemble computes b and the diagonal from rows formed on the fly and the
+ *                   solver's storage forms are filled the same way — bit for bit the values assembleA (src/FiniteVolume.jl:75-108) gives.
+ *                   ~190 B of HBM per cell instead of ~490 during a transient run, and no int32 CSR offsets: 8e8 cells on one GPU where
+ *                   the CSR ends at 3e8.  Transient and steady Jacobi-PCG solves, fv_spmv, states and trajectories work as always;
+ *                   what needs the faces or the CSR — fv_get_csc, fv_problem_get_grid's face arrays, the AMG preconditioner, fv_dist_setup,
+ *                   the parameter gradients — returns FV_ERR_STATE, and so does a solve when scattered Dirichlet cells leave a
+ *                   64-row slice with more than 8 distinct column offsets.  0 never, 1 every grid of >= 4096 cells, 2 [default]
+ *                   grids whose CSR would not fit int32 offsets (7 N > 2^31: before, FV_ERR_TOO_LARGE).  Read when a problem is created. */
+#define FV_OPT_LEAN_SETUP 2
 int fv_ctx_set_option(fv_ctx *ctx, int option, int value);
 int fv_ctx_get_option(fv_ctx *ctx, int option, int *value);
 /* on = 1: HIP event pairs around every K1 / K2 / K3 launch of the PCG loop; on = 2: around K1 (the SpMV) only — an event

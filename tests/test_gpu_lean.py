@@ -1,0 +1,168 @@
+"""GPU: FV_OPT_LEAN_SETUP — a regulargrid problem without face arrays, incident lists and CSR in HBM (csrc/fv_lean.hip): b, the
+diagonal and every storage form of the solver filled from rows formed on the fly.  The claim is "the same doubles as the CSR
+route", so every check here is bit for bit against the same problem created with the option off: b, products with random
+vectors in every form (plain and with the shift folded in), whole transient runs (heads, iteration counts, the kernels that ran).
+What needs the faces or the CSR must fail loudly."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MINS, MAXS = [-50.0, -50.0, 0.0], [50.0, 50.0, 10.0]
+
+
+def _dirichlet(ns, kind):
+    n1, n2, n3 = ns
+    idx = np.arange(n1 * n2 * n3).reshape(n1, n2, n3)
+    if kind == "xfaces":
+        d = np.r_[idx[0].ravel(), idx[-1].ravel()]
+    elif kind == "lateral":
+        m = np.zeros((n1, n2, n3), bool)
+        m[:, 0, :] = m[:, -1, :] = m[:, :, 0] = m[:, :, -1] = True
+        d = idx[m]
+    elif kind == "xy":  # the x- and the y-faces
+        m = np.zeros((n1, n2, n3), bool)
+        m[0] = m[-1] = True
+        m[:, 0, :] = m[:, -1, :] = True
+        d = idx[m]
+    elif kind == "well":  # the x-faces and one column of cells through the box
+        d = np.r_[idx[0].ravel(), idx[-1].ravel(), idx[1:-1, n2 // 2, n3 // 3]]
+    else:
+        raise ValueError(kind)
+    return (np.unique(d) + 1).astype(np.int64)
+
+
+def _conductivities(F, kind, rng):
+    if kind == "uniform":
+        return np.array([1e-5]), None, False
+    if kind == "faces":
+        return np.exp(np.log(1e-5) + 0.7 * rng.standard_normal(F)), None, False
+    if kind == "log":
+        return np.log(1e-5) + 0.7 * rng.standard_normal(F), None, True
+    if kind == "meta":
+        return np.exp(np.log(1e-5) + rng.standard_normal(17)), rng.integers(1, 18, F).astype(np.int64), False
+    raise ValueError(kind)
+
+
+def _pair(fv, ns, dkind, kkind, seed):
+    rng = np.random.default_rng(seed)
+    dn = _dirichlet(ns, dkind)
+    ps = [fv.Problem.regulargrid(MINS, MAXS, list(ns), dn, lean=lean) for lean in (False, True)]
+    assert (ps[0].N, ps[0].F, ps[0].n, ps[0].nnz) == (ps[1].N, ps[1].F, ps[1].n, ps[1].nnz)
+    K, meta, logt = _conductivities(ps[0].F, kkind, rng)
+    src = np.zeros(ps[0].N)
+    free = np.setdiff1d(np.arange(1, ps[0].N + 1), dn)
+    src[free[rng.integers(0, len(free), 5)] - 1] = -1e-3 * rng.random(5)
+    dh = 1000.0 + rng.random(len(dn))
+    for p in ps:
+        p.assemble(K, src, dh, metaindex=meta, logtransformconductivity=logt)
+    return ps, rng, dn
+
+
+SHAPES = [((20, 18, 70), "xfaces"), ((20, 18, 70), "lateral"), ((12, 30, 66), "xy"), ((36, 182, 186), "xfaces"), ((34, 184, 188), "lateral")]
+
+
+@pytest.mark.parametrize("ns,dkind", SHAPES)
+@pytest.mark.parametrize("kkind", ["uniform", "faces", "log", "meta"])
+def test_lean_assembly_and_products_are_the_csr_route_bit_for_bit(fv, ns, dkind, kkind):
+    """assembleb's vector, and A x / (A + sigma D) x for random x — in the sliced-DIA form (small boxes) and the symmetric tiled form
+    (boxes of > 2^20 rows) — come out with the same bits as from the problem that holds faces and CSR."""
+    if kkind in ("log", "meta") and ns[0] > 30:
+        pytest.skip("the large boxes take the two plain kinds")
+    (p0, p1), rng, dn = _pair(fv, ns, dkind, kkind, seed=sum(ns) + 7 * len(dkind) + len(kkind))
+    assert np.array_equal(p0.b(), p1.b())
+    x = rng.standard_normal(p0.n)
+    y0, y1 = p0.spmv(x), p1.spmv(x)
+    assert p0.spmv_form()[0] == p1.spmv_form()[0] and np.array_equal(y0, y1)
+    u0 = 1000.0 + rng.random(p0.N)
+    for p in (p0, p1):
+        p.transient_begin(0.1, None, u0)
+    for sigma in (1.0 / 60.0, 0.37):
+        assert np.array_equal(p0.spmv(x, sigma), p1.spmv(x, sigma)), sigma
+    # a second assembly (other conductivities, other heads) refills every form
+    K2 = np.array([3e-5])
+    for p in (p0, p1):
+        p.assemble(K2, np.zeros(p.N), np.full(len(dn), 7.0))
+    assert np.array_equal(p0.b(), p1.b()) and np.array_equal(p0.spmv(x, 0.37), p1.spmv(x, 0.37))
+    for p in (p0, p1):
+        p.close()
+
+
+@pytest.mark.parametrize("dkind,kkind", [("lateral", "uniform"), ("xfaces", "faces"), ("xy", "uniform")])
+def test_lean_transient_runs_are_the_csr_route_bit_for_bit(fv, dkind, kkind):
+    """Fixed-dt runs through every regime of the stepping loop (one-iteration fused steps, the many-iteration loop, zero-iteration
+    steps, a new dt: every form refilled with another folded shift): heads, iteration counts and the forms that ran are those of
+    the problem with faces and CSR."""
+    ns = (34, 184, 188) if dkind != "xy" else (36, 130, 260)
+    (p0, p1), rng, dn = _pair(fv, ns, dkind, kkind, seed=5)
+    # smooth heads (one PCG iteration per small step, as in tests/test_gpu_fused.py): Dirichlet heads on the same smooth field
+    c = np.indices(ns).reshape(3, -1).astype(np.float64)
+    field = 1000.0 + 0.5 * np.sin(c[0] / 5.0) * np.cos(c[1] / 40.0) + 0.001 * c[2]
+    K, meta, logt = _conductivities(p0.F, kkind, np.random.default_rng(6))
+    src = np.zeros(p0.N)
+    src[np.setdiff1d(np.arange(p0.N), dn - 1)[p0.n // 2]] = -1e-3
+    for p in (p0, p1):
+        p.assemble(K, src, field[dn - 1] + 0.25, metaindex=meta, logtransformconductivity=logt)
+    smooth = field + 1e-3 * rng.random(p0.N)
+    DT = 2.0**-10  # far below the diffusion time of a cell: the one-iteration regime
+    sched = [(DT, 14, 1e-11), (40.0, 3, 1e-12), (DT, 9, 1e-11), (DT, 6, 1e-3), (300.0, 4, 1e-12), (DT / 2, 7, 1e-12)]
+    out = []
+    for p in (p0, p1):
+        st = p.transient_begin(0.1, None, smooth)
+        its = []
+        for dt, nsteps, rtol in sched:
+            it, info, _ = p.run_fixed(st, dt, nsteps, rtol=rtol, maxiter=2000)
+            assert info.converged
+            its.append(it.copy())
+        out.append((st.node_values(), np.concatenate(its), p.fused_form(), p.spmv_form()[0], p.fused_traversal(), p.loop_form()))
+    a, b = out
+    assert a[2][0] > 10 and a[2] == b[2] and a[3:] == b[3:], (a[2:], b[2:])
+    assert np.array_equal(a[1], b[1]) and (a[1] > 1).any()
+    assert np.array_equal(a[0], b[0])
+    # a steady solve on the same problems (no shift)
+    h0, _, c0 = p0.solve_steady(None, 1e-9, 20000, want_resnorm=False)
+    h1, _, c1 = p1.solve_steady(None, 1e-9, 20000, want_resnorm=False)
+    assert c0.isconverged and c0.iters == c1.iters and np.array_equal(h0, h1)
+    for p in (p0, p1):
+        p.close()
+
+
+def test_lean_problem_refuses_what_needs_faces_or_csr(fv):
+    ns = (20, 18, 70)
+    (p0, p1), rng, dn = _pair(fv, ns, "xfaces", "uniform", seed=2)
+    lib = fv.load()
+    for call in (lambda: p1.csc(), lambda: p1.set_preconditioner("amg"), lambda: p1.amg_info()):
+        with pytest.raises(fv.FVError) as e:
+            call()
+        assert e.value.code == 6 and "lean" in str(e.value)  # FV_ERR_STATE
+    n1 = np.empty(p1.F, np.int64)
+    with pytest.raises(fv.FVError):
+        p1.check(lib.fv_problem_get_grid(p1.handle, n1.ctypes.data, None, None, None))
+    vol = np.empty(p1.N)
+    p1.check(lib.fv_problem_get_grid(p1.handle, None, None, None, vol.ctypes.data))  # (the volumes are kept)
+    vol0 = np.empty(p0.N)
+    p0.check(lib.fv_problem_get_grid(p0.handle, None, None, None, vol0.ctypes.data))
+    assert np.array_equal(vol, vol0)
+    p1.transient_begin(0.1, None, np.full(p1.N, 1000.0))
+    with pytest.raises(fv.FVError):
+        p1.param_jacobian_apply(np.zeros(p1.n), np.zeros(p1.n))
+    ctx = fv.default_context()
+    assert ctx.get_option(fv._lib.FV_OPT_LEAN_SETUP) == 2  # the default: lean only where the CSR would not fit
+    for p in (p0, p1):
+        p.close()
+
+
+@pytest.mark.parametrize("scattered", [False, True])
+def test_lean_problem_with_dirichlet_cells_inside_the_box_says_what_it_cannot_do(fv, scattered):
+    """Dirichlet cells inside the box (a column of them, or cells sprinkled over it) leave 64-row slices with more than eight distinct
+    column offsets: such slices need the CSR kernel.  The lean problem says so at its first product instead of computing anything else."""
+    ns = (20, 18, 70)
+    rng = np.random.default_rng(3)
+    N = ns[0] * ns[1] * ns[2]
+    dn = np.sort(rng.choice(N, N // 15, replace=False) + 1).astype(np.int64) if scattered else _dirichlet(ns, "well")
+    p = fv.Problem.regulargrid(MINS, MAXS, list(ns), dn, lean=True)
+    p.assemble(np.array([1e-5]), np.zeros(N), np.full(len(dn), 1.0))
+    with pytest.raises(fv.FVError) as e:
+        p.spmv(np.ones(p.n))
+    assert e.value.code == 6 and "distinct column offsets" in str(e.value)
+    p.close()
