@@ -345,6 +345,8 @@ def main():
     ap.add_argument("--no-multi-iteration", action="store_true", help="skip the second measured block (dt = 1 h, ~10 PCG iterations per step)")
     ap.add_argument("--no-hetero", action="store_true", help="skip the same workload with a heterogeneous conductivity (the matrix then streams as doubles: 73 B per row)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
+    ap.add_argument("--lean", choices=("auto", "on", "off"), default="auto",
+                    help="FV_OPT_LEAN_SETUP for the bench problem: no face arrays / incident lists / CSR in HBM (auto: only where the CSR would not fit int32 offsets)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -371,7 +373,7 @@ def main():
     mins, maxs = spacing_box(ns)
     dn, src = box_setup(ns)
     t_setup = time.perf_counter()
-    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx, lean={"auto": None, "on": True, "off": False}[args.lean])
     t_symbolic = time.perf_counter() - t_setup
     t1 = time.perf_counter()
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
@@ -435,6 +437,7 @@ def main():
             "setup_s": {"grid+symbolic": t_symbolic, "assemble": t_assemble, "total": t_setup},
             "device_ms_total": dev_ms,
             "hbm_in_use_gb": (free0 - ctx.mem_info()[0]) / 1e9,
+            "lean_setup": bool(p.lean),  # FV_OPT_LEAN_SETUP: the storage forms filled from rows formed on the fly (no faces, no CSR in HBM)
             "other_kernels": kern,
         },
         "roofline": roof,

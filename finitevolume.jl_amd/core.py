@@ -165,6 +165,7 @@ class Problem:
         self.N, self.F, self.n, self.nnz = N.value, F.value, n.value, nnz.value
         self._sources = None
         self._dheads = None
+        self.lean = False  # FV_OPT_LEAN_SETUP took effect for this problem (Problem.regulargrid sets it)
 
     @classmethod
     def create(cls, neighbors, areasoverlengths, N, dirichletnodes, ctx=None):
@@ -193,7 +194,11 @@ class Problem:
             ctx.check(load().fv_problem_create_regulargrid(ctx.handle, ptr(mins_), ptr(maxs_), ptr(ns_), len(d), ptr(d), C.byref(h)))
         finally:
             ctx.set_option(_lib.FV_OPT_LEAN_SETUP, before)
-        return cls(h, ctx)
+        p = cls(h, ctx)
+        N = int(ns_[0]) * int(ns_[1]) * int(ns_[2])
+        want = before if lean is None else (1 if lean else 0)
+        p.lean = bool(N >= 4096 and (want == 1 or (want == 2 and 7 * N > 2**31 - 3)))  # (fv_problem_create_regulargrid's rule)
+        return p
 
     @classmethod
     def regulargrid_slab(cls, mins, maxs, ns, dirichletnodes, i1_lo, i1_hi, ctx=None):

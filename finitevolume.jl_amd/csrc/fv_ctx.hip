@@ -37,6 +37,7 @@ void fv_warm_gradient(hipStream_t);
 void fv_warm_grid(hipStream_t);
 void fv_warm_lean(hipStream_t);
 void fv_warm_pcg(hipStream_t);
+void fv_warm_place(hipStream_t);
 void fv_warm_reorder(hipStream_t);
 void fv_warm_small(hipStream_t);
 void fv_warm_spmv(hipStream_t);
@@ -61,6 +62,7 @@ static int fv_warm_modules(fv_ctx *ctx)
     fv_warm_grid(ctx->stream);
     fv_warm_lean(ctx->stream);
     fv_warm_pcg(ctx->stream);
+    fv_warm_place(ctx->stream);
     fv_warm_reorder(ctx->stream);
     fv_warm_small(ctx->stream);
     fv_warm_spmv(ctx->stream);
@@ -149,6 +151,10 @@ extern "C" int fv_ctx_create(int device, fv_ctx **out)
         static bool env_read = false;
         if (!env_read) {
             env_read = true;
+            if (const char *e = getenv("FV_PLACE")) // 0: the loop's vectors from plain allocations (fv_place.hip)
+                g_place = atoi(e) != 0;
+            if (const char *e = getenv("FV_ALLOC_SKEW")) // bytes by which consecutive large arrays are staggered inside their allocations (DevBuf, fv_internal.h)
+                g_alloc_skew_bytes = atoi(e) > 0 ? atoi(e) / 256 * 256 : 0;
             if (const char *e = getenv("FV_TUNE")) {
                 const char *s = e;
                 while (*s) {

@@ -1919,8 +1919,8 @@ int fv_fused_prepare(fv_problem *p)
     if (p->fz_part.p)
         return FV_OK;
     const size_t n = (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD;
-    FV_TRY(p->qv.alloc(ctx, n));
-    FV_TRY(p->qv2.alloc(ctx, n));
+    FV_TRY(fv_vec_alloc(p, p->qv, n, true));
+    FV_TRY(fv_vec_alloc(p, p->qv2, n, true));
     FV_TRY(p->qv.zero(ctx));
     FV_TRY(p->qv2.zero(ctx));
     FV_TRY(p->fz_part.alloc(ctx, (size_t)2 * 7 * FV_FUSED_PARTS));
@@ -2031,6 +2031,8 @@ static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt, bool doubles)
 static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
 {
     if (!g_fused_chunk || !p->kc_code.p || p->kc_state != (coded ? 1 : 2) || (coded && !a.mcode))
+        return false;
+    if (!coded && p->sym_big) // (fused_chunkd_kernel addresses whole arrays by 32-bit byte offsets; the 2-D tiles have 64-bit plane bases)
         return false;
     a.kcode = p->kc_code.p;
     a.kdiag = p->kc_dtab;

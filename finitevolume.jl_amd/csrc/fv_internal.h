@@ -218,6 +218,8 @@ struct GridRows {
     double sigma;
 };
 constexpr int DIA_K = 8; // distinct column offsets a 64-row slice of the sliced-DIA form can have
+struct fv_problem;
+void fv_vec_release_spares(fv_problem *p); // fv_place.hip
 
 struct fv_problem {
     fv_ctx *ctx = nullptr;
@@ -291,6 +293,7 @@ struct fv_problem {
     DevBuf<uint8_t> sym_ok;   // per 64-row slice: every stored offset of the slice is 0 or +-sym_d[k]
     DevBuf<int32_t> sym_rest; // the DIA slices where that does not hold (slice-by-slice kernel)
     int64_t sym_d[3] = {0, 0, 0}, sym_ld = 0, sym_front = 0, sym_nrest = 0, sym_epoch = -1;
+    bool sym_big = false; // more than 2^32 bytes per array: only the kernels with 64-bit row indices / plane bases may serve the copy
     double sym_tag = 0.0;
     // slices whose diagonal the symmetric kernel re-derives from the six arms it holds (bit 1 of sym_ok; symdia_rowsum_kernel)
     int64_t sym_nderived = 0;
@@ -431,6 +434,15 @@ struct fv_problem {
     int32_t ploop_bytes[3] = {0, 0, 0}; // fv_step_form: set-up, first pass, flush of the most recent such solve (bytes per row)
     bool fused_chunked = false; // the most recent fused launch ran on chunks of a plane (fused_chunk_kernel), not on 2-D tiles
     int32_t loop_bytes = 0;  // bytes per row and iteration of the most recent many-iteration solve when its passes ran through the fused kernel (else 0)
+    // fv_place.hip: candidates for the vectors the loop writes in every step, timed and not yet handed out
+    struct PlacedSpare {
+        void *base = nullptr;
+        size_t count = 0;
+        double rate = 0.0;
+    };
+    std::vector<PlacedSpare> spares;
+    double place_best = 0.0; // the fastest chunked write seen among this problem's candidates (bytes per second)
+    int place_probes = 0;
     DevBuf<double> hist;
     DevBuf<PcgScalars> scal;
     int64_t hist_cap = 0;
@@ -450,6 +462,7 @@ struct fv_problem {
         for (void *s : slot_bases)
             if (s)
                 (void)hipFree(s);
+        fv_vec_release_spares(this);
         for (hipEvent_t e : prof_ev)
             (void)hipEventDestroy(e);
         delete dist;
@@ -485,6 +498,11 @@ int64_t fv_grid_face_offset(const int64_t ns[3], int64_t i1);
 // ---- fv_assembly.hip
 int fv_build_maps(fv_problem *p, const int64_t *dirichletnodes_host_or_dev);
 int fv_build_symbolic(fv_problem *p);
+// fv_place.hip: a vector of the stepping loop, chosen by its write class where that shows (hot: written in every step)
+int fv_vec_alloc(fv_problem *p, DevBuf<double> &buf, size_t count, bool hot);
+int fv_vec_alloc_raw(fv_problem *p, size_t count, bool hot, void **base_out);
+size_t fv_vec_skew(size_t bytes); // the stagger to add to the base (FV_ALLOC_SKEW; 0 by default)
+extern int g_place;
 // fv_lean.hip: the set-up of a lean problem (no faces, no CSR) from rows formed on the fly
 GridRows fv_grid_rows(const fv_problem *p, double sigma);
 int fv_require_csr(fv_problem *p, const char *what); // FV_ERR_STATE with a message for a lean problem, FV_OK otherwise

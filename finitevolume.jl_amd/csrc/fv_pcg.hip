@@ -1280,12 +1280,13 @@ int fv_pcg_prepare(fv_problem *p)
     if (p->r.p)
         return FV_OK;
     const size_t n = (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD; // slack for double2 tails and whole x lines; halo slots of a row block
-    FV_TRY(p->r.alloc(ctx, n));
-    FV_TRY(p->pvec.alloc(ctx, n));
-    FV_TRY(p->q.alloc(ctx, n));
-    FV_TRY(p->minv.alloc(ctx, n));
-    FV_TRY(p->rhs.alloc(ctx, n));
-    FV_TRY(p->tmp.alloc(ctx, n));
+    // (the vectors every step writes first — fv_place.hip —: the ones that are only read take what they leave)
+    FV_TRY(fv_vec_alloc(p, p->pvec, n, true));
+    FV_TRY(fv_vec_alloc(p, p->q, n, true));
+    FV_TRY(fv_vec_alloc(p, p->r, n, true));
+    FV_TRY(fv_vec_alloc(p, p->minv, n, false));
+    FV_TRY(fv_vec_alloc(p, p->rhs, n, false));
+    FV_TRY(fv_vec_alloc(p, p->tmp, n, false));
     // two launches (sliced-DIA part + CSR part) may each leave up to FV_MAX_PARTIALS partials
     FV_TRY(p->part_pq.alloc(ctx, 4 * FV_MAX_PARTIALS)); // distributed: interior + boundary pass, each DIA + CSR
     FV_TRY(p->part_rz.alloc(ctx, 2 * FV_VEC_PARTIALS));
@@ -1392,7 +1393,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     const bool speculate = !resume && sys.speculate && sys.x_next && sys.implicit_step && !sys.b_times_D && !compute_minv && !g_fuse_init &&
                            fv_step_precond(p) != FV_PRECOND_AMG && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
-        FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+        FV_TRY(fv_vec_alloc(p, p->pnext, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD, true));
     // K2S without the b' stream when b' (the assembled b) is sparse: its share of rhs.rhs comes from a gather over its support
     int64_t bsupport = -1;
     if (speculate && g_sparse_b && sys.rhs == p->b.p)
@@ -1594,13 +1595,13 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
     if (ploop) {
         const size_t nv = (size_t)n + (size_t)p->nhalo + FV_VEC_PAD;
         if (!p->pnext.p)
-            FV_TRY(p->pnext.alloc(ctx, nv));
+            FV_TRY(fv_vec_alloc(p, p->pnext, nv, true));
         if (!p->zalt.p) {
-            FV_TRY(p->zalt.alloc(ctx, nv));
+            FV_TRY(fv_vec_alloc(p, p->zalt, nv, true));
             FV_TRY(p->zalt.zero(ctx));
         }
         if (!p->walt.p) {
-            FV_TRY(p->walt.alloc(ctx, nv));
+            FV_TRY(fv_vec_alloc(p, p->walt, nv, true));
             FV_TRY(p->walt.zero(ctx));
         }
         double *zb[2] = {p->r.p, p->zalt.p}, *pb[2] = {p->pvec.p, p->pnext.p}, *wb[2] = {p->q.p, p->walt.p};
@@ -1767,7 +1768,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 FV_TRY(minv_positive(p, &mpos));
                 zloop = mpos && fv_fused_iteration_applicable(p, sigma, folded != nullptr) ? 2 : 0;
                 if (zloop == 2 && !p->pnext.p) // the pass writes the new direction beside the old one (halo rows of other tiles still read it)
-                    FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+                    FV_TRY(fv_vec_alloc(p, p->pnext, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD, true));
             }
             if (zloop == 2) {
                 const uint8_t *mvc = nullptr;
@@ -2467,7 +2468,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
     }
     const bool speculate = !resume && speculate_in && x_next && !compute_minv && p->last_iters == 1 && maxiter > 0;
     if (speculate && !p->pnext.p)
-        FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+        FV_TRY(fv_vec_alloc(p, p->pnext, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD, true));
     int64_t bsupport = -1; // the block's b is as sparse as the global one: its share of rhs.rhs by the gather blocks of K2S
     if (speculate && g_sparse_b)
         FV_TRY(ensure_b_support(p, &bsupport));
@@ -2618,7 +2619,7 @@ static int dist_step(fv_problem *p, double *u, double dt, double rtol, int64_t m
             FV_TRY(p->cg_scal.alloc(ctx, 4));
         }
         if (!p->pnext.p)
-            FV_TRY(p->pnext.alloc(ctx, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD));
+            FV_TRY(fv_vec_alloc(p, p->pnext, (size_t)n + (size_t)p->nhalo + FV_VEC_PAD, true));
         CgcgScalars *cg = reinterpret_cast<CgcgScalars *>(p->cg_scal.p);
         double *uu = p->cg_u.p, *ss = p->pnext.p, *ww = p->q.p;
         // u0 = M^-1 r0 is what the set-up left in pvec; w0 = A u0, delta0 = w0.u0

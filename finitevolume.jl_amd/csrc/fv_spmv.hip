@@ -1736,7 +1736,11 @@ static int build_symdia(fv_problem *p)
     p->sym_d[2] = d3;
     p->sym_front = ((int64_t)d3 + 128 + 63) / 64 * 64;
     p->sym_ld = p->sym_front + (ns << 6) + 256;
-    if (p->sym_ld * 8 >= ((int64_t)1 << 32) || (p->n + p->nhalo + 256) * 8 >= ((int64_t)1 << 32)) // the kernel's 32-bit byte offsets
+    // beyond 2^32 bytes per array (5.4e8 rows) the plane-marching kernel's 32-bit byte offsets end; the tiled traversal (64-bit row
+    // indices) and the fused step's kernels with 64-bit plane bases go on: such an operator takes the symmetric form only where they apply
+    p->sym_big = p->sym_ld * 8 >= ((int64_t)1 << 32) || (p->n + p->nhalo + 256) * 8 >= ((int64_t)1 << 32);
+    if (p->sym_big && !(g_sym_tile && d1 == 1 && d2 >= 64 && d2 <= 2 * FV_TILE_T && d2 % 2 == 0 && d3 % 2 == 0 && d3 % d2 == 0 && d3 >= FV_TILE_R + d2 &&
+                        p->n % d3 == 0 && p->n / d3 >= 3 && !p->dist))
         return FV_OK;
     FV_TRY(p->sym_vals.alloc(ctx, (size_t)(4 * p->sym_ld)));
     FV_HIP(ctx, hipMemsetAsync(p->sym_vals.p, 0, (size_t)(4 * p->sym_ld) * sizeof(double), ctx->stream));
@@ -2543,6 +2547,8 @@ int spmv_apply(fv_problem *p, const double *x, double *y, double sigma, const do
             const int64_t tnz = p->sym_d[1], td3 = p->sym_d[2];
             tile = g_sym_tile && p->sym_d[0] == 1 && tnz >= 64 && tnz <= 2 * FV_TILE_T && tnz % 2 == 0 && td3 % 2 == 0 && td3 % tnz == 0 &&
                    td3 >= FV_TILE_R + tnz && p->n % td3 == 0 && p->n / td3 >= 3;
+            if (p->sym_big && !tile) // (the tiled traversal switched off on a live problem of more than 2^32 bytes per array: the seven-diagonal forms serve it)
+                sym = false;
         }
         const bool march_pays = sym || g_march == 2 || (p->n + p->nhalo) * (int64_t)sizeof(double) > (int64_t)g_march_min_mb * 1048576;
         const bool march = may_march && march_pays;

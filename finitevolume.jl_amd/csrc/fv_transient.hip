@@ -38,14 +38,8 @@ int fv_slot_new(fv_problem *p, int32_t *slot)
             return FV_OK;
         }
     void *base = nullptr;
-    const size_t bytes = ((size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD) * sizeof(double);
-    const size_t skew = (g_alloc_skew_bytes > 0 && bytes >= ((size_t)1 << 22)) ? (size_t)(g_alloc_skew_count++ % 16) * (size_t)g_alloc_skew_bytes : 0;
-    hipError_t e = hipMalloc(&base, bytes + skew);
-    if (e != hipSuccess) {
-        fv_set_error(p->ctx, "hipMalloc of a state vector failed: %s", hipGetErrorString(e));
-        return FV_ERR_NOMEM;
-    }
-    double *d = reinterpret_cast<double *>(static_cast<char *>(base) + skew);
+    FV_TRY(fv_vec_alloc_raw(p, (size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD, true, &base)); // (a state is written in every step: fv_place.hip)
+    double *d = reinterpret_cast<double *>(static_cast<char *>(base) + fv_vec_skew(((size_t)p->n + (size_t)p->nhalo + FV_VEC_PAD) * sizeof(double)));
     p->slot_bases.push_back(base);
     p->slots.push_back(d);
     p->slot_used.push_back(1);
@@ -560,6 +554,8 @@ extern "C" int fv_transient_run_fixed(fv_problem *p, int32_t slot, double dt, in
     (void)hipEventDestroy(e1);
     if (last_info)
         *last_info = inf;
+    if (nsteps >= 8)
+        fv_vec_release_spares(p); // (every vector of the loop exists by now: the candidates nobody asked for go back — fv_place.hip)
     return rc;
 }
 

@@ -67,6 +67,7 @@ def _run(fv, case, fused, schedule, Ss=0.1, tune=()):
 # 34 x 182 x 186 again with the four lateral faces Dirichlet (every slice holds rows next to a Dirichlet cell).
 BOX, BOX2, BOX3 = (36, 182, 186), (36, 165, 200), (34, 184, 188)
 BOX4 = (36, 58, 602)  # lines longer than the chunk kernels' block: their halo rows take three rounds of its threads
+BOX5 = (36, 40, 900)  # ... four rounds (lines of up to 1024 rows: the tiled product's own limit)
 DT = 2.0**-10  # far below the diffusion time of a cell: the one-iteration regime
 
 
@@ -208,7 +209,7 @@ def test_matrix_as_codes_gives_the_same_bits(fv):
 
 
 # ------------------------------------------------------------------ the chunk traversal (round 4; fused_chunk_kernel, fv_tune key 60)
-@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True), (BOX4, False), (BOX4, True)])
+@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True), (BOX4, False), (BOX4, True), (BOX5, False)])
 def test_chunk_traversal_against_the_tiles_and_the_oracle(fv, oracle, ns, lateral):
     """With the matrix as codes the fused step walks contiguous chunks of a plane's rows instead of 2-D tiles (no column halos,
     the diagonal of rows next to a Dirichlet cell out of a table by a per-row code, everything that needs a diagonal formed when
@@ -245,7 +246,7 @@ def test_chunk_traversal_against_the_tiles_and_the_oracle(fv, oracle, ns, latera
     assert relerr(chunks[0], u) < 1e-8
 
 
-@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True), (BOX4, False), (BOX4, True)])
+@pytest.mark.parametrize("ns,lateral", [(BOX, False), (BOX2, False), (BOX3, True), (BOX4, False), (BOX4, True), (BOX5, False)])
 def test_chunk_traversal_with_the_matrix_as_doubles_against_the_tiles_and_the_oracle(fv, oracle, ns, lateral):
     """Round 5: a heterogeneous conductivity (one value per face, /root/reference/src/FiniteVolume.jl:75-108) has no matrix codes; its
     fused step / pass walks the same chunks with the three upper diagonals streamed as doubles (fused_chunkd_kernel: U2 through an

@@ -16,7 +16,7 @@ mins, maxs = bench.spacing_box(ns)
 dn, src = bench.box_setup(ns)
 keep = []
 for rep in range(int(sys.argv[2]) if len(sys.argv) > 2 else 6):
-    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, lean=(len(sys.argv) > 3 and sys.argv[3] == "lean") or None)
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
     st = p.transient_begin(0.1, None, np.full(p.N, 1e3))
     p.run_fixed(st, 60.0, 4, 1e-10)
