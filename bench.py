@@ -345,6 +345,7 @@ def main():
     ap.add_argument("--no-multi-iteration", action="store_true", help="skip the second measured block (dt = 1 h, ~10 PCG iterations per step)")
     ap.add_argument("--no-hetero", action="store_true", help="skip the same workload with a heterogeneous conductivity (the matrix then streams as doubles: 73 B per row)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
+    ap.add_argument("--no-lean-block", action="store_true", help="skip the same steps on a lean problem (no faces / CSR in HBM)")
     ap.add_argument("--lean", choices=("auto", "on", "off"), default="auto",
                     help="FV_OPT_LEAN_SETUP for the bench problem: no face arrays / incident lists / CSR in HBM (auto: only where the CSR would not fit int32 offsets)")
     args = ap.parse_args()
@@ -449,6 +450,12 @@ def main():
             out["config"]["multi_iteration"] = "failed: %r" % (e,)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
+    if not args.no_lean_block and not p.lean:
+        p.close()
+        try:
+            out["config"]["lean_setup_block"] = lean_block(fv, ctx, args, mins, maxs, ns, dn, src)
+        except Exception as e:
+            out["config"]["lean_setup_block"] = "failed: %r" % (e,)
     if not args.no_hetero:
         p.close()
         try:
@@ -730,6 +737,32 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
         except Exception:
             pass
     return roof, kern
+
+
+def lean_block(fv, ctx, args, mins, maxs, ns, dn, src):
+    """The same workload on a problem created with FV_OPT_LEAN_SETUP (csrc/fv_lean.hip): no face arrays, incident lists or CSR in HBM, every
+    storage form filled from rows formed on the fly — the same doubles (tests/test_gpu_lean.py), the same kernels, a third of the memory."""
+    ctx.synchronize()
+    free0 = ctx.mem_info()[0]
+    t0 = time.perf_counter()
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx, lean=True)
+    p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
+    state = p.transient_begin(0.1, None, np.full(p.N, 1e3))
+    t_setup = time.perf_counter() - t0
+    if args.warmup > 0:
+        p.run_fixed(state, args.dt, args.warmup, args.rtol, args.maxiter)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    iters, info, _ = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
+    ctx.synchronize()
+    sec = time.perf_counter() - t0
+    in_use = (free0 - ctx.mem_info()[0]) / 1e9
+    out = {"workload": "the headline's %d^3 box, dt, tolerance and steps on a lean problem (FV_OPT_LEAN_SETUP = 1)" % ns[0], "ms_per_step": sec / args.steps * 1e3,
+           "value": p.N * args.steps / sec, "pcg_iters_per_step": float(np.mean(iters)), "converged": bool(info.converged), "hbm_in_use_gb": in_use,
+           "bytes_per_cell_in_hbm": in_use * 1e9 / p.N, "setup_s": t_setup, "fused_launches": p.fused_form()[0], "traversal": "chunks" if p.fused_traversal() == 1 else "tiles",
+           "larger_boxes": "profiles/r05_bench832_lean.json (5.8e8 cells), r05_bench928_lean.json (8.0e8 cells, 5.6e9 non-zeros): the same command with --ns"}
+    p.close()
+    return out
 
 
 def multi_iteration_block(p, args):

@@ -585,3 +585,73 @@ def test_row_block_driver_with_one_rank_costs_what_the_plain_loop_costs(fv):
     d = blocks["config"]["per_rank"][0]["diagnosis"]
     # (one rank: nothing travels — no all-reduce is issued, no halo is waited for —, the passes are timed)
     assert d["interior_spmv_per_step"] >= 1 and d["interior_spmv_ms_per_step"] > 0 and d["halo_wait_ms_per_step"] == 0.0 and d["allreduce_ms_per_step"] == 0.0
+
+
+def test_lean_box_beyond_the_int32_csr_and_two_to_the_32_bytes_per_vector(fv, oracle):
+    """Round 5 (FV_OPT_LEAN_SETUP, csrc/fv_lean.hip): 832^3 = 5.76e8 cells on one GPU — 4.0e9 non-zeros, which the int32 CSR cannot index, and
+    4.6 GB per vector, beyond the 32-bit byte offsets some kernels address by (the symmetric form then runs through the tiled product and the
+    chunk kernels' 64-bit plane bases only).  No oracle at this size, but with heads on the two x-faces, one conductivity and a start state that
+    depends on x only the 3-D solution IS the 1-D one in every (y, z) column (volumes and areas scale alike: src/grid.jl:72-105), and the 1-D problem
+    is the oracle's on an n1 x 2 x 2 box.  Then the same steps through kernels that share no indexing code with the first run (seven-diagonal
+    slices, unfused K1 / K2 / K3) on the same lean problem."""
+    ns = [832, 832, 832]
+    mins, maxs = bench.spacing_box(ns)
+    n1, plane = ns[0], ns[1] * ns[2]
+    dn = np.r_[np.arange(plane), (n1 - 1) * plane + np.arange(plane)].astype(np.int64) + 1
+    xs = np.linspace(mins[0], maxs[0], n1)
+    prof = 1000.0 + 2.0 * np.sin(xs / 150.0) + 1e-3 * xs  # the start state along x
+    dh = np.r_[np.full(plane, prof[0] + 0.5), np.full(plane, prof[-1] - 0.25)]
+    K, Ss, dt, nsteps = 1e-5, 0.1, 900.0, 6
+    # the 1-D reference: the oracle on n1 x 2 x 2 cells of the same spacing in x
+    o = oracle
+    _, a1, a2, aol1, vol1 = o.regulargrid([mins[0], 0.0, 0.0], [maxs[0], 1.0, 1.0], [n1, 2, 2], want_coords=False)
+    dn1 = np.r_[np.arange(4), (n1 - 1) * 4 + np.arange(4)].astype(np.int64) + 1
+    dh1 = np.r_[np.full(4, dh[0]), np.full(4, dh[-1])]
+    u1 = np.repeat(prof, 4)
+    us, _ = o.backwardeulerintegrate(u1, (0.0, dt * nsteps), Ss, vol1, a1, a2, aol1, np.full(len(aol1), K), np.zeros(len(vol1)), dn1, dh1,
+                                     stepper=o.fixedbackwardeulerstep, dt0=dt, linearsolver=o.tightcgsolver(1e-14))
+    ref = us[-1].reshape(n1, 4)
+    assert np.abs(ref - ref[:, :1]).max() < 1e-9  # (the oracle's own columns agree)
+    ref = ref[:, 0]
+    assert np.abs(ref - prof)[1:-1].max() > 1e-3  # the state moved
+
+    lib = fv.load()
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+    assert p.lean and p.n * 8 > 2**32 and p.nnz > 2**31  # the default setting went lean by itself
+    p.assemble(np.array([K]), np.zeros(p.N), dh)
+    u0 = np.repeat(prof, plane)
+    st = p.transient_begin(Ss, None, u0)
+    it, info, _ = p.run_fixed(st, dt, nsteps, 1e-12, 4000)
+    assert info.converged and p.spmv_form()[0] == 4 and p.loop_form() in (67, 76, 83), (p.spmv_form(), p.loop_form())
+    got = st.node_values().reshape(n1, plane)
+    spread = np.abs(got - got[:, :1]).max()
+    err = np.abs(got[:, 0] - ref).max()
+    print("832^3 lean: %s iterations, columns agree to %.2e, against the 1-D oracle %.2e" % (it, spread, err))
+    assert spread < 5e-8 and err < 5e-8
+    first = got[:, ::4099].copy()
+    del got
+    # one-iteration fused steps on the same problem from a state that varies in y and z too (the bench's dt), then the same through the
+    # seven-diagonal slices and the unfused chain
+    u0 = (prof[:, None, None] + 0.05 * np.sin(np.arange(ns[1]) / 37.0)[None, :, None] * np.cos(np.arange(ns[2]) / 11.0)[None, None, :]).reshape(-1)
+    out = []
+    for tune in (None, ((41, 0), (27, 1))):
+        try:
+            for k, v in tune or ():
+                assert lib.fv_tune(k, v) == 0
+            q = p if tune is None else fv.Problem.regulargrid(mins, maxs, ns, dn)
+            if tune is not None:
+                p.close()
+                q.assemble(np.array([K]), np.zeros(q.N), dh)
+            s2 = q.transient_begin(Ss, None, u0)
+            i2, inf2, _ = q.run_fixed(s2, 60.0, 20, 1e-10, 2000)  # (the bench's dt and tolerance: one iteration per step)
+            assert inf2.converged
+            out.append((s2.free_values()[:: 8191].copy(), i2.copy(), q.fused_form()[0], q.spmv_form()[0], q.fused_traversal()))
+            if tune is not None:
+                q.close()
+        finally:
+            lib.fv_tune(41, 1)
+            lib.fv_tune(27, 4)
+    (a, ia, fa, forma, trava), (b, ib, fb, formb, travb) = out
+    assert fa >= 6 and trava == 1 and fb == 0 and forma == 4 and formb in (1, 2), (fa, trava, fb, forma, formb, ia, ib)
+    assert np.array_equal(ia, ib) and np.abs(a - b).max() < 1e-9 * 1e3, (ia, ib, np.abs(a - b).max())
+    del first
