@@ -1224,7 +1224,7 @@ __device__ __forceinline__ double kd_from_below(double v, double edge) // v of t
     return __hiloint2double(hi, lo);
 }
 
-template <int NT, int NP, int MODE, int PD, int PU, int HR = 2> // (HR as in fused_chunk_kernel)
+template <int NT, int NP, int MODE, int PD, int PU, int HR = 2, bool BIG = false> // (HR as in fused_chunk_kernel; BIG: vectors of more than 4 GiB)
 __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
 {
     // Rolling prefetch: the loads a pair needs (its batch z, v, x, U2, code byte for step (a); U1, U3 and the edge element for (c))
@@ -1326,19 +1326,27 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
         // plane + the plane's offset (a scalar) [+ the front padding of the symmetric arrays, whose rows -d3 .. -1 read zeros].  No
         // per-plane 64-bit bases: eleven arrays x three planes of them cost ~90 spilled scalar registers.  Every vector is < 4 GiB (the
         // host checks when it builds the symmetric copy); offsets are taken modulo 2^32, plane -1 of a padded array included.
+        // BIG: ... counted from the plane in front of the item's segment (the 32-bit offsets span a segment, not the array — vectors of more
+        // than 4 GiB are served as long as (planes of a segment + 3) x d3 x 8 bytes stay below 2^32, which kc_plan sees to; the rebased array
+        // starts are scalar 64-bit sums, formed once per item; the one-launch iteration then spills 8 B per lane, hence a variant of its own)
         const uint32_t d3b = (uint32_t)d3 * 8u, fb = a.front * 8u;
-        const char *u1f = reinterpret_cast<const char *>(a.u1 - a.front), *u2f = reinterpret_cast<const char *>(a.u2 - a.front),
-                   *u3f = reinterpret_cast<const char *>(a.u3 - a.front), *dgf = reinterpret_cast<const char *>(a.dg - a.front);
-        auto OFF = [&](int32_t pl) -> uint32_t { return (uint32_t)pl * d3b; };
+        const int32_t pb = BIG ? (p0 > 0 ? p0 - 1 : 0) : 0; // (below 4 GiB per vector the offsets count from the arrays' starts, as they always did)
+        const uint64_t rb8 = BIG ? (uint64_t)((int64_t)pb * d3) * 8u : 0u;
+        const char *u1f = reinterpret_cast<const char *>(a.u1 - a.front) + rb8, *u2f = reinterpret_cast<const char *>(a.u2 - a.front) + rb8,
+                   *u3f = reinterpret_cast<const char *>(a.u3 - a.front) + rb8, *dgf = reinterpret_cast<const char *>(a.dg - a.front) + rb8;
+        const uint8_t *kcode_s = a.kcode + (rb8 >> 3);
+        auto RB = [&](const void *arr) -> const char * { return reinterpret_cast<const char *>(arr) + rb8; };
+        auto RBW = [&](void *arr) -> char * { return reinterpret_cast<char *>(arr) + rb8; };
+        auto OFF = [&](int32_t pl) -> uint32_t { return (uint32_t)(pl - pb) * d3b; };
         auto LD2 = [&](const char *base, uint32_t off) -> double2 { return *reinterpret_cast<const double2 *>(base + off); };
         auto LD2nt = [&](const char *base, uint32_t off) -> double2 {
             const double *b = reinterpret_cast<const double *>(base + off);
             return make_double2(__builtin_nontemporal_load(b), __builtin_nontemporal_load(b + 1));
         };
-        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
-        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2nt(reinterpret_cast<const char *>(arr), ob[k] + OFF(pl)); };
+        auto P2 = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2(RB(arr), ob[k] + OFF(pl)); };
+        auto P2nt = [&](const double *arr, int32_t pl, int k) -> double2 { return LD2nt(RB(arr), ob[k] + OFF(pl)); };
         auto PUL = [&](const char *basef, int32_t pl, int k) -> double2 { return LD2nt(basef, fb + ob[k] + OFF(pl)); }; // a padded array (its start + front)
-        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (uint32_t) * reinterpret_cast<const uint16_t *>(a.kcode + ((ob[k] + OFF(pl)) >> 3)); };
+        auto C2 = [&](int32_t pl, int k) -> uint32_t { return (uint32_t) * reinterpret_cast<const uint16_t *>(kcode_s + ((ob[k] + OFF(pl)) >> 3)); };
         auto SD = [&](uint32_t c) -> double2 { return make_double2(tab[c & 15u], tab[(c >> 8) & 15u]); };
         auto E1L = [&](int32_t pl, int k) -> double {
             // (a wave-uniform address, loaded as a vector all the same: through the constant address space — a scalar load — the launch measured
@@ -1350,16 +1358,16 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
             const int64_t off = (int64_t)pl * d3 * 8 + (int64_t)hb[r];
             return off >= 0 && off < nrows8;
         };
-        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(arr) + ((uint32_t)hb[r] + OFF(pl))); };
+        auto H1 = [&](const double *arr, int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(RB(arr) + ((uint32_t)hb[r] + OFF(pl))); };
         auto HZ = [&](int32_t pl, int r) -> double { // the direction on a halo row, formed from its streams (the row exists)
             if (MODE == 3)
                 return LW ? (H1(a.z, pl, r) + ax * H1(a.w, pl, r)) + alpha * H1(a.v, pl, r) : H1(a.z, pl, r);
             return H1(a.z, pl, r) + alpha * H1(a.v, pl, r);
         };
         auto HU = [&](int32_t pl, int r) -> double { return *reinterpret_cast<const double *>(u2f + (fb + (uint32_t)hb[r] + OFF(pl))); };
-        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl))) = val; };
+        auto ST2 = [&](double *arr, int32_t pl, int k, double2 val) { *reinterpret_cast<double2 *>(RBW(arr) + (ob[k] + OFF(pl))) = val; };
         auto ST2nt = [&](double *arr, int32_t pl, int k, double2 val) {
-            double *q = reinterpret_cast<double *>(reinterpret_cast<char *>(arr) + (ob[k] + OFF(pl)));
+            double *q = reinterpret_cast<double *>(RBW(arr) + (ob[k] + OFF(pl)));
             __builtin_nontemporal_store(val.x, q);
             __builtin_nontemporal_store(val.y, q + 1);
         };
@@ -1388,7 +1396,7 @@ __global__ __launch_bounds__(NT) void fused_chunkd_kernel(KfArgs a)
                 }
             }
             if (MODE == 0 && vec_first && own[k]) { // plane 0: its whole vector part, with the stored diagonal
-                const double2 xi = P2(a.x, 0, k), dd = LD2(dgf, fb + ob[k]), ss = SD(C2(0, k));
+                const double2 xi = P2(a.x, 0, k), dd = LD2(dgf, fb + ob[k] + OFF(0)), ss = SD(C2(0, k));
                 const VRow ra = vrow(xi.x, zz.x, vv.x, dd.x, ss.x, alpha), rb = vrow(xi.y, zz.y, vv.y, dd.y, ss.y, alpha);
                 ST2(a.xout, 0, k, make_double2(ra.xn, rb.xn));
                 ST2(a.znext, 0, k, Zm[k]);
@@ -2018,6 +2026,7 @@ static bool kf_codes(fv_problem *p, KfArgs &a)
 constexpr size_t KC_LDS_MAX = 160 * 1024;
 struct KcPlan {
     int nt, np, grid, hr;
+    bool big; // vectors of more than 4 GiB (fv_problem::sym_big): the doubles kernel's offsets count from the item's segment
     size_t lds;
     bool doubles; // fused_chunkd_kernel (the matrix as doubles) instead of fused_chunk_kernel (as 16-bit codes)
 };
@@ -2032,8 +2041,7 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
 {
     if (!g_fused_chunk || !p->kc_code.p || p->kc_state != (coded ? 1 : 2) || (coded && !a.mcode))
         return false;
-    if (!coded && p->sym_big) // (fused_chunkd_kernel addresses whole arrays by 32-bit byte offsets; the 2-D tiles have 64-bit plane bases)
-        return false;
+
     a.kcode = p->kc_code.p;
     a.kdiag = p->kc_dtab;
     a.pfirst = 1;
@@ -2082,6 +2090,9 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
         const int64_t Ke = (d3 + Cr - 1) / Cr;
         const int nprod = a.nplanes - a.pfirst; // product planes
         for (int m = 1; m <= 64 && m <= nprod; m++) {
+            // (fused_chunkd_kernel's 32-bit byte offsets span a segment with the plane in front of it and the two behind, and the symmetric arrays' front padding)
+            if (!coded && p->sym_big && (((int64_t)(nprod + m - 1) / m + 4) * d3 + (int64_t)p->sym_front + 2 * nz) * 8 >= ((int64_t)1 << 32))
+                continue;
             const int64_t rounds = (Ke * m + resident - 1) / resident;
             const double cost = (double)rounds * (double)((nprod + m - 1) / m + 3) * ((double)Cr + 0.6 * (double)nz);
             if (best < 0.0 || cost < best) {
@@ -2107,15 +2118,16 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     pl.grid = (int)g;
     pl.lds = kc_lds_bytes(bestC, nz, nt, !coded);
     pl.doubles = !coded;
+    pl.big = p->sym_big;
     return true;
 }
-template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2, int HR = 2>
+template <int NT, int NP, int MODE, bool DOUBLES, int PD = 2, int PU = 2, int HR = 2, bool BIG = false>
 static int kc_launch_one(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
 {
     static bool raised = false; // (per instantiation: the dynamic LDS limit of the kernel, above the 64 KB default)
     void (*kern)(KfArgs);
     if constexpr (DOUBLES)
-        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU, HR>;
+        kern = &fused_chunkd_kernel<NT, NP, MODE, PD, PU, HR, BIG>;
     else
         kern = &fused_chunk_kernel<NT, NP, MODE, HR>;
     if (!raised) {
@@ -2132,6 +2144,13 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
         // 512 threads x 4 pairs, the batch three pairs ahead, U1 / U3 two, the wave's edge element by a vector load: measured 464^3, one process, ms
         // per step (tiles 1.531): (2,2) 1.376, (3,3) 1.373, (4,4) 1.378, (2,1) 1.347, (3,2) 1.335, (1,1) 1.344; 5 pairs spill (60-124 B per lane):
         // 1.384-1.477; the edge element by a scalar load (constant address space): +1.8 %; 64-bit plane bases: +0.1 % (profiles/r05_hetero_ab_*.log)
+        if (pl.big) { // (vectors of more than 4 GiB: 5.4e8 rows and more)
+            if (pl.hr == 4)
+                return kc_launch_one<512, 4, MODE, true, 3, 2, 4, true>(ctx, a, pl);
+            if (pl.hr == 3)
+                return kc_launch_one<512, 4, MODE, true, 3, 2, 3, true>(ctx, a, pl);
+            return kc_launch_one<512, 4, MODE, true, 3, 2, 2, true>(ctx, a, pl);
+        }
         if (pl.hr == 4)
             return kc_launch_one<512, 4, MODE, true, 3, 2, 4>(ctx, a, pl);
         if (pl.hr == 3)

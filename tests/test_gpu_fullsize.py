@@ -630,28 +630,34 @@ def test_lean_box_beyond_the_int32_csr_and_two_to_the_32_bytes_per_vector(fv, or
     assert spread < 5e-8 and err < 5e-8
     first = got[:, ::4099].copy()
     del got
-    # one-iteration fused steps on the same problem from a state that varies in y and z too (the bench's dt), then the same through the
-    # seven-diagonal slices and the unfused chain
+    # one-iteration fused steps from a state that varies in y and z too (the bench's dt), with one conductivity (the matrix as codes:
+    # fused_chunk_kernel) and with a conductivity per face (as doubles: fused_chunkd_kernel, its offsets counted from the segment: BIG) —
+    # each time against the seven-diagonal slices and the unfused chain on a second lean problem
     u0 = (prof[:, None, None] + 0.05 * np.sin(np.arange(ns[1]) / 37.0)[None, :, None] * np.cos(np.arange(ns[2]) / 11.0)[None, None, :]).reshape(-1)
-    out = []
-    for tune in (None, ((41, 0), (27, 1))):
-        try:
-            for k, v in tune or ():
-                assert lib.fv_tune(k, v) == 0
-            q = p if tune is None else fv.Problem.regulargrid(mins, maxs, ns, dn)
-            if tune is not None:
-                p.close()
-                q.assemble(np.array([K]), np.zeros(q.N), dh)
-            s2 = q.transient_begin(Ss, None, u0)
-            i2, inf2, _ = q.run_fixed(s2, 60.0, 20, 1e-10, 2000)  # (the bench's dt and tolerance: one iteration per step)
-            assert inf2.converged
-            out.append((s2.free_values()[:: 8191].copy(), i2.copy(), q.fused_form()[0], q.spmv_form()[0], q.fused_traversal()))
-            if tune is not None:
+    p.close()
+    F = p.F
+    block = np.exp(np.log(K) + 0.3 * np.sin(2 * np.pi * np.arange(1 << 20) / (1 << 20)) + 0.01 * np.random.default_rng(4).standard_normal(1 << 20))  # (smooth along the face list)
+    for kind, cond in (("uniform", np.array([K])), ("faces", np.tile(block, F // len(block) + 1)[:F])):
+        out = []
+        for tune in (None, ((41, 0), (27, 1))):
+            try:
+                for k, v in tune or ():
+                    assert lib.fv_tune(k, v) == 0
+                q = fv.Problem.regulargrid(mins, maxs, ns, dn)
+                q.assemble(cond, np.zeros(q.N), dh)
+                s2 = q.transient_begin(Ss, None, u0)
+                i2, inf2, _ = q.run_fixed(s2, 60.0 if kind == "uniform" else 7.5, 20, 1e-10, 2000)  # (the bench's dt and tolerance: one iteration per step)
+                i3, inf3, _ = q.run_fixed(s2, 600.0, 3, 1e-10, 2000)  # ... and a few steps of several iterations (the one-launch iteration)
+                assert inf2.converged and inf3.converged
+                out.append((s2.free_values()[::8191].copy(), np.r_[i2, i3], q.fused_form(), q.spmv_form()[0], q.fused_traversal(), q.loop_form()))
                 q.close()
-        finally:
-            lib.fv_tune(41, 1)
-            lib.fv_tune(27, 4)
-    (a, ia, fa, forma, trava), (b, ib, fb, formb, travb) = out
-    assert fa >= 6 and trava == 1 and fb == 0 and forma == 4 and formb in (1, 2), (fa, trava, fb, forma, formb, ia, ib)
-    assert np.array_equal(ia, ib) and np.abs(a - b).max() < 1e-9 * 1e3, (ia, ib, np.abs(a - b).max())
+            finally:
+                lib.fv_tune(41, 1)
+                lib.fv_tune(27, 4)
+        (a, ia, fa, forma, trava, loopa), (b, ib, fb, formb, travb, loopb) = out
+        print("832^3 lean, %s: iterations %s, fused form %s, loop form %s, fused against unfused slices %.2e" % (kind, ia, fa, loopa, np.abs(a - b).max()))
+        assert loopa == (67 if kind == "uniform" else 89) and loopb == 0 and ia[-1] > 2, (loopa, loopb, ia)
+        assert fa[0] >= 6 and trava == 1 and fb[0] == 0 and forma == 4 and formb in (1, 2), (kind, fa, trava, fb, forma, formb, ia, ib)
+        assert fa[1] == (51 if kind == "uniform" else 73), fa
+        assert np.abs(ia.astype(int) - ib.astype(int)).max() <= 1 and np.abs(a - b).max() < 1e-9 * 1e3, (kind, ia, ib, np.abs(a - b).max())
     del first
