@@ -33,6 +33,23 @@ def smooth_gaussian_field(ns, seed=0, radius_cells=(10, 10, 10), passes=3):
     return g.reshape(-1)  # C order of (n1,n2,n3) == node order i3 + n3*(i2 + n2*i1)
 
 
+def grid_face_means(ns, nodevalues):
+    """0.5 (v[node1] + v[node2]) for every face of regulargrid(ns) in the face list's order (a cell's x-, y-, z-face, cells in node order:
+    /root/reference/src/grid.jl:72-105) — nodehycos2neighborhycos(neighbors, v, true) (grid.jl:27) without the face list, for grids
+    whose 2 F face ends would not fit the host comfortably (or a lean problem, which keeps none)."""
+    n1, n2, n3 = ns
+    v = np.asarray(nodevalues, np.float64).reshape(n1, n2, n3)
+    vals = np.empty((n1, n2, n3, 3))
+    have = np.zeros((n1, n2, n3, 3), bool)
+    vals[:-1, :, :, 0] = 0.5 * (v[:-1] + v[1:])
+    have[:-1, :, :, 0] = True
+    vals[:, :-1, :, 1] = 0.5 * (v[:, :-1] + v[:, 1:])
+    have[:, :-1, :, 1] = True
+    vals[:, :, :-1, 2] = 0.5 * (v[:, :, :-1] + v[:, :, 1:])
+    have[:, :, :-1, 2] = True
+    return vals[have]
+
+
 def box_model_dirichlet(ns):
     """Dirichlet 1.0 on x = xmin, 0.0 on x = xmax (examples/box_model/ex.jl:29-37)."""
     n1, n2, n3 = ns

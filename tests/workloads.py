@@ -11,3 +11,4 @@ _spec.loader.exec_module(_mod)
 smooth_gaussian_field = _mod.smooth_gaussian_field
 box_model_dirichlet = _mod.box_model_dirichlet
 fractures_like = _mod.fractures_like
+grid_face_means = _mod.grid_face_means
