@@ -1679,7 +1679,7 @@ int fv_pcg_solve(fv_problem *p, double *x, const PcgSystem &sys, double rtol, in
                 FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
             }
         }
-        if (hs->iters >= 1 || j >= 1) {
+        if (hs->iters >= 1 || (j >= 1 && hs->done != 1)) { // (a solve that sat converged at its set-up: its launches stopped at their prologues, nothing moved)
             const int64_t full = hs->done == 1 ? (int64_t)hs->iters - 1 : j - 1; // launches beyond the first that ran their pass
             acct += (int64_t)(p->loop_bytes == 67 ? 19 : 41) * n + (full > 0 ? full : 0) * (int64_t)p->loop_bytes * n + ((itf >= 1 && !deferred) ? 48 * n : 0);
         }
