@@ -2052,8 +2052,9 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     // 512 threads x 5 pairs of rows per thread: the variant whose state fits the register file without spills — 247 VGPRs at two waves per SIMD.
     // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
-    const int nt = 512, np = coded ? 5 : 4; // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill)
     const int64_t nz = a.nz, d3 = a.d3;
+    static const bool hr4_np5 = getenv("FV_HR4_NP5") != nullptr; // (A/B: profiles/r05_hr4_pairs.log)
+    const int nt = 512, np = (coded && (2 * nz <= 3 * nt || hr4_np5)) ? 5 : 4; // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill; so do five with four halo rounds)
     // the 2 nz halo rows are covered in two rounds of the block (three for the coded kernel on lines of 513 .. 768 rows: 640^3, the largest box one
     // GPU holds with 32-bit indices); longer lines stay with the tiles
     pl.hr = (int)((2 * nz + nt - 1) / nt);
@@ -2160,8 +2161,8 @@ static int kc_launch(fv_ctx *ctx, const KfArgs &a, const KcPlan &pl)
     // the coded kernel: streaming hints as compile-time constants (stores stay 16-byte instructions): 464^3, one process, ms per step 0.8965 -> 0.8702;
     // with 32-bit offsets instead of 64-bit plane bases on top the median of five rounds was WORSE (0.965 / 0.941, minimum 0.893 / 0.874: two
     // modes), so its bases stay (profiles/r05_step_ab_coded_addressing.log)
-    if (pl.hr == 4)
-        return kc_launch_one<512, 5, MODE, false, 2, 2, 4>(ctx, a, pl);
+    if (pl.hr == 4) // (lines of 769 .. 1024 rows: five pairs per thread spill 40-88 B per lane with four halo rounds, four pairs do not)
+        return pl.np == 5 ? kc_launch_one<512, 5, MODE, false, 2, 2, 4>(ctx, a, pl) : kc_launch_one<512, 4, MODE, false, 2, 2, 4>(ctx, a, pl);
     if (pl.hr == 3)
         return kc_launch_one<512, 5, MODE, false, 2, 2, 3>(ctx, a, pl);
     return kc_launch_one<512, 5, MODE, false>(ctx, a, pl);
