@@ -2037,7 +2037,7 @@ static size_t kc_lds_bytes(int64_t C, int64_t nz, int nt, bool doubles)
     return (size_t)(16 * (C + 2 * nz) + 4 * (C + nz) + 8 * (2 * FV_STORAGE_CODES + 3 * FV_MATRIX_CODES + nt / 64));
 }
 // false: the 2-D tiles serve the launch (lines longer than the block, chunks that would not fit the LDS, no code bytes)
-static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
+static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded, int mode = 0)
 {
     if (!g_fused_chunk || !p->kc_code.p || p->kc_state != (coded ? 1 : 2) || (coded && !a.mcode))
         return false;
@@ -2053,8 +2053,10 @@ static bool kc_plan(fv_problem *p, KfArgs &a, KcPlan &pl, bool coded)
     // Measured before the others were removed (464^3, one process, ms per step): tiles 1.070, (512, 5) 0.951, (512, 6) 0.995 with 27 spilled
     // registers, (1024, 2) 1.43, (1024, 3) 2.00, (768, 4) 1.44 (profiles/r04_step_ab_chunks*.log).
     const int64_t nz = a.nz, d3 = a.d3;
-    static const bool hr4_np5 = getenv("FV_HR4_NP5") != nullptr; // (A/B: profiles/r05_hr4_pairs.log)
-    const int nt = 512, np = (coded && (2 * nz <= 3 * nt || hr4_np5)) ? 5 : 4; // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill; so do five with four halo rounds)
+    // (the kernel with the matrix as doubles carries more state per pair: four fit 256 registers, five spill.  With four halo rounds — lines of
+    // 769 .. 1024 rows — five pairs spill in the coded kernel too, 40 B per lane in the step and 88 in the one-launch iteration: 928^3, alternating
+    // runs, the step 6.99 ms with five pairs and 7.20 with four, an iteration's launches 90.5 against 87.9 per six steps: profiles/r05_hr4_pairs.log)
+    const int nt = 512, np = (coded && !(2 * nz > 3 * nt && mode == 3)) ? 5 : 4;
     // the 2 nz halo rows are covered in two rounds of the block (three for the coded kernel on lines of 513 .. 768 rows: 640^3, the largest box one
     // GPU holds with 32-bit indices); longer lines stay with the tiles
     pl.hr = (int)((2 * nz + nt - 1) / nt);
@@ -2441,7 +2443,7 @@ bool fv_ploop_applicable(fv_problem *p, double sigma, bool folded)
     KfArgs a{};
     kf_setup(p, a);
     KcPlan kc{};
-    return kc_plan(p, a, kc, kf_codes(p, a)) && a.pfirst == 0;
+    return kc_plan(p, a, kc, kf_codes(p, a), 3) && a.pfirst == 0;
 }
 
 // Launch j of a solve's loop (j = 0: the first pass, direction = z, nothing but w' stored).  z, w, pold: iterate j - 1's scaled residual,
@@ -2477,7 +2479,7 @@ int fv_ploop_pass(fv_problem *p, int j, const double *folded, const double *z, c
     a.n = p->n;
     const bool coded = kf_codes(p, a);
     KcPlan kc{};
-    if (!kc_plan(p, a, kc, coded) || a.pfirst != 0) {
+    if (!kc_plan(p, a, kc, coded, 3) || a.pfirst != 0) {
         fv_set_error(ctx, "internal: the one-launch PCG iteration on an operator it does not serve");
         return FV_ERR_STATE;
     }
