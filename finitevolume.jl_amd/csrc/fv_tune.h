@@ -52,7 +52,9 @@ extern "C" {
  *   FV_SMALL_TWOSTEP=0   small systems: the three solves of a step-doubling attempt one by one instead of in one launch (the same bits: tested)
  *   FV_AMG_KCYCLE=k      AMG K-cycle on the coarse levels 1 .. k (the PCG around it becomes flexible) [2]; 0 = V-cycle (round 5: was fv_tune key 52)
  *   FV_AMG_GALERKIN=sort the AMG's Galerkin products by the global stable sort instead of the row merge (the same bits: tested)
- *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments) */
+ *   FV_BAND=rows         band height of the CSR stream kernel's traversal order (experiments)
+ *   FV_PLACE=0           the vectors a step writes from plain allocations instead of chosen by their write class (fv_place.hip; timing only)
+ *   FV_ALLOC_SKEW=bytes  stagger consecutive large arrays inside their allocations by (k mod 16) x bytes (an experiment of rounds 2 and 5: no effect) */
 int fv_tune(int key, int value);
 /* Test infrastructure, like fv_tune: the loopback transport for rehearsals of the row-block driver on ONE device (RCCL refuses two ranks on one
  * GPU).  nranks host threads of one process, each with its own context on the same device, join the group `group_id`; halos then move by
