@@ -1066,7 +1066,8 @@ extern "C" int fv_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, doubl
         fv_set_error(ctx, "fv_get_csc: call fv_assemble first");
         return FV_ERR_STATE;
     }
-    FV_TRY(fv_require_csr(p, "fv_get_csc"));
+    if (p->lean) // (written out from the rows formed on the fly, a window at a time: fv_lean.hip)
+        return fv_lean_get_csc(p, colptr, rowval, nzval);
     if (p->reordered)
         return get_csc_canonical(p, colptr, rowval, nzval);
     DevBuf<int64_t> w;

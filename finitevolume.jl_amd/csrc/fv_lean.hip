@@ -356,4 +356,85 @@ int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int
     return FV_OK;
 }
 
+// ------------------------------------------------------------------ fv_get_csc of a lean problem: assembleA's matrix written out from the rows, a
+// window of rows at a time (the CSR never exists as a whole: 2^24 rows — at most 1.2e8 entries, 1.9 GB of scratch — per pass).  A is
+// symmetric in pattern and bit for bit in value (one face, one product), so the rows are the columns.
+__global__ __launch_bounds__(FV_BLOCK) void lean_len_kernel(GridRows g, int64_t r0, int64_t count, int32_t *__restrict__ len)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= count)
+        return;
+    GridRow e;
+    grid_row(g, r0 + i, e, false);
+    len[i] = e.len;
+}
+
+__global__ __launch_bounds__(FV_BLOCK) void lean_export_kernel(GridRows g, int64_t r0, int64_t count, const int32_t *__restrict__ start, int64_t base,
+                                                                int64_t *__restrict__ colptr, int64_t *__restrict__ rowval, double *__restrict__ nzval,
+                                                                int want_vals)
+{
+    const int64_t i = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (i >= count)
+        return;
+    const int64_t r = r0 + i;
+    GridRow e;
+    grid_row(g, r, e, want_vals != 0);
+    const int64_t s = start[i];
+    if (colptr)
+        colptr[i] = base + s + 1; // 1-based, like the reference's SparseMatrixCSC
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        if (k < e.len) {
+            if (rowval)
+                rowval[s + k] = r + (int64_t)e.off[k] + 1;
+            if (want_vals)
+                nzval[s + k] = e.val[k];
+        }
+}
+
+int fv_lean_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval)
+{
+    fv_ctx *ctx = p->ctx;
+    const int64_t n = p->n, W = (int64_t)1 << 24;
+    DevBuf<int32_t> len, start;
+    DevBuf<int64_t> cp, rv;
+    DevBuf<double> nv;
+    FV_TRY(len.alloc(ctx, (size_t)W));
+    FV_TRY(start.alloc(ctx, (size_t)W + 1));
+    if (colptr)
+        FV_TRY(cp.alloc(ctx, (size_t)W));
+    if (rowval)
+        FV_TRY(rv.alloc(ctx, (size_t)7 * W));
+    if (nzval)
+        FV_TRY(nv.alloc(ctx, (size_t)7 * W));
+    const GridRows g = fv_grid_rows(p, 0.0);
+    int64_t base = 0;
+    for (int64_t r0 = 0; r0 < n; r0 += W) {
+        const int64_t count = n - r0 < W ? n - r0 : W;
+        hipLaunchKernelGGL(lean_len_kernel, dim3(fv_blocks(count)), dim3(FV_BLOCK), 0, ctx->stream, g, r0, count, len.p);
+        FV_LAUNCH_CHECK(ctx);
+        int64_t total = 0;
+        FV_TRY(fv_exclusive_scan_i32(ctx, len.p, start.p, count, &total));
+        hipLaunchKernelGGL(lean_export_kernel, dim3(fv_blocks(count)), dim3(FV_BLOCK), 0, ctx->stream, g, r0, count, (const int32_t *)start.p, base,
+                           colptr ? cp.p : (int64_t *)nullptr, rowval ? rv.p : (int64_t *)nullptr, nzval ? nv.p : (double *)nullptr, nzval ? 1 : 0);
+        FV_LAUNCH_CHECK(ctx);
+        if (colptr)
+            FV_TRY(fv_copy(ctx, colptr + r0, cp.p, (size_t)count * sizeof(int64_t)));
+        if (rowval)
+            FV_TRY(fv_copy(ctx, rowval + base, rv.p, (size_t)total * sizeof(int64_t)));
+        if (nzval)
+            FV_TRY(fv_copy(ctx, nzval + base, nv.p, (size_t)total * sizeof(double)));
+        base += total;
+    }
+    if (colptr) {
+        const int64_t last = base + 1;
+        FV_TRY(fv_copy(ctx, colptr + n, &last, sizeof last));
+    }
+    if (base != p->nnz) {
+        fv_set_error(ctx, "internal: the rows of the lean problem hold %lld entries, %lld were counted at its creation", (long long)base, (long long)p->nnz);
+        return FV_ERR_STATE;
+    }
+    return FV_OK;
+}
+
 FV_WARM_TU(lean)

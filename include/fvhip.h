@@ -263,8 +263,9 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *                   closed form (src/grid.jl:56-110), so fv_assemble computes b and the diagonal from rows formed on the fly and the
  *                   solver's storage forms are filled the same way — bit for bit the values assembleA (src/FiniteVolume.jl:75-108) gives.
  *                   ~190 B of HBM per cell instead of ~490 during a transient run, and no int32 CSR offsets: 8e8 cells on one GPU where
- *                   the CSR ends at 3e8.  Transient and steady Jacobi-PCG solves, fv_spmv, states and trajectories work as always;
- *                   what needs the faces or the CSR — fv_get_csc, fv_problem_get_grid's face arrays, the AMG preconditioner, fv_dist_setup,
+ *                   the CSR ends at 3e8.  Transient and steady Jacobi-PCG solves, fv_spmv, states and trajectories work as always, and
+ *                   fv_get_csc writes assembleA's matrix out from the rows (a window at a time; the same arrays as from the CSR route);
+ *                   what needs the faces or a resident CSR — fv_problem_get_grid's face arrays, the AMG preconditioner, fv_dist_setup,
  *                   the parameter gradients — returns FV_ERR_STATE, and so does a solve when scattered Dirichlet cells leave a
  *                   64-row slice with more than 8 distinct column offsets.  0 never, 1 every grid of >= 4096 cells, 2 [default]
  *                   grids whose CSR would not fit int32 offsets (7 N > 2^31: before, FV_ERR_TOO_LARGE).  Read when a problem is created. */
