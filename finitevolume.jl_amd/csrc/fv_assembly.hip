@@ -954,8 +954,32 @@ extern "C" int fv_problem_get_grid(fv_problem *p, int64_t *node1, int64_t *node2
         fv_set_error(ctx, "fv_problem_get_grid: problem has no faces");
         return FV_ERR_STATE;
     }
-    if (node1 || node2 || areasoverlengths)
-        FV_TRY(fv_require_csr(p, "fv_problem_get_grid (faces)"));
+    if (p->lean && (node1 || node2 || areasoverlengths)) { // the face list is not kept: generated again, handed out, released
+        if (p->F > 0x7fffffffLL) {
+            fv_set_error(ctx, "fv_problem_get_grid: F=%lld exceeds the int32 range of the face generator", (long long)p->F);
+            return FV_ERR_TOO_LARGE;
+        }
+        DevBuf<int32_t> t1, t2;
+        DevBuf<double> ta;
+        DevBuf<int64_t> w;
+        FV_TRY(t1.alloc(ctx, (size_t)p->F));
+        FV_TRY(t2.alloc(ctx, (size_t)p->F));
+        FV_TRY(ta.alloc(ctx, (size_t)p->F));
+        FV_TRY(fv_grid_generate_device(ctx, p->lean_mins, p->lean_maxs, p->ns, t1.p, t2.p, ta.p, nullptr, nullptr));
+        FV_TRY(w.alloc(ctx, (size_t)p->F));
+        if (node1) {
+            FV_TRY(fv_widen_indices(ctx, t1.p, w.p, p->F, 1));
+            FV_TRY(fv_copy(ctx, node1, w.p, (size_t)p->F * sizeof(int64_t)));
+        }
+        if (node2) {
+            FV_TRY(fv_widen_indices(ctx, t2.p, w.p, p->F, 1));
+            FV_TRY(fv_copy(ctx, node2, w.p, (size_t)p->F * sizeof(int64_t)));
+        }
+        if (areasoverlengths)
+            FV_TRY(fv_copy(ctx, areasoverlengths, ta.p, (size_t)p->F * sizeof(double)));
+        node1 = node2 = nullptr;
+        areasoverlengths = nullptr;
+    }
     if (node1 || node2) {
         DevBuf<int64_t> w;
         FV_TRY(w.alloc(ctx, (size_t)p->F));

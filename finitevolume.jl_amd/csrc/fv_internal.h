@@ -233,6 +233,7 @@ struct fv_problem {
     // filled from rows formed on the fly (fv_lean.hip); what needs the CSR or the faces (fv_get_csc, AMG, row blocks, gradients) fails loudly
     bool lean = false;
     double lean_d[3] = {0, 0, 0}; // grid spacing, as regulargrid_kernel forms it (axis[1] - axis[0])
+    double lean_mins[3] = {0, 0, 0}, lean_maxs[3] = {0, 0, 0}; // the box (fv_problem_get_grid generates the face list again when asked for it)
     DevBuf<double> lean_K;        // the conductivities of the last fv_assemble as handed over (1, or one per face / per metaindex target)
     DevBuf<int64_t> lean_meta;    // ... and its metaindex (1-based), when one came
     int64_t lean_nK = 0;

@@ -70,8 +70,11 @@ int fv_lean_finish(fv_problem *p, const int64_t *dirichletnodes, const double mi
         fv_set_error(ctx, "regulargrid needs ns[d] >= 2 in every dimension");
         return FV_ERR_ARG;
     }
-    for (int d = 0; d < 3; d++)
+    for (int d = 0; d < 3; d++) {
         p->lean_d[d] = ax[d][1] - ax[d][0]; // grid.jl:65-67, as regulargrid_kernel forms it
+        p->lean_mins[d] = mins[d];
+        p->lean_maxs[d] = maxs[d];
+    }
     FV_TRY(fv_build_maps(p, dirichletnodes));
     FV_TRY(p->dnodes0.alloc(ctx, (size_t)p->ndir));
     if (p->ndir > 0) {
