@@ -606,6 +606,43 @@ __global__ __launch_bounds__(FV_BLOCK) void assemble_rows_kernel(
     b[r] = bacc;
 }
 
+int fv_face_arrays(fv_problem *p, FaceArrays &fa)
+{
+    fv_ctx *ctx = p->ctx;
+    if (!p->lean) {
+        fa.node1 = p->node1.p;
+        fa.node2 = p->node2.p;
+        fa.cond = p->cond.p;
+        fa.aol = p->aol.p;
+        return FV_OK;
+    }
+    if (p->F > 0x7fffffffLL) {
+        fv_set_error(ctx, "F=%lld exceeds the int32 range of the face generator", (long long)p->F);
+        return FV_ERR_TOO_LARGE;
+    }
+    if (!p->assembled || !p->lean_K.p) {
+        fv_set_error(ctx, "call fv_assemble first");
+        return FV_ERR_STATE;
+    }
+    FV_TRY(fa.t1.alloc(ctx, (size_t)p->F));
+    FV_TRY(fa.t2.alloc(ctx, (size_t)p->F));
+    FV_TRY(fa.ta.alloc(ctx, (size_t)p->F));
+    FV_TRY(fa.tc.alloc(ctx, (size_t)p->F));
+    FV_TRY(fv_grid_generate_device(ctx, p->lean_mins, p->lean_maxs, p->ns, fa.t1.p, fa.t2.p, fa.ta.p, nullptr, nullptr));
+    DevBuf<int> dbad;
+    FV_TRY(dbad.alloc(ctx, 1));
+    FV_TRY(dbad.zero(ctx));
+    if (p->F > 0)
+        hipLaunchKernelGGL(conductance_kernel, dim3(fv_blocks(p->F)), dim3(FV_BLOCK), 0, ctx->stream, p->F, p->lean_nK, (const double *)p->lean_K.p,
+                           (const int64_t *)p->lean_meta.p, (const double *)fa.ta.p, p->lean_logt, fa.tc.p, dbad.p);
+    FV_LAUNCH_CHECK(ctx);
+    fa.node1 = fa.t1.p;
+    fa.node2 = fa.t2.p;
+    fa.aol = fa.ta.p;
+    fa.cond = fa.tc.p;
+    return FV_OK;
+}
+
 // metaindex entries outside 1:nK?
 __global__ __launch_bounds__(FV_BLOCK) void meta_range_kernel(int64_t F, int64_t nK, const int64_t *__restrict__ metaindex, int *__restrict__ bad)
 {

@@ -147,7 +147,6 @@ extern "C" int fv_param_jacobian_apply(fv_problem *p, const double *x_free, cons
         fv_set_error(ctx, "fv_param_jacobian_apply: needs a mesh problem after fv_assemble (not a CSC import or a row block)");
         return FV_ERR_STATE;
     }
-    FV_TRY(fv_require_csr(p, "fv_param_jacobian_apply"));
     if (scale_by_storage && !p->transient_ready) {
         fv_set_error(ctx, "fv_param_jacobian_apply: the D^-1 scaling needs fv_transient_begin (Ss, volumes)");
         return FV_ERR_STATE;
@@ -163,10 +162,11 @@ extern "C" int fv_param_jacobian_apply(fv_problem *p, const double *x_free, cons
     FV_TRY(fv_free_in(p, X.p, x_free)); // (the caller's numbering of the free cells)
     FV_TRY(fv_free_in(p, L.p, lam_free));
     const double *D = scale_by_storage ? p->D.p : nullptr;
+    FaceArrays fa; // (a lean problem's face arrays exist for the duration of this call)
+    FV_TRY(fv_face_arrays(p, fa));
     if (F > 0)
         hipLaunchKernelGGL(jacobian_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, (const double *)X.p, (const double *)L.p, D,
-                           (const int32_t *)p->node1.p, (const int32_t *)p->node2.p, (const int32_t *)p->nodemap.p, (const double *)p->cond.p,
-                           (const double *)p->aol.p, (const double *)p->dheads.p, logtransform ? 1 : 0, gk.p, gd.p);
+                           fa.node1, fa.node2, (const int32_t *)p->nodemap.p, fa.cond, fa.aol, (const double *)p->dheads.p, logtransform ? 1 : 0, gk.p, gd.p);
     if (n > 0)
         hipLaunchKernelGGL(jacobian_row_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (const double *)L.p, D, gs.p);
     FV_LAUNCH_CHECK(ctx);
@@ -181,15 +181,17 @@ int fv_param_gradient_integral_device(fv_problem *p, int64_t kc, const double *t
                                       int logtransform, int accumulate, double *gk, double *gd, double *gs)
 {
     fv_ctx *ctx = p->ctx;
-    FV_TRY(fv_require_csr(p, "the parameter gradient"));
     const int64_t n = p->n, F = p->F;
+    FaceArrays fa;
+    FV_TRY(fv_face_arrays(p, fa));
     if (F > 0)
-        hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, ts_dev, X, L, D,
-                           (const int32_t *)p->node1.p, (const int32_t *)p->node2.p, (const int32_t *)p->nodemap.p, (const double *)p->cond.p,
-                           (const double *)p->aol.p, (const double *)p->dheads.p, logtransform ? 1 : 0, accumulate, gk, gd);
+        hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, ts_dev, X, L, D, fa.node1, fa.node2,
+                           (const int32_t *)p->nodemap.p, fa.cond, fa.aol, (const double *)p->dheads.p, logtransform ? 1 : 0, accumulate, gk, gd);
     if (n > 0)
         hipLaunchKernelGGL(gradient_row_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (int)kc, ts_dev, L, D, accumulate, gs);
     FV_LAUNCH_CHECK(ctx);
+    if (p->lean)
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (the generated face arrays go with this call)
     return FV_OK;
 }
 
@@ -203,7 +205,6 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
         fv_set_error(ctx, "fv_param_gradient_integral: needs a mesh problem after fv_assemble (not a CSC import or a row block)");
         return FV_ERR_STATE;
     }
-    FV_TRY(fv_require_csr(p, "fv_param_gradient_integral"));
     if (scale_by_storage && !p->transient_ready) {
         fv_set_error(ctx, "fv_param_gradient_integral: the D^-1 scaling needs fv_transient_begin (Ss, volumes)");
         return FV_ERR_STATE;
@@ -231,6 +232,8 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
     FV_TRY(gd.alloc(ctx, (size_t)F));
     FV_TRY(gs.alloc(ctx, (size_t)n));
     const double *D = scale_by_storage ? p->D.p : nullptr;
+    FaceArrays fa;
+    FV_TRY(fv_face_arrays(p, fa));
     int accumulate = 0;
     for (int64_t k0 = 0; k0 + 1 < nt; k0 += chunk - 1) {
         const int64_t kc = nt - k0 < chunk ? nt - k0 : chunk;
@@ -239,9 +242,8 @@ extern "C" int fv_param_gradient_integral(fv_problem *p, int64_t nt, const doubl
         FV_HIP(ctx, hipMemcpyAsync(T.p, ts + k0, (size_t)kc * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         if (F > 0)
             hipLaunchKernelGGL(gradient_face_kernel, dim3(fv_blocks(F)), dim3(FV_BLOCK), 0, ctx->stream, F, n, (int)kc, (const double *)T.p,
-                               (const double *)X.p, (const double *)L.p, D, (const int32_t *)p->node1.p, (const int32_t *)p->node2.p,
-                               (const int32_t *)p->nodemap.p, (const double *)p->cond.p, (const double *)p->aol.p, (const double *)p->dheads.p,
-                               logtransform ? 1 : 0, accumulate, gk.p, gd.p);
+                               (const double *)X.p, (const double *)L.p, D, fa.node1, fa.node2, (const int32_t *)p->nodemap.p, fa.cond, fa.aol,
+                               (const double *)p->dheads.p, logtransform ? 1 : 0, accumulate, gk.p, gd.p);
         if (n > 0)
             hipLaunchKernelGGL(gradient_row_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, n, (int)kc, (const double *)T.p,
                                (const double *)L.p, D, accumulate, gs.p);

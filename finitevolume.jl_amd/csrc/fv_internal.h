@@ -513,6 +513,14 @@ int fv_lean_plane_stride(fv_problem *p, int64_t *stride);
 int fv_lean_count_far_stride(fv_problem *p, int64_t stride, int64_t *agree);
 int fv_lean_dia_pattern(fv_problem *p, uint8_t *sl_noff, int32_t *sl_off, int32_t *is_dia, int32_t *is_csr);
 int fv_lean_dia_fill(fv_problem *p, double sigma, int64_t count, const int32_t *list);
+// the face arrays a per-face kernel reads: the problem's own, or — a lean problem — generated for the duration of the call
+struct FaceArrays {
+    const int32_t *node1 = nullptr, *node2 = nullptr;
+    const double *cond = nullptr, *aol = nullptr;
+    DevBuf<int32_t> t1, t2;
+    DevBuf<double> ta, tc;
+};
+int fv_face_arrays(fv_problem *p, FaceArrays &fa); // fv_assembly.hip
 int fv_lean_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval);
 int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int32_t d3, double *dg, double *u1, double *u2, double *u3);
 int fv_widen_indices(fv_ctx *ctx, const int32_t *src, int64_t *dst, int64_t n, int64_t add);

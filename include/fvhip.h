@@ -265,9 +265,10 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *                   ~190 B of HBM per cell instead of ~490 during a transient run, and no int32 CSR offsets: 8e8 cells on one GPU where
  *                   the CSR ends at 3e8.  Transient and steady Jacobi-PCG solves, fv_spmv, states and trajectories work as always, and
  *                   fv_get_csc writes assembleA's matrix out from the rows (a window at a time; the same arrays as from the CSR route);
- *                   what needs the faces or a resident CSR — fv_problem_get_grid's face arrays, the AMG preconditioner, fv_dist_setup,
- *                   the parameter gradients — returns FV_ERR_STATE, and so does a solve when scattered Dirichlet cells leave a
- *                   64-row slice with more than 8 distinct column offsets.  0 never, 1 every grid of >= 4096 cells, 2 [default]
+ *                   fv_problem_get_grid and the parameter gradients generate the face arrays for the duration of the call (F < 2^31).
+ *                   What needs a resident CSR — the AMG preconditioner, fv_dist_setup — returns FV_ERR_STATE, and so does a solve when
+ *                   Dirichlet cells inside the box leave a 64-row slice with more than 8 distinct column offsets (a well as a source
+ *                   term changes no pattern).  0 never, 1 every grid of >= 4096 cells, 2 [default]
  *                   grids whose CSR would not fit int32 offsets (7 N > 2^31: before, FV_ERR_TOO_LARGE).  Read when a problem is created. */
 #define FV_OPT_LEAN_SETUP 2
 int fv_ctx_set_option(fv_ctx *ctx, int option, int value);

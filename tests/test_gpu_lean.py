@@ -130,7 +130,7 @@ def test_lean_transient_runs_are_the_csr_route_bit_for_bit(fv, dkind, kkind):
         p.close()
 
 
-def test_lean_problem_refuses_what_needs_faces_or_csr(fv):
+def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can(fv):
     ns = (20, 18, 70)
     (p0, p1), rng, dn = _pair(fv, ns, "xfaces", "uniform", seed=2)
     lib = fv.load()
@@ -144,9 +144,12 @@ def test_lean_problem_refuses_what_needs_faces_or_csr(fv):
         p.check(lib.fv_problem_get_grid(p.handle, n1.ctypes.data, n2.ctypes.data, aol.ctypes.data, vol.ctypes.data))
         grids.append((n1, n2, aol, vol))
     assert all(np.array_equal(a, b) for a, b in zip(*grids))
-    p1.transient_begin(0.1, None, np.full(p1.N, 1000.0))
-    with pytest.raises(fv.FVError):
-        p1.param_jacobian_apply(np.zeros(p1.n), np.zeros(p1.n))
+    xs, ls = rng.standard_normal(p0.n), rng.standard_normal(p0.n)
+    outs = []
+    for p in (p0, p1):  # (the parameter gradients read face arrays generated for the call)
+        p.transient_begin(0.1, None, np.full(p.N, 1000.0))
+        outs.append(p.param_jacobian_apply(xs, ls, scale_by_storage=True))
+    assert all(np.array_equal(a, b) for a, b in zip(*outs))
     ctx = fv.default_context()
     assert ctx.get_option(fv._lib.FV_OPT_LEAN_SETUP) == 2  # the default: lean only where the CSR would not fit
     for p in (p0, p1):
