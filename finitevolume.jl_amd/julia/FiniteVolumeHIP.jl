@@ -67,6 +67,21 @@ function check(ctx::Context, rc)
 	error(unsafe_string(ccall((:fv_last_error, libfvhip), Cstring, (Ptr{Cvoid},), ctx.handle)))
 end
 
+# Per-context options (include/fvhip.h): FV_OPT_REORDER — locality re-numbering of face-list meshes (0 never / 1 auto / 2 always);
+# FV_OPT_LEAN_SETUP — regular-grid problems without face arrays, incident lists and CSR in HBM (0 never / 1 every grid of >= 4096 cells /
+# 2 [default] grids whose CSR would not fit int32 offsets: 8e8 cells on one GPU).  Read when a problem is created in the context.
+const FV_OPT_REORDER = 1
+const FV_OPT_LEAN_SETUP = 2
+function setoption!(option::Integer, value::Integer; ctx::Context=context())
+	check(ctx, ccall((:fv_ctx_set_option, libfvhip), Cint, (Ptr{Cvoid}, Cint, Cint), ctx.handle, option, value))
+	return nothing
+end
+function getoption(option::Integer; ctx::Context=context())
+	v = Ref{Cint}(0)
+	check(ctx, ccall((:fv_ctx_get_option, libfvhip), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}), ctx.handle, option, v))
+	return Int(v[])
+end
+
 mutable struct Problem      # fv_problem: mesh + Dirichlet set + CSR operator on the GPU
 	handle::Ptr{Cvoid}
 	ctx::Context
