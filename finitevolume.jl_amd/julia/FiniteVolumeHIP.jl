@@ -161,6 +161,16 @@ function createproblem(neighbors::Array{Pair{Int, Int}, 1}, areasoverlengths::Ve
 	return Problem(h[], ctx)
 end
 
+# The problem of regulargrid(mins, maxs, ns, ...) (src/grid.jl:56-110) without the face list crossing the boundary: the grid is generated on the
+# device, and — FV_OPT_LEAN_SETUP — kept as a closed form where the face arrays and the CSR would not fit (beyond 3.06e8 cells) or are not wanted.
+function createproblem(mins::Vector, maxs::Vector, ns::Vector, dirichletnodes::Array{Int, 1})
+	ctx = context()
+	h = Ref{Ptr{Cvoid}}(C_NULL)
+	check(ctx, ccall((:fv_problem_create_regulargrid, libfvhip), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Int64, Ptr{Int64}, Ref{Ptr{Cvoid}}),
+		ctx.handle, Float64[mins...], Float64[maxs...], Int64[ns...], length(dirichletnodes), Int64[dirichletnodes...], h))
+	return Problem(h[], ctx)
+end
+
 function assemble!(p::Problem, conductivities::Vector, sources::Vector, dirichletheads::Vector, metaindex, logtransformconductivity::Bool)
 	# closures cannot cross the C ABI: metaindex.(1:F) is evaluated here (SURVEY.md §7 risk 6)
 	mi = metaindex === nothing ? Ptr{Int64}(C_NULL) : Int64[metaindex(i) for i = 1:p.F]
