@@ -2,7 +2,7 @@
 # The loop's vectors chosen by their write class (fv_place.hip) against plain allocations: alternating runs of the driver's command.
 mkdir -p gpurun_out
 B="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-hetero --no-multi-iteration ${EXTRA:-}"
-for rep in 1 2 3 4 5 6 7 8; do
+for rep in 1 2 3 4 5 6 7 8 9 10 11 12; do
 for place in 0 1; do
   FV_PLACE=$place python bench.py --ns ${NS:-464} $B 2>/dev/null | python -c "
 import sys, json
