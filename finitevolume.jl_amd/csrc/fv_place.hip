@@ -63,7 +63,19 @@ int fv_vec_alloc_raw(fv_problem *p, size_t count, bool hot, void **base_out)
     *base_out = nullptr;
     if (count == 0)
         count = 1;
-    const bool placed = g_place && count * sizeof(double) >= PLACE_MIN_BYTES;
+    bool placed = g_place && count * sizeof(double) >= PLACE_MIN_BYTES;
+    if (placed) { // candidates are a luxury of free memory: with less than eight such vectors' worth left (1e9 cells on one GPU) every request takes what
+                  // it gets, and the candidates at hand go back first
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < 8 * count * sizeof(double)) {
+            placed = false;
+            bool mine = false;
+            for (auto &s : p->spares)
+                mine = mine || s.count == count;
+            if (!mine)
+                fv_vec_release_spares(p);
+        }
+    }
     // candidates of another size (the problem was re-dimensioned: never happens today) are of no use to this request
     auto usable = [&](const fv_problem::PlacedSpare &s) { return s.count == count; };
     if (placed && hot) {
@@ -98,10 +110,10 @@ int fv_vec_alloc_raw(fv_problem *p, size_t count, bool hot, void **base_out)
             p->spares.erase(p->spares.begin() + f);
             return FV_OK;
         }
-    } else if (placed) { // read-only in the loop: the slowest candidate at hand, if any
+    } else if (!p->spares.empty()) { // read-only in the loop: the slowest candidate at hand, if any (no memory for new candidates: the fastest for a vector the loop writes)
         int s = -1;
         for (size_t i = 0; i < p->spares.size(); i++)
-            if (usable(p->spares[i]) && (s < 0 || p->spares[i].rate < p->spares[(size_t)s].rate))
+            if (usable(p->spares[i]) && (s < 0 || (hot ? p->spares[i].rate > p->spares[(size_t)s].rate : p->spares[i].rate < p->spares[(size_t)s].rate)))
                 s = (int)i;
         if (s >= 0) {
             *base_out = p->spares[(size_t)s].base;
