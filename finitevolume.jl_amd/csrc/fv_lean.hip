@@ -359,6 +359,66 @@ int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int
     return FV_OK;
 }
 
+// ------------------------------------------------------------------ the product over the 64-row groups the sliced-DIA form does not take (Dirichlet cells
+// inside the box leave groups with more than eight distinct column offsets): the CSR route hands them to the wave-stream kernel; here each
+// row is formed and applied on the spot — terms in ascending column order, the shift last, like that kernel.  A handful of groups per plane.
+template <bool DOT>
+__global__ __launch_bounds__(FV_BLOCK) void lean_rows_spmv_kernel(GridRows g, int64_t n, const double *__restrict__ x, double *__restrict__ y,
+                                                                   const double *__restrict__ shift, double sigma, double *__restrict__ partials,
+                                                                   const PcgScalars *__restrict__ scal, const int32_t *__restrict__ list, int64_t count)
+{
+    constexpr int WPB = FV_BLOCK / 64;
+    __shared__ double smem[WPB];
+    if (scal && scal->done)
+        return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double dacc = 0.0;
+    for (int64_t pos = (int64_t)blockIdx.x * WPB + wave; pos < count; pos += (int64_t)gridDim.x * WPB) {
+        const int64_t row = ((list ? (int64_t)list[pos] : pos) << 6) + lane; // (no list: every group, in order)
+        if (row < n) {
+            GridRow e;
+            grid_row(g, row, e, true);
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 7; k++)
+                if (k < e.len)
+                    sum += e.val[k] * x[row + e.off[k]];
+            const double xr = x[row];
+            if (shift)
+                sum += sigma * shift[row] * xr;
+            y[row] = sum;
+            if (DOT)
+                dacc += xr * sum;
+        }
+    }
+    if (DOT) {
+        for (int off = 32; off > 0; off >>= 1)
+            dacc += __shfl_xor(dacc, off, 64);
+        if (lane == 0)
+            smem[wave] = dacc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < WPB; w++)
+                t += smem[w];
+            partials[blockIdx.x] = t;
+        }
+    }
+}
+
+int fv_lean_rows_spmv(fv_problem *p, double tag, const double *x, double *y, const double *shift, double sigma, bool dot, double *partials, const PcgScalars *scal,
+                      const int32_t *list, int64_t count, int grid)
+{
+    fv_ctx *ctx = p->ctx;
+    const GridRows g = fv_grid_rows(p, tag);
+    if (dot)
+        hipLaunchKernelGGL(lean_rows_spmv_kernel<true>, dim3(grid), dim3(FV_BLOCK), 0, ctx->stream, g, p->n, x, y, shift, sigma, partials, scal, list, count);
+    else
+        hipLaunchKernelGGL(lean_rows_spmv_kernel<false>, dim3(grid), dim3(FV_BLOCK), 0, ctx->stream, g, p->n, x, y, shift, sigma, partials, scal, list, count);
+    FV_LAUNCH_CHECK(ctx);
+    return FV_OK;
+}
+
 // ------------------------------------------------------------------ fv_get_csc of a lean problem: assembleA's matrix written out from the rows, a
 // window of rows at a time (the CSR never exists as a whole: 2^24 rows — at most 1.2e8 entries, 1.9 GB of scratch — per pass).  A is
 // symmetric in pattern and bit for bit in value (one face, one product), so the rows are the columns.

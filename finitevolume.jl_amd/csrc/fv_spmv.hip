@@ -2185,12 +2185,6 @@ int fv_build_dia(fv_problem *p)
     FV_TRY(p->csr_list.alloc(ctx, (size_t)ns));
     FV_TRY(fv_compact_flags(ctx, fd.p, ns, p->dia_list.p, &p->ndia));
     FV_TRY(fv_compact_flags(ctx, fc.p, ns, p->csr_list.p, &p->ncsr_groups));
-    if (p->lean && p->ncsr_groups > 0) { // (Dirichlet cells scattered so that some 64-row slice sees more than 8 distinct column offsets)
-        p->dia_built = false;
-        fv_set_error(ctx, "lean set-up: %lld of %lld 64-row slices have more than %d distinct column offsets and would need the CSR, which a lean problem "
-                          "does not keep: create the problem with FV_OPT_LEAN_SETUP at 0", (long long)p->ncsr_groups, (long long)ns, DIA_K);
-        return FV_ERR_STATE;
-    }
     if (p->ndia * 2 < ns) { // mostly irregular: keep the pure CSR form
         p->ndia = 0;
         p->ncsr_groups = ns;
@@ -2366,7 +2360,16 @@ static int launch_irregular(fv_problem *p, const double *vals, double vals_tag, 
 {
     fv_ctx *ctx = p->ctx;
     *used_sell = false;
-    FV_TRY(fv_require_csr(p, "the SpMV of groups outside the sliced-DIA form"));
+    if (p->lean) { // (Dirichlet cells inside the box: the groups with more than DIA_K distinct offsets, rows formed and applied on the spot — fv_lean.hip)
+        if (mode == SPMV_INIT) {
+            fv_set_error(ctx, "internal: the fused set-up on a lean problem");
+            return FV_ERR_STATE;
+        }
+        const int G = stream_grid(count);
+        FV_TRY(fv_lean_rows_spmv(p, vals_tag, x, y, shift, sigma, mode == SPMV_DOT, partials, scal, list, count, G)); // (no list: every group, in order)
+        *nparts = G;
+        return FV_OK;
+    }
     // (a pure-CSR operator hands over its traversal order of ALL groups: the SELL form then covers every group, in ascending order)
     if (mode != SPMV_INIT && !p->dist && p->nhalo == 0)
         FV_TRY(ensure_sell(p, list == p->group_order.p ? nullptr : list, count, vals, vals_tag));

@@ -157,16 +157,32 @@ def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can
 
 
 @pytest.mark.parametrize("scattered", [False, True])
-def test_lean_problem_with_dirichlet_cells_inside_the_box_says_what_it_cannot_do(fv, scattered):
-    """Dirichlet cells inside the box (a column of them, or cells sprinkled over it) leave 64-row slices with more than eight distinct
-    column offsets: such slices need the CSR kernel.  The lean problem says so at its first product instead of computing anything else."""
-    ns = (20, 18, 70)
+def test_lean_problem_with_dirichlet_cells_inside_the_box(fv, scattered):
+    """Dirichlet cells inside the box (a column of them through it, or cells sprinkled over it) leave 64-row groups with more than eight distinct
+    column offsets: the sliced-DIA form hands such groups to the CSR kernel, and a lean problem has no CSR — it forms and applies their rows on the
+    spot (lean_rows_spmv_kernel).  Same operator, other summation kernel: products and transient runs agree with the CSR route to rounding."""
+    ns = (24, 40, 70) if scattered else (40, 96, 260)
     rng = np.random.default_rng(3)
     N = ns[0] * ns[1] * ns[2]
     dn = np.sort(rng.choice(N, N // 15, replace=False) + 1).astype(np.int64) if scattered else _dirichlet(ns, "well")
-    p = fv.Problem.regulargrid(MINS, MAXS, list(ns), dn, lean=True)
-    p.assemble(np.array([1e-5]), np.zeros(N), np.full(len(dn), 1.0))
-    with pytest.raises(fv.FVError) as e:
-        p.spmv(np.ones(p.n))
-    assert e.value.code == 6 and "distinct column offsets" in str(e.value)
-    p.close()
+    K = np.exp(np.log(1e-5) + 0.5 * rng.standard_normal(3 * N))  # (one per face: the first F count)
+    src = np.zeros(N)
+    dh = 1000.0 + rng.random(len(dn))
+    x = None
+    out = []
+    for lean in (False, True):
+        p = fv.Problem.regulargrid(MINS, MAXS, list(ns), dn, lean=lean)
+        p.assemble(K[: p.F], src, dh)
+        x = rng.standard_normal(p.n) if x is None else x
+        y0 = p.spmv(x)
+        st = p.transient_begin(0.1, None, 1000.0 + rng.random(N) * 0 + np.linspace(0.0, 1.0, N))
+        y1 = p.spmv(x, 0.05)
+        it, info, _ = p.run_fixed(st, 30.0, 6, rtol=1e-11, maxiter=4000)
+        assert info.converged
+        out.append((y0, y1, it.copy(), st.free_values(), p.spmv_form()[0], p.b()))
+        p.close()
+    a, b = out
+    scale = np.abs(a[0]).max()
+    assert np.array_equal(a[5], b[5]) and a[4] == b[4]
+    assert np.abs(a[0] - b[0]).max() < 1e-13 * scale and np.abs(a[1] - b[1]).max() < 1e-13 * np.abs(a[1]).max()
+    assert np.abs(a[2].astype(int) - b[2].astype(int)).max() <= 1 and np.abs(a[3] - b[3]).max() < 1e-9 * 1e3
