@@ -1353,6 +1353,12 @@ static int amg_build_pooled(fv_problem *p)
         L->rowptr = a->loc_rowptr.p;
         L->colind = a->loc_colind.p;
         L->vals = a->loc_vals.p;
+    } else if (p->lean) { // level 0's structure for the set-up alone (matching, Galerkin products, diagonal): written out from the rows, given back below
+        FV_TRY(fv_lean_csr32(p, a->loc_rowptr, a->loc_colind, a->loc_vals));
+        L->nnz = p->nnz;
+        L->rowptr = a->loc_rowptr.p;
+        L->colind = a->loc_colind.p;
+        L->vals = a->loc_vals.p;
     } else {
         L->nnz = p->nnz;
         L->rowptr = p->rowptr.p;
@@ -1458,6 +1464,13 @@ static int amg_build_pooled(fv_problem *p)
         hipLaunchKernelGGL(amg_diag_kernel, dim3(fv_blocks(l->n)), dim3(FV_BLOCK), 0, ctx->stream, l->n, l->rowptr, l->colind, l->vals, l->diag.p);
         FV_LAUNCH_CHECK(ctx);
     }
+    if (p->lean && a->lev.size() > 1) { // the cycles run level 0 through the problem's own product: its CSR has done its work
+        a->loc_rowptr.release();
+        a->loc_colind.release();
+        a->loc_vals.release();
+        a->lev[0]->rowptr = a->lev[0]->colind = nullptr;
+        a->lev[0]->vals = nullptr;
+    }
     AmgLevel *last = a->lev.back();
     a->nco = last->n;
     a->dense = last->n <= 2 * (int64_t)g_coarse_max && last->n > 0; // also a tiny problem as a whole: the "cycle" is then the exact inverse
@@ -1529,7 +1542,6 @@ static int amg_set_sigma(fv_problem *p, double sigma)
 
 int fv_amg_prepare(fv_problem *p, double sigma)
 {
-    FV_TRY(fv_require_csr(p, "the AMG hierarchy"));
     if (!p->amg || p->amg->epoch != p->assemble_epoch || p->amg->storage_epoch != p->storage_epoch)
         FV_TRY(amg_build(p));
     return amg_set_sigma(p, sigma);
@@ -1831,8 +1843,6 @@ extern "C" int fv_precond_set(fv_problem *p, int kind)
     if (gathered)
         kind = FV_PRECOND_AMG; // (the same solver paths; the hierarchy differs: amg_build_pooled)
     // (validation first, state afterwards: a refused call leaves the problem's preconditioner and hierarchy as they were — ADVICE r4)
-    if (kind != FV_PRECOND_JACOBI)
-        FV_TRY(fv_require_csr(p, "the AMG preconditioner"));
     if (kind != FV_PRECOND_JACOBI && p->nhalo && !p->dist) {
         fv_set_error(p->ctx, "the AMG preconditioner needs a whole operator or a row block set up by fv_dist_setup");
         return FV_ERR_STATE;

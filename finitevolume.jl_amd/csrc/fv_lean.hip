@@ -419,6 +419,56 @@ int fv_lean_rows_spmv(fv_problem *p, double tag, const double *x, double *y, con
     return FV_OK;
 }
 
+__global__ void lean_len_kernel(GridRows g, int64_t r0, int64_t count, int32_t *__restrict__ len);
+// ------------------------------------------------------------------ the operator as a CSR with int32 offsets, for a set-up that needs one and gives it
+// back (the AMG hierarchy's matching and Galerkin products read level 0 once; its cycles use the problem's own product): nnz < 2^31
+__global__ __launch_bounds__(FV_BLOCK) void lean_csr32_kernel(GridRows g, int64_t n, const int32_t *__restrict__ rowptr, int32_t *__restrict__ colind,
+                                                               double *__restrict__ vals)
+{
+    const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
+    if (r >= n)
+        return;
+    GridRow e;
+    grid_row(g, r, e, true);
+    const int32_t s = rowptr[r];
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        if (k < e.len) {
+            colind[s + k] = (int32_t)(r + (int64_t)e.off[k]);
+            vals[s + k] = e.val[k];
+        }
+}
+
+int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colind, DevBuf<double> &vals)
+{
+    fv_ctx *ctx = p->ctx;
+    if (p->nnz >= 0x7fffffffLL - 2) {
+        fv_set_error(ctx, "the operator's %lld entries do not fit a CSR with int32 offsets", (long long)p->nnz);
+        return FV_ERR_TOO_LARGE;
+    }
+    const int64_t n = p->n;
+    DevBuf<int32_t> len;
+    FV_TRY(len.alloc(ctx, (size_t)n));
+    FV_TRY(rowptr.alloc(ctx, (size_t)n + 1));
+    const GridRows g = fv_grid_rows(p, 0.0);
+    hipLaunchKernelGGL(lean_len_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, g, (int64_t)0, n, len.p);
+    FV_LAUNCH_CHECK(ctx);
+    int64_t total = 0;
+    FV_TRY(fv_exclusive_scan_i32(ctx, len.p, rowptr.p, n, &total));
+    if (total != p->nnz) {
+        fv_set_error(ctx, "internal: the rows of the lean problem hold %lld entries, %lld were counted at its creation", (long long)total, (long long)p->nnz);
+        return FV_ERR_STATE;
+    }
+    FV_TRY(colind.alloc(ctx, (size_t)total + 2));
+    FV_TRY(vals.alloc(ctx, (size_t)total + 2));
+    FV_TRY(colind.zero(ctx));
+    FV_TRY(vals.zero(ctx));
+    hipLaunchKernelGGL(lean_csr32_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, g, n, (const int32_t *)rowptr.p, colind.p, vals.p);
+    FV_LAUNCH_CHECK(ctx);
+    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return FV_OK;
+}
+
 // ------------------------------------------------------------------ fv_get_csc of a lean problem: assembleA's matrix written out from the rows, a
 // window of rows at a time (the CSR never exists as a whole: 2^24 rows — at most 1.2e8 entries, 1.9 GB of scratch — per pass).  A is
 // symmetric in pattern and bit for bit in value (one face, one product), so the rows are the columns.

@@ -266,7 +266,8 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *                   the CSR ends at 3e8.  Transient and steady Jacobi-PCG solves, fv_spmv, states and trajectories work as always, and
  *                   fv_get_csc writes assembleA's matrix out from the rows (a window at a time; the same arrays as from the CSR route);
  *                   fv_problem_get_grid and the parameter gradients generate the face arrays for the duration of the call (F < 2^31).
- *                   What needs a resident CSR — the AMG preconditioner, fv_dist_setup — returns FV_ERR_STATE.  Dirichlet cells inside
+ *                   The AMG preconditioner writes level 0's CSR out for its set-up and gives it back (operators of < 2^31 entries).
+ *                   fv_dist_setup, which cuts a row block out of a resident CSR, returns FV_ERR_STATE.  Dirichlet cells inside
  *                   the box (not only on its faces) are served: the few 64-row groups around them, which the CSR route hands to its CSR
  *                   kernel, have their rows formed and applied on the spot.  0 never, 1 every grid of >= 4096 cells, 2 [default]
  *                   grids whose CSR would not fit int32 offsets (7 N > 2^31: before, FV_ERR_TOO_LARGE).  Read when a problem is created. */

@@ -134,10 +134,6 @@ def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can
     ns = (20, 18, 70)
     (p0, p1), rng, dn = _pair(fv, ns, "xfaces", "uniform", seed=2)
     lib = fv.load()
-    for call in (lambda: p1.set_preconditioner("amg"), lambda: p1.amg_info()):
-        with pytest.raises(fv.FVError) as e:
-            call()
-        assert e.value.code == 6 and "lean" in str(e.value)  # FV_ERR_STATE
     grids = []
     for p in (p0, p1):  # (the volumes are kept; the face list is generated again when asked for)
         n1, n2, aol, vol = np.empty(p.F, np.int64), np.empty(p.F, np.int64), np.empty(p.F), np.empty(p.N)
@@ -150,10 +146,36 @@ def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can
         p.transient_begin(0.1, None, np.full(p.N, 1000.0))
         outs.append(p.param_jacobian_apply(xs, ls, scale_by_storage=True))
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
+    import ctypes as C
+
+    out = C.c_void_p()
+    with pytest.raises(fv.FVError) as e:  # a row block is cut out of a resident CSR
+        p1.check(lib.fv_dist_setup(p1.handle, 1, 0, C.byref(out)))
+    assert e.value.code == 6 and "lean" in str(e.value)  # FV_ERR_STATE
     ctx = fv.default_context()
     assert ctx.get_option(fv._lib.FV_OPT_LEAN_SETUP) == 2  # the default: lean only where the CSR would not fit
     for p in (p0, p1):
         p.close()
+
+
+def test_lean_amg_is_the_csr_routes_hierarchy(fv):
+    """The aggregation-AMG preconditioner (where the reference uses AlgebraicMultigrid: src/FiniteVolume.jl:159-161) on a lean problem: level 0's CSR
+    is written out from the rows for the set-up alone and given back; the cycles run level 0 through the problem's own product.  Same hierarchy, same
+    iterates: level sizes, iteration counts and heads of a steady solve and of AMG-preconditioned time steps equal the CSR route's bit for bit."""
+    (p0, p1), rng, dn = _pair(fv, (36, 182, 186), "xfaces", "faces", seed=9)
+    res = []
+    for p in (p0, p1):
+        p.set_preconditioner("amg")
+        rows, nnz = p.amg_info()
+        h, _, ch = p.solve_steady(None, 1e-10, 500, want_resnorm=False)
+        st = p.transient_begin(0.1, None, np.full(p.N, 1000.0))
+        it, info, _ = p.run_fixed(st, 86400.0, 3, rtol=1e-10, maxiter=500)
+        assert ch.isconverged and info.converged
+        res.append((rows, nnz, ch.iters, h, it.copy(), st.free_values()))
+        p.close()
+    a, b = res
+    assert len(a[0]) >= 3 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
 
 
 @pytest.mark.parametrize("scattered", [False, True])
