@@ -158,6 +158,24 @@ def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can
         p.close()
 
 
+def test_lean_adaptive_stepper_and_trajectory_are_the_csr_routes(fv):
+    """The step-doubling stepper (a new dt, i.e. a new folded shift and every form refilled, at almost every step) with its states recorded in HBM:
+    the same outer steps, times and states as on the problem with faces and CSR."""
+    (p0, p1), rng, dn = _pair(fv, (24, 40, 70), "lateral", "faces", seed=12)  # (> 32768 rows: below, the CSR route has its single-launch solver)
+    res = []
+    for p in (p0, p1):
+        st = p.transient_begin(0.1, None, 1000.0 + rng.random(p.N) * 0 + np.linspace(0.0, 2.0, p.N))
+        tr = p.new_trajectory()
+        p.record(tr, 0.0)
+        out = p.run_adaptive(st, 0.0, 2000.0, dt0=1.0, atol=1e-3, rtol=1e-10, maxiter=2000)
+        p.record(None)
+        res.append((st.free_values(), np.asarray(tr.ts), tr.free_values(len(tr) - 1), out))
+        tr.close()
+        p.close()
+    a, b = res
+    assert len(a[1]) > 5 and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
 def test_lean_amg_is_the_csr_routes_hierarchy(fv):
     """The aggregation-AMG preconditioner (where the reference uses AlgebraicMultigrid: src/FiniteVolume.jl:159-161) on a lean problem: level 0's CSR
     is written out from the rows for the set-up alone and given back; the cycles run level 0 through the problem's own product.  Same hierarchy, same
