@@ -59,6 +59,33 @@ def _pair(fv, ns, dkind, kkind, seed):
     return ps, rng, dn
 
 
+@pytest.mark.parametrize("kkind", ["faces", "log", "meta"])
+def test_lean_assembly_against_the_oracle_directly(fv, oracle, kkind):
+    """assembleA / assembleb (/root/reference/src/FiniteVolume.jl:75-155) as restated by the oracle on regulargrid's own face list, against the matrix a
+    lean problem writes out from its rows and its b: colptr, rowval, nzval and b bit for bit — no CSR-route problem in between."""
+    ns = [17, 16, 18]
+    rng = np.random.default_rng(21)
+    _, n1, n2, aol, vol = oracle.regulargrid(MINS, MAXS, ns, want_coords=False)
+    dn = _dirichlet(ns, "lateral")
+    K, meta, logt = _conductivities(len(aol), kkind, rng)
+    src = np.zeros(len(vol))
+    src[np.setdiff1d(np.arange(len(vol)), dn - 1)[::97]] = rng.standard_normal(len(np.setdiff1d(np.arange(len(vol)), dn - 1)[::97]))
+    dh = 1000.0 + rng.random(len(dn))
+    mi = None if meta is None else (lambda i: int(meta[i - 1]))
+    Ao = oracle.assembleA(n1, n2, aol, K, src, dn, dh, metaindex=mi, logtransformconductivity=logt)
+    bo = oracle.assembleb(n1, n2, aol, K, src, dn, dh, metaindex=mi, logtransformconductivity=logt)
+    p = fv.Problem.regulargrid(MINS, MAXS, ns, dn, lean=True)
+    assert p.lean and p.nnz == len(Ao.nzval)
+    p.assemble(K, src, dh, metaindex=meta, logtransformconductivity=logt)
+    A = p.csc()
+    assert np.array_equal(A.colptr, Ao.colptr) and np.array_equal(A.rowval, Ao.rowval)
+    if logt:  # (the device's exp and the host's differ in the last place: the CSR route's own tests allow the same)
+        assert np.allclose(A.nzval, Ao.nzval, rtol=1e-14, atol=0) and np.allclose(p.b(), bo, rtol=1e-13, atol=0)
+    else:
+        assert np.array_equal(A.nzval, Ao.nzval) and np.array_equal(p.b(), bo)
+    p.close()
+
+
 SHAPES = [((20, 18, 70), "xfaces"), ((20, 18, 70), "lateral"), ((12, 30, 66), "xy"), ((36, 182, 186), "xfaces"), ((34, 184, 188), "lateral")]
 
 
