@@ -257,7 +257,24 @@ static int dist_setup_impl(fv_problem *pg, int nranks, int rank, const int64_t *
         fv_set_error(ctx, "fv_dist_setup: call fv_assemble and fv_transient_begin on the global problem first");
         return FV_ERR_STATE;
     }
-    FV_TRY(fv_require_csr(pg, "fv_dist_setup"));
+    // a lean global problem (FV_OPT_LEAN_SETUP) lends itself a CSR for the duration of this call: the block's rows are cut out of it, then it goes back
+    struct CsrLoan {
+        fv_problem *p;
+        bool on = false;
+        ~CsrLoan()
+        {
+            if (on) {
+                p->rowptr.release();
+                p->colind.release();
+                p->vals.release();
+                p->diagpos.release();
+            }
+        }
+    } loan{pg};
+    if (pg->lean) {
+        loan.on = true;
+        FV_TRY(fv_lean_csr32(pg, pg->rowptr, pg->colind, pg->vals, &pg->diagpos));
+    }
     if (pg->dist || pg->nhalo) {
         fv_set_error(ctx, "fv_dist_setup: problem is already a row block");
         return FV_ERR_STATE;

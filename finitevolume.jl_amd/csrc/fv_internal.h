@@ -523,7 +523,7 @@ struct FaceArrays {
 int fv_face_arrays(fv_problem *p, FaceArrays &fa); // fv_assembly.hip
 int fv_lean_rows_spmv(fv_problem *p, double tag, const double *x, double *y, const double *shift, double sigma, bool dot, double *partials, const PcgScalars *scal,
                       const int32_t *list, int64_t count, int grid);
-int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colind, DevBuf<double> &vals);
+int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colind, DevBuf<double> &vals, DevBuf<int32_t> *diagpos = nullptr);
 int fv_lean_get_csc(fv_problem *p, int64_t *colptr, int64_t *rowval, double *nzval);
 int fv_lean_symdia_fill(fv_problem *p, double sigma, int32_t d1, int32_t d2, int32_t d3, double *dg, double *u1, double *u2, double *u3);
 int fv_widen_indices(fv_ctx *ctx, const int32_t *src, int64_t *dst, int64_t n, int64_t add);

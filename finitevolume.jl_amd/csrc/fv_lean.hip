@@ -423,7 +423,7 @@ __global__ void lean_len_kernel(GridRows g, int64_t r0, int64_t count, int32_t *
 // ------------------------------------------------------------------ the operator as a CSR with int32 offsets, for a set-up that needs one and gives it
 // back (the AMG hierarchy's matching and Galerkin products read level 0 once; its cycles use the problem's own product): nnz < 2^31
 __global__ __launch_bounds__(FV_BLOCK) void lean_csr32_kernel(GridRows g, int64_t n, const int32_t *__restrict__ rowptr, int32_t *__restrict__ colind,
-                                                               double *__restrict__ vals)
+                                                               double *__restrict__ vals, int32_t *__restrict__ diagpos)
 {
     const int64_t r = (int64_t)blockIdx.x * FV_BLOCK + threadIdx.x;
     if (r >= n)
@@ -436,10 +436,12 @@ __global__ __launch_bounds__(FV_BLOCK) void lean_csr32_kernel(GridRows g, int64_
         if (k < e.len) {
             colind[s + k] = (int32_t)(r + (int64_t)e.off[k]);
             vals[s + k] = e.val[k];
+            if (diagpos && e.off[k] == 0)
+                diagpos[r] = s + k;
         }
 }
 
-int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colind, DevBuf<double> &vals)
+int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colind, DevBuf<double> &vals, DevBuf<int32_t> *diagpos)
 {
     fv_ctx *ctx = p->ctx;
     if (p->nnz >= 0x7fffffffLL - 2) {
@@ -463,7 +465,10 @@ int fv_lean_csr32(fv_problem *p, DevBuf<int32_t> &rowptr, DevBuf<int32_t> &colin
     FV_TRY(vals.alloc(ctx, (size_t)total + 2));
     FV_TRY(colind.zero(ctx));
     FV_TRY(vals.zero(ctx));
-    hipLaunchKernelGGL(lean_csr32_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, g, n, (const int32_t *)rowptr.p, colind.p, vals.p);
+    if (diagpos)
+        FV_TRY(diagpos->alloc(ctx, (size_t)n));
+    hipLaunchKernelGGL(lean_csr32_kernel, dim3(fv_blocks(n)), dim3(FV_BLOCK), 0, ctx->stream, g, n, (const int32_t *)rowptr.p, colind.p, vals.p,
+                       diagpos ? diagpos->p : (int32_t *)nullptr);
     FV_LAUNCH_CHECK(ctx);
     FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return FV_OK;

@@ -267,7 +267,7 @@ int fv_amg_apply(fv_problem *p, const double *r_free, double sigma, double *z_fr
  *                   fv_get_csc writes assembleA's matrix out from the rows (a window at a time; the same arrays as from the CSR route);
  *                   fv_problem_get_grid and the parameter gradients generate the face arrays for the duration of the call (F < 2^31).
  *                   The AMG preconditioner writes level 0's CSR out for its set-up and gives it back (operators of < 2^31 entries).
- *                   fv_dist_setup, which cuts a row block out of a resident CSR, returns FV_ERR_STATE.  Dirichlet cells inside
+ *                   fv_dist_setup lends the problem a CSR for the call and cuts the rank's rows out of it (same limit).  Dirichlet cells inside
  *                   the box (not only on its faces) are served: the few 64-row groups around them, which the CSR route hands to its CSR
  *                   kernel, have their rows formed and applied on the spot.  0 never, 1 every grid of >= 4096 cells, 2 [default]
  *                   grids whose CSR would not fit int32 offsets (7 N > 2^31: before, FV_ERR_TOO_LARGE).  Read when a problem is created. */

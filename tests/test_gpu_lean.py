@@ -157,7 +157,7 @@ def test_lean_transient_runs_are_the_csr_route_bit_for_bit(fv, dkind, kkind):
         p.close()
 
 
-def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can(fv):
+def test_lean_problem_rebuilds_what_needs_faces_for_the_call(fv):
     ns = (20, 18, 70)
     (p0, p1), rng, dn = _pair(fv, ns, "xfaces", "uniform", seed=2)
     lib = fv.load()
@@ -173,12 +173,6 @@ def test_lean_problem_refuses_what_needs_a_resident_csr_and_rebuilds_what_it_can
         p.transient_begin(0.1, None, np.full(p.N, 1000.0))
         outs.append(p.param_jacobian_apply(xs, ls, scale_by_storage=True))
     assert all(np.array_equal(a, b) for a, b in zip(*outs))
-    import ctypes as C
-
-    out = C.c_void_p()
-    with pytest.raises(fv.FVError) as e:  # a row block is cut out of a resident CSR
-        p1.check(lib.fv_dist_setup(p1.handle, 1, 0, C.byref(out)))
-    assert e.value.code == 6 and "lean" in str(e.value)  # FV_ERR_STATE
     ctx = fv.default_context()
     assert ctx.get_option(fv._lib.FV_OPT_LEAN_SETUP) == 2  # the default: lean only where the CSR would not fit
     for p in (p0, p1):
@@ -201,6 +195,61 @@ def test_lean_adaptive_stepper_and_trajectory_are_the_csr_routes(fv):
         p.close()
     a, b = res
     assert len(a[1]) > 5 and np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2])
+
+
+def test_row_blocks_cut_from_a_lean_problem(fv):
+    """fv_dist_setup on a lean global problem: it lends itself a CSR for the call, the rank's rows are cut out of it, and it goes back.  Two ranks (host
+    threads, the loopback transport) with whole planes each: states, iteration counts and the forms that ran equal those of blocks cut from the CSR route."""
+    import threading
+
+    from fvamd import dist
+
+    ns = (34, 184, 188)
+    dn = _dirichlet(ns, "lateral")
+    N = ns[0] * ns[1] * ns[2]
+    rng = np.random.default_rng(17)
+    c = np.indices(ns).reshape(3, -1).astype(np.float64)
+    field = 1000.0 + 0.5 * np.sin(c[0] / 5.0) * np.cos(c[1] / 40.0) + 0.001 * c[2]
+    src = np.zeros(N)
+    u0 = field + 1e-3 * rng.random(N)
+    lib = fv.load()
+    results = {}
+    for gid, lean in ((31, False), (32, True)):
+        out, errors = [None, None], []
+
+        def worker(rank, lean=lean, gid=gid, out=out, errors=errors):
+            try:
+                ctx = fv.Context(0)
+                dist.comm_init_local(ctx, 2, rank, gid)
+                p = fv.Problem.regulargrid(MINS, MAXS, list(ns), dn, ctx, lean=lean)
+                p.assemble(np.array([1e-5]), src, field[dn - 1] + 0.25)
+                p.transient_begin(0.1, None, u0)
+                d3 = p.n // ns[0]
+                blk = dist.RowBlock(p, 2, rank, np.array([0, 16, 34]) * d3)
+                assert p.lean == lean and p.spmv(np.ones(p.n)).shape == (p.n,)  # (the lean problem is whole again after the loan)
+                p.close()
+                its = []
+                for dt, nsteps, rtol in ((2.0**-10, 12, 1e-11), (40.0, 3, 1e-12)):
+                    it, info, _ = blk.run_fixed(dt, nsteps, rtol, maxiter=2000)
+                    assert info.converged
+                    its.append(it.copy())
+                out[rank] = (blk.lo, blk.hi, blk.state(), np.concatenate(its), blk.fused_form())
+                blk.close()
+                lib.fv_comm_destroy(ctx.handle)
+            except BaseException as e:  # noqa: BLE001
+                errors.append((rank, repr(e)))
+
+        threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert all(not t.is_alive() for t in threads)
+        results[lean] = out
+    for r in range(2):
+        a, b = results[False][r], results[True][r]
+        assert a[:2] == b[:2] and np.array_equal(a[3], b[3]) and a[4] == b[4] and np.array_equal(a[2], b[2]), (r, a[3], b[3], a[4], b[4])
 
 
 def test_lean_amg_is_the_csr_routes_hierarchy(fv):
