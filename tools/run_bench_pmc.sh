@@ -7,7 +7,7 @@ if [ -n "${2:-}" ]; then export FV_TUNE="$2"; fi
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out
 mkdir -p $O
-ARGS="--steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-other-configs --no-multi-iteration --no-hetero"
+ARGS="${EXTRA_ARGS:-} --steps 6 --warmup 2 --repeats 1 --no-cpu-baseline --no-profile --no-other-configs --no-multi-iteration --no-hetero"
 rm -rf $O/${TAG}_rd $O/${TAG}_wr $O/${TAG}_sq
 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum --output-format csv -d $O/${TAG}_rd -- python3 $R/bench.py $ARGS > $O/${TAG}_rd.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/${TAG}_wr -- python3 $R/bench.py $ARGS > $O/${TAG}_wr.log 2>&1
