@@ -753,11 +753,14 @@ def lean_block(fv, ctx, args, mins, maxs, ns, dn, src):
     t_setup = time.perf_counter() - t0
     if args.warmup > 0:
         p.run_fixed(state, args.dt, args.warmup, args.rtol, args.maxiter)
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    iters, info, _ = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
-    ctx.synchronize()
-    sec = time.perf_counter() - t0
+    regions = []
+    for rep in range(max(args.repeats, 1)):  # (as for the headline: the median of the timed regions)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        iters, info, _ = p.run_fixed(state, args.dt, args.steps, args.rtol, args.maxiter)
+        ctx.synchronize()
+        regions.append(time.perf_counter() - t0)
+    sec = float(np.median(regions))
     in_use = (free0 - ctx.mem_info()[0]) / 1e9
     out = {"workload": "the headline's %d^3 box, dt, tolerance and steps on a lean problem (FV_OPT_LEAN_SETUP = 1)" % ns[0], "ms_per_step": sec / args.steps * 1e3,
            "value": p.N * args.steps / sec, "pcg_iters_per_step": float(np.mean(iters)), "converged": bool(info.converged), "hbm_in_use_gb": in_use,
