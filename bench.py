@@ -7,7 +7,8 @@ Workload (BASELINE.json configs[4] / the 10^8-cell target of
 `north_star`): structured box of ns^3 cells (default 464^3 = 9.99e7), 1000 x 1000
 x 100 m, K = 1e-5 m/s, Ss = 0.1, Dirichlet head 1e3 on the four lateral faces,
 u0 = 1e3, one pumping well (-1e-3 m^3/s) down the centre column, fixed dt = 60 s,
-PCG rtol 1e-10.  Grid, connectivity and CSR are generated/assembled on the device.
+PCG rtol 1e-10.  The grid is generated and assembled on the device; by default the problem is lean (FV_OPT_LEAN_SETUP: no faces / CSR in HBM,
+the same doubles and kernels), the line's `csr_route_block` times the route through faces and CSR beside it (--lean off swaps the two).
 
     python bench.py --gpus 1 --steps 20 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -346,8 +347,9 @@ def main():
     ap.add_argument("--no-hetero", action="store_true", help="skip the same workload with a heterogeneous conductivity (the matrix then streams as doubles: 73 B per row)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing inside the timed region")
     ap.add_argument("--no-lean-block", action="store_true", help="skip the same steps on a lean problem (no faces / CSR in HBM)")
-    ap.add_argument("--lean", choices=("auto", "on", "off"), default="auto",
-                    help="FV_OPT_LEAN_SETUP for the bench problem: no face arrays / incident lists / CSR in HBM (auto: only where the CSR would not fit int32 offsets)")
+    ap.add_argument("--lean", choices=("auto", "on", "off"), default="on",
+                    help="FV_OPT_LEAN_SETUP for the bench problem: no face arrays / incident lists / CSR in HBM — the same doubles, the same kernels (tests/test_gpu_lean.py); "
+                         "off: the route through faces and CSR (the side block of the line measures the other route); auto: lean only where the CSR would not fit int32 offsets")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -450,12 +452,14 @@ def main():
             out["config"]["multi_iteration"] = "failed: %r" % (e,)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.dt, args.rtol)
-    if not args.no_lean_block and not p.lean:
+    if not args.no_lean_block and 7 * p.N < 2**31 - 3:  # the other route of the set-up on the same workload (where a CSR with int32 offsets exists at all)
+        other_lean = not p.lean
         p.close()
+        key = "lean_setup_block" if other_lean else "csr_route_block"
         try:
-            out["config"]["lean_setup_block"] = lean_block(fv, ctx, args, mins, maxs, ns, dn, src)
+            out["config"][key] = lean_block(fv, ctx, args, mins, maxs, ns, dn, src, other_lean)
         except Exception as e:
-            out["config"]["lean_setup_block"] = "failed: %r" % (e,)
+            out["config"][key] = "failed: %r" % (e,)
     if not args.no_hetero:
         p.close()
         try:
@@ -741,13 +745,14 @@ def roofline_block(p, prof, iters_per_step, ns, fused_launches=0, nsteps=0):
     return roof, kern
 
 
-def lean_block(fv, ctx, args, mins, maxs, ns, dn, src):
-    """The same workload on a problem created with FV_OPT_LEAN_SETUP (csrc/fv_lean.hip): no face arrays, incident lists or CSR in HBM, every
-    storage form filled from rows formed on the fly — the same doubles (tests/test_gpu_lean.py), the same kernels, a third of the memory."""
+def lean_block(fv, ctx, args, mins, maxs, ns, dn, src, lean=True):
+    """The same workload on a problem created the other way: with FV_OPT_LEAN_SETUP (csrc/fv_lean.hip: no face arrays, incident lists or CSR in
+    HBM, every storage form filled from rows formed on the fly) or through faces and CSR — the same doubles (tests/test_gpu_lean.py), the same
+    kernels, a third of the memory."""
     ctx.synchronize()
     free0 = ctx.mem_info()[0]
     t0 = time.perf_counter()
-    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx, lean=True)
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, ctx, lean=lean)
     p.assemble(np.array([1e-5]), src, np.full(len(dn), 1e3))
     state = p.transient_begin(0.1, None, np.full(p.N, 1e3))
     t_setup = time.perf_counter() - t0
@@ -762,7 +767,8 @@ def lean_block(fv, ctx, args, mins, maxs, ns, dn, src):
         regions.append(time.perf_counter() - t0)
     sec = float(np.median(regions))
     in_use = (free0 - ctx.mem_info()[0]) / 1e9
-    out = {"workload": "the headline's %d^3 box, dt, tolerance and steps on a lean problem (FV_OPT_LEAN_SETUP = 1)" % ns[0], "ms_per_step": sec / args.steps * 1e3,
+    out = {"workload": "the headline's %d^3 box, dt, tolerance and steps on %s" % (ns[0], "a lean problem (FV_OPT_LEAN_SETUP = 1)" if lean else "a problem that holds faces, incident lists and CSR (FV_OPT_LEAN_SETUP = 0)"),
+           "ms_per_step": sec / args.steps * 1e3,
            "value": p.N * args.steps / sec, "pcg_iters_per_step": float(np.mean(iters)), "converged": bool(info.converged), "hbm_in_use_gb": in_use,
            "bytes_per_cell_in_hbm": in_use * 1e9 / p.N, "setup_s": t_setup, "fused_launches": p.fused_form()[0], "traversal": "chunks" if p.fused_traversal() == 1 else "tiles",
            "larger_boxes": "profiles/r05_bench832_lean.json (5.8e8 cells), r05_bench928_lean.json (8.0e8 cells, 5.6e9 non-zeros): the same command with --ns"}

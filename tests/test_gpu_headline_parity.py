@@ -95,8 +95,8 @@ class OracleSystem:
         return self.heads(u), iters
 
 
-def _device_run(fv, mins, maxs, ns, K, src, dn, dh, Ss, u0_value, schedule, rtol):
-    p = fv.Problem.regulargrid(mins, maxs, ns, dn)
+def _device_run(fv, mins, maxs, ns, K, src, dn, dh, Ss, u0_value, schedule, rtol, lean=None):
+    p = fv.Problem.regulargrid(mins, maxs, ns, dn, lean=lean)
     p.assemble(K, src, dh)
     st = p.transient_begin(Ss, None, np.full(p.N, u0_value))
     its, fused = [], []
@@ -157,6 +157,10 @@ def test_bench_workload_coded_fused_step_vs_oracle(fv, oracle, n, steps):
     assert (its[0] == 1).all()  # the headline's regime: one PCG iteration per step
     assert fused[0][0] >= steps - 2 and fused[0][1] == 51  # the fused launches ran, in the coded instantiation ...
     assert _device_run.traversal == 1  # ... on chunks of a plane: fused_chunk_kernel<512, 5, 0>, the kernel of the bench line
+    # bench.py's problem is lean by default (FV_OPT_LEAN_SETUP: no faces / CSR in HBM): the same heads bit for bit, or the legs below would not be its
+    lean = _device_run(fv, mins, maxs, ns, np.array([1e-5]), src, dn, dh, 0.1, 1e3, sched, rtol=1e-10, lean=True)
+    assert np.array_equal(lean[0], head) and np.array_equal(lean[1][0], its[0]) and lean[2] == fused and lean[3] == loop and _device_run.traversal == 1
+    del lean
     t0 = time.perf_counter()
     F = 3 * n**3 - 3 * n * n
     sysm = OracleSystem(oracle, mins, maxs, ns, np.full(F, 1e-5), src, dn, dh, 0.1)
