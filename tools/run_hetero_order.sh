@@ -1,0 +1,9 @@
+for rep in 1 2; do
+for extra in "" "--no-lean-block" "--lean off"; do
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $extra 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); c = d['config']; h = c['heterogeneous_K']
+print('[$extra] headline %.4f; hetero dt=60: %.3f ms frac %.3f; dt=7.5: %.3f ms frac %.3f' % (d['ms_per_step'], h['ms_per_step'], h['roofline']['frac'], h['one_iteration_regime']['ms_per_step'], h['one_iteration_regime']['roofline']['frac']))
+"
+done
+done
