@@ -1222,6 +1222,33 @@ __global__ __launch_bounds__(FV_BLOCK) void amg_scatter_piece_kernel(int64_t lo,
     }
 }
 
+// Every rank's verdict on a stretch of local work (allocations, scans) before the next collective: a rank that failed alone would return while
+// the others wait in that collective for ever.  One double through the all-reduce the ranks share; the failing rank keeps its own
+// message, the others learn that somebody failed.
+static int amg_agree(fv_problem *p, int rc)
+{
+    fv_ctx *ctx = p->ctx;
+    fv_dist *d = p->dist;
+    const double flag = rc != FV_OK ? 1.0 : 0.0;
+    double total = 0.0;
+    int rc2 = FV_OK;
+    if (hipMemcpyAsync(d->red.p, &flag, sizeof flag, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        rc2 = FV_ERR_HIP;
+    if (rc2 == FV_OK)
+        rc2 = fv_comm_allreduce_sum(ctx, d, d->red.p, 1, ctx->stream);
+    if (rc2 == FV_OK && fv_memcpy_sync(ctx, &total, d->red.p, sizeof total, hipMemcpyDeviceToHost) != hipSuccess)
+        rc2 = FV_ERR_HIP;
+    if (rc != FV_OK)
+        return rc;
+    if (rc2 != FV_OK)
+        return rc2;
+    if (total > 0.0) {
+        fv_set_error(ctx, "gathered AMG level: the set-up failed on another rank");
+        return FV_ERR_STATE;
+    }
+    return FV_OK;
+}
+
 // agg_loc: the rank's own aggregation of its n rows (local ids 0 .. nc_loc - 1, -1 = none).  On return L carries the transfer to the
 // gathered level (global ids) and C is that level.
 static int amg_gather_level1(fv_problem *p, AmgLevel *L, DevBuf<int32_t> &agg_loc, int64_t nc_loc, AmgLevel *C)
@@ -1232,11 +1259,15 @@ static int amg_gather_level1(fv_problem *p, AmgLevel *L, DevBuf<int32_t> &agg_lo
     const int R = d->nranks;
     // every rank's number of aggregates -> my offset, the size of the level
     DevBuf<double> counts;
-    FV_TRY(counts.alloc(ctx, (size_t)R));
-    FV_TRY(counts.zero(ctx));
-    const double mine = (double)nc_loc;
-    FV_HIP(ctx, hipMemcpyAsync(counts.p + d->rank, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
-    FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto phase0 = [&]() -> int {
+        FV_TRY(counts.alloc(ctx, (size_t)R));
+        FV_TRY(counts.zero(ctx));
+        const double mine = (double)nc_loc;
+        FV_HIP(ctx, hipMemcpyAsync(counts.p + d->rank, &mine, sizeof mine, hipMemcpyHostToDevice, ctx->stream));
+        FV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return FV_OK;
+    };
+    FV_TRY(amg_agree(p, phase0()));
     FV_TRY(fv_comm_allreduce_sum(ctx, d, counts.p, R, ctx->stream));
     std::vector<double> hc((size_t)R);
     FV_HIP(ctx, fv_memcpy_sync(ctx, hc.data(), counts.p, (size_t)R * sizeof(double), hipMemcpyDeviceToHost));
@@ -1246,60 +1277,71 @@ static int amg_gather_level1(fv_problem *p, AmgLevel *L, DevBuf<int32_t> &agg_lo
             off += (int64_t)hc[(size_t)r];
         ncg += (int64_t)hc[(size_t)r];
     }
-    if (ncg <= 0 || ncg >= 0x7fffffffLL) {
+    if (ncg <= 0 || ncg >= 0x7fffffffLL) { // (the same sum on every rank: all return together)
         fv_set_error(ctx, "gathered AMG level: %lld aggregates over all ranks", (long long)ncg);
         return FV_ERR_STATE;
     }
     // global aggregate ids of my rows and, through the halo exchange, of my halo columns
     DevBuf<double> gid;
     DevBuf<int32_t> agg_ext;
-    FV_TRY(gid.alloc(ctx, (size_t)next + FV_VEC_PAD));
-    FV_TRY(agg_ext.alloc(ctx, (size_t)next));
-    hipLaunchKernelGGL(amg_global_ids_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, n, next, (const int32_t *)agg_loc.p, (double)off, gid.p);
-    FV_LAUNCH_CHECK(ctx);
+    auto phase1 = [&]() -> int {
+        FV_TRY(gid.alloc(ctx, (size_t)next + FV_VEC_PAD));
+        FV_TRY(agg_ext.alloc(ctx, (size_t)next));
+        hipLaunchKernelGGL(amg_global_ids_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, n, next, (const int32_t *)agg_loc.p, (double)off, gid.p);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    };
+    FV_TRY(amg_agree(p, phase1()));
     FV_TRY(fv_dist_exchange(p, gid.p));
-    hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, next, (const double *)gid.p, agg_ext.p);
-    FV_LAUNCH_CHECK(ctx);
-    gid.release();
-    // my rows of P^T A P, in the row space of the whole level (the rows of other ranks stay empty)
-    FV_TRY(amg_members(ctx, n, agg_ext.p, ncg, L->memptr, L->mem));
+    // my rows of P^T A P, in the row space of the whole level (the rows of other ranks stay empty); row lengths of the whole level
     DevBuf<int32_t> prp, pci;
     DevBuf<double> pva, pD;
     int64_t pnnz = 0;
-    FV_TRY(amg_galerkin(ctx, n, p->nnz, p->rowptr.p, p->colind.p, p->vals.p, L->D, agg_ext.p, ncg, L->memptr.p, L->mem.p, prp, pci, pva, pD, &pnnz, next));
-    // row lengths of the whole level -> its row pointers
     DevBuf<double> dcnt;
     DevBuf<int32_t> icnt;
-    FV_TRY(dcnt.alloc(ctx, (size_t)ncg));
-    FV_TRY(icnt.alloc(ctx, (size_t)ncg));
-    hipLaunchKernelGGL(amg_row_counts_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const int32_t *)prp.p, dcnt.p);
-    FV_LAUNCH_CHECK(ctx);
+    auto phase2 = [&]() -> int {
+        hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(next)), dim3(FV_BLOCK), 0, ctx->stream, next, (const double *)gid.p, agg_ext.p);
+        FV_LAUNCH_CHECK(ctx);
+        gid.release();
+        FV_TRY(amg_members(ctx, n, agg_ext.p, ncg, L->memptr, L->mem));
+        FV_TRY(amg_galerkin(ctx, n, p->nnz, p->rowptr.p, p->colind.p, p->vals.p, L->D, agg_ext.p, ncg, L->memptr.p, L->mem.p, prp, pci, pva, pD, &pnnz, next));
+        FV_TRY(dcnt.alloc(ctx, (size_t)ncg));
+        FV_TRY(icnt.alloc(ctx, (size_t)ncg));
+        hipLaunchKernelGGL(amg_row_counts_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const int32_t *)prp.p, dcnt.p);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    };
+    FV_TRY(amg_agree(p, phase2()));
     FV_TRY(fv_comm_allreduce_sum(ctx, d, dcnt.p, (int)ncg, ctx->stream));
-    hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const double *)dcnt.p, icnt.p);
-    FV_LAUNCH_CHECK(ctx);
-    FV_TRY(C->o_rowptr.alloc(ctx, (size_t)ncg + 1));
     int64_t gnnz = 0;
-    FV_TRY(fv_exclusive_scan_i32(ctx, icnt.p, C->o_rowptr.p, ncg, &gnnz));
-    if (gnnz <= 0 || gnnz >= 0x7fffffffLL - 2) {
-        fv_set_error(ctx, "gathered AMG level: %lld entries", (long long)gnnz);
-        return FV_ERR_STATE;
-    }
-    dcnt.release();
-    icnt.release();
-    // entries: every rank writes its rows' segments, the sum over the ranks is the level
     DevBuf<double> gc;
-    FV_TRY(gc.alloc(ctx, (size_t)gnnz));
-    FV_TRY(gc.zero(ctx));
-    FV_TRY(C->o_vals.alloc(ctx, (size_t)gnnz + 2));
-    FV_TRY(C->o_vals.zero(ctx));
-    if (nc_loc > 0)
-        hipLaunchKernelGGL(amg_scatter_piece_kernel, dim3(fv_blocks(nc_loc)), dim3(FV_BLOCK), 0, ctx->stream, off, off + nc_loc, (const int32_t *)prp.p,
-                           (const int32_t *)pci.p, (const double *)pva.p, (const int32_t *)C->o_rowptr.p, gc.p, C->o_vals.p);
-    FV_LAUNCH_CHECK(ctx);
+    auto phase3 = [&]() -> int {
+        hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(ncg)), dim3(FV_BLOCK), 0, ctx->stream, ncg, (const double *)dcnt.p, icnt.p);
+        FV_LAUNCH_CHECK(ctx);
+        FV_TRY(C->o_rowptr.alloc(ctx, (size_t)ncg + 1));
+        FV_TRY(fv_exclusive_scan_i32(ctx, icnt.p, C->o_rowptr.p, ncg, &gnnz));
+        if (gnnz <= 0 || gnnz >= 0x7fffffffLL - 2) {
+            fv_set_error(ctx, "gathered AMG level: %lld entries", (long long)gnnz);
+            return FV_ERR_STATE;
+        }
+        dcnt.release();
+        icnt.release();
+        // entries: every rank writes its rows' segments, the sum over the ranks is the level
+        FV_TRY(gc.alloc(ctx, (size_t)gnnz));
+        FV_TRY(gc.zero(ctx));
+        FV_TRY(C->o_vals.alloc(ctx, (size_t)gnnz + 2));
+        FV_TRY(C->o_vals.zero(ctx));
+        FV_TRY(C->o_colind.alloc(ctx, (size_t)gnnz + 2));
+        FV_TRY(C->o_colind.zero(ctx));
+        if (nc_loc > 0)
+            hipLaunchKernelGGL(amg_scatter_piece_kernel, dim3(fv_blocks(nc_loc)), dim3(FV_BLOCK), 0, ctx->stream, off, off + nc_loc, (const int32_t *)prp.p,
+                               (const int32_t *)pci.p, (const double *)pva.p, (const int32_t *)C->o_rowptr.p, gc.p, C->o_vals.p);
+        FV_LAUNCH_CHECK(ctx);
+        return FV_OK;
+    };
+    FV_TRY(amg_agree(p, phase3()));
     FV_TRY(fv_comm_allreduce_sum(ctx, d, gc.p, (int)gnnz, ctx->stream));
     FV_TRY(fv_comm_allreduce_sum(ctx, d, C->o_vals.p, (int)gnnz, ctx->stream));
-    FV_TRY(C->o_colind.alloc(ctx, (size_t)gnnz + 2));
-    FV_TRY(C->o_colind.zero(ctx));
     hipLaunchKernelGGL(amg_to_int_kernel, dim3(fv_blocks(gnnz)), dim3(FV_BLOCK), 0, ctx->stream, gnnz, (const double *)gc.p, C->o_colind.p);
     FV_LAUNCH_CHECK(ctx);
     if (L->D) {
