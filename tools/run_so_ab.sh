@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of two builds of the library on the heterogeneous block of the bench (alternating processes): .ab/libfvhip_base.so against the tree's.
+# A/B of two builds of the library on the heterogeneous block of the bench (alternating processes): put the other build at .ab/libfvhip_base.so
+# (mkdir .ab; cp finitevolume.jl_amd/libfvhip.so .ab/libfvhip_base.so before the change under test); the tree's build is the second one.
 mkdir -p gpurun_out
 cp finitevolume.jl_amd/libfvhip.so .ab/libfvhip_new.so
 B="--steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-multi-iteration --no-lean-block"
